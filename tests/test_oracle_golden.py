@@ -1,0 +1,94 @@
+"""Pins the CPU oracle (oracle/acq_oracle.c) against golden vectors generated from the imported
+reference (tools/gen_golden_acq.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import acq as orc
+
+STRATS = ["entropy", "least_confidence", "margin_sampling"]
+FILL = {"entropy": 0.0, "least_confidence": 0.0, "margin_sampling": 1.0}
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "acq_scores_topk.npz"))
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+@pytest.mark.parametrize("st", STRATS)
+def test_score_maps_match_reference(g, si, st):
+    logits = g[f"s{si}_logits"]
+    ref = g[f"s{si}_map_{st}"]
+    got = orc.score_map(logits, st)
+    # float32 exp/log implementations differ by ulps between libm and torch's vectorised kernels
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+@pytest.mark.parametrize("st", STRATS)
+def test_nhwc_strides_give_same_map(g, si, st):
+    logits = g[f"s{si}_logits"]
+    nhwc = np.ascontiguousarray(logits.transpose(0, 2, 3, 1)).transpose(0, 3, 1, 2)  # NCHW view of NHWC storage
+    assert not nhwc.flags["C_CONTIGUOUS"]
+    np.testing.assert_array_equal(orc.score_map(nhwc, st), orc.score_map(logits, st))
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+@pytest.mark.parametrize("st", STRATS)
+def test_topk_index_sets_and_order_bit_exact(g, si, st):
+    logits, excl = g[f"s{si}_logits"], g[f"s{si}_exclude"]
+    idx, val = orc.score_topk(logits, excl, st, 20)
+    for b in range(logits.shape[0]):
+        assert sorted(idx[b].tolist()) == g[f"s{si}_sel_{st}"][b].tolist()
+        # gap-guarded fixtures: the value-sorted order is pinned as well
+        assert idx[b].tolist() == g[f"s{si}_order_{st}"][b].tolist()
+
+
+@pytest.mark.parametrize("st", STRATS)
+def test_select_modes_top_percent_order(golden_dir, st):
+    m = np.load(os.path.join(golden_dir, "acq_select_modes.npz"))
+    uc = m[f"{st}_uc"]
+    k = int(uc.size * 0.05)
+    idx, _ = orc.topk(uc, k, largest=st != "margin_sampling")
+    assert idx.tolist() == m[f"{st}_top5_order"].tolist()
+    # subsample exactly like query.py:63-64
+    np.random.seed(int(m["np_seed_top5"]))
+    sub = np.random.choice(idx.astype(np.int64), 10, False)
+    assert sorted(sub.tolist()) == m[f"{st}_top5_sel"].tolist()
+
+
+def test_edges_nan_and_few(golden_dir):
+    e = np.load(os.path.join(golden_dir, "acq_edges.npz"))
+    ent = orc.score_map(e["nan_logits"], "entropy")[0]
+    ref = e["nan_entropy_map"]
+    assert np.array_equal(np.isnan(ent), np.isnan(ref))
+    np.testing.assert_allclose(ent[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(orc.score_map(e["nan_logits"], "least_confidence")[0], e["nan_lc_map"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(orc.score_map(e["nan_logits"], "margin_sampling")[0], e["nan_margin_map"], rtol=2e-5, atol=2e-6)
+    idx, val = orc.topk(ent, 4, True)
+    # NaN first (both NaN pixels, lower index first under our tiebreak); then the two largest finite
+    assert np.isnan(val[:2]).all() and not np.isnan(val[2:]).any()
+    assert set(idx[:2].tolist()) == set(e["nan_top4_idx"][:2].tolist())
+    assert idx[2:].tolist() == e["nan_top4_idx"][2:].tolist()
+    assert idx[0] < idx[1]
+    # k == #free and k > #free
+    uc = e["few_uc"]
+    idx5, _ = orc.topk(uc, 5, True)
+    assert sorted(idx5.tolist()) == e["few_sel_k5"].tolist()
+    idx8, _ = orc.topk(uc, 8, True)
+    assert len(set(idx8.tolist())) == 8 == int(e["few_sel_k8_count"])
+    assert set(e["few_sel_k5"].tolist()) <= set(idx8.tolist())
+    # excluded extras: lowest flat index first (fixed tiebreak)
+    extras = [i for i in idx8.tolist() if i not in set(e["few_sel_k5"].tolist())]
+    excl_idx = np.flatnonzero(e["few_exclude"].reshape(-1))
+    assert extras == excl_idx[:3].tolist()
+
+
+def test_tiebreak_and_signed_zero():
+    s = np.array([1.0, 2.0, 2.0, -0.0, 0.0, 2.0, np.nan], dtype=np.float32)
+    idx, _ = orc.topk(s, 7, True)
+    assert idx.tolist() == [6, 1, 2, 5, 0, 3, 4]
+    idx, _ = orc.topk(s, 7, False)
+    assert idx.tolist() == [3, 4, 0, 1, 2, 5, 6]

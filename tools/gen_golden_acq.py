@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate acquisition golden vectors by IMPORTING the reference (authoring container only).
+
+Runs only where /root/reference exists.  Writes small .npz fixtures into tests/golden/.
+The fixtures are data (inputs + the reference's outputs); no reference source is copied.
+
+Reference call sites exercised:
+  query.py:229-239   UncertaintySampler._entropy/_least_confidence/_margin_sampling   (G1)
+  query.py:33-69     QuerySelector._select_queries (k=n_pixels_by_us and top_n_percent modes) (G2)
+  query.py:230       0*log(0)=NaN behaviour, k > #unmasked behaviour                  (G3)
+  query.py:144-221   QuerySelector.__call__ with a fake dataloader + 1x1-conv model   (G4)
+  query.py:71-142    encode_query / decode_queries                                    (G5)
+  query.py:320-351   merge_previous_query_files                                       (G5)
+"""
+import os
+import sys
+import pickle as pkl
+import tempfile
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+import query as refq  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+STRATS = ["entropy", "least_confidence", "margin_sampling"]
+FILL = {"entropy": 0.0, "least_confidence": 0.0, "margin_sampling": 1.0}
+
+
+def mk_args(strategy, n_classes, k=20, top_n_percent=0.0, reverse_order=False, dataset_name="cs",
+            ignore_index=None, dir_root="/tmp"):
+    return Namespace(dataset_name=dataset_name, debug=False, dir_root=dir_root, experim_name="golden",
+                     ignore_index=n_classes if ignore_index is None else ignore_index, mc_n_steps=20,
+                     n_classes=n_classes, n_pixels_by_us=k, network_name="deeplab",
+                     query_strategy=strategy, reverse_order=reverse_order, stride_total=8,
+                     top_n_percent=top_n_percent, use_mc_dropout=False, vote_type="hard")
+
+
+def gap_ok(vals_sorted_desc_or_asc, k, rel=1e-4):
+    """k-th vs (k+1)-th gap guard."""
+    a, b = float(vals_sorted_desc_or_asc[k - 1]), float(vals_sorted_desc_or_asc[k])
+    return abs(a - b) >= rel * max(abs(a), abs(b), 1e-30)
+
+
+def all_gaps_ok(vals, rel=1e-4):
+    v = np.asarray(vals, dtype=np.float64)
+    d = np.abs(np.diff(v))
+    return bool(np.all(d >= rel * np.maximum(np.abs(v[1:]), np.abs(v[:-1]))))
+
+
+# ----------------------------------------------------------------------------- G1 + G2 (k=20)
+def gen_scores_and_topk():
+    shapes = [(1, 19, 32, 64), (1, 11, 45, 60), (2, 21, 37, 53)]
+    out = {}
+    for si, (b, c, h, w) in enumerate(shapes):
+        seed = 100 + si
+        while True:
+            torch.manual_seed(seed)
+            logits = torch.randn(b, c, h, w) * 3
+            rng = np.random.RandomState(seed)
+            excl = np.zeros((b, h, w), dtype=np.uint8)
+            for i in range(b):
+                idx = rng.choice(h * w, 40, replace=False)
+                excl[i].reshape(-1)[idx] = 1
+                excl[i][rng.rand(h, w) < 0.05] = 1
+            prob = F.softmax(logits, dim=1)
+            ok = True
+            rec = {}
+            for st in STRATS:
+                sampler = refq.UncertaintySampler(st)
+                uc = sampler(prob)  # b,h,w
+                rec[f"map_{st}"] = uc.numpy().copy()
+                largest = st in ["entropy", "least_confidence"]
+                sets, orders = [], []
+                for i in range(b):
+                    args = mk_args(st, c, k=20)
+                    qs = refq.QuerySelector(args, dataloader=None, device=torch.device("cpu"))
+                    m = uc[i].clone()
+                    m[torch.from_numpy(excl[i].astype(bool))] = FILL[st]
+                    # gap guard on this image
+                    srt = torch.sort(m.flatten(), descending=largest).values.numpy()
+                    if not gap_ok(srt, 20) or not all_gaps_ok(srt[:21]):
+                        ok = False
+                    qmask = qs._select_queries(m.clone())
+                    sets.append(np.flatnonzero(qmask.reshape(-1)).astype(np.int64))
+                    orders.append(m.flatten().topk(20, largest=largest).indices.numpy().astype(np.int64))
+                rec[f"sel_{st}"] = np.stack(sets)
+                rec[f"order_{st}"] = np.stack(orders)
+            if ok:
+                break
+            seed += 1000
+        out[f"s{si}_logits"] = logits.numpy()
+        out[f"s{si}_exclude"] = excl
+        out[f"s{si}_seed"] = np.int64(seed)
+        for kk, v in rec.items():
+            out[f"s{si}_{kk}"] = v
+    np.savez_compressed(os.path.join(OUT, "acq_scores_topk.npz"), **out)
+    print("G1/G2 written", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+# ----------------------------------------------------------------------------- G2 top-p% + subsample, reverse_order
+def gen_select_modes():
+    """_select_queries on a GIVEN uc_map (query.py:33-69): top_n_percent mode depends on the
+    value-sorted order of topk + numpy RNG; reverse_order mode on numpy RNG only."""
+    out = {}
+    h, w = 48, 80
+    for st in STRATS:
+        largest = st in ["entropy", "least_confidence"]
+        torch.manual_seed(7)
+        # distinct values everywhere (a random permutation scaled) -> order is implementation independent
+        vals = torch.randperm(h * w).float() / (h * w)
+        uc = vals.reshape(h, w).clone()
+        out[f"{st}_uc"] = uc.numpy().copy()
+        # top 5% then subsample 10 with seed
+        args = mk_args(st, 19, k=10, top_n_percent=0.05)
+        qs = refq.QuerySelector(args, None, device=torch.device("cpu"))
+        np.random.seed(1234)
+        q = qs._select_queries(uc.clone())
+        out[f"{st}_top5_sel"] = np.flatnonzero(q.reshape(-1)).astype(np.int64)
+        kk = int(h * w * 0.05)
+        out[f"{st}_top5_order"] = uc.flatten().topk(kk, largest=largest).indices.numpy().astype(np.int64)
+        # reverse order: random 5% candidates then top-n
+        args = mk_args(st, 19, k=10, top_n_percent=0.05, reverse_order=True)
+        qs = refq.QuerySelector(args, None, device=torch.device("cpu"))
+        np.random.seed(4321)
+        q = qs._select_queries(uc.clone())
+        out[f"{st}_rev_sel"] = np.flatnonzero(q.reshape(-1)).astype(np.int64)
+    out["np_seed_top5"] = np.int64(1234)
+    out["np_seed_rev"] = np.int64(4321)
+    np.savez_compressed(os.path.join(OUT, "acq_select_modes.npz"), **out)
+    print("G2 modes written")
+
+
+# ----------------------------------------------------------------------------- G3 edge cases
+def gen_edges():
+    out = {}
+    # (a) underflow -> NaN entropy pixel (query.py:230): logit gap > ~104 makes p underflow to 0
+    torch.manual_seed(3)
+    logits = torch.randn(1, 5, 8, 8) * 2
+    logits[0, :, 2, 3] = torch.tensor([200.0, 0.0, -5.0, 1.0, 2.0])
+    logits[0, :, 6, 1] = torch.tensor([0.0, 150.0, -5.0, 1.0, 2.0])
+    prob = F.softmax(logits, dim=1)
+    ent = refq.UncertaintySampler("entropy")(prob)[0]
+    out["nan_logits"] = logits.numpy()
+    out["nan_entropy_map"] = ent.numpy().copy()
+    assert torch.isnan(ent[2, 3]) and torch.isnan(ent[6, 1])
+    top = ent.flatten().topk(4, largest=True)
+    out["nan_top4_idx"] = top.indices.numpy().astype(np.int64)   # NaNs first (torch semantic)
+    out["nan_top4_isnan"] = torch.isnan(top.values).numpy()
+    # LC and margin on the same logits (finite)
+    out["nan_lc_map"] = refq.UncertaintySampler("least_confidence")(prob)[0].numpy().copy()
+    out["nan_margin_map"] = refq.UncertaintySampler("margin_sampling")(prob)[0].numpy().copy()
+
+    # (b) k == unmasked count / k > unmasked count: reference returns excluded pixels too.
+    torch.manual_seed(5)
+    h, w = 6, 7
+    uc = torch.rand(h, w) + 0.5       # all > 0 so that excluded (0.0) sort last for entropy
+    excl = np.ones((h, w), dtype=bool)
+    free = [3, 11, 17, 25, 40]
+    excl.reshape(-1)[free] = False
+    m = uc.clone()
+    m[torch.from_numpy(excl)] = 0.0
+    out["few_uc"] = m.numpy().copy()
+    out["few_exclude"] = excl.astype(np.uint8)
+    args = mk_args("entropy", 19, k=5)
+    qs = refq.QuerySelector(args, None, device=torch.device("cpu"))
+    out["few_sel_k5"] = np.flatnonzero(qs._select_queries(m.clone()).reshape(-1)).astype(np.int64)
+    # k=8 > 5 free: the 3 extra come from the excluded (all 0.0, tie order implementation-defined in
+    # torch) -> only the count and the superset property are pinned.
+    args = mk_args("entropy", 19, k=8)
+    qs = refq.QuerySelector(args, None, device=torch.device("cpu"))
+    q8 = qs._select_queries(m.clone())
+    out["few_sel_k8_count"] = np.int64(q8.sum())
+    out["few_sel_k8_contains_free"] = np.bool_(all(q8.reshape(-1)[free]))
+    np.savez_compressed(os.path.join(OUT, "acq_edges.npz"), **out)
+    print("G3 written")
+
+
+# ----------------------------------------------------------------------------- G4 end to end
+class FakeDataset:
+    def __init__(self, xs, ys, queries, names):
+        self.xs, self.ys, self.queries, self.names = xs, ys, queries, names
+        self.labelled = None
+
+    def label_queries(self, dict_queries, nth):
+        self.labelled = (dict_queries, nth)
+
+
+class FakeLoader:
+    def __init__(self, ds):
+        self.dataset = ds
+
+    def __iter__(self):
+        for i in range(len(self.dataset.xs)):
+            yield {"x": self.dataset.xs[i][None], "y": self.dataset.ys[i][None], "p_img": [self.dataset.names[i]]}
+
+    def __len__(self):
+        return len(self.dataset.xs)
+
+
+class OneConv(torch.nn.Module):
+    def __init__(self, w, b):
+        super().__init__()
+        self.w, self.b = w, b
+
+    def forward(self, x):
+        return {"pred": F.conv2d(x, self.w, self.b)}
+
+
+def gen_end_to_end():
+    out = {}
+    C, h, w, n_img = 19, 40, 56, 3
+    for st in STRATS:
+        seed = 50
+        while True:
+            torch.manual_seed(seed)
+            rng = np.random.RandomState(seed)
+            W = torch.randn(C, 3, 1, 1) * 2.0
+            Bv = torch.randn(C) * 0.5
+            xs = [torch.randn(3, h, w) * 1.5 for _ in range(n_img)]
+            ys = [torch.from_numpy(rng.randint(0, C + 1, size=(h, w)).astype(np.int64)) for _ in range(n_img)]
+            for y in ys:   # ~6% void
+                y[torch.from_numpy(rng.rand(h, w) < 0.06)] = C
+            prev = []
+            for _ in range(n_img):
+                q = np.zeros((h, w), dtype=bool)
+                q.reshape(-1)[rng.choice(h * w, 30, replace=False)] = True
+                prev.append(q)
+            names = [f"/data/img_{i:03d}.png" for i in range(n_img)]
+            model = OneConv(W, Bv)
+            # gap guard
+            largest = st in ["entropy", "least_confidence"]
+            ok = True
+            with torch.no_grad():
+                for i in range(n_img):
+                    prob = F.softmax(model(xs[i][None])["pred"], dim=1)
+                    uc = refq.UncertaintySampler(st)(prob)[0]
+                    uc[torch.from_numpy(prev[i])] = FILL[st]
+                    uc[ys[i] == C] = FILL[st]
+                    srt = torch.sort(uc.flatten(), descending=largest).values.numpy()
+                    if not all_gaps_ok(srt[:21]):
+                        ok = False
+            if ok:
+                break
+            seed += 1
+        ds = FakeDataset(xs, ys, prev, names)
+        with tempfile.TemporaryDirectory() as td:
+            args = mk_args(st, C, k=20, dir_root=td)
+            qs = refq.QuerySelector(args, FakeLoader(ds), device=torch.device("cpu"))
+            dq = qs(nth_query=1, model=model)
+            stats = pkl.load(open(f"{td}/checkpoints/golden/1_query/query_stats.pkl", "rb"))
+        out[f"{st}_W"] = W.numpy()
+        out[f"{st}_b"] = Bv.numpy()
+        out[f"{st}_xs"] = torch.stack(xs).numpy()
+        out[f"{st}_ys"] = torch.stack(ys).numpy()
+        out[f"{st}_prev"] = np.stack(prev)
+        for i, nme in enumerate(names):
+            out[f"{st}_x_{i}"] = np.asarray(dq[nme]["x_coords"], dtype=np.int64)
+            out[f"{st}_y_{i}"] = np.asarray(dq[nme]["y_coords"], dtype=np.int64)
+        out[f"{st}_stats_label_cnt"] = np.array([stats["label_distribution"][l] for l in range(C)], dtype=np.int64)
+        out[f"{st}_stats_avg_entropy"] = np.float64(stats["avg_entropy"])
+        out[f"{st}_stats_avg_n_unique"] = np.float64(stats["avg_n_unique_labels"])
+        out[f"{st}_stats_avg_cov"] = np.float64(stats["avg_spatial_coverage"])
+        assert ds.labelled is not None and ds.labelled[1] == 1
+    out["names"] = np.array([f"/data/img_{i:03d}.png" for i in range(n_img)])
+    np.savez_compressed(os.path.join(OUT, "acq_end_to_end.npz"), **out)
+    print("G4 written")
+
+
+# ----------------------------------------------------------------------------- G5 codec
+def gen_codec():
+    out = {}
+    rng = np.random.RandomState(9)
+    h, w = 12, 17
+    q = rng.rand(h, w) < 0.1
+    enc = refq.QuerySelector.encode_query("a/b.png", (h, w), q)
+    out["mask"] = q
+    out["enc_x"] = enc["a/b.png"]["x_coords"].astype(np.int64)
+    out["enc_y"] = enc["a/b.png"]["y_coords"].astype(np.int64)
+    dec = refq.QuerySelector.decode_queries(enc)
+    assert len(dec) == 1 and (dec[0] == q).all()
+    out["dec_single"] = dec[0]
+    # with category ids -> int64 label map with ignore_index fill
+    enc2 = {"z.png": dict(enc["a/b.png"]), "a.png": dict(enc["a/b.png"])}
+    cat = rng.randint(0, 11, size=int(q.sum()))
+    enc2["z.png"]["category_id"] = cat.tolist()
+    d2 = refq.QuerySelector.decode_queries(enc2, ignore_index=11, return_as_dict=True)
+    out["cat"] = cat.astype(np.int64)
+    out["dec_cat_z"] = d2["z.png"]
+    out["dec_plain_a"] = d2["a.png"]
+    l2 = refq.QuerySelector.decode_queries(enc2, ignore_index=11)
+    out["dec_list_order_first_is_a"] = np.bool_(l2[0].dtype == np.bool_)   # sorted by key: a.png first
+    # merge_previous_query_files
+    with tempfile.TemporaryDirectory() as td:
+        files = []
+        maps = []
+        for r in range(3):
+            os.makedirs(f"{td}/{r}_query")
+            qq = rng.rand(h, w) < 0.05
+            yy, xx = np.where(qq)
+            e = {"img0.png": {"height": h, "width": w, "x_coords": xx, "y_coords": yy,
+                              "category_id": rng.randint(0, 11, size=len(xx)).tolist()}}
+            if r != 1:
+                qq2 = rng.rand(h, w) < 0.05
+                yy2, xx2 = np.where(qq2)
+                e["img1.png"] = {"height": h, "width": w, "x_coords": xx2, "y_coords": yy2,
+                                 "category_id": rng.randint(0, 11, size=len(xx2)).tolist()}
+            pkl.dump(e, open(f"{td}/{r}_query/queries.pkl", "wb"))
+            files.append(f"{td}/{r}_query/queries.pkl")
+            maps.append(e)
+        found = sorted(refq.gather_previous_query_files(td))
+        assert found == sorted(files)
+        merged = refq.merge_previous_query_files(files, ignore_index=11, verbose=False)
+        out["merge_img0"] = merged["img0.png"]
+        out["merge_img1"] = merged["img1.png"]
+        for r, e in enumerate(maps):
+            for nme, info in e.items():
+                tag = nme.split(".")[0]
+                out[f"merge_in_{r}_{tag}_x"] = np.asarray(info["x_coords"], dtype=np.int64)
+                out[f"merge_in_{r}_{tag}_y"] = np.asarray(info["y_coords"], dtype=np.int64)
+                out[f"merge_in_{r}_{tag}_c"] = np.asarray(info["category_id"], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "acq_codec.npz"), **out)
+    print("G5 written")
+
+
+if __name__ == "__main__":
+    gen_scores_and_topk()
+    gen_select_modes()
+    gen_edges()
+    gen_end_to_end()
+    gen_codec()
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden dir bytes:", tot)
