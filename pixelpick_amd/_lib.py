@@ -1,0 +1,71 @@
+"""ctypes binding of libpixelpick_hip.so (the C ABI in include/pixelpick_hip.h).
+
+The library is the product: if it is missing this module raises — there is no CPU/eager fallback.
+torch is imported first so that the HIP runtime already loaded by PyTorch-ROCm (same soname,
+libamdhip64.so.7) is the one our kernels, streams and pointers live in.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads PyTorch's libamdhip64 first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixelpick_hip.so")
+
+_i64, _p, _int, _sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/pixelpick_hip.h declares
+SIGNATURES = {
+    "pp_version": (_int, []),
+    "pp_last_error": (ctypes.c_char_p, []),
+    "pp_acq_workspace_bytes": (_sz, [_i64] * 5),
+    "pp_acq_score_topk": (_int, [_p] + [_i64] * 8 + [_p, _int, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pp_acq_score_map": (_int, [_p] + [_i64] * 8 + [_p, _int, _p, _p]),
+    "pp_uncertainty_from_prob": (_int, [_p] + [_i64] * 8 + [_int, _p, _p]),
+    "pp_topk_workspace_bytes": (_sz, [_i64] * 3),
+    "pp_topk_select": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p, _sz, _p]),
+    "pp_debug_set_reduce_mode": (None, [_int]),
+    "pp_debug_set_kernel_events": (None, [_p, _p, _int]),
+}
+
+_lib = None
+
+
+class PixelPickHipError(RuntimeError):
+    pass
+
+
+def _preload_torch_hip():
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PixelPickHipError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                f"(python -m pixelpick_amd.build, or __graft_entry__.build()). No fallback path exists.")
+        _preload_torch_hip()
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().pp_last_error().decode("utf-8", "replace")
+        if rc in (-1, -2):
+            raise ValueError(f"{what}: {msg} (code {rc})")
+        raise PixelPickHipError(f"{what}: {msg} (code {rc})")
+
+
+def current_stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,115 @@
+"""Host-side functional API over the acquisition entry points of the C ABI.
+
+Everything here only marshals torch device tensors (pointers, strides, current stream) into
+include/pixelpick_hip.h calls; all arithmetic runs in the hand-written HIP kernels (csrc/acq.hip).
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+STRATEGY_ID = {"entropy": 0, "least_confidence": 1, "margin_sampling": 2, "margin": 2}
+LARGEST = {"entropy": True, "least_confidence": True, "margin_sampling": False, "margin": False}
+FILL = {"entropy": 0.0, "least_confidence": 0.0, "margin_sampling": 1.0, "margin": 1.0}
+
+
+def _require_cuda_f32(t: torch.Tensor, name: str, ndim: int):
+    if not isinstance(t, torch.Tensor) or t.ndim != ndim:
+        raise ValueError(f"{name} must be a {ndim}-d tensor")
+    if not t.is_cuda:
+        raise _lib.PixelPickHipError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+
+
+def _exclude_u8(exclude, B, H, W, device):
+    if exclude is None:
+        return None
+    ex = torch.as_tensor(exclude)
+    if ex.dtype == torch.bool:
+        ex = ex.to(torch.uint8)
+    elif ex.dtype != torch.uint8:
+        ex = (ex != 0).to(torch.uint8)
+    ex = ex.to(device, non_blocking=True).reshape(B, H, W).contiguous()
+    return ex
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def score_topk(logits: torch.Tensor, exclude, strategy: str, k: int, return_map: bool = False
+               ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """softmax -> score -> exclusion -> per-image top-k in one pass (query.py:190-204,57-61).
+
+    logits [B,C,H,W] f32 on the GPU with any strides (NCHW, channels_last, cropped view).
+    Returns (idx int32 [B,k] flat h*W+w value-sorted, val f32 [B,k], map f32 [B,H,W] | None).
+    """
+    _require_cuda_f32(logits, "logits", 4)
+    B, C, H, W = logits.shape
+    L = _lib.lib()
+    dev = logits.device
+    ex = _exclude_u8(exclude, B, H, W, dev)
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    val = torch.empty((B, k), dtype=torch.float32, device=dev)
+    omap = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_map else None
+    nbytes = L.pp_acq_workspace_bytes(B, C, H, W, k)
+    ws = _ws(nbytes, dev)
+    sB, sC, sH, sW = logits.stride()
+    with torch.cuda.device(dev):
+        rc = L.pp_acq_score_topk(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW,
+                                 ex.data_ptr() if ex is not None else None, STRATEGY_ID[strategy], k,
+                                 idx.data_ptr(), val.data_ptr(), omap.data_ptr() if omap is not None else None,
+                                 ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "pp_acq_score_topk")
+    return idx, val, omap
+
+
+def score_map(logits: torch.Tensor, exclude, strategy: str) -> torch.Tensor:
+    """[B,C,H,W] logits -> [B,H,W] uncertainty map after exclusion (query.py:190-201)."""
+    _require_cuda_f32(logits, "logits", 4)
+    B, C, H, W = logits.shape
+    L = _lib.lib()
+    dev = logits.device
+    ex = _exclude_u8(exclude, B, H, W, dev)
+    omap = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    sB, sC, sH, sW = logits.stride()
+    with torch.cuda.device(dev):
+        rc = L.pp_acq_score_map(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW,
+                                ex.data_ptr() if ex is not None else None, STRATEGY_ID[strategy],
+                                omap.data_ptr(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "pp_acq_score_map")
+    return omap
+
+
+def uncertainty_from_prob(prob: torch.Tensor, strategy: str) -> torch.Tensor:
+    """UncertaintySampler.__call__ on an already-softmaxed tensor (query.py:229-239,246-247)."""
+    _require_cuda_f32(prob, "prob", 4)
+    B, C, H, W = prob.shape
+    L = _lib.lib()
+    dev = prob.device
+    omap = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    sB, sC, sH, sW = prob.stride()
+    with torch.cuda.device(dev):
+        rc = L.pp_uncertainty_from_prob(prob.data_ptr(), B, C, H, W, sB, sC, sH, sW, STRATEGY_ID[strategy],
+                                        omap.data_ptr(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "pp_uncertainty_from_prob")
+    return omap
+
+
+def topk_select(scores: torch.Tensor, k: int, largest: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """scores [B,N] f32 -> (idx int32 [B,k], val f32 [B,k]); uc_map.flatten().topk (query.py:57-61)."""
+    _require_cuda_f32(scores, "scores", 2)
+    scores = scores.contiguous()
+    B, N = scores.shape
+    L = _lib.lib()
+    dev = scores.device
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    val = torch.empty((B, k), dtype=torch.float32, device=dev)
+    ws = _ws(L.pp_topk_workspace_bytes(B, N, k), dev)
+    with torch.cuda.device(dev):
+        rc = L.pp_topk_select(scores.data_ptr(), B, N, k, int(bool(largest)), idx.data_ptr(), val.data_ptr(),
+                              ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "pp_topk_select")
+    return idx, val

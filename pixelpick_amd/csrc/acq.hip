@@ -1,0 +1,638 @@
+// acq.hip — fused acquisition for PixelPick on gfx950 (MI355X).
+//
+// Replaces, for a batch of images and in ONE read of the logits:
+//   query.py:190      prob = F.softmax(model(x)["pred"][:, :, :h, :w], dim=1)
+//   query.py:229-239  UncertaintySampler._entropy / _least_confidence / _margin_sampling
+//   query.py:195-201  uc_map[mask] = fill ; uc_map[mask_void] = fill
+//   query.py:57-61    uc_map.flatten().topk(k, largest).indices
+//
+// Bandwidth-bound integer/float streaming work: no MFMA.  Each lane keeps the C class logits of its
+// pixels in registers (softmax needs no second memory pass), planes are read as 16 B/lane coalesced
+// loads, per-wave top-k candidates are extracted with DPP reductions and merged by a tiny second
+// kernel, so the logits are read exactly once and nothing full-size is written unless asked for.
+#include "pp_common.h"
+
+namespace pp {
+
+static int g_reduce_mode = 0;
+
+// Optional profiling hook (bench.py): caller-owned hipEvent pairs recorded right around the dominant
+// kernel's launch, pair i for the i-th launch after pp_debug_set_kernel_events().
+static hipEvent_t* g_ev_start = nullptr;
+static hipEvent_t* g_ev_stop = nullptr;
+static int g_ev_n = 0, g_ev_i = 0;
+
+struct EventScope {
+    hipStream_t st;
+    bool on;
+    explicit EventScope(hipStream_t s) : st(s), on(g_ev_i < g_ev_n)
+    {
+        if (on) (void)hipEventRecord(g_ev_start[g_ev_i], st);
+    }
+    ~EventScope()
+    {
+        if (on) (void)hipEventRecord(g_ev_stop[g_ev_i++], st);
+    }
+};
+
+constexpr int kBlock = 256;
+constexpr int kSmallKMax = 64;        // fused per-wave extraction up to this k; beyond: map + radix select
+constexpr int kMergeItems = 16;       // merge kernel: candidates per thread
+constexpr int kMergeChunk = kBlock * kMergeItems;
+constexpr int kLargeThreads = 1024;
+constexpr int kLargeLdsMaxP = 16384;  // 128 KiB of u64 sort keys in LDS
+
+struct AcqParams {
+    const float* logits;
+    const uint8_t* exclude;
+    float* out_map;      // [B,N] or null
+    uint64_t* cand;      // [B, waves_per_image, k] or null
+    int64_t sB, sC, sH, sW;
+    int C, W;
+    int64_t N;           // H*W
+    int blocks_per_image;
+    int k;
+    int strategy;
+    int reduce_mode;
+    int from_prob;       // 1: input already holds probabilities (UncertaintySampler.__call__, query.py:246-247)
+};
+
+// ---- per-pixel score ----------------------------------------------------------------------------
+// Same operation order as the reference: p_c = exp(x_c - m) / S ; then the strategy's formula.
+template <int CMAX, bool EXACT>
+__device__ __forceinline__ float pixel_score(const float (&x)[CMAX], int C, int strategy, int from_prob)
+{
+    if (from_prob) {  // x is prob: the UncertaintySampler formulas verbatim
+        if (strategy == PP_ACQ_ENTROPY) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C) acc += (-x[c]) * logf(x[c]);
+            return acc;
+        }
+        float t1 = -INFINITY, t2 = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (EXACT || c < C) {
+                t2 = fmaxf(t2, fminf(t1, x[c]));
+                t1 = fmaxf(t1, x[c]);
+            }
+        return strategy == PP_ACQ_LEAST_CONFIDENCE ? 1.0f - t1 : fabsf(t1 - t2);
+    }
+    float m = x[0];
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c)
+        if (EXACT || c < C) m = fmaxf(m, x[c]);
+    float e[CMAX];
+    float S = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (EXACT || c < C) {
+            e[c] = expf(x[c] - m);
+            S += e[c];
+        }
+    if (strategy == PP_ACQ_ENTROPY) {  // query.py:230  (-p*log p).sum(dim=1); 0*log 0 -> NaN as reference
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (EXACT || c < C) {
+                float p = e[c] / S;
+                acc += (-p) * logf(p);
+            }
+        return acc;
+    } else if (strategy == PP_ACQ_LEAST_CONFIDENCE) {  // query.py:234  1 - max_c p ; max e == exp(0) == 1
+        return 1.0f - 1.0f / S;
+    } else {  // query.py:238-239  |top1 - top2| of p ; division is monotone so top-2 of e give top-2 of p
+        float t1 = -INFINITY, t2 = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (EXACT || c < C) {
+                t2 = fmaxf(t2, fminf(t1, e[c]));
+                t1 = fmaxf(t1, e[c]);
+            }
+        return fabsf(t1 / S - t2 / S);
+    }
+}
+
+// ---- per-wave top-k extraction -------------------------------------------------------------------
+// Each lane holds PPT (key, ~idx) pairs; k rounds of {lane-local max, two DPP wave reductions,
+// knock out the winner}.  Winner order == global order (key desc, index asc).  Lane 0 stores.
+template <int PPT>
+__device__ __forceinline__ void wave_extract_topk(uint32_t (&kh)[PPT], uint32_t (&kl)[PPT], int k,
+                                                  uint64_t* dst, int mode)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int r = 0; r < k; ++r) {
+        uint32_t lh = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) lh = kh[j] > lh ? kh[j] : lh;
+        uint32_t ll = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) ll = (kh[j] == lh && kl[j] > ll) ? kl[j] : ll;
+        const uint32_t mh = wave_umax(lh, mode);
+        const uint32_t ml = wave_umax(lh == mh ? ll : 0u, mode);
+        if (lane == 0) dst[r] = mh == 0u ? 0ull : (((uint64_t)mh << 32) | ml);
+        if (mh == 0u) {  // exhausted (wave-uniform)
+            for (int q = r + 1; q < k; ++q)
+                if (lane == 0) dst[q] = 0ull;
+            break;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (kh[j] == mh && kl[j] == ml) kh[j] = 0u;
+    }
+}
+
+// ---- main kernel ---------------------------------------------------------------------------------
+// VEC == 4: planes are flat & 16-B aligned (sW == 1, sH == W, N % 4 == 0): float4 per class plane.
+// VEC == 1: arbitrary element strides (NHWC views, cropped views), one pixel per load.
+// A block covers kBlock*VEC*G consecutive pixels of ONE image.
+template <int CMAX, bool EXACT, int VEC, int G>
+__global__ __launch_bounds__(kBlock) void acq_kernel(AcqParams p)
+{
+    constexpr int PPT = VEC * G;
+    const int img = blockIdx.x / p.blocks_per_image;
+    const int blk = blockIdx.x - img * p.blocks_per_image;
+    const int tid = threadIdx.x;
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const float* base = p.logits + (int64_t)img * p.sB;
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+    float* omap = p.out_map ? p.out_map + (int64_t)img * p.N : nullptr;
+
+    uint32_t kh[PPT], kl[PPT];
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t pix0 = ((int64_t)blk * G + g) * (kBlock * VEC) + (int64_t)tid * VEC;
+        float s[VEC];
+        if (pix0 < p.N) {
+            if constexpr (VEC == 4) {
+                float x[4][CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (EXACT || c < p.C) {
+                        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * p.sC + pix0);
+                        x[0][c] = v.x; x[1][c] = v.y; x[2][c] = v.z; x[3][c] = v.w;
+                    }
+                uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    s[v] = pixel_score<CMAX, EXACT>(x[v], p.C, p.strategy, p.from_prob);
+                    if ((ex >> (8 * v)) & 0xFFu) s[v] = fill;
+                }
+                if (omap) *reinterpret_cast<float4*>(omap + pix0) = make_float4(s[0], s[1], s[2], s[3]);
+            } else {
+                const int64_t h = pix0 / p.W, w = pix0 - h * p.W;
+                const float* px = base + h * p.sH + w * p.sW;
+                float x[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (EXACT || c < p.C) x[c] = px[(int64_t)c * p.sC];
+                s[0] = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, p.from_prob);
+                if (excl && excl[pix0]) s[0] = fill;
+                if (omap) omap[pix0] = s[0];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                kh[g * VEC + v] = order_key(s[v], largest);
+                kl[g * VEC + v] = 0xFFFFFFFFu - (uint32_t)(pix0 + v);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { kh[g * VEC + v] = 0u; kl[g * VEC + v] = 0u; }
+        }
+    }
+
+    if (p.cand) {
+        const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
+        const int waves_per_image = p.blocks_per_image * (kBlock / kWave);
+        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
+        wave_extract_topk<PPT>(kh, kl, p.k, dst, p.reduce_mode);
+    }
+}
+
+// ---- small-k selection straight from a score map (pp_topk_select) ------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlock) void topk_small_from_scores_kernel(const float* scores, int64_t N,
+                                                                        int blocks_per_image, int k,
+                                                                        int largest, uint64_t* cand, int mode)
+{
+    const int img = blockIdx.x / blocks_per_image;
+    const int blk = blockIdx.x - img * blocks_per_image;
+    const int tid = threadIdx.x;
+    const float* s = scores + (int64_t)img * N;
+    uint32_t kh[G], kl[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t pix = ((int64_t)blk * G + g) * kBlock + tid;
+        if (pix < N) {
+            kh[g] = order_key(s[pix], largest != 0);
+            kl[g] = 0xFFFFFFFFu - (uint32_t)pix;
+        } else {
+            kh[g] = 0u; kl[g] = 0u;
+        }
+    }
+    const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
+    const int waves_per_image = blocks_per_image * (kBlock / kWave);
+    wave_extract_topk<G>(kh, kl, k, cand + ((int64_t)img * waves_per_image + wave_in_image) * k, mode);
+}
+
+// ---- candidate merge ---------------------------------------------------------------------------------
+// grid (nchunks, B): block (c,b) reduces up to kMergeChunk candidate keys of image b to their top-k.
+// The last level (nchunks == 1) decodes to out_idx / out_val.
+__global__ __launch_bounds__(kBlock) void cand_merge_kernel(const uint64_t* in, int64_t n_in, uint64_t* out_keys,
+                                                           int32_t* out_idx, float* out_val, int k, int largest,
+                                                           int mode)
+{
+    __shared__ uint32_t sh[2][kBlock / kWave];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const uint64_t* src = in + (int64_t)b * n_in;
+    const int64_t lo = (int64_t)c * kMergeChunk;
+    uint32_t kh[kMergeItems], kl[kMergeItems];
+#pragma unroll
+    for (int j = 0; j < kMergeItems; ++j) {
+        const int64_t i = lo + (int64_t)j * kBlock + tid;
+        uint64_t v = i < n_in ? src[i] : 0ull;
+        kh[j] = (uint32_t)(v >> 32);
+        kl[j] = (uint32_t)v;
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = 0; r < k; ++r) {
+        uint32_t lh = 0;
+#pragma unroll
+        for (int j = 0; j < kMergeItems; ++j) lh = kh[j] > lh ? kh[j] : lh;
+        uint32_t ll = 0;
+#pragma unroll
+        for (int j = 0; j < kMergeItems; ++j) ll = (kh[j] == lh && kl[j] > ll) ? kl[j] : ll;
+        uint32_t wh = wave_umax(lh, mode);
+        if (lane == 0) sh[0][wave] = wh;
+        __syncthreads();
+        uint32_t mh = 0;
+#pragma unroll
+        for (int q = 0; q < kBlock / kWave; ++q) mh = sh[0][q] > mh ? sh[0][q] : mh;
+        uint32_t wl = wave_umax(lh == mh ? ll : 0u, mode);
+        if (lane == 0) sh[1][wave] = wl;
+        __syncthreads();
+        uint32_t ml = 0;
+#pragma unroll
+        for (int q = 0; q < kBlock / kWave; ++q) ml = sh[1][q] > ml ? sh[1][q] : ml;
+        if (tid == 0) {
+            if (out_keys) {
+                out_keys[((int64_t)b * gridDim.x + c) * k + r] = mh == 0u ? 0ull : (((uint64_t)mh << 32) | ml);
+            } else {
+                out_idx[(int64_t)b * k + r] = mh == 0u ? -1 : (int32_t)(0xFFFFFFFFu - ml);
+                if (out_val) out_val[(int64_t)b * k + r] = key_to_float(mh, largest != 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMergeItems; ++j)
+            if (kh[j] == mh && kl[j] == ml) kh[j] = 0u;
+    }
+}
+
+// ---- large-k: radix select + bitonic sort, one 1024-thread block per image ------------------------------
+// query.py:36 top_n_percent mode: k = int(h*w*0.05) (6553 at 256x512) value-sorted indices.
+__global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* scores, int64_t N, int k, int largest,
+                                                                  uint64_t* gbuf, int P, int32_t* out_idx,
+                                                                  float* out_val)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);            // 256
+    uint32_t* misc = hist + 256;                                   // 64
+    uint64_t* buf = gbuf ? gbuf + (int64_t)blockIdx.x * P : reinterpret_cast<uint64_t*>(smem + (256 + 64) * 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = scores + (int64_t)blockIdx.x * N;
+    const bool lg = largest != 0;
+
+    // 1. radix select: T = k-th largest key, need_eq = how many keys == T to take (lowest index first)
+    uint32_t prefix = 0, mask = 0, remaining = (uint32_t)k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < N; i += kLargeThreads) {
+            const uint32_t key = order_key(s[i], lg);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                const uint32_t cnt = hist[d];
+                if (cum + cnt >= remaining) break;
+                cum += cnt;
+            }
+            misc[0] = (uint32_t)d;
+            misc[1] = remaining - cum;
+        }
+        __syncthreads();
+        prefix |= misc[0] << shift;
+        mask |= 0xFFu << shift;
+        remaining = misc[1];
+        __syncthreads();
+    }
+    const uint32_t T = prefix, need_eq = remaining;
+
+    // 2. compaction (index order matters only among keys == T)
+    if (tid == 0) { misc[2] = 0; /* out count */ misc[3] = 0; /* eq seen so far */ }
+    __syncthreads();
+    for (int64_t base = 0; base < N; base += kLargeThreads) {
+        const int64_t i = base + tid;
+        const uint32_t key = i < N ? order_key(s[i], lg) : 0u;
+        const bool gt = key > T, eq = (i < N) && key == T;
+        const unsigned long long bal = __ballot(eq);
+        if (lane == 0) misc[8 + wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = misc[3];
+        for (int q = 0; q < wave; ++q) before += misc[8 + q];
+        const uint32_t rank = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        const bool take = gt || (eq && rank < need_eq);
+        if (take) {
+            const uint32_t pos = atomicAdd(&misc[2], 1u);
+            buf[pos] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int q = 0; q < kLargeThreads / kWave; ++q) tot += misc[8 + q];
+            misc[3] += tot;
+        }
+        __syncthreads();
+    }
+    for (int j = k + tid; j < P; j += kLargeThreads) buf[j] = 0ull;
+    __syncthreads();
+
+    // 3. bitonic sort, descending
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += kLargeThreads) {
+                const int pos = 2 * t - (t & (stride - 1));
+                const uint64_t a = buf[pos], b = buf[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if ((a < b) == desc) { buf[pos] = b; buf[pos + stride] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += kLargeThreads) {
+        const uint64_t v = buf[j];
+        out_idx[(int64_t)blockIdx.x * k + j] = (int32_t)(0xFFFFFFFFu - (uint32_t)v);
+        if (out_val) out_val[(int64_t)blockIdx.x * k + j] = key_to_float((uint32_t)(v >> 32), lg);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static int next_pow2(int64_t v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+struct Plan {
+    bool vec4;            // flat float4 path
+    int ppt;              // pixels per thread
+    int blocks_per_image;
+    int waves_per_image;
+};
+
+static bool is_flat_vec4(const float* logits, const uint8_t* exclude, const float* out_map, int64_t H, int64_t W,
+                         int64_t sB, int64_t sC, int64_t sH, int64_t sW)
+{
+    const int64_t N = H * W;
+    return sW == 1 && (sH == W || H == 1) && N % 4 == 0 && sC % 4 == 0 && sB % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(exclude) & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(out_map) & 15) == 0;
+}
+
+// Deterministic in (B, N, vec4) so that pp_acq_workspace_bytes can size the candidate buffer.
+static Plan make_plan(int64_t B, int64_t N, bool vec4)
+{
+    Plan pl;
+    pl.vec4 = vec4;
+    // want >= ~2048 waves in flight (256 CUs x 8) before growing the per-thread tile
+    const int64_t waves16 = B * cdiv(N, (int64_t)kBlock * 16) * (kBlock / kWave);
+    pl.ppt = waves16 >= 2048 ? 16 : 4;
+    pl.blocks_per_image = (int)cdiv(N, (int64_t)kBlock * pl.ppt);
+    pl.waves_per_image = pl.blocks_per_image * (kBlock / kWave);
+    return pl;
+}
+
+static size_t merge_ws_bytes(int64_t B, int64_t n_cand, int64_t k)
+{
+    // ping-pong: level-0 list + the (smaller) next level
+    size_t a = align_up((size_t)B * n_cand * 8, 256);
+    size_t b = align_up((size_t)B * cdiv(n_cand, kMergeChunk) * k * 8, 256);
+    return a + b;
+}
+
+static int run_merge(uint64_t* cand, int64_t n_cand, uint64_t* other, int64_t B, int k, int largest,
+                     int32_t* out_idx, float* out_val, hipStream_t st)
+{
+    uint64_t* cur = cand;
+    uint64_t* nxt = other;
+    int64_t n = n_cand;
+    for (;;) {
+        const int nch = (int)cdiv(n, kMergeChunk);
+        dim3 grid(nch, (unsigned)B);
+        if (nch == 1) {
+            hipLaunchKernelGGL(cand_merge_kernel, grid, dim3(kBlock), 0, st, cur, n, (uint64_t*)nullptr, out_idx,
+                               out_val, k, largest, g_reduce_mode);
+            return check_launch("cand_merge_kernel");
+        }
+        hipLaunchKernelGGL(cand_merge_kernel, grid, dim3(kBlock), 0, st, cur, n, nxt, (int32_t*)nullptr,
+                           (float*)nullptr, k, largest, g_reduce_mode);
+        if (int rc = check_launch("cand_merge_kernel")) return rc;
+        n = (int64_t)nch * k;
+        uint64_t* t = cur; cur = nxt; nxt = t;
+    }
+}
+
+static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int largest, uint64_t* gbuf,
+                     int32_t* out_idx, float* out_val, hipStream_t st)
+{
+    const int P = next_pow2(k);
+    const bool in_lds = P <= kLargeLdsMaxP;
+    const size_t lds = (256 + 64) * 4 + (in_lds ? (size_t)P * 8 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_large_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest,
+                       in_lds ? (uint64_t*)nullptr : gbuf, P, out_idx, out_val);
+    return check_launch("topk_large_kernel");
+}
+
+template <int CMAX, bool EXACT>
+static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t st)
+{
+    EventScope ev(st);
+    dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
+    if (pl.vec4) {
+        if constexpr (CMAX <= 32) {
+            if (pl.ppt == 16) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 4>), grid, block, 0, st, p);
+            else              hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 1>), grid, block, 0, st, p);
+        }
+    } else {
+        if (pl.ppt == 16) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 16>), grid, block, 0, st, p);
+        else              hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 4>), grid, block, 0, st, p);
+    }
+    return check_launch("acq_kernel");
+}
+
+static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
+{
+    if (p.C > 32) pl.vec4 = false;  // 64-class bucket only on the scalar path (register budget)
+    switch (p.C) {
+        case 11: return launch_acq<11, true>(p, pl, B, st);   // CamVid      (args.py:109-116)
+        case 19: return launch_acq<19, true>(p, pl, B, st);   // Cityscapes  (args.py:89-94)
+        case 21: return launch_acq<21, true>(p, pl, B, st);   // VOC 2012    (args.py:131-141)
+        default: break;
+    }
+    if (p.C <= 32) return launch_acq<32, false>(p, pl, B, st);
+    return launch_acq<64, false>(p, pl, B, st);
+}
+
+static int validate(const float* logits, int64_t B, int64_t C, int64_t H, int64_t W, int strategy)
+{
+    if (!logits) return fail(PP_ERR_BAD_ARG, "logits is null");
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(PP_ERR_BAD_ARG, "bad shape B=%lld C=%lld H=%lld W=%lld",
+                                                        (long long)B, (long long)C, (long long)H, (long long)W);
+    if (C > PP_ACQ_MAX_CLASSES) return fail(PP_ERR_UNSUPPORTED, "C=%lld > %d", (long long)C, PP_ACQ_MAX_CLASSES);
+    if (H * W > 0x7FFFFFFFll || B * H * W / 1024 > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "image too large");
+    if (strategy < 0 || strategy > 2) return fail(PP_ERR_BAD_ARG, "unknown strategy %d", strategy);
+    return PP_OK;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" {
+
+void pp_debug_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
+
+void pp_debug_set_kernel_events(void** starts, void** stops, int n)
+{
+    g_ev_start = reinterpret_cast<hipEvent_t*>(starts);
+    g_ev_stop = reinterpret_cast<hipEvent_t*>(stops);
+    g_ev_n = (starts && stops) ? n : 0;
+    g_ev_i = 0;
+}
+
+size_t pp_topk_workspace_bytes(int64_t B, int64_t N, int64_t k)
+{
+    if (B < 1 || N < 1 || k < 1) return 0;
+    if (k <= kSmallKMax) {
+        Plan pl = make_plan(B, N, false);
+        return merge_ws_bytes(B, (int64_t)pl.waves_per_image * k, k);
+    }
+    const int P = next_pow2(k);
+    return P <= kLargeLdsMaxP ? 256 : align_up((size_t)B * P * 8, 256);
+}
+
+size_t pp_acq_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_t k)
+{
+    (void)C;
+    if (B < 1 || H < 1 || W < 1 || k < 1) return 0;
+    const int64_t N = H * W;
+    if (k <= kSmallKMax) {
+        // vec4 or not does not change waves_per_image (same ppt rule)
+        Plan pl = make_plan(B, N, true);
+        return merge_ws_bytes(B, (int64_t)pl.waves_per_image * k, k);
+    }
+    // score map (used when the caller passes no out_map) + large-k scratch
+    return align_up((size_t)B * N * 4, 256) + pp_topk_workspace_bytes(B, N, k);
+}
+
+int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC,
+                     int64_t sH, int64_t sW, const uint8_t* exclude, int strategy, float* out_map,
+                     pp_stream_t stream)
+{
+    if (int rc = validate(logits, B, C, H, W, strategy)) return rc;
+    if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
+    const int64_t N = H * W;
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW));
+    AcqParams p{logits, exclude, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
+                strategy, g_reduce_mode, 0};
+    return dispatch_acq(p, pl, B, as_stream(stream));
+}
+
+int pp_uncertainty_from_prob(const float* prob, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC,
+                             int64_t sH, int64_t sW, int strategy, float* out_map, pp_stream_t stream)
+{
+    if (int rc = validate(prob, B, C, H, W, strategy)) return rc;
+    if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
+    const int64_t N = H * W;
+    Plan pl = make_plan(B, N, is_flat_vec4(prob, nullptr, out_map, H, W, sB, sC, sH, sW));
+    AcqParams p{prob, nullptr, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
+                strategy, g_reduce_mode, 1};
+    return dispatch_acq(p, pl, B, as_stream(stream));
+}
+
+int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC,
+                      int64_t sH, int64_t sW, const uint8_t* exclude, int strategy, int64_t k, int32_t* out_idx,
+                      float* out_val, float* out_map, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (int rc = validate(logits, B, C, H, W, strategy)) return rc;
+    const int64_t N = H * W;
+    if (k < 1 || k > N) return fail(PP_ERR_BAD_K, "k=%lld outside [1, H*W=%lld]", (long long)k, (long long)N);
+    if (!out_idx) return fail(PP_ERR_BAD_ARG, "out_idx is null");
+    const size_t need = pp_acq_workspace_bytes(B, C, H, W, k);
+    if (!workspace || ws_bytes < need)
+        return fail(PP_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(PP_ERR_BAD_ARG, "workspace must be 256-B aligned");
+    hipStream_t st = as_stream(stream);
+    const int largest = strategy != PP_ACQ_MARGIN;
+
+    if (k <= kSmallKMax) {
+        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW));
+        const int64_t n_cand = (int64_t)pl.waves_per_image * k;
+        uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
+        uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
+                                                      align_up((size_t)B * n_cand * 8, 256));
+        AcqParams p{logits, exclude, out_map, cand, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image,
+                    (int)k, strategy, g_reduce_mode, 0};
+        if (int rc = dispatch_acq(p, pl, B, st)) return rc;
+        return run_merge(cand, n_cand, other, B, (int)k, largest, out_idx, out_val, st);
+    }
+    // large k: materialise the score map once, then radix-select + sort per image
+    float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
+    uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW));
+    AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
+                g_reduce_mode, 0};
+    if (int rc = dispatch_acq(p, pl, B, st)) return rc;
+    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st);
+}
+
+int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int largest, int32_t* out_idx,
+                   float* out_val, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!scores || !out_idx) return fail(PP_ERR_BAD_ARG, "null pointer");
+    if (B < 1 || N < 1 || N > 0x7FFFFFFFll) return fail(PP_ERR_BAD_ARG, "bad shape B=%lld N=%lld", (long long)B, (long long)N);
+    if (k < 1 || k > N) return fail(PP_ERR_BAD_K, "k=%lld outside [1, N=%lld]", (long long)k, (long long)N);
+    const size_t need = pp_topk_workspace_bytes(B, N, k);
+    if (!workspace || ws_bytes < need)
+        return fail(PP_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(PP_ERR_BAD_ARG, "workspace must be 256-B aligned");
+    hipStream_t st = as_stream(stream);
+    if (k <= kSmallKMax) {
+        Plan pl = make_plan(B, N, false);
+        const int64_t n_cand = (int64_t)pl.waves_per_image * k;
+        uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
+        uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
+                                                      align_up((size_t)B * n_cand * 8, 256));
+        dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
+        if (pl.ppt == 16)
+            hipLaunchKernelGGL((topk_small_from_scores_kernel<16>), grid, block, 0, st, scores, N,
+                               pl.blocks_per_image, (int)k, largest, cand, g_reduce_mode);
+        else
+            hipLaunchKernelGGL((topk_small_from_scores_kernel<4>), grid, block, 0, st, scores, N,
+                               pl.blocks_per_image, (int)k, largest, cand, g_reduce_mode);
+        if (int rc = check_launch("topk_small_from_scores_kernel")) return rc;
+        return run_merge(cand, n_cand, other, B, (int)k, largest, out_idx, out_val, st);
+    }
+    return run_large(scores, B, N, k, largest, reinterpret_cast<uint64_t*>(workspace), out_idx, out_val, st);
+}
+
+}  // extern "C"

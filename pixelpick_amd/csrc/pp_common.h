@@ -1,0 +1,94 @@
+// pp_common.h — shared host/device helpers for libpixelpick_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "pixelpick_hip.h"
+
+namespace pp {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// thread-local error text behind pp_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(pp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return PP_OK;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---- wave64 reductions -------------------------------------------------------------------------
+// DPP row_shr 1/2/4/8 builds the row maximum in lane 15 of each 16-lane row, row_bcast15/31 carry it
+// to lane 63 (canonical GFX9 reduction); result broadcast with readlane.  No LDS traffic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umax_step(uint32_t v)
+{
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v > t ? v : t;
+}
+
+__device__ __forceinline__ uint32_t wave_umax_dpp(uint32_t v)
+{
+    v = dpp_umax_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_umax_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_umax_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_umax_step<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_umax_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_umax_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_umax_shfl(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = v > t ? v : t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v, int mode)
+{
+    return mode == 0 ? wave_umax_dpp(v) : wave_umax_shfl(v);
+}
+
+// ---- order-preserving float <-> u32 keys --------------------------------------------------------
+// Larger key == selected earlier.  Policy: NaN first for largest, last for smallest;
+// -0.0 == +0.0; key 0 is reserved for "no element".
+__device__ __forceinline__ uint32_t order_key(float v, bool largest)
+{
+    uint32_t u;
+    if (v != v) {
+        u = 0xFFFFFFFFu;
+    } else {
+        v = v + 0.0f;
+        u = __float_as_uint(v);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    u = largest ? u : ~u;
+    return u == 0u ? 1u : u;  // only NaN under !largest maps to 0 -> 1 (still below every real key)
+}
+
+__device__ __forceinline__ float key_to_float(uint32_t key, bool largest)
+{
+    uint32_t u = largest ? key : ~key;
+    if (!largest && key == 1u) return __uint_as_float(0x7FC00000u);  // NaN under !largest
+    if (u == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    return __uint_as_float(u);
+}
+#endif  // __HIPCC__
+
+}  // namespace pp

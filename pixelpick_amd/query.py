@@ -1,0 +1,335 @@
+"""Host-side mirror of the reference's `query.py` call surface on top of the HIP acquisition kernels.
+
+Same class / function names, argument meaning, return formats and error behaviour as the reference
+(`/root/reference/query.py`; line numbers below refer to it), so a driver written against the
+reference (`model.py:44,83`, `train.py:9,82`, `datasets/*.py` codecs) runs unchanged.  Differences:
+
+  * softmax -> score -> exclusion -> top-k run fused in ONE HIP kernel pass over the logits
+    (csrc/acq.hip via the C ABI) instead of five ATen passes (query.py:190-204,57-61);
+  * top-k ties break towards the lower flat index and NaN scores (0*log 0, query.py:230) sort
+    first — the reference inherits an implementation-defined order from torch.topk;
+  * the MC-dropout branch (query.py:177-187, NameError `up_map` in the reference) is implemented as
+    the evident intent: mean over `mc_n_steps` stochastic passes;
+  * there is no CPU fallback: tensors must live on the GPU and the extension must be built.
+"""
+import os
+import pickle as pkl
+from math import ceil
+from pathlib import Path
+from typing import Dict, List, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import acquisition as acq
+
+_LARGEST_STRATEGIES = ("entropy", "least_confidence")
+
+
+class QuerySelector:
+    """query.py:12-221."""
+
+    def __init__(self, args, dataloader, device=torch.device("cuda:0")):
+        # same attribute set as query.py:14-31
+        self.dataset_name = args.dataset_name
+        self.dataloader = dataloader
+        self.debug = args.debug
+        self.device = device
+        self.dir_checkpoints = f"{args.dir_root}/checkpoints/{args.experim_name}"
+        self.ignore_index = args.ignore_index
+        self.mc_n_steps = args.mc_n_steps
+        self.n_classes = args.n_classes
+        self.n_pixels_by_us = args.n_pixels_by_us
+        self.network_name = args.network_name
+        self.query_stats = QueryStats(args)
+        self.query_strategy = args.query_strategy
+        self.reverse_order = args.reverse_order
+        self.stride_total = args.stride_total
+        self.top_n_percent = args.top_n_percent
+        self.uncertainty_sampler = UncertaintySampler(args.query_strategy)
+        self.use_mc_dropout = args.use_mc_dropout
+        self.vote_type = args.vote_type
+
+    # ------------------------------------------------------------------ selection (query.py:33-69)
+    @property
+    def _largest(self) -> bool:
+        return self.query_strategy in _LARGEST_STRATEGIES
+
+    def _k_topk(self, h: int, w: int) -> int:
+        return int(h * w * self.top_n_percent) if self.top_n_percent > 0. else self.n_pixels_by_us
+
+    def _reverse_order_sampling_mask(self, h: int, w: int) -> np.ndarray:
+        """query.py:38-42: a random candidate set of k = 5 % pixels (numpy global RNG, as the reference)."""
+        assert self.top_n_percent > 0.
+        k = self._k_topk(h, w)
+        ind = np.random.choice(range(h * w), k, False)
+        sampling_mask = np.zeros(h * w, dtype=np.bool_)
+        sampling_mask[ind] = True
+        return sampling_mask
+
+    def _finish_selection(self, ind_sorted: np.ndarray, h: int, w: int) -> np.ndarray:
+        """query.py:63-68: optional random subsample of the value-sorted top-k, then bool mask."""
+        if (not self.reverse_order) and self.top_n_percent > 0.:
+            ind_sorted = np.random.choice(ind_sorted, self.n_pixels_by_us, False)
+        query = np.zeros(h * w, dtype=np.bool_)
+        query[ind_sorted] = True
+        return query.reshape(h, w)
+
+    def _select_queries(self, uc_map) -> np.ndarray:
+        """uc_map [h,w] (torch tensor, any device, or numpy) -> bool [h,w].  Top-k on the GPU
+        (pp_topk_select); RNG steps on the host with numpy's global state exactly as the reference."""
+        uc = torch.as_tensor(uc_map)
+        h, w = uc.shape[-2:]
+        uc = uc.reshape(1, h * w).to(self.device, torch.float32)
+        if self.reverse_order:
+            sampling_mask = torch.from_numpy(self._reverse_order_sampling_mask(h, w)).to(self.device)
+            uc = uc.clone()
+            uc[0, ~sampling_mask] = 0. if self._largest else 1.0
+            k = self.n_pixels_by_us
+        else:
+            k = self._k_topk(h, w)
+        idx, _ = acq.topk_select(uc, k, self._largest)
+        return self._finish_selection(idx[0].cpu().numpy().astype(np.int64), h, w)
+
+    def _select_from_logits(self, logits: torch.Tensor, exclude: np.ndarray) -> np.ndarray:
+        """Fused path used by __call__: logits [1,C,h,w] on the GPU, exclude bool [h,w] (host)."""
+        h, w = logits.shape[-2:]
+        if self.reverse_order:
+            exclude = exclude | ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
+            k = self.n_pixels_by_us
+        else:
+            k = self._k_topk(h, w)
+        idx, _, _ = acq.score_topk(logits, torch.from_numpy(np.ascontiguousarray(exclude))[None],
+                                   self.query_strategy, k)
+        return self._finish_selection(idx[0].cpu().numpy().astype(np.int64), h, w)
+
+    # ------------------------------------------------------------------ codecs (query.py:71-142)
+    @staticmethod
+    def encode_query(p_img: str, size: Tuple[int, int], query: np.ndarray) -> Dict[str, dict]:
+        y_coords, x_coords = np.nonzero(query)  # row-major order, int64 (query.py:77)
+        return {p_img: {"height": size[0], "width": size[1], "x_coords": x_coords, "y_coords": y_coords}}
+
+    @staticmethod
+    def decode_queries(encoded_query: Dict[str, dict], ignore_index: int = 255, return_as_dict: bool = False
+                       ) -> Union[List[np.ndarray], Dict[str, np.ndarray]]:
+        def decode_one(info: dict) -> np.ndarray:
+            ys = np.asarray(info["y_coords"], dtype=np.int64)
+            xs = np.asarray(info["x_coords"], dtype=np.int64)
+            labels = info.get("category_id", None)
+            if labels is None:
+                out = np.zeros((info["height"], info["width"]), dtype=np.bool_)
+                out[ys, xs] = True
+            else:
+                out = np.full((info["height"], info["width"]), ignore_index, dtype=np.int64)
+                n = min(len(ys), len(labels))  # zip() semantics of query.py:93,101
+                out[ys[:n], xs[:n]] = np.asarray(labels, dtype=np.int64)[:n]
+            return out
+
+        if len(encoded_query) == 0:
+            raise ValueError(len(encoded_query))  # query.py:129
+        items = sorted(encoded_query.items()) if len(encoded_query) > 1 else list(encoded_query.items())
+        if return_as_dict:
+            return {p_img: decode_one(info) for p_img, info in items}
+        return [decode_one(info) for _, info in items]
+
+    # ------------------------------------------------------------------ the loop (query.py:144-221)
+    def _forward_logits(self, model, x, h, w) -> torch.Tensor:
+        return model(x)["pred"][:, :, :h, :w]
+
+    def __call__(self, nth_query, model, human_labels: bool = False):
+        dataset = self.dataloader.dataset
+        prev_queries = dataset.list_labelled_queries if human_labels else dataset.queries
+
+        model.eval()
+        if self.use_mc_dropout:
+            model.turn_on_dropout()
+
+        print(f"Choosing pixels by {self.query_strategy}")
+        list_queries, n_pixels = list(), 0
+        dict_queries: dict = dict()
+        y = None
+
+        with torch.no_grad():
+            for batch_ind, dict_data in enumerate(self.dataloader):
+                x = dict_data['x'].to(self.device)
+                y = dict_data.get('y', None)
+                mask = np.asarray(prev_queries[batch_ind])  # h x w
+
+                h, w = x.shape[2:]
+                exclude = (mask != self.ignore_index) if human_labels else mask.astype(np.bool_)
+                if y is not None:
+                    y = y.squeeze(dim=0).numpy()  # h x w
+                    exclude = exclude | (y == self.ignore_index)
+
+                if self.dataset_name == "voc":  # query.py:171-174
+                    pad_h = ceil(h / self.stride_total) * self.stride_total - h
+                    pad_w = ceil(w / self.stride_total) * self.stride_total - w
+                    x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
+
+                if self.use_mc_dropout:
+                    # mean uncertainty / mean probability over mc_n_steps stochastic passes
+                    uc_map = torch.zeros((h, w), device=self.device)
+                    logits_for_stats = None
+                    prob = torch.zeros((x.shape[0], self.n_classes, h, w), device=self.device)
+                    for _ in range(self.mc_n_steps):
+                        logits = self._forward_logits(model, x, h, w)
+                        uc_map += acq.score_map(logits, None, self.query_strategy)[0]
+                        prob += F.softmax(logits, dim=1)
+                    uc_map /= self.mc_n_steps
+                    prob /= self.mc_n_steps
+                    uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0
+                    query = self._select_queries(uc_map)
+                else:
+                    logits = self._forward_logits(model, x, h, w)
+                    prob = None
+                    logits_for_stats = logits
+                    query = self._select_from_logits(logits, exclude)
+
+                list_queries.append(query)
+                n_pixels += query.sum()
+
+                if not human_labels and y is not None:
+                    if logits_for_stats is not None:
+                        self.query_stats.update_from_logits(query, y, logits_for_stats)
+                    else:
+                        self.query_stats.update(query, y, prob)
+                dict_queries.update(self.encode_query(dict_data["p_img"][0], size=(h, w), query=query))
+
+                if self.debug:
+                    break
+
+        assert len(list_queries) > 0, f"no queries are chosen!"
+        if not human_labels and y is not None:
+            self.query_stats.save(nth_query)
+            print(f"{n_pixels} labelled pixels  are chosen by {self.query_strategy} strategy")
+            # updates labels for the query dataloader only (query.py:219-220)
+            dataset.label_queries(dict_queries, nth_query)
+        return dict_queries
+
+
+class UncertaintySampler:
+    """query.py:224-247.  `prob` is an already-softmaxed [b,c,h,w] GPU tensor -> [b,h,w]."""
+
+    def __init__(self, query_strategy):
+        self.query_strategy = query_strategy
+
+    @staticmethod
+    def _entropy(prob):
+        return acq.uncertainty_from_prob(prob, "entropy")
+
+    @staticmethod
+    def _least_confidence(prob):
+        return acq.uncertainty_from_prob(prob, "least_confidence")
+
+    @staticmethod
+    def _margin_sampling(prob):
+        return acq.uncertainty_from_prob(prob, "margin_sampling")
+
+    @staticmethod
+    def _random(prob):
+        b, _, h, w = prob.shape
+        return torch.rand((b, h, w))  # CPU tensor, as query.py:244
+
+    def __call__(self, prob):
+        return getattr(self, f"_{self.query_strategy}")(prob)
+
+
+class QueryStats:
+    """query.py:250-308: label histogram, entropy at the picked pixels, #unique labels, mean pairwise distance."""
+
+    def __init__(self, args):
+        self.dir_checkpoints = f"{args.dir_root}/checkpoints/{args.experim_name}"
+        self.list_entropy, self.list_n_unique_labels, self.list_spatial_coverage = list(), list(), list()
+        self.dict_label_cnt = {l: 0 for l in range(args.n_classes)}
+
+    def _count_labels(self, query, y):
+        for l in y.flatten()[query.flatten()]:
+            self.dict_label_cnt[l] += 1
+
+    @staticmethod
+    def _get_entropy(query, prob):
+        """Entropy of `prob` ([1,C,h,w], GPU) at the queried pixels, row-major order (query.py:261-264)."""
+        ys, xs = np.nonzero(query)
+        picked = prob[0][:, torch.from_numpy(ys).to(prob.device), torch.from_numpy(xs).to(prob.device)]  # C x n
+        ent = acq.uncertainty_from_prob(picked.reshape(1, picked.shape[0], 1, -1).contiguous(), "entropy")
+        return ent.reshape(-1).cpu().numpy().tolist()
+
+    @staticmethod
+    def _get_entropy_from_logits(query, logits):
+        """Same quantity from the LOGITS at the picked pixels only: no full-size prob, no full-map D2H."""
+        ys, xs = np.nonzero(query)
+        picked = logits[0][:, torch.from_numpy(ys).to(logits.device), torch.from_numpy(xs).to(logits.device)]
+        ent = acq.score_map(picked.reshape(1, picked.shape[0], 1, -1).contiguous(), None, "entropy")
+        return ent.reshape(-1).cpu().numpy().tolist()
+
+    @staticmethod
+    def _n_unique_labels(query, y):
+        return len(set(y.flatten()[query.flatten()]))
+
+    @staticmethod
+    def _spatial_coverage(query):
+        a, b = np.nonzero(query)
+        n = a.shape[0]
+        if n < 2:
+            return np.nan
+        pts = np.stack([a, b], axis=1).astype(np.float64)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        return d[~np.eye(n, dtype=np.bool_)].reshape(n, -1).mean()
+
+    def save(self, nth_query):
+        dict_stats = {
+            "label_distribution": self.dict_label_cnt,
+            "avg_entropy": np.mean(self.list_entropy),
+            "avg_n_unique_labels": np.mean(self.list_n_unique_labels),
+            "avg_spatial_coverage": np.mean(self.list_spatial_coverage)
+        }
+        for k, v in dict_stats.items():
+            print(f"{k}: {v}")
+        os.makedirs(f"{self.dir_checkpoints}/{nth_query}_query", exist_ok=True)
+        with open(f"{self.dir_checkpoints}/{nth_query}_query/query_stats.pkl", "wb") as f:
+            pkl.dump(dict_stats, f)
+
+    def update_from_picked(self, query, y, pixel_entropy):
+        """Host-only part of update(): everything except the entropy evaluation."""
+        self._count_labels(query, y)
+        self.list_entropy.extend(pixel_entropy)
+        self.list_n_unique_labels.append(self._n_unique_labels(query, y))
+        self.list_spatial_coverage.append(self._spatial_coverage(query))
+
+    def update(self, query, y, prob):
+        self.update_from_picked(query, y, self._get_entropy(query, prob))
+
+    def update_from_logits(self, query, y, logits):
+        self.update_from_picked(query, y, self._get_entropy_from_logits(query, logits))
+
+
+def gather_previous_query_files(dir_base: str, ext="pkl") -> List[str]:
+    """query.py:311-313."""
+    pattern = f"*/queries.{ext}" if ext is not None else "*"
+    return [str(p) for p in Path(dir_base).rglob(pattern)]
+
+
+def merge_previous_query_files(list_previous_query_files: List[str], ignore_index: int, verbose: bool = True
+                               ) -> Dict[str, np.ndarray]:
+    """query.py:316-351: per image, overlay the label maps of all rounds (later files win)."""
+    per_image: Dict[str, List[np.ndarray]] = dict()
+    for p_file in list_previous_query_files:
+        with open(p_file, "rb") as f:
+            encoded = pkl.load(f)
+        decoded = QuerySelector.decode_queries(encoded, ignore_index=ignore_index, return_as_dict=True)
+        for img_path, q in decoded.items():
+            per_image.setdefault(img_path, []).append(q)
+
+    cnt = 0
+    merged_all: Dict[str, np.ndarray] = dict()
+    for p_img, maps in per_image.items():
+        merged = np.full_like(maps[0], ignore_index, dtype=np.int64)
+        for q in maps:
+            sel = q != ignore_index
+            merged[sel] = q[sel]
+            cnt += sel.sum()
+        merged_all[p_img] = merged
+    if verbose:
+        print(f"# merged pixels: {cnt}")
+    return merged_all

@@ -1,0 +1,139 @@
+"""CPU-only: C-ABI symbol coverage, host-side codec / stats / selection plumbing vs reference goldens."""
+import os
+import pickle as pkl
+import re
+import subprocess
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from pixelpick_amd import _lib
+from pixelpick_amd import query as ppq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure_built():
+    if not os.path.exists(_lib.LIB_PATH):
+        from pixelpick_amd import build
+        build.build(verbose=False)
+
+
+def test_abi_exports_every_declared_symbol():
+    _ensure_built()
+    decl = set()
+    for hdr in os.listdir(os.path.join(ROOT, "include")):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        decl |= set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", txt))
+    assert decl, "no declarations parsed"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (pp_[a-z0-9_]+)", out))
+    assert decl <= exported, f"declared but not exported: {decl - exported}"
+    assert decl == set(_lib.SIGNATURES), f"ctypes table out of sync: {decl ^ set(_lib.SIGNATURES)}"
+    L = _lib.lib()           # loads without a GPU
+    assert L.pp_version() >= 100
+
+
+def test_abi_argument_validation_without_gpu():
+    _ensure_built()
+    L = _lib.lib()
+    assert L.pp_acq_score_topk(None, 1, 19, 4, 4, 0, 0, 0, 0, None, 0, 5, None, None, None, None, 0, None) == -1
+    assert b"null" in L.pp_last_error()
+    assert L.pp_acq_workspace_bytes(256, 19, 256, 512, 20) > 0
+    assert L.pp_acq_workspace_bytes(1, 19, 256, 512, 6553) >= 256 * 512 * 4
+    assert L.pp_topk_select(None, 1, 10, 3, 1, None, None, None, 0, None) == -1
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpixelpick_hip.so")
+    with pytest.raises(_lib.PixelPickHipError):
+        _lib.lib()
+
+
+def test_cpu_tensor_is_rejected_not_silently_computed():
+    import torch
+    from pixelpick_amd import acquisition as acq
+    with pytest.raises(_lib.PixelPickHipError):
+        acq.score_topk(torch.zeros(1, 19, 4, 4), None, "entropy", 2)
+
+
+def test_codec_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "acq_codec.npz"))
+    enc = ppq.QuerySelector.encode_query("a/b.png", g["mask"].shape, g["mask"])
+    info = enc["a/b.png"]
+    assert info["height"], info["width"] == g["mask"].shape
+    assert info["x_coords"].dtype == np.int64
+    np.testing.assert_array_equal(info["x_coords"], g["enc_x"])
+    np.testing.assert_array_equal(info["y_coords"], g["enc_y"])
+    dec = ppq.QuerySelector.decode_queries(enc)
+    assert len(dec) == 1 and dec[0].dtype == np.bool_
+    np.testing.assert_array_equal(dec[0], g["dec_single"])
+    enc2 = {"z.png": dict(info), "a.png": dict(info)}
+    enc2["z.png"]["category_id"] = g["cat"].tolist()
+    d2 = ppq.QuerySelector.decode_queries(enc2, ignore_index=11, return_as_dict=True)
+    assert d2["z.png"].dtype == np.int64
+    np.testing.assert_array_equal(d2["z.png"], g["dec_cat_z"])
+    np.testing.assert_array_equal(d2["a.png"], g["dec_plain_a"])
+    l2 = ppq.QuerySelector.decode_queries(enc2, ignore_index=11)
+    assert (l2[0].dtype == np.bool_) == bool(g["dec_list_order_first_is_a"])
+    with pytest.raises(ValueError):
+        ppq.QuerySelector.decode_queries({})
+
+
+def test_merge_previous_query_files_matches_reference(golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "acq_codec.npz"))
+    h, w = g["merge_img0"].shape
+    files = []
+    for r in range(3):
+        d = tmp_path / f"{r}_query"
+        d.mkdir()
+        e = {}
+        for tag in ("img0", "img1"):
+            key = f"merge_in_{r}_{tag}_x"
+            if key in g:
+                e[f"{tag}.png"] = {"height": h, "width": w, "x_coords": g[key], "y_coords": g[f"merge_in_{r}_{tag}_y"],
+                                   "category_id": g[f"merge_in_{r}_{tag}_c"].tolist()}
+        with open(d / "queries.pkl", "wb") as f:
+            pkl.dump(e, f)
+        files.append(str(d / "queries.pkl"))
+    assert sorted(ppq.gather_previous_query_files(str(tmp_path))) == sorted(files)
+    merged = ppq.merge_previous_query_files(files, ignore_index=11, verbose=False)
+    np.testing.assert_array_equal(merged["img0.png"], g["merge_img0"])
+    np.testing.assert_array_equal(merged["img1.png"], g["merge_img1"])
+
+
+def _args(**kw):
+    base = dict(dataset_name="cs", debug=False, dir_root="/tmp", experim_name="t", ignore_index=19, mc_n_steps=20,
+                n_classes=19, n_pixels_by_us=10, network_name="deeplab", query_strategy="entropy",
+                reverse_order=False, stride_total=8, top_n_percent=0.0, use_mc_dropout=False, vote_type="hard")
+    base.update(kw)
+    return Namespace(**base)
+
+
+@pytest.mark.parametrize("st", ["entropy", "least_confidence", "margin_sampling"])
+def test_top_percent_subsample_host_step_matches_reference(golden_dir, st):
+    """query.py:63-68 host RNG step, given the reference's value-sorted top-5% order."""
+    g = np.load(os.path.join(golden_dir, "acq_select_modes.npz"))
+    h, w = g[f"{st}_uc"].shape
+    qs = ppq.QuerySelector(_args(query_strategy=st, top_n_percent=0.05), None, device="cpu")
+    np.random.seed(int(g["np_seed_top5"]))
+    q = qs._finish_selection(g[f"{st}_top5_order"], h, w)
+    assert np.flatnonzero(q.reshape(-1)).tolist() == g[f"{st}_top5_sel"].tolist()
+
+
+def test_query_stats_host_part_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "acq_end_to_end.npz"))
+    st = "entropy"
+    qs = ppq.QueryStats(_args())
+    ys = g[f"{st}_ys"]
+    for i in range(ys.shape[0]):
+        q = np.zeros(ys[i].shape, dtype=bool)
+        q[g[f"{st}_y_{i}"], g[f"{st}_x_{i}"]] = True
+        qs.update_from_picked(q, ys[i], [0.0] * int(q.sum()))
+    cnt = np.array([qs.dict_label_cnt[l] for l in range(19)])
+    np.testing.assert_array_equal(cnt, g[f"{st}_stats_label_cnt"])
+    assert np.isclose(np.mean(qs.list_n_unique_labels), float(g[f"{st}_stats_avg_n_unique"]))
+    assert np.isclose(np.mean(qs.list_spatial_coverage), float(g[f"{st}_stats_avg_cov"]))
