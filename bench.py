@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--strategy", default="entropy")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-occ", type=int, default=0)
+    ap.add_argument("--tune-ppt", type=int, default=0)
+    ap.add_argument("--reduce-mode", type=int, default=0)
+    ap.add_argument("--exact-formula", type=int, default=0)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +124,9 @@ def main():
     from pixelpick_amd import _lib
     from pixelpick_amd import acquisition as acq
     L = _lib.lib()
+    L.pp_debug_set_acq_tuning(a.tune_occ, a.tune_ppt)
+    L.pp_debug_set_reduce_mode(a.reduce_mode)
+    L.pp_debug_set_exact_formula(a.exact_formula)
 
     B, C, H, W, k = a.batch, a.classes, a.height, a.width, a.k
     gen = torch.Generator(device=dev).manual_seed(rank)

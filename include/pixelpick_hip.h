@@ -86,8 +86,17 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
                    int32_t* out_idx, float* out_val,
                    void* workspace, size_t ws_bytes, pp_stream_t stream);
 
-/* Debug/bench knob: 0 = DPP wave reductions (default), 1 = ds_bpermute (__shfl) reductions. */
+/* Debug/bench knobs.
+ * reduce mode: 0 = threshold-prefiltered per-wave top-k with DPP reductions (default), 1 = same with
+ *              ds_bpermute (__shfl) reductions, 2 = plain k-round extraction loop (no prefilter).
+ * exact formula: 0 = default scorer (entropy = log S + sum e_c (m - x_c) / S, v_exp_f32 exponentials;
+ *              identical NaN behaviour), 1 = the reference's operation order p_c = exp(x_c - m) / S,
+ *              sum(-p_c log p_c) with libm-accurate exp/log (query.py:190,230). */
 void pp_debug_set_reduce_mode(int mode);
+void pp_debug_set_exact_formula(int on);
+/* Tuning knob for the C == 19 flat path: occupancy bound (2/3/4 waves per SIMD, 0 = default) and
+ * pixels per thread (4/8/16, 0 = automatic). */
+void pp_debug_set_acq_tuning(int occ, int ppt);
 
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The
  * i-th launch of the dominant acquisition kernel after this call records starts[i] / stops[i] on its

@@ -25,6 +25,8 @@ SIGNATURES = {
     "pp_topk_workspace_bytes": (_sz, [_i64] * 3),
     "pp_topk_select": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p, _sz, _p]),
     "pp_debug_set_reduce_mode": (None, [_int]),
+    "pp_debug_set_exact_formula": (None, [_int]),
+    "pp_debug_set_acq_tuning": (None, [_int, _int]),
     "pp_debug_set_kernel_events": (None, [_p, _p, _int]),
 }
 

@@ -15,6 +15,9 @@
 namespace pp {
 
 static int g_reduce_mode = 0;
+static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel)
+static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
+static int g_tune_ppt = 0;
 
 // Optional profiling hook (bench.py): caller-owned hipEvent pairs recorded right around the dominant
 // kernel's launch, pair i for the i-th launch after pp_debug_set_kernel_events().
@@ -114,6 +117,47 @@ __device__ __forceinline__ float pixel_score(const float (&x)[CMAX], int C, int 
     }
 }
 
+// Default scorer: algebraically identical, ~5x fewer VALU slots.  With d_c = x_c - m, e_c = exp(d_c):
+//   entropy = -sum p_c log p_c = log S + (sum e_c (m - x_c)) / S      (both terms >= 0: no cancellation)
+//   least-confidence = 1 - 1/S ;  margin = |1/S - exp(x_(2) - m)/S|
+// e_c uses v_exp_f32 on d*log2(e): absolute error <= ~1e-7 on every term (terms are <= 1), the same
+// class as the ulp differences between libm implementations.  The reference's 0*log 0 = NaN behaviour
+// (query.py:230) is kept exactly: NaN iff the smallest p_c = exp(x_min - m)/S rounds to 0.
+__device__ __forceinline__ float fast_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896340736f); }
+
+template <int CMAX, bool EXACT>
+__device__ __forceinline__ float pixel_score_fast(const float (&x)[CMAX], int C, int strategy)
+{
+    float m = x[0], x2 = -INFINITY, xmin = x[0];
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c)
+        if (EXACT || c < C) {
+            x2 = fmaxf(x2, fminf(m, x[c]));
+            m = fmaxf(m, x[c]);
+            xmin = fminf(xmin, x[c]);
+        }
+    float S = 0.0f, T = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (EXACT || c < C) {
+            const float d = x[c] - m;
+            const float e = fast_exp(d);
+            S += e;
+            T = fmaf(e, -d, T);
+        }
+    if (strategy == PP_ACQ_ENTROPY) {
+        float ent = logf(S) + T / S;
+        if (xmin - m < -87.0f) {                    // rare: possible underflow of the smallest probability
+            if (expf(xmin - m) / S == 0.0f) ent = __uint_as_float(0x7FC00000u);
+        }
+        return ent;
+    } else if (strategy == PP_ACQ_LEAST_CONFIDENCE) {
+        return 1.0f - 1.0f / S;
+    } else {
+        return fabsf(1.0f / S - expf(x2 - m) / S);
+    }
+}
+
 // ---- per-wave top-k extraction -------------------------------------------------------------------
 // Each lane holds PPT (key, ~idx) pairs; k rounds of {lane-local max, two DPP wave reductions,
 // knock out the winner}.  Winner order == global order (key desc, index asc).  Lane 0 stores.
@@ -143,14 +187,67 @@ __device__ __forceinline__ void wave_extract_topk(uint32_t (&kh)[PPT], uint32_t 
     }
 }
 
+// Threshold-prefiltered variant (same result).  tau = k-th largest of the 64 lane-local maxima (ballot
+// bit search, mostly SALU); the wave's top-k all have key >= tau, and typically only ~k..2k keys survive.
+// Survivors go to a per-wave LDS list, each is ranked against the list (broadcast reads) and written
+// straight to its sorted slot.  Falls back to the exact loop when ties blow the list up (e.g. a wave
+// that sees only excluded pixels).
+constexpr int kSurvCap = 128;
+
+template <int PPT>
+__device__ __forceinline__ void wave_extract_topk_prefilter(uint32_t (&kh)[PPT], uint32_t (&kl)[PPT], int k,
+                                                            uint64_t* dst, int mode, volatile uint64_t* sbuf,
+                                                            volatile uint32_t* scnt)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t lm = 0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) lm = kh[j] > lm ? kh[j] : lm;
+    uint32_t tau = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t t = tau | (1u << bit);
+        if (__popcll(__ballot(lm >= t)) >= k) tau = t;
+    }
+    if (tau == 0u) tau = 1u;  // fewer than k lanes hold a valid key: every valid key survives
+    if (lane == 0) *scnt = 0u;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+        if (kh[j] >= tau) {
+            const uint32_t pos = atomicAdd(const_cast<uint32_t*>(scnt), 1u);
+            if (pos < (uint32_t)kSurvCap) sbuf[pos] = ((uint64_t)kh[j] << 32) | kl[j];
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t total = *scnt;
+    if (total > (uint32_t)kSurvCap) {  // wave-uniform
+        wave_extract_topk<PPT>(kh, kl, k, dst, mode);
+        return;
+    }
+    const uint64_t s0 = (uint32_t)lane < total ? sbuf[lane] : 0ull;
+    const uint64_t s1 = (uint32_t)(lane + 64) < total ? sbuf[lane + 64] : 0ull;
+    int r0 = 0, r1 = 0;
+    for (uint32_t i = 0; i < total; ++i) {
+        const uint64_t v = sbuf[i];
+        r0 += v > s0;
+        r1 += v > s1;
+    }
+    if (s0 != 0ull && r0 < k) dst[r0] = s0;
+    if (s1 != 0ull && r1 < k) dst[r1] = s1;
+    for (int r = (int)total + lane; r < k; r += kWave) dst[r] = 0ull;
+}
+
 // ---- main kernel ---------------------------------------------------------------------------------
 // VEC == 4: planes are flat & 16-B aligned (sW == 1, sH == W, N % 4 == 0): float4 per class plane.
 // VEC == 1: arbitrary element strides (NHWC views, cropped views), one pixel per load.
 // A block covers kBlock*VEC*G consecutive pixels of ONE image.
-template <int CMAX, bool EXACT, int VEC, int G>
-__global__ __launch_bounds__(kBlock) void acq_kernel(AcqParams p)
+// MATH: 0 = default scorer, 1 = reference operation order, 2 = input already holds probabilities.
+template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3>
+__global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
 {
     constexpr int PPT = VEC * G;
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
     const int img = blockIdx.x / p.blocks_per_image;
     const int blk = blockIdx.x - img * p.blocks_per_image;
     const int tid = threadIdx.x;
@@ -178,8 +275,10 @@ __global__ __launch_bounds__(kBlock) void acq_kernel(AcqParams p)
                 uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    s[v] = pixel_score<CMAX, EXACT>(x[v], p.C, p.strategy, p.from_prob);
+                    if constexpr (MATH == 0) s[v] = pixel_score_fast<CMAX, EXACT>(x[v], p.C, p.strategy);
+                    else s[v] = pixel_score<CMAX, EXACT>(x[v], p.C, p.strategy, MATH == 2);
                     if ((ex >> (8 * v)) & 0xFFu) s[v] = fill;
+                    __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time (VGPR budget)
                 }
                 if (omap) *reinterpret_cast<float4*>(omap + pix0) = make_float4(s[0], s[1], s[2], s[3]);
             } else {
@@ -189,7 +288,8 @@ __global__ __launch_bounds__(kBlock) void acq_kernel(AcqParams p)
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
                     if (EXACT || c < p.C) x[c] = px[(int64_t)c * p.sC];
-                s[0] = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, p.from_prob);
+                if constexpr (MATH == 0) s[0] = pixel_score_fast<CMAX, EXACT>(x, p.C, p.strategy);
+                else s[0] = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, MATH == 2);
                 if (excl && excl[pix0]) s[0] = fill;
                 if (omap) omap[pix0] = s[0];
             }
@@ -202,13 +302,18 @@ __global__ __launch_bounds__(kBlock) void acq_kernel(AcqParams p)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { kh[g * VEC + v] = 0u; kl[g * VEC + v] = 0u; }
         }
+        // keep one group's class vector live at a time (occupancy hides the HBM latency, not hoisted loads)
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     if (p.cand) {
         const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
         const int waves_per_image = p.blocks_per_image * (kBlock / kWave);
         uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
-        wave_extract_topk<PPT>(kh, kl, p.k, dst, p.reduce_mode);
+        if (p.reduce_mode == 2)
+            wave_extract_topk<PPT>(kh, kl, p.k, dst, 0);
+        else
+            wave_extract_topk_prefilter<PPT>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
     }
 }
 
@@ -233,9 +338,15 @@ __global__ __launch_bounds__(kBlock) void topk_small_from_scores_kernel(const fl
             kh[g] = 0u; kl[g] = 0u;
         }
     }
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
     const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
     const int waves_per_image = blocks_per_image * (kBlock / kWave);
-    wave_extract_topk<G>(kh, kl, k, cand + ((int64_t)img * waves_per_image + wave_in_image) * k, mode);
+    uint64_t* dst = cand + ((int64_t)img * waves_per_image + wave_in_image) * k;
+    if (mode == 2)
+        wave_extract_topk<G>(kh, kl, k, dst, 0);
+    else
+        wave_extract_topk_prefilter<G>(kh, kl, k, dst, mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
 }
 
 // ---- candidate merge ---------------------------------------------------------------------------------
@@ -403,13 +514,14 @@ static bool is_flat_vec4(const float* logits, const uint8_t* exclude, const floa
 }
 
 // Deterministic in (B, N, vec4) so that pp_acq_workspace_bytes can size the candidate buffer.
-static Plan make_plan(int64_t B, int64_t N, bool vec4)
+static Plan make_plan(int64_t B, int64_t N, bool vec4, bool force_ppt4 = false)
 {
     Plan pl;
     pl.vec4 = vec4;
     // want >= ~2048 waves in flight (256 CUs x 8) before growing the per-thread tile
     const int64_t waves16 = B * cdiv(N, (int64_t)kBlock * 16) * (kBlock / kWave);
-    pl.ppt = waves16 >= 2048 ? 16 : 4;
+    pl.ppt = (waves16 >= 2048 && !force_ppt4) ? 16 : 4;
+    if (g_tune_ppt && vec4 && !force_ppt4) pl.ppt = g_tune_ppt;
     pl.blocks_per_image = (int)cdiv(N, (int64_t)kBlock * pl.ppt);
     pl.waves_per_image = pl.blocks_per_image * (kBlock / kWave);
     return pl;
@@ -467,15 +579,40 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
 {
     EventScope ev(st);
     dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
+    // the non-default scorers (reference-order, from-prob) are only built for the 4-pixel tile
+    const bool alt = p.from_prob || g_exact_formula;
+#define PP_LAUNCH_ACQ4(VEC, G)                                                                                    \
+    do {                                                                                                          \
+        if (p.from_prob)          hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 2>), grid, block, 0, st, p); \
+        else if (g_exact_formula) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 1>), grid, block, 0, st, p); \
+        else                      hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 0>), grid, block, 0, st, p); \
+    } while (0)
     if (pl.vec4) {
+        if constexpr (CMAX == 19) {
+            if (!alt && g_tune_occ) {
+#define PP_TUNE(G)                                                                                          \
+    do {                                                                                                    \
+        if (g_tune_occ == 2)      hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 2>), grid, block, 0, st, p); \
+        else if (g_tune_occ == 4) hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 4>), grid, block, 0, st, p); \
+        else                      hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 3>), grid, block, 0, st, p); \
+    } while (0)
+                if (pl.ppt == 16) PP_TUNE(4);
+                else if (pl.ppt == 8) PP_TUNE(2);
+                else PP_TUNE(1);
+#undef PP_TUNE
+                return check_launch("acq_kernel");
+            }
+        }
         if constexpr (CMAX <= 32) {
-            if (pl.ppt == 16) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 4>), grid, block, 0, st, p);
-            else              hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 1>), grid, block, 0, st, p);
+            if (pl.ppt == 16 && !alt)     hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 4, 0>), grid, block, 0, st, p);
+            else if (pl.ppt == 8 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 2, 0>), grid, block, 0, st, p);
+            else                          PP_LAUNCH_ACQ4(4, 1);
         }
     } else {
-        if (pl.ppt == 16) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 16>), grid, block, 0, st, p);
-        else              hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 4>), grid, block, 0, st, p);
+        if (pl.ppt == 16 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 16, 0>), grid, block, 0, st, p);
+        else                      PP_LAUNCH_ACQ4(1, 4);
     }
+#undef PP_LAUNCH_ACQ4
     return check_launch("acq_kernel");
 }
 
@@ -509,7 +646,15 @@ using namespace pp;
 
 extern "C" {
 
-void pp_debug_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
+void pp_debug_set_reduce_mode(int mode) { g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
+
+void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
+
+void pp_debug_set_acq_tuning(int occ, int ppt)
+{
+    g_tune_occ = (occ == 2 || occ == 3 || occ == 4) ? occ : 0;
+    g_tune_ppt = (ppt == 4 || ppt == 8 || ppt == 16) ? ppt : 0;
+}
 
 void pp_debug_set_kernel_events(void** starts, void** stops, int n)
 {
@@ -536,8 +681,8 @@ size_t pp_acq_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_
     if (B < 1 || H < 1 || W < 1 || k < 1) return 0;
     const int64_t N = H * W;
     if (k <= kSmallKMax) {
-        // vec4 or not does not change waves_per_image (same ppt rule)
-        Plan pl = make_plan(B, N, true);
+        // sized for the 4-pixel tile (most waves), an upper bound for every plan
+        Plan pl = make_plan(B, N, true, true);
         return merge_ws_bytes(B, (int64_t)pl.waves_per_image * k, k);
     }
     // score map (used when the caller passes no out_map) + large-k scratch
@@ -551,7 +696,7 @@ int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64
     if (int rc = validate(logits, B, C, H, W, strategy)) return rc;
     if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
     const int64_t N = H * W;
-    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW));
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0);
     AcqParams p{logits, exclude, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
                 strategy, g_reduce_mode, 0};
     return dispatch_acq(p, pl, B, as_stream(stream));
@@ -563,7 +708,7 @@ int pp_uncertainty_from_prob(const float* prob, int64_t B, int64_t C, int64_t H,
     if (int rc = validate(prob, B, C, H, W, strategy)) return rc;
     if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
     const int64_t N = H * W;
-    Plan pl = make_plan(B, N, is_flat_vec4(prob, nullptr, out_map, H, W, sB, sC, sH, sW));
+    Plan pl = make_plan(B, N, is_flat_vec4(prob, nullptr, out_map, H, W, sB, sC, sH, sW), true);
     AcqParams p{prob, nullptr, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
                 strategy, g_reduce_mode, 1};
     return dispatch_acq(p, pl, B, as_stream(stream));
@@ -585,7 +730,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     const int largest = strategy != PP_ACQ_MARGIN;
 
     if (k <= kSmallKMax) {
-        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW));
+        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0);
         const int64_t n_cand = (int64_t)pl.waves_per_image * k;
         uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
         uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
@@ -598,7 +743,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     // large k: materialise the score map once, then radix-select + sort per image
     float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
     uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
-    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW));
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), g_exact_formula != 0);
     AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
                 g_reduce_mode, 0};
     if (int rc = dispatch_acq(p, pl, B, st)) return rc;

@@ -25,7 +25,7 @@ def g(golden_dir):
     return np.load(os.path.join(golden_dir, "acq_scores_topk.npz"))
 
 
-@pytest.fixture(params=[0, 1], ids=["dpp", "shfl"])
+@pytest.fixture(params=[0, 1, 2], ids=["prefilter-dpp", "prefilter-shfl", "plain-loop"])
 def reduce_mode(request):
     _lib.lib().pp_debug_set_reduce_mode(request.param)
     yield request.param
@@ -83,6 +83,25 @@ def test_vs_oracle_random(st, shape, reduce_mode):
     assert flips <= 2 * B
 
 
+def test_void_regions_force_the_tie_fallback(reduce_mode):
+    """Whole waves of excluded pixels (Cityscapes ego-vehicle / border void areas) make every key in
+    the wave equal: the prefilter must fall back to the exact loop and still honour the tiebreak."""
+    rng = np.random.RandomState(11)
+    logits = (rng.randn(2, 19, 64, 512) * 3).astype(np.float32)
+    excl = np.zeros((2, 64, 512), dtype=np.uint8)
+    excl[0, :40] = 1            # 20480 consecutive excluded pixels
+    excl[1] = 1
+    excl[1, 63, 500:] = 0       # only 12 free pixels < k
+    for st in STRATS:
+        o_idx, _ = orc.score_topk(logits, excl, st, 20)
+        idx, val, omap = acq.score_topk(torch.from_numpy(logits).to(DEV), torch.from_numpy(excl), st, 20, return_map=True)
+        dmap = omap.cpu().numpy()
+        for b in range(2):
+            e_idx, _ = orc.topk(dmap[b], 20, st != "margin_sampling")
+            assert idx[b].cpu().numpy().tolist() == e_idx.tolist()
+        assert sorted(idx[1].cpu().numpy().tolist())[:8] == list(range(8))  # excluded extras: lowest index first
+
+
 @pytest.mark.parametrize("largest", [True, False])
 @pytest.mark.parametrize("B,N,k", [(1, 1000, 1), (3, 4096, 20), (2, 70001, 64), (2, 5000, 65), (1, 131072, 6553),
                                    (2, 9000, 9000), (1, 40000, 20000), (1, 300, 300)])
@@ -116,6 +135,39 @@ def test_select_modes_golden(golden_dir, st):
     k = int(uc.numel() * 0.05)
     idx, _ = acq.topk_select(uc.reshape(1, -1).to(DEV), k, st != "margin_sampling")
     assert idx[0].cpu().numpy().tolist() == m[f"{st}_top5_order"].tolist()
+
+
+@pytest.fixture(params=[0, 1], ids=["default-scorer", "reference-order-scorer"])
+def exact_formula(request):
+    _lib.lib().pp_debug_set_exact_formula(request.param)
+    yield request.param
+    _lib.lib().pp_debug_set_exact_formula(0)
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+@pytest.mark.parametrize("st", STRATS)
+def test_both_scorers_match_golden(g, si, st, exact_formula):
+    logits, excl = g[f"s{si}_logits"], g[f"s{si}_exclude"]
+    t = torch.from_numpy(logits).to(DEV)
+    m = acq.score_map(t, None, st).cpu().numpy()
+    np.testing.assert_allclose(m, g[f"s{si}_map_{st}"], rtol=RTOL, atol=ATOL)
+    idx, _, _ = acq.score_topk(t, torch.from_numpy(excl), st, 20)
+    for b in range(logits.shape[0]):
+        assert idx[b].cpu().numpy().tolist() == g[f"s{si}_order_{st}"][b].tolist()
+
+
+def test_scorers_agree_on_full_size_and_nan_semantics(exact_formula):
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    logits = torch.randn((2, 19, 256, 512), device=DEV, generator=gen) * 3
+    logits[0, :, 5, 7] = torch.tensor([300.0] + [0.0] * 18, device=DEV)      # p underflows -> NaN (query.py:230)
+    logits[1, :, 9, 1] = torch.tensor([95.0] + [0.0] * 18, device=DEV)       # denormal p: finite in the reference
+    m = acq.score_map(logits, None, "entropy")
+    assert torch.isnan(m[0, 5, 7]) and torch.isfinite(m[1, 9, 1])
+    assert int(torch.isnan(m).sum()) == 1
+    ref = orc.score_map(logits[:, :, :16, :64].contiguous().cpu().numpy(), "entropy")
+    got = m[:, :16, :64].cpu().numpy()
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=RTOL, atol=ATOL)
 
 
 def test_edges(golden_dir):
