@@ -86,6 +86,118 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
                    int32_t* out_idx, float* out_val,
                    void* workspace, size_t ws_bytes, pp_stream_t stream);
 
+
+/* =============================================================================================
+ * Network layers (DeepLabv3+-MobileNetV2 / FPN-ResNet50 forward + backward), NHWC fp32.
+ *
+ * Activations are [B,H,W,C] with an explicit pixel stride `ld` (elements): a channel slice of a wider
+ * tensor is addressed by offsetting the pointer, which is how the reference's torch.cat tensors
+ * (aspp.py:73, deeplab.py:50) are produced and consumed without a copy.  Dense-conv weights are HWIO
+ * [kh][kw][Cin][Cout]; depthwise weights [3][3][C].  All reductions are deterministic (two-stage, no
+ * float atomics).  Workspaces are caller-owned.
+ * ============================================================================================= */
+
+/* nn.Conv2d forward (dense, groups=1) as an implicit GEMM on the fp32 MFMA pipe.
+ * networks/mobilenet_v2.py:9,42,48,56; aspp.py:9-10,55,58; deeplab.py:24; decoders.py:107,111,116;
+ * backbones/resnet_models.py Bottleneck convs; decoders.py:25-28,92 (bias != NULL).
+ * y[b,oh,ow,n] = bias[n] + sum x[b, oh*stride - pad + th*dil, ow*stride - pad + tw*dil, c] * w[th,tw,c,n] */
+int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, pp_stream_t stream);
+
+/* dL/dx of the above for stride-1 convolutions (what autograd computes at model.py:121). */
+int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, pp_stream_t stream);
+
+/* dL/dw (HWIO) and optionally dL/dbias [Cout]; workspace holds the split-M partial sums. */
+size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                         int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                         void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* Column-reduction workspace shared by pp_bn_train_fwd, pp_bn_bwd and pp_dwconv3x3_bwd_weight. */
+size_t pp_colreduce_workspace_bytes(int64_t M, int C);
+
+/* nn.BatchNorm2d, training mode (mobilenet_v2.py:10,39,49,57; aspp.py:11,56,59; deeplab.py:25;
+ * decoders.py:108,112): batch mean / biased variance over the M = B*H*W rows, running-stat update
+ * (momentum, unbiased variance), and the per-channel affine  scale = gamma*invstd,
+ * shift = beta - mean*scale  to be applied by pp_scale_shift_act.  running_* may be NULL. */
+int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                    float* shift, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* nn.BatchNorm2d, eval mode: scale/shift from the running statistics. */
+int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, pp_stream_t stream);
+
+/* y = act(x*scale + shift [+ residual]);  act 0 none, 1 ReLU, 2 ReLU6.  BN apply + nn.ReLU/ReLU6
+ * (+ the residual add of mobilenet_v2.py:62-63 / resnet Bottleneck) in one pass. */
+int pp_scale_shift_act(const float* x, int64_t ldx, int64_t M, int C, const float* scale, const float* shift,
+                       const float* residual, int64_t ldr, int act, float* y, int64_t ldy, pp_stream_t stream);
+
+/* Backward of [BN(train) -> (+residual) -> act]: g = dy * act'(y_act); dgamma, dbeta, dx; dres = g
+ * (NULL if no residual).  y_act is the activation OUTPUT (needed when act != 0). */
+int pp_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+              int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+              float* dx, int64_t lddx, float* dres, int64_t lddr, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* Depthwise 3x3 convolution (groups = C), mobilenet_v2.py:38,52; generic stride / padding / dilation.
+ * H, W are always the INPUT spatial size. */
+int pp_dwconv3x3_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
+                     float* y, int64_t ldy, pp_stream_t stream);
+int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, int C, const float* w, int stride, int pad,
+                          int dil, float* dx, int64_t lddx, pp_stream_t stream);
+int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
+                            int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* fixed_padding (mobilenet_v2.py:15-21): zero-pad [B,H,W,C] to [B,Hp,Wp,C]; and its adjoint
+ * y = crop(xp) (+ add), used for the gradient of the padded block input (+ the residual gradient). */
+int pp_pad2d(const float* x, int64_t ldx, int B, int H, int W, int C, int pad_top, int pad_left, int Hp, int Wp, float* y,
+             int64_t ldy, pp_stream_t stream);
+int pp_crop2d_add(const float* xp, int64_t ldxp, int B, int Hp, int Wp, int C, int pad_top, int pad_left, const float* add,
+                  int64_t ldadd, float* y, int64_t ldy, int H, int W, pp_stream_t stream);
+
+/* F.interpolate(mode="bilinear") with torch's index arithmetic (deeplab.py:49,55; aspp.py:70;
+ * decoders.py:82,101).  align_corners as given; scale_h/scale_w > 0 reproduce the `scale_factor=`
+ * call form (decoders.py:101), 0 uses in/out.  out_nchw: y is [B,C,Ho,Wo] contiguous (the model's
+ * "pred", deeplab.py:55-56).  Backward is a deterministic gather; dy_nchw likewise. */
+int pp_bilinear_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, float* y, int64_t ldy, int Ho, int Wo,
+                    int align_corners, float scale_h, float scale_w, int out_nchw, pp_stream_t stream);
+int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C, float* dx, int64_t lddx, int H, int W,
+                    int align_corners, float scale_h, float scale_w, int dy_nchw, pp_stream_t stream);
+
+/* out[b][c] = mul * sum_p x[b][p][c]  (nn.AdaptiveAvgPool2d(1), aspp.py:54, with mul = 1/P; also the
+ * adjoint of the broadcast below) and y[b][p][c] = mul * v[b][c] (the 1x1 -> HxW bilinear broadcast of
+ * aspp.py:70, and the adjoint of the pool). */
+int pp_image_colsum(const float* x, int64_t ldx, int B, int64_t P, int C, float mul, float* out, int64_t ldo, pp_stream_t stream);
+int pp_image_broadcast(const float* v, int64_t ldv, int B, int64_t P, int C, float mul, float* y, int64_t ldy, pp_stream_t stream);
+
+/* nn.Dropout (aspp.py:61; decoders.py:110,114): y = x * keep / (1-p), keep from a counter-based hash of
+ * (seed, element index) — the backward pass calls this again on dy with the same seed. */
+int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed, pp_stream_t stream);
+
+/* F.cross_entropy(logits, target, ignore_index) (model.py:116) on NCHW logits (plane stride 1 within a
+ * class: element (b,c,pix) at b*sB + c*sC + pix): *loss = mean over labelled pixels, *count = their
+ * number; dlogits (NULL to skip) = grad_out * (softmax - onehot)/count on labelled pixels, 0 elsewhere,
+ * [B,C,HW] contiguous.  grad_out NULL means 1. */
+size_t pp_sparse_ce_workspace_bytes(void);
+int pp_sparse_ce_fwd_bwd(const float* logits, int B, int C, int64_t HW, int64_t sB, int64_t sC, const int64_t* target,
+                         int ignore_index, float* loss, float* count, const float* grad_out, float* dlogits, void* workspace,
+                         size_t ws_bytes, pp_stream_t stream);
+
+/* torch.optim.Adam step on flat buffers (utils/utils.py:125-141): elements [0,n_split) use lr_a (the
+ * backbone/encoder group at lr/10), the rest lr_b; L2 weight decay; `step` is 1-based; grads are
+ * multiplied by grad_scale first (1/world_size after the gradient all-reduce). */
+int pp_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_split,
+                      float lr_a, float lr_b, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                      float grad_scale, pp_stream_t stream);
+
+/* y = a + b on [M,C] matrices with pixel strides (gradient accumulation for tensors with several
+ * consumers: the residual input of mobilenet_v2.py:62, the ASPP input of aspp.py:64-69). */
+int pp_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int C, pp_stream_t stream);
+
+/* [B,C,H,W] -> [B,H,W,C] (the network input; deeplab.py:43 receives NCHW). */
+int pp_nchw_to_nhwc(const float* x, int B, int C, int64_t HW, float* y, int64_t ldy, pp_stream_t stream);
+
 /* Debug/bench knobs.
  * reduce mode: 0 = threshold-prefiltered per-wave top-k with DPP reductions (default), 1 = same with
  *              ds_bpermute (__shfl) reductions, 2 = plain k-round extraction loop (no prefilter).
@@ -95,7 +207,7 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
 void pp_debug_set_reduce_mode(int mode);
 void pp_debug_set_exact_formula(int on);
 /* Tuning knob for the C == 19 flat path: occupancy bound (2/3/4 waves per SIMD, 0 = default) and
- * pixels per thread (4/8/16, 0 = automatic). */
+ * pixels per thread (4/8, 0 = automatic). */
 void pp_debug_set_acq_tuning(int occ, int ppt);
 
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads PyTorch's libamdhip64 first)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpixelpick_hip.so")
 
-_i64, _p, _int, _sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_i64, _p, _int, _sz, _f = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); must list every symbol include/pixelpick_hip.h declares
 SIGNATURES = {
@@ -24,6 +24,30 @@ SIGNATURES = {
     "pp_uncertainty_from_prob": (_int, [_p] + [_i64] * 8 + [_int, _p, _p]),
     "pp_topk_workspace_bytes": (_sz, [_i64] * 3),
     "pp_topk_select": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p, _sz, _p]),
+    "pp_conv2d_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p]),
+    "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p]),
+    "pp_conv2d_bwd_weight_workspace_bytes": (_sz, [_int] * 10),
+    "pp_conv2d_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p]),
+    "pp_colreduce_workspace_bytes": (_sz, [_i64, _int]),
+    "pp_bn_train_fwd": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pp_bn_eval_affine": (_int, [_int, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "pp_scale_shift_act": (_int, [_p, _i64, _i64, _int, _p, _p, _p, _i64, _int, _p, _i64, _p]),
+    "pp_bn_bwd": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
+    "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
+    "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
+    "pp_dwconv3x3_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p]),
+    "pp_pad2d": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p]),
+    "pp_crop2d_add": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _p, _i64, _p, _i64, _int, _int, _p]),
+    "pp_bilinear_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p]),
+    "pp_bilinear_bwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p]),
+    "pp_image_colsum": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
+    "pp_image_broadcast": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
+    "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p]),
+    "pp_sparse_ce_workspace_bytes": (_sz, []),
+    "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
+    "pp_adam_step_flat": (_int, [_p, _p, _p, _p, _i64, _i64, _f, _f, _f, _f, _f, _f, _i64, _f, _p]),
+    "pp_add2d": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _p]),
+    "pp_nchw_to_nhwc": (_int, [_p, _int, _int, _i64, _p, _i64, _p]),
     "pp_debug_set_reduce_mode": (None, [_int]),
     "pp_debug_set_exact_formula": (None, [_int]),
     "pp_debug_set_acq_tuning": (None, [_int, _int]),

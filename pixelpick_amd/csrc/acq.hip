@@ -519,8 +519,10 @@ static Plan make_plan(int64_t B, int64_t N, bool vec4, bool force_ppt4 = false)
     Plan pl;
     pl.vec4 = vec4;
     // want >= ~2048 waves in flight (256 CUs x 8) before growing the per-thread tile
-    const int64_t waves16 = B * cdiv(N, (int64_t)kBlock * 16) * (kBlock / kWave);
-    pl.ppt = (waves16 >= 2048 && !force_ppt4) ? 16 : 4;
+    // measured on MI355X (profiles/r01_acq_tuning.txt): 8 pixels/thread at 3 waves/SIMD streams at 5.95 TB/s;
+    // 16 pixels/thread spills, 4 waves/SIMD spills.
+    const int64_t waves8 = B * cdiv(N, (int64_t)kBlock * 8) * (kBlock / kWave);
+    pl.ppt = (waves8 >= 2048 && !force_ppt4) ? 8 : 4;
     if (g_tune_ppt && vec4 && !force_ppt4) pl.ppt = g_tune_ppt;
     pl.blocks_per_image = (int)cdiv(N, (int64_t)kBlock * pl.ppt);
     pl.waves_per_image = pl.blocks_per_image * (kBlock / kWave);
@@ -596,21 +598,19 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
         else if (g_tune_occ == 4) hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 4>), grid, block, 0, st, p); \
         else                      hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 3>), grid, block, 0, st, p); \
     } while (0)
-                if (pl.ppt == 16) PP_TUNE(4);
-                else if (pl.ppt == 8) PP_TUNE(2);
+                if (pl.ppt == 8) PP_TUNE(2);
                 else PP_TUNE(1);
 #undef PP_TUNE
                 return check_launch("acq_kernel");
             }
         }
         if constexpr (CMAX <= 32) {
-            if (pl.ppt == 16 && !alt)     hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 4, 0>), grid, block, 0, st, p);
-            else if (pl.ppt == 8 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 2, 0>), grid, block, 0, st, p);
-            else                          PP_LAUNCH_ACQ4(4, 1);
+            if (pl.ppt == 8 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 2, 0>), grid, block, 0, st, p);
+            else                     PP_LAUNCH_ACQ4(4, 1);
         }
     } else {
-        if (pl.ppt == 16 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 16, 0>), grid, block, 0, st, p);
-        else                      PP_LAUNCH_ACQ4(1, 4);
+        if (pl.ppt == 8 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 1, 8, 0>), grid, block, 0, st, p);
+        else                     PP_LAUNCH_ACQ4(1, 4);
     }
 #undef PP_LAUNCH_ACQ4
     return check_launch("acq_kernel");
@@ -653,7 +653,7 @@ void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
 void pp_debug_set_acq_tuning(int occ, int ppt)
 {
     g_tune_occ = (occ == 2 || occ == 3 || occ == 4) ? occ : 0;
-    g_tune_ppt = (ppt == 4 || ppt == 8 || ppt == 16) ? ppt : 0;
+    g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
 }
 
 void pp_debug_set_kernel_events(void** starts, void** stops, int n)
@@ -768,8 +768,8 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
         uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
                                                       align_up((size_t)B * n_cand * 8, 256));
         dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
-        if (pl.ppt == 16)
-            hipLaunchKernelGGL((topk_small_from_scores_kernel<16>), grid, block, 0, st, scores, N,
+        if (pl.ppt == 8)
+            hipLaunchKernelGGL((topk_small_from_scores_kernel<8>), grid, block, 0, st, scores, N,
                                pl.blocks_per_image, (int)k, largest, cand, g_reduce_mode);
         else
             hipLaunchKernelGGL((topk_small_from_scores_kernel<4>), grid, block, 0, st, scores, N,

@@ -1,0 +1,581 @@
+// conv_igemm.hip — dense convolutions of the PixelPick networks as NHWC implicit GEMMs on the fp32
+// MFMA pipe of gfx950 (v_mfma_f32_32x32x2_f32: exact f32 fma chains at 157 TF peak).
+//
+// Replaces the ATen/cuDNN calls behind every dense nn.Conv2d of the reference (SURVEY.md §8 N3, N7, N9,
+// N10, N12, N13 and R2/R3): networks/mobilenet_v2.py:42,48,56 (pointwise), networks/aspp.py:9-10,49-58
+// (1x1 + atrous 3x3), networks/deeplab.py:24 (low-level 1x1), networks/decoders.py:107,111,116
+// (SegmentHead 3x3 + classifier), and their autograd backward (model.py:121).
+//
+//   forward      Y[m][n]   = sum_{t,c} X[pix(m,t)][c] * W[t][c][n] (+ bias[n])     m = (b,oh,ow)
+//   backward-x   dX[m][c]  = sum_{t,n} dY[pix'(m,t)][n] * W[t][c][n]               (stride 1)
+//   backward-w   dW[t][c][n] = sum_m X[pix(m,t)][c] * dY[m][n]                     (split over m)
+//
+// Layouts: activations NHWC with an explicit pixel stride `ld` (so channel slices of a wider tensor —
+// the reference's torch.cat inputs/outputs, aspp.py:73, deeplab.py:50 — are read and written in place);
+// weights HWIO = [kh][kw][Cin][Cout].  Taps that fall outside the image for every output pixel
+// (atrous d=18 on a 16x32 map) are dropped on the host.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 16; operands staged through LDS by
+// registers (next K-step's global loads are in flight while the current one is multiplied).  A fragment
+// reads are ds_read_b128 using a permuted K order (lane-half h consumes k = 8q+4h+j), B fragment reads
+// are conflict-free ds_read_b32.
+#include "pp_common.h"
+
+namespace pp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int BK = 16;
+constexpr int kMaxTaps = 49;
+
+struct ConvTaps {
+    int n;                      // number of live taps
+    short dh[kMaxTaps];         // input row offset of tap (already includes -pad / flip)
+    short dw[kMaxTaps];
+    unsigned char widx[kMaxTaps];  // index of the tap in the weight tensor (kh*KW + kw)
+};
+
+struct ConvParams {
+    const float* x;   // A-side activations (X for fwd/wgrad, dY for bwd-data)
+    const float* w;   // HWIO weights
+    const float* bias;
+    float* y;         // output (Y, dX)
+    int64_t ldx, ldy;
+    int B, H, W;      // A-side spatial size
+    int Ho, Wo;       // output spatial size (rows of the GEMM)
+    int Ck;           // reduction channels (Cin for fwd, Cout for bwd-data)
+    int Cn;           // output channels  (Cout for fwd, Cin for bwd-data)
+    int Cin, Cout;    // weight tensor dims (for addressing)
+    int stride;
+    int64_t M;        // B*Ho*Wo
+    ConvTaps taps;
+};
+
+// ---- LDS tiles ---------------------------------------------------------------------------------------
+// "MK" form: tile[rows][BK + 4]   (K contiguous, 80-B row pitch: conflict-free ds_read_b128)
+// "KM" form: tile[BK][rows + 4]   (rows contiguous: conflict-free ds_read_b32)
+constexpr int kPitchMK = BK + 4;
+
+// One K-step (16) of MFMAs for a wave tile of TM x TN 32x32 blocks.
+//   A_MK: A tile in MK form, else KM form.   B_NK: B tile in "NK" (= MK-like) form, else KN form.
+template <int TM, int TN, bool A_MK, bool B_NK, int PITCH_A, int PITCH_B>
+__device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a_row0, int b_col0, f32x16 (&acc)[TM][TN])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+        float a[TM][4], b[TN][4];
+        const int k0 = 8 * q + 4 * h;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int r = a_row0 + tm * 32 + l31;
+            if constexpr (A_MK) {
+                const float4 v = *reinterpret_cast<const float4*>(As + r * PITCH_A + k0);
+                a[tm][0] = v.x; a[tm][1] = v.y; a[tm][2] = v.z; a[tm][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[tm][j] = As[(k0 + j) * PITCH_A + r];
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int c = b_col0 + tn * 32 + l31;
+            if constexpr (B_NK) {
+                const float4 v = *reinterpret_cast<const float4*>(Bs + c * PITCH_B + k0);
+                b[tn][0] = v.x; b[tn][1] = v.y; b[tn][2] = v.z; b[tn][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(k0 + j) * PITCH_B + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+}
+
+// ---- forward / backward-data kernel ---------------------------------------------------------------------
+// BWD == false: B operand W[t][c][n]  -> KN form (n contiguous in memory)
+// BWD == true : B operand W[t][n'][k'] with k' = conv Cout contiguous -> NK form
+template <int BM, int BN, int WM, int WN, bool BWD>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
+{
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int PITCH_A = kPitchMK;
+    constexpr int PITCH_B = BWD ? kPitchMK : BN + 4;
+    constexpr int A_F4 = BM * BK / 4 / kThreads;                 // float4 per thread for the A tile
+    constexpr int B_TOTAL = BN * BK / 4;
+    constexpr int B_F4 = (B_TOTAL + kThreads - 1) / kThreads;
+    static_assert(A_F4 >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) float As[BM * PITCH_A];
+    __shared__ __attribute__((aligned(16))) float Bs[BWD ? BN * kPitchMK : BK * (BN + 4)];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // A staging: thread -> (row, k-quad); rows fixed for the whole K loop
+    const int a_kq = tid & 3;
+    int a_b[A_F4], a_ih[A_F4], a_iw[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int64_t m = m0 + (tid >> 2) + i * 64;
+        if (m < p.M) {
+            const int ow = (int)(m % p.Wo);
+            const int64_t t = m / p.Wo;
+            const int oh = (int)(t % p.Ho);
+            a_b[i] = (int)(t / p.Ho);
+            a_ih[i] = oh * p.stride;
+            a_iw[i] = ow * p.stride;
+        } else {
+            a_b[i] = -1; a_ih[i] = 0; a_iw[i] = 0;
+        }
+    }
+
+    const int nchunk = (p.Ck + BK - 1) / BK;
+    const int nk = p.taps.n * nchunk;
+    const bool w_vec = BWD ? (p.Cout % 4 == 0) : (p.Cout % 4 == 0);
+
+    float4 ra[A_F4], rb[B_F4];
+
+    auto load_tiles = [&](int ks) {
+        const int ti = ks / nchunk;
+        const int c0 = (ks - ti * nchunk) * BK;
+        const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
+        const int wt = p.taps.widx[ti];
+        // A: gather BK channels of the tap's input pixel for each row
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+            const int c = c0 + a_kq * 4;
+            if (a_b[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && c < p.Ck) {
+                const float* src = p.x + (((int64_t)a_b[i] * p.H + ih) * p.W + iw) * p.ldx + c;
+                if (c + 3 < p.Ck) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (c + 1 < p.Ck) v.y = src[1];
+                    if (c + 2 < p.Ck) v.z = src[2];
+                }
+            }
+            ra[i] = v;
+        }
+        // B
+        if constexpr (!BWD) {
+            // rows k = c0 + kr (Cin index), cols n0 + nq*4 ..   W[(wt*Cin + c)*Cout + n]
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int e = tid + i * kThreads;          // float4 index in the BK x BN tile
+                const int kr = e / (BN / 4), nq = e % (BN / 4);
+                const int c = c0 + kr, n = n0 + nq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < B_TOTAL && c < p.Cin && n < p.Cout) {
+                    const float* src = p.w + ((int64_t)wt * p.Cin + c) * p.Cout + n;
+                    if (w_vec) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (n + 1 < p.Cout) v.y = src[1];
+                        if (n + 2 < p.Cout) v.z = src[2];
+                        if (n + 3 < p.Cout) v.w = src[3];
+                    }
+                }
+                rb[i] = v;
+            }
+        } else {
+            // output column = conv Cin index (n0 + col), k = conv Cout index (c0 + kq*4), contiguous in memory
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int e = tid + i * kThreads;
+                const int col = e >> 2, kq = e & 3;
+                const int cin = n0 + col, k = c0 + kq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < B_TOTAL && cin < p.Cin && k < p.Cout) {
+                    const float* src = p.w + ((int64_t)wt * p.Cin + cin) * p.Cout + k;
+                    if (w_vec && k + 3 < p.Cout) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (k + 1 < p.Cout) v.y = src[1];
+                        if (k + 2 < p.Cout) v.z = src[2];
+                        if (k + 3 < p.Cout) v.w = src[3];
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i)
+            *reinterpret_cast<float4*>(As + ((tid >> 2) + i * 64) * PITCH_A + a_kq * 4) = ra[i];
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int e = tid + i * kThreads;
+                const int kr = e / (BN / 4), nq = e % (BN / 4);
+                if (e < B_TOTAL) *reinterpret_cast<float4*>(Bs + kr * PITCH_B + nq * 4) = rb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < B_TOTAL) *reinterpret_cast<float4*>(Bs + (e >> 2) * PITCH_B + (e & 3) * 4) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_tiles(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        store_tiles();
+        __syncthreads();
+        if (ks + 1 < nk) load_tiles(ks + 1);
+        mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + l31;
+        if (n >= p.Cn) continue;
+        const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m < p.M) p.y[m * p.ldy + n] = acc[tm][tn][r] + bv;
+            }
+        }
+    }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------------
+// GEMM rows = Cin (c), cols = Cout (n), reduction = output pixels m of one split; one tap per blockIdx.z/..
+struct WgradParams {
+    const float* x;    // forward input activations
+    const float* dy;   // output gradient
+    float* part;       // [splits][ntaps_live][Cin][Cout] partial sums
+    int64_t ldx, lddy;
+    int B, H, W, Ho, Wo, Cin, Cout, stride;
+    int64_t M;
+    int64_t m_per_split;
+    ConvTaps taps;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
+{
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int PITCH_A = BM + 4, PITCH_B = BN + 4;
+    constexpr int A_F4 = BM * BK / 4 / kThreads, B_F4 = BN * BK / 4 / kThreads;
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) float As[BK * PITCH_A];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * PITCH_B];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ctiles = (p.Cin + BM - 1) / BM;
+    const int c0 = (blockIdx.x % ctiles) * BM;
+    const int ti = blockIdx.x / ctiles;            // live tap index
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int64_t m_beg = (int64_t)split * p.m_per_split;
+    const int64_t m_end = m_beg + p.m_per_split < p.M ? m_beg + p.m_per_split : p.M;
+    const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
+    const bool dy_vec = (p.lddy % 4 == 0) && (p.Cout % 4 == 0);
+    const bool x_vec = (p.ldx % 4 == 0) && (p.Cin % 4 == 0);
+
+    float4 ra[A_F4], rb[B_F4];
+
+    auto load_tiles = [&](int64_t mb) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int e = tid + i * kThreads;
+            const int kr = e / (BM / 4), cq = e % (BM / 4);
+            const int64_t m = mb + kr;
+            const int c = c0 + cq * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end && c < p.Cin) {
+                const int ow = (int)(m % p.Wo);
+                const int64_t t = m / p.Wo;
+                const int oh = (int)(t % p.Ho);
+                const int b = (int)(t / p.Ho);
+                const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+                    const float* src = p.x + (((int64_t)b * p.H + ih) * p.W + iw) * p.ldx + c;
+                    if (x_vec) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (c + 1 < p.Cin) v.y = src[1];
+                        if (c + 2 < p.Cin) v.z = src[2];
+                        if (c + 3 < p.Cin) v.w = src[3];
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int e = tid + i * kThreads;
+            const int kr = e / (BN / 4), nq = e % (BN / 4);
+            const int64_t m = mb + kr;
+            const int n = n0 + nq * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end && n < p.Cout) {
+                const float* src = p.dy + m * p.lddy + n;
+                if (dy_vec) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (n + 1 < p.Cout) v.y = src[1];
+                    if (n + 2 < p.Cout) v.z = src[2];
+                    if (n + 3 < p.Cout) v.w = src[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int e = tid + i * kThreads;
+            *reinterpret_cast<float4*>(As + (e / (BM / 4)) * PITCH_A + (e % (BM / 4)) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int e = tid + i * kThreads;
+            *reinterpret_cast<float4*>(Bs + (e / (BN / 4)) * PITCH_B + (e % (BN / 4)) * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (m_beg < m_end) {
+        load_tiles(m_beg);
+        for (int64_t mb = m_beg; mb < m_end; mb += BK) {
+            store_tiles();
+            __syncthreads();
+            if (mb + BK < m_end) load_tiles(mb + BK);
+            mma_step<TM, TN, false, false, PITCH_A, PITCH_B>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
+            __syncthreads();
+        }
+    }
+
+    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + l31;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (c < p.Cin) out[(int64_t)c * p.Cout + n] = acc[tm][tn][r];
+            }
+    }
+}
+
+// dW[widx[ti]][c][n] = sum_split part[split][ti][c][n]  (fixed order: deterministic); dead taps stay 0.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int splits, int ntaps, int64_t cn,
+                                                          ConvTaps taps, float* dw)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)ntaps * cn) return;
+    const int ti = (int)(i / cn);
+    const int64_t e = i - (int64_t)ti * cn;
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += part[((int64_t)k * ntaps + ti) * cn + e];
+    dw[(int64_t)taps.widx[ti] * cn + e] = s;
+}
+
+// dbias[n] = sum_m dy[m][n]   (one block per 64 channels, fixed-order tree: deterministic)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dy, int64_t M, int C, int64_t ld, float* dbias)
+{
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < C)
+        for (int64_t m = ry; m < M; m += 4) s += dy[m * ld + c];
+    sh[ry][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) dbias[c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------
+// live taps for forward-style indexing: input row = oh*stride + (th*dil - pad)
+static void build_taps(ConvTaps& t, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho, int Wo, bool flip)
+{
+    t.n = 0;
+    for (int th = 0; th < kh; ++th)
+        for (int tw = 0; tw < kw; ++tw) {
+            const int dh = flip ? pad - th * dil : th * dil - pad;
+            const int dw = flip ? pad - tw * dil : tw * dil - pad;
+            // any output row oh in [0,Ho) with 0 <= oh*stride + dh < H ?
+            bool okh = false, okw = false;
+            for (int oh = 0; oh < Ho && !okh; ++oh) okh = (unsigned)(oh * stride + dh) < (unsigned)H;
+            for (int ow = 0; ow < Wo && !okw; ++ow) okw = (unsigned)(ow * stride + dw) < (unsigned)W;
+            if (!(okh && okw)) continue;
+            t.dh[t.n] = (short)dh;
+            t.dw[t.n] = (short)dw;
+            t.widx[t.n] = (unsigned char)(th * kw + tw);
+            ++t.n;
+        }
+}
+
+template <bool BWD>
+static int launch_conv(const ConvParams& p, hipStream_t st)
+{
+    const int64_t mt128 = cdiv(p.M, 128), mt64 = cdiv(p.M, 64);
+    if (p.Cn <= 32) {
+        dim3 grid((unsigned)mt128, 1);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD>), grid, dim3(kThreads), 0, st, p);
+    } else if (p.Cn > 64 && mt128 * cdiv(p.Cn, 128) >= 384) {
+        dim3 grid((unsigned)mt128, (unsigned)cdiv(p.Cn, 128));
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD>), grid, dim3(kThreads), 0, st, p);
+    } else {
+        dim3 grid((unsigned)mt64, (unsigned)cdiv(p.Cn, 64));
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD>), grid, dim3(kThreads), 0, st, p);
+    }
+    return check_launch("conv_igemm_kernel");
+}
+
+static int conv_common_check(const void* a, const void* b, const void* c, int B, int H, int W, int Cin, int Cout,
+                             int kh, int kw, int stride, int pad, int dil)
+{
+    if (!a || !b || !c) return fail(PP_ERR_BAD_ARG, "conv: null pointer");
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(PP_ERR_BAD_ARG, "conv: bad shape");
+    if (kh < 1 || kw < 1 || kh * kw > kMaxTaps) return fail(PP_ERR_UNSUPPORTED, "conv: kernel %dx%d unsupported", kh, kw);
+    if (stride < 1 || dil < 1 || pad < 0) return fail(PP_ERR_BAD_ARG, "conv: bad stride/dilation/padding");
+    return PP_OK;
+}
+
+static inline int out_size(int in, int k, int stride, int pad, int dil) { return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1; }
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" {
+
+int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, pp_stream_t stream)
+{
+    if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
+    if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return fail(PP_ERR_BAD_ARG, "conv fwd: empty output");
+    ConvParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldx = ldx; p.ldy = ldy;
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Ck = Cin; p.Cn = Cout; p.Cin = Cin; p.Cout = Cout;
+    p.stride = stride; p.M = (int64_t)B * Ho * Wo;
+    build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+    if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
+    return launch_conv<false>(p, as_stream(stream));
+}
+
+int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin,
+                       pp_stream_t stream)
+{
+    if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
+    if (stride != 1) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: stride %d (only stride 1 convolutions need dX here)", stride);
+    if (Ho != out_size(H, kh, 1, pad, dil) || Wo != out_size(W, kw, 1, pad, dil))
+        return fail(PP_ERR_BAD_ARG, "conv bwd_data: inconsistent sizes");
+    ConvParams p{};
+    p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.ldx = lddy; p.ldy = lddx;
+    p.B = B; p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.Ck = Cout; p.Cn = Cin; p.Cin = Cin; p.Cout = Cout;
+    p.stride = 1; p.M = (int64_t)B * H * W;
+    // dX(ih,iw) = sum_t dY(ih + pad - th*dil, iw + pad - tw*dil) W[t]
+    build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true);
+    if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv bwd_data: no live tap");
+    return launch_conv<true>(p, as_stream(stream));
+}
+
+size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                            int dil)
+{
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    const int64_t M = (int64_t)B * Ho * Wo;
+    // splits chosen in pp_conv2d_bwd_weight never exceed 64
+    (void)M;
+    return align_up((size_t)64 * kh * kw * Cin * Cout * 4, 256);
+}
+
+int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                         int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                         void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (int rc = conv_common_check(x, dy, dw, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    hipStream_t st = as_stream(stream);
+    WgradParams p{};
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout; p.stride = stride;
+    p.M = (int64_t)B * Ho * Wo;
+    build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+    const bool big = Cin > 64 && Cout > 64;
+    const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+    const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
+    int64_t splits = cdiv(1024, tiles);
+    const int64_t max_by_m = cdiv(p.M, 256);       // at least 256 pixels per split
+    if (splits > max_by_m) splits = max_by_m;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    p.m_per_split = cdiv(cdiv(p.M, splits), BK) * BK;
+    splits = cdiv(p.M, p.m_per_split);
+    const size_t need = (size_t)splits * p.taps.n * Cin * Cout * 4;
+    if (!workspace || ws_bytes < need) return fail(PP_ERR_WORKSPACE, "conv bwd_weight: workspace %zu < %zu", ws_bytes, need);
+    p.part = reinterpret_cast<float*>(workspace);
+    if (p.taps.n != kh * kw)
+        if (hipMemsetAsync(dw, 0, (size_t)kh * kw * Cin * Cout * 4, st) != hipSuccess)
+            return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
+    dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
+    if (big) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(kThreads), 0, st, p);
+    else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(kThreads), 0, st, p);
+    if (int rc = check_launch("conv_wgrad_kernel")) return rc;
+    const int64_t cn = (int64_t)Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(p.taps.n * cn, 256)), dim3(256), 0, st, p.part,
+                       (int)splits, p.taps.n, cn, p.taps, dw);
+    if (int rc = check_launch("wgrad_reduce_kernel")) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)cdiv(Cout, 64)), dim3(256), 0, st, dy, p.M, Cout, lddy, dbias);
+        if (int rc = check_launch("bias_grad_kernel")) return rc;
+    }
+    return PP_OK;
+}
+
+}  // extern "C"

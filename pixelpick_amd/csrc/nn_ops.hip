@@ -1,0 +1,998 @@
+// nn_ops.hip — bandwidth-bound layers of the PixelPick networks for gfx950, NHWC, fp32.
+//
+// Everything here is HBM-bound: 16 B/lane coalesced accesses along the channel axis, one pass per
+// tensor, deterministic two-stage reductions (no float atomics), no MFMA.
+//
+//   BatchNorm2d (train + eval)   networks/mobilenet_v2.py:10,39-57; aspp.py:11,56,59; deeplab.py:25;
+//                                decoders.py:108,112                                 
+//   ReLU / ReLU6 / residual add  mobilenet_v2.py:11,40,50,54,62-63                   (N5)
+//   depthwise 3x3 conv           mobilenet_v2.py:38,52 (stride 1/2, dilation, "valid" on the padded map) (N4)
+//   fixed_padding                mobilenet_v2.py:15-21                               (N2)
+//   bilinear interpolate         deeplab.py:49,55; aspp.py:70; decoders.py:82,101    (N11, N14)
+//   AdaptiveAvgPool2d(1)         aspp.py:54                                          (N8)
+//   Dropout                      aspp.py:61; decoders.py:110,114                     (own counter-based RNG)
+//   cross_entropy(ignore_index)  model.py:116                                        (L2)
+//   Adam step                    utils/utils.py:125-141 (torch.optim.Adam semantics) (L4)
+#include "pp_common.h"
+
+namespace pp {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float act_fwd(float z, int act)
+{
+    if (act == 1) return fmaxf(z, 0.0f);
+    if (act == 2) return fminf(fmaxf(z, 0.0f), 6.0f);
+    return z;
+}
+// derivative mask from the activation OUTPUT y (relu: y>0, relu6: 0<y<6)
+__device__ __forceinline__ float act_mask(float y, int act)
+{
+    if (act == 1) return y > 0.0f ? 1.0f : 0.0f;
+    if (act == 2) return (y > 0.0f && y < 6.0f) ? 1.0f : 0.0f;
+    return 1.0f;
+}
+
+// ================================================================================================
+// Column reductions over an [M, C] matrix (pixel stride ld): partial sums per row-block, then a finalize.
+// Thread mapping: float4 column q = t % cq_blk, row lane ry = t / cq_blk (consecutive threads walk the
+// channel axis: coalesced for every C).  MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g*xhat) for BN backward.
+// ================================================================================================
+struct ColReduceGeom {
+    int cq;            // C/4
+    int cq_blk;        // float4 columns per block (<= 256)
+    int rows_per_pass; // 256 / cq_blk
+    int64_t rows_per_block;
+    int nblk_rows;     // grid.x
+    int nblk_cols;     // grid.y
+};
+
+static ColReduceGeom col_geom(int64_t M, int C)
+{
+    ColReduceGeom g;
+    g.cq = C / 4;
+    g.cq_blk = g.cq < kT ? g.cq : kT;
+    g.rows_per_pass = kT / g.cq_blk;
+    g.nblk_cols = (int)cdiv(g.cq, g.cq_blk);
+    int64_t want_blocks = 1024 / g.nblk_cols;
+    if (want_blocks < 1) want_blocks = 1;
+    int64_t rpb = cdiv(cdiv(M, want_blocks), g.rows_per_pass) * g.rows_per_pass;
+    if (rpb < g.rows_per_pass * 4) rpb = g.rows_per_pass * 4;
+    g.rows_per_block = rpb;
+    g.nblk_rows = (int)cdiv(M, rpb);
+    return g;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kT) void col_reduce_kernel(const float* x, const float* dy, const float* yact, int act,
+                                                       const float* mean, const float* invstd, int64_t M, int C,
+                                                       int64_t ldx, int64_t lddy, int64_t ldya, ColReduceGeom g,
+                                                       float* part /*[nblk_rows][2][C]*/)
+{
+    __shared__ float4 sh[2][kT];
+    const int t = threadIdx.x;
+    const int ql = t % g.cq_blk, ry = t / g.cq_blk;
+    const int q = blockIdx.y * g.cq_blk + ql;
+    const bool active = ry < g.rows_per_pass && q < g.cq;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (active) {
+        float4 mu = s0, is = s0;
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const float4*>(mean + q * 4);
+            is = *reinterpret_cast<const float4*>(invstd + q * 4);
+        }
+        const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
+        const int64_t r1 = r0 + g.rows_per_block < M ? r0 + g.rows_per_block : M;
+        for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
+            if (MODE == 0) {
+                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+                s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y);
+                s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
+            } else {
+                float4 gg = *reinterpret_cast<const float4*>(dy + r * lddy + q * 4);
+                if (act != 0) {
+                    const float4 ya = *reinterpret_cast<const float4*>(yact + r * ldya + q * 4);
+                    gg.x *= act_mask(ya.x, act); gg.y *= act_mask(ya.y, act);
+                    gg.z *= act_mask(ya.z, act); gg.w *= act_mask(ya.w, act);
+                }
+                s0.x += gg.x; s0.y += gg.y; s0.z += gg.z; s0.w += gg.w;
+                s1.x = fmaf(gg.x, (v.x - mu.x) * is.x, s1.x); s1.y = fmaf(gg.y, (v.y - mu.y) * is.y, s1.y);
+                s1.z = fmaf(gg.z, (v.z - mu.z) * is.z, s1.z); s1.w = fmaf(gg.w, (v.w - mu.w) * is.w, s1.w);
+            }
+        }
+    }
+    sh[0][t] = s0;
+    sh[1][t] = s1;
+    __syncthreads();
+    if (ry == 0 && q < g.cq) {
+        for (int k = 1; k < g.rows_per_pass; ++k) {
+            const float4 a = sh[0][k * g.cq_blk + ql], b = sh[1][k * g.cq_blk + ql];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        float* p0 = part + ((int64_t)blockIdx.x * 2 + 0) * C + q * 4;
+        float* p1 = part + ((int64_t)blockIdx.x * 2 + 1) * C + q * 4;
+        *reinterpret_cast<float4*>(p0) = s0;
+        *reinterpret_cast<float4*>(p1) = s1;
+    }
+}
+
+// BN forward finalize: batch mean / biased var (fp64 combine), running-stat update (momentum, unbiased var),
+// scale = gamma*invstd, shift = beta - mean*scale.   nn.BatchNorm2d training semantics.
+__global__ __launch_bounds__(kT) void bn_finalize_kernel(const float* part, int nblk, int C, double count,
+                                                        const float* gamma, const float* beta, float eps,
+                                                        float momentum, float* running_mean, float* running_var,
+                                                        float* mean, float* invstd, float* scale, float* shift)
+{
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((int64_t)b * 2 + 0) * C + c];
+        ss += (double)part[((int64_t)b * 2 + 1) * C + c];
+    }
+    const double mu = s / count;
+    double var = ss / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval-mode BN: scale/shift from running statistics
+__global__ __launch_bounds__(kT) void bn_eval_affine_kernel(int C, const float* gamma, const float* beta,
+                                                           const float* running_mean, const float* running_var,
+                                                           float eps, float* scale, float* shift)
+{
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// y = act(x*scale + shift [+ res]) ; float4 along channels
+__global__ __launch_bounds__(kT) void bn_apply_kernel(const float* x, int64_t ldx, const float* scale,
+                                                     const float* shift, const float* res, int64_t ldr, int act,
+                                                     float* y, int64_t ldy, int64_t M, int cq)
+{
+    const int64_t total = M * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t r = e / cq;
+        const int q = (int)(e - r * cq);
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
+        const float4 sf = *reinterpret_cast<const float4*>(shift + q * 4);
+        float4 o;
+        o.x = fmaf(v.x, sc.x, sf.x); o.y = fmaf(v.y, sc.y, sf.y); o.z = fmaf(v.z, sc.z, sf.z); o.w = fmaf(v.w, sc.w, sf.w);
+        if (res) {
+            const float4 rr = *reinterpret_cast<const float4*>(res + r * ldr + q * 4);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+        *reinterpret_cast<float4*>(y + r * ldy + q * 4) = o;
+    }
+}
+
+// BN backward finalize: dbeta = sum g, dgamma = sum g*xhat (fixed-order fp64 combine)
+__global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta)
+{
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((int64_t)b * 2 + 0) * C + c];
+        ss += (double)part[((int64_t)b * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)ss;
+}
+
+// dx = gamma*invstd * (g - dbeta/N - xhat*dgamma/N),  g = dy * act'(y).   eval_mode: dx = g*gamma*invstd.
+// dres (optional) receives g (gradient of the residual branch, added before the activation).
+__global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* x, int64_t ldx, const float* dy, int64_t lddy,
+                                                         const float* yact, int64_t ldya, int act, const float* mean,
+                                                         const float* invstd, const float* gamma, const float* dgamma,
+                                                         const float* dbeta, float inv_count, float* dx, int64_t lddx,
+                                                         float* dres, int64_t lddr, int64_t M, int cq)
+{
+    const int64_t total = M * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t r = e / cq;
+        const int q = (int)(e - r * cq);
+        float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + q * 4);
+        if (act != 0) {
+            const float4 ya = *reinterpret_cast<const float4*>(yact + r * ldya + q * 4);
+            g.x *= act_mask(ya.x, act); g.y *= act_mask(ya.y, act); g.z *= act_mask(ya.z, act); g.w *= act_mask(ya.w, act);
+        }
+        if (dres) *reinterpret_cast<float4*>(dres + r * lddr + q * 4) = g;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + q * 4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + q * 4);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + q * 4);
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + q * 4);
+        const float4 db = *reinterpret_cast<const float4*>(dbeta + q * 4);
+        float4 o;
+        o.x = ga.x * is.x * (g.x - db.x * inv_count - (v.x - mu.x) * is.x * dg.x * inv_count);
+        o.y = ga.y * is.y * (g.y - db.y * inv_count - (v.y - mu.y) * is.y * dg.y * inv_count);
+        o.z = ga.z * is.z * (g.z - db.z * inv_count - (v.z - mu.z) * is.z * dg.z * inv_count);
+        o.w = ga.w * is.w * (g.w - db.w * inv_count - (v.w - mu.w) * is.w * dg.w * inv_count);
+        *reinterpret_cast<float4*>(dx + r * lddx + q * 4) = o;
+    }
+}
+
+// ================================================================================================
+// depthwise 3x3 (weights [3][3][C]); generic stride / dilation / padding.
+// ================================================================================================
+__global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
+                                                       const float* w, int stride, int pad, int dil, float* y,
+                                                       int64_t ldy, int Ho, int Wo)
+{
+    const int C = cq * 4;
+    const int64_t total = (int64_t)B * Ho * Wo * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const int ih = oh * stride - pad + th * dil;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int iw = ow * stride - pad + tw * dil;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
+                const float4 ww = *reinterpret_cast<const float4*>(w + (th * 3 + tw) * C + q * 4);
+                acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
+                acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(y + (((int64_t)b * Ho + oh) * Wo + ow) * ldy + q * 4) = acc;
+    }
+}
+
+// dx(ih,iw) = sum_t dy((ih + pad - th*dil)/stride, ...) * w[t]  where divisible
+__global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq,
+                                                            const float* w, int stride, int pad, int dil, float* dx,
+                                                            int64_t lddx, int H, int W)
+{
+    const int C = cq * 4;
+    const int64_t total = (int64_t)B * H * W * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const int nh = ih + pad - th * dil;
+            if (nh < 0 || nh % stride != 0) continue;
+            const int oh = nh / stride;
+            if (oh >= Ho) continue;
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int nw = iw + pad - tw * dil;
+                if (nw < 0 || nw % stride != 0) continue;
+                const int ow = nw / stride;
+                if (ow >= Wo) continue;
+                const float4 g = *reinterpret_cast<const float4*>(dy + (((int64_t)b * Ho + oh) * Wo + ow) * lddy + q * 4);
+                const float4 ww = *reinterpret_cast<const float4*>(w + (th * 3 + tw) * C + q * 4);
+                acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
+                acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4) = acc;
+    }
+}
+
+// dw[t][c] = sum_{b,oh,ow} x[..]*dy[..]: per row-block partials [nblk][9][C], then fixed-order finalize
+__global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
+                                                              const float* dy, int64_t lddy, int Ho, int Wo, int stride,
+                                                              int pad, int dil, ColReduceGeom g, float* part)
+{
+    __shared__ float4 sh[kT];
+    const int C = cq * 4;
+    const int t = threadIdx.x;
+    const int ql = t % g.cq_blk, ry = t / g.cq_blk;
+    const int q = blockIdx.y * g.cq_blk + ql;
+    const bool active = ry < g.rows_per_pass && q < cq;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
+        const int64_t r1 = r0 + g.rows_per_block < M ? r0 + g.rows_per_block : M;
+        for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
+            const int ow = (int)(r % Wo);
+            const int64_t tt = r / Wo;
+            const int oh = (int)(tt % Ho);
+            const int b = (int)(tt / Ho);
+            const float4 gg = *reinterpret_cast<const float4*>(dy + r * lddy + q * 4);
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                const int ih = oh * stride - pad + th * dil;
+                if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                    const int iw = ow * stride - pad + tw * dil;
+                    if ((unsigned)iw >= (unsigned)W) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
+                    float4& a = acc[th * 3 + tw];
+                    a.x = fmaf(v.x, gg.x, a.x); a.y = fmaf(v.y, gg.y, a.y);
+                    a.z = fmaf(v.z, gg.z, a.z); a.w = fmaf(v.w, gg.w, a.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        sh[t] = acc[k];
+        __syncthreads();
+        if (ry == 0 && q < cq) {
+            float4 s = acc[k];
+            for (int j = 1; j < g.rows_per_pass; ++j) {
+                const float4 a = sh[j * g.cq_blk + ql];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * 9 + k) * C + q * 4) = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kT) void sum_partials_kernel(const float* part, int nblk, int64_t n, float* out, float mul)
+{
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * n + i];
+    out[i] = (float)(s * (double)mul);
+}
+
+// ================================================================================================
+// zero padding / cropping (mobilenet_v2.py:15-21 fixed_padding and its adjoint)
+// ================================================================================================
+__global__ __launch_bounds__(kT) void pad_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq, int pt, int pl,
+                                                float* y, int64_t ldy, int Hp, int Wp)
+{
+    const int64_t total = (int64_t)B * Hp * Wp * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int pw = (int)(t % Wp); t /= Wp;
+        const int ph = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const int ih = ph - pt, iw = pw - pl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
+        *reinterpret_cast<float4*>(y + (((int64_t)b * Hp + ph) * Wp + pw) * ldy + q * 4) = v;
+    }
+}
+
+// y = crop(x_padded) [+ add]
+__global__ __launch_bounds__(kT) void crop_kernel(const float* xp, int64_t ldxp, int B, int Hp, int Wp, int cq, int pt, int pl,
+                                                 const float* add, int64_t ldadd, float* y, int64_t ldy, int H, int W)
+{
+    const int64_t total = (int64_t)B * H * W * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        float4 v = *reinterpret_cast<const float4*>(xp + (((int64_t)b * Hp + ih + pt) * Wp + iw + pl) * ldxp + q * 4);
+        const int64_t r = ((int64_t)b * H + ih) * W + iw;
+        if (add) {
+            const float4 a = *reinterpret_cast<const float4*>(add + r * ldadd + q * 4);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(y + r * ldy + q * 4) = v;
+    }
+}
+
+// ================================================================================================
+// bilinear interpolation, torch semantics (upsample_bilinear2d): source index computed in fp32 as
+//   align_corners:  src = scale*dst,               scale = (in-1)/(out-1)   (0 if out == 1)
+//   otherwise:      src = max(scale*(dst+0.5)-0.5, 0),  scale = in/out (or 1/scale_factor)
+// ================================================================================================
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_src(int dst, int in, float scale, int align)
+{
+    float src = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.0f);
+    Lerp L;
+    L.i0 = (int)src;
+    if (L.i0 > in - 1) L.i0 = in - 1;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.0f - L.l1;
+    return L;
+}
+
+// NHWC -> NHWC (channel slices allowed) or NHWC -> NCHW (out_nchw: y is [B,C,Ho,Wo] contiguous)
+template <bool OUT_NCHW>
+__global__ __launch_bounds__(kT) void bilinear_fwd_kernel(const float* x, int64_t ldx, int B, int H, int W, int C,
+                                                         float* y, int64_t ldy, int Ho, int Wo, float sh, float sw,
+                                                         int align)
+{
+    if constexpr (!OUT_NCHW) {
+        const int cq = C / 4;
+        const int64_t total = (int64_t)B * Ho * Wo * cq;
+        for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+            const int q = (int)(e % cq);
+            int64_t t = e / cq;
+            const int ow = (int)(t % Wo); t /= Wo;
+            const int oh = (int)(t % Ho);
+            const int b = (int)(t / Ho);
+            const Lerp lh = lerp_src(oh, H, sh, align), lw = lerp_src(ow, W, sw, align);
+            const float* base = x + (int64_t)b * H * W * ldx + q * 4;
+            const float4 v00 = *reinterpret_cast<const float4*>(base + ((int64_t)lh.i0 * W + lw.i0) * ldx);
+            const float4 v01 = *reinterpret_cast<const float4*>(base + ((int64_t)lh.i0 * W + lw.i1) * ldx);
+            const float4 v10 = *reinterpret_cast<const float4*>(base + ((int64_t)lh.i1 * W + lw.i0) * ldx);
+            const float4 v11 = *reinterpret_cast<const float4*>(base + ((int64_t)lh.i1 * W + lw.i1) * ldx);
+            float4 o;
+            o.x = lh.l0 * (lw.l0 * v00.x + lw.l1 * v01.x) + lh.l1 * (lw.l0 * v10.x + lw.l1 * v11.x);
+            o.y = lh.l0 * (lw.l0 * v00.y + lw.l1 * v01.y) + lh.l1 * (lw.l0 * v10.y + lw.l1 * v11.y);
+            o.z = lh.l0 * (lw.l0 * v00.z + lw.l1 * v01.z) + lh.l1 * (lw.l0 * v10.z + lw.l1 * v11.z);
+            o.w = lh.l0 * (lw.l0 * v00.w + lw.l1 * v01.w) + lh.l1 * (lw.l0 * v10.w + lw.l1 * v11.w);
+            *reinterpret_cast<float4*>(y + (((int64_t)b * Ho + oh) * Wo + ow) * ldy + q * 4) = o;
+        }
+    } else {
+        // one thread per output pixel (b,c,oh,ow): consecutive threads walk ow -> coalesced NCHW stores;
+        // the 4 source pixels are shared by ~scale^2 neighbours (L1/L2 hits)
+        const int64_t total = (int64_t)B * C * Ho * Wo;
+        for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+            const int ow = (int)(e % Wo);
+            int64_t t = e / Wo;
+            const int oh = (int)(t % Ho); t /= Ho;
+            const int c = (int)(t % C);
+            const int b = (int)(t / C);
+            const Lerp lh = lerp_src(oh, H, sh, align), lw = lerp_src(ow, W, sw, align);
+            const float* base = x + (int64_t)b * H * W * ldx + c;
+            const float v00 = base[((int64_t)lh.i0 * W + lw.i0) * ldx], v01 = base[((int64_t)lh.i0 * W + lw.i1) * ldx];
+            const float v10 = base[((int64_t)lh.i1 * W + lw.i0) * ldx], v11 = base[((int64_t)lh.i1 * W + lw.i1) * ldx];
+            y[e] = lh.l0 * (lw.l0 * v00 + lw.l1 * v01) + lh.l1 * (lw.l0 * v10 + lw.l1 * v11);
+        }
+    }
+}
+
+// Backward as a GATHER (deterministic, no atomics): input pixel (ih,iw) collects from every output pixel
+// whose i0 or i1 equals it.  Candidate output rows: a conservative window around ih/scale.
+__device__ __forceinline__ void out_window(int i, int in, int out, float scale, int align, int& lo, int& hi)
+{
+    // outputs o with i0(o) in {i-1, i}:  src in [i-1, i+1)
+    float inv = scale > 0.0f ? 1.0f / scale : 0.0f;
+    float a = ((float)i - 1.0f) * inv, b = ((float)i + 1.0f) * inv;
+    if (!align) { a -= 0.5f; b += 0.5f; }
+    lo = (int)floorf(a) - 1;
+    hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+    if (scale == 0.0f) { lo = 0; hi = out - 1; }
+}
+
+template <bool DY_NCHW>
+__global__ __launch_bounds__(kT) void bilinear_bwd_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C,
+                                                         float* dx, int64_t lddx, int H, int W, float sh, float sw,
+                                                         int align)
+{
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int c = (int)(e % C);
+        int64_t t = e / C;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        int h0, h1, w0, w1;
+        out_window(ih, H, Ho, sh, align, h0, h1);
+        out_window(iw, W, Wo, sw, align, w0, w1);
+        float acc = 0.0f;
+        for (int oh = h0; oh <= h1; ++oh) {
+            const Lerp lh = lerp_src(oh, H, sh, align);
+            float wh = 0.0f;
+            if (lh.i0 == ih) wh += lh.l0;
+            if (lh.i1 == ih) wh += lh.l1;
+            if (wh == 0.0f) continue;
+            float row = 0.0f;
+            for (int ow = w0; ow <= w1; ++ow) {
+                const Lerp lw = lerp_src(ow, W, sw, align);
+                float ww = 0.0f;
+                if (lw.i0 == iw) ww += lw.l0;
+                if (lw.i1 == iw) ww += lw.l1;
+                if (ww == 0.0f) continue;
+                const float g = DY_NCHW ? dy[(((int64_t)b * C + c) * Ho + oh) * Wo + ow]
+                                        : dy[(((int64_t)b * Ho + oh) * Wo + ow) * lddy + c];
+                row = fmaf(ww, g, row);
+            }
+            acc = fmaf(wh, row, acc);
+        }
+        dx[(((int64_t)b * H + ih) * W + iw) * lddx + c] = acc;
+    }
+}
+
+// ================================================================================================
+// per-image spatial mean (AdaptiveAvgPool2d(1)) / column sum, and its adjoint (broadcast)
+// ================================================================================================
+// out[b][c] = mul * sum_p x[b][p][c]   ; one block per (image, 64-channel group), 4 row lanes
+__global__ __launch_bounds__(kT) void image_colsum_kernel(const float* x, int64_t ldx, int64_t P, int C, float mul,
+                                                         float* out, int64_t ldo)
+{
+    __shared__ float sh[4][64];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < C) {
+        const float* base = x + (int64_t)b * P * ldx + c;
+        for (int64_t p = ry; p < P; p += 4) s += base[p * ldx];
+    }
+    sh[ry][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const int l = threadIdx.x;
+        out[(int64_t)b * ldo + c] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) * mul;
+    }
+}
+
+// y[b][p][c] = mul * v[b][c]
+__global__ __launch_bounds__(kT) void image_broadcast_kernel(const float* v, int64_t ldv, int B, int64_t P, int cq, float mul,
+                                                            float* y, int64_t ldy)
+{
+    const int64_t total = (int64_t)B * P * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        const int64_t r = e / cq;
+        const int b = (int)(r / P);
+        float4 a = *reinterpret_cast<const float4*>(v + (int64_t)b * ldv + q * 4);
+        a.x *= mul; a.y *= mul; a.z *= mul; a.w *= mul;
+        *reinterpret_cast<float4*>(y + r * ldy + q * 4) = a;
+    }
+}
+
+// ================================================================================================
+// dropout: counter-based RNG (SplitMix64-style hash of (seed, flat element index)); the mask is regenerated
+// in the backward pass from the same seed, never stored.
+// ================================================================================================
+__device__ __forceinline__ uint32_t hash_rng(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__global__ __launch_bounds__(kT) void dropout_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C,
+                                                    float p, float inv_keep, uint64_t seed)
+{
+    const int64_t total = M * C;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t r = e / C;
+        const int c = (int)(e - r * C);
+        const float u = (float)(hash_rng(seed, (uint64_t)e) >> 8) * (1.0f / 16777216.0f);
+        y[r * ldy + c] = u >= p ? x[r * ldx + c] * inv_keep : 0.0f;
+    }
+}
+
+// ================================================================================================
+// cross entropy with ignore_index on NCHW logits (model.py:116): loss = mean over labelled pixels of
+// (logsumexp - x[target]); dlogits = (softmax - onehot)/N at labelled pixels, 0 elsewhere.
+// ================================================================================================
+__global__ __launch_bounds__(kT) void ce_partial_kernel(const float* logits, const int64_t* target, int B, int C, int64_t HW,
+                                                       int64_t sB, int64_t sC, int ignore_index, float* part /*[nblk][2]*/)
+{
+    __shared__ float sh[2][kT];
+    float ls = 0.0f, cnt = 0.0f;
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t tg = target[e];
+        if (tg == ignore_index) continue;
+        const int64_t b = e / HW, pix = e - b * HW;
+        const float* px = logits + b * sB + pix;
+        float m = px[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, px[c * sC]);
+        float S = 0.0f;
+        for (int c = 0; c < C; ++c) S += expf(px[c * sC] - m);
+        const float xt = (tg >= 0 && tg < C) ? px[tg * sC] : 0.0f;
+        ls += (m + logf(S)) - xt;
+        cnt += 1.0f;
+    }
+    sh[0][threadIdx.x] = ls;
+    sh[1][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = kT / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = sh[0][0]; part[blockIdx.x * 2 + 1] = sh[1][0]; }
+}
+
+__global__ void ce_finalize_kernel(const float* part, int nblk, float* loss, float* count)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0, n = 0.0;
+        for (int b = 0; b < nblk; ++b) { s += (double)part[b * 2]; n += (double)part[b * 2 + 1]; }
+        *count = (float)n;
+        *loss = (float)(s / n);  // 0/0 = NaN when no pixel is labelled, like F.cross_entropy
+    }
+}
+
+// dlogits (NCHW contiguous) = grad_scale * (softmax - onehot) / N at labelled pixels, 0 elsewhere
+__global__ __launch_bounds__(kT) void ce_bwd_kernel(const float* logits, const int64_t* target, int B, int C, int64_t HW,
+                                                   int64_t sB, int64_t sC, int ignore_index, const float* count,
+                                                   const float* grad_out, float* dlogits)
+{
+    const int64_t total = (int64_t)B * HW;
+    const float gs = (grad_out ? *grad_out : 1.0f) / *count;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t tg = target[e];
+        const int64_t b = e / HW, pix = e - b * HW;
+        float* dst = dlogits + (b * C) * HW + pix;
+        if (tg == ignore_index) {
+            for (int c = 0; c < C; ++c) dst[c * HW] = 0.0f;
+            continue;
+        }
+        const float* px = logits + b * sB + pix;
+        float m = px[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, px[c * sC]);
+        float S = 0.0f;
+        for (int c = 0; c < C; ++c) S += expf(px[c * sC] - m);
+        const float inv = 1.0f / S;
+        for (int c = 0; c < C; ++c) {
+            const float pr = expf(px[c * sC] - m) * inv;
+            dst[c * HW] = gs * (pr - (c == tg ? 1.0f : 0.0f));
+        }
+    }
+}
+
+// ================================================================================================
+// Adam on flat buffers, torch.optim.Adam semantics (L2 weight decay, bias correction), two lr segments
+// (utils/utils.py:125-141: backbone/encoder at lr/10).
+// ================================================================================================
+__global__ __launch_bounds__(kT) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_split,
+                                                 float lr_a, float lr_b, float beta1, float beta2, float eps, float wd,
+                                                 float bc1, float bc2_sqrt, float grad_scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) {
+        const float lr = i < n_split ? lr_a : lr_b;
+        float grad = g[i] * grad_scale;
+        const float par = p[i];
+        grad = fmaf(wd, par, grad);
+        const float mm = m[i] + (grad - m[i]) * (1.0f - beta1);
+        const float vv = fmaf(grad * grad, 1.0f - beta2, v[i] * beta2);
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = par - (lr / bc1) * (mm / denom);
+    }
+}
+
+// NCHW -> NHWC (network input, 3 channels) ; generic small-C transpose
+__global__ __launch_bounds__(kT) void nchw_to_nhwc_kernel(const float* x, int B, int C, int64_t HW, float* y, int64_t ldy)
+{
+    const int64_t total = (int64_t)B * HW * C;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int c = (int)(e % C);
+        const int64_t r = e / C;
+        const int64_t b = r / HW, pix = r - b * HW;
+        y[r * ldy + c] = x[(b * C + c) * HW + pix];
+    }
+}
+
+// y = a + b  (gradient accumulation where a tensor has several consumers)
+__global__ __launch_bounds__(kT) void add2d_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, float* y,
+                                                  int64_t ldy, int64_t M, int C)
+{
+    const int64_t total = M * C;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t r = e / C;
+        const int c = (int)(e - r * C);
+        y[r * ldy + c] = a[r * lda + c] + b[r * ldb + c];
+    }
+}
+
+static inline unsigned grid_for(int64_t total)
+{
+    int64_t b = cdiv(total, kT);
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static int need_c4(int C, const char* what)
+{
+    if (C < 4 || C % 4 != 0) return fail(PP_ERR_UNSUPPORTED, "%s: C=%d must be a positive multiple of 4", what, C);
+    return PP_OK;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" {
+
+// ---- batch norm -----------------------------------------------------------------------------------
+size_t pp_colreduce_workspace_bytes(int64_t M, int C)
+{
+    if (M < 1 || C < 4) return 256;
+    ColReduceGeom g = col_geom(M, C);
+    size_t a = (size_t)g.nblk_rows * 2 * C * 4;
+    size_t b = (size_t)g.nblk_rows * 9 * C * 4;  // depthwise weight-gradient partials share the geometry
+    return align_up(a > b ? a : b, 256);
+}
+
+int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                    float* shift, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift) return fail(PP_ERR_BAD_ARG, "bn_train_fwd: null");
+    if (int rc = need_c4(C, "bn_train_fwd")) return rc;
+    if (M < 1 || ldx % 4 != 0) return fail(PP_ERR_BAD_ARG, "bn_train_fwd: bad M/ld");
+    ColReduceGeom g = col_geom(M, C);
+    if (!workspace || ws_bytes < (size_t)g.nblk_rows * 2 * C * 4) return fail(PP_ERR_WORKSPACE, "bn_train_fwd: workspace");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, (const float*)nullptr,
+                       (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, M, C, ldx, (int64_t)0,
+                       (int64_t)0, g, part);
+    if (int rc = check_launch("col_reduce_kernel<0>")) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, kT)), dim3(kT), 0, st, part, g.nblk_rows, C, (double)M,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    return check_launch("bn_finalize_kernel");
+}
+
+int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, pp_stream_t stream)
+{
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return fail(PP_ERR_BAD_ARG, "bn_eval_affine: null");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)cdiv(C, kT)), dim3(kT), 0, as_stream(stream), C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    return check_launch("bn_eval_affine_kernel");
+}
+
+int pp_scale_shift_act(const float* x, int64_t ldx, int64_t M, int C, const float* scale, const float* shift,
+                       const float* residual, int64_t ldr, int act, float* y, int64_t ldy, pp_stream_t stream)
+{
+    if (!x || !scale || !shift || !y) return fail(PP_ERR_BAD_ARG, "scale_shift_act: null");
+    if (int rc = need_c4(C, "scale_shift_act")) return rc;
+    if (ldx % 4 || ldy % 4 || (residual && ldr % 4)) return fail(PP_ERR_BAD_ARG, "scale_shift_act: ld must be multiples of 4");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(kT), 0, as_stream(stream), x, ldx, scale, shift,
+                       residual, ldr, act, y, ldy, M, C / 4);
+    return check_launch("bn_apply_kernel");
+}
+
+int pp_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+              int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+              float* dx, int64_t lddx, float* dres, int64_t lddr, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!x || !dy || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx) return fail(PP_ERR_BAD_ARG, "bn_bwd: null");
+    if (act != 0 && !y_act) return fail(PP_ERR_BAD_ARG, "bn_bwd: activation output needed for the mask");
+    if (int rc = need_c4(C, "bn_bwd")) return rc;
+    ColReduceGeom g = col_geom(M, C);
+    if (!workspace || ws_bytes < (size_t)g.nblk_rows * 2 * C * 4) return fail(PP_ERR_WORKSPACE, "bn_bwd: workspace");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, dy, y_act, act, mean,
+                       invstd, M, C, ldx, lddy, ldya, g, part);
+    if (int rc = check_launch("col_reduce_kernel<1>")) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, kT)), dim3(kT), 0, st, part, g.nblk_rows, C, dgamma, dbeta);
+    if (int rc = check_launch("bn_bwd_finalize_kernel")) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(kT), 0, st, x, ldx, dy, lddy, y_act, ldya, act,
+                       mean, invstd, gamma, dgamma, dbeta, 1.0f / (float)M, dx, lddx, dres, lddr, M, C / 4);
+    return check_launch("bn_bwd_apply_kernel");
+}
+
+// ---- depthwise 3x3 ---------------------------------------------------------------------------------
+int pp_dwconv3x3_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
+                     float* y, int64_t ldy, pp_stream_t stream)
+{
+    if (!x || !w || !y) return fail(PP_ERR_BAD_ARG, "dwconv fwd: null");
+    if (int rc = need_c4(C, "dwconv fwd")) return rc;
+    const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    if (Ho < 1 || Wo < 1) return fail(PP_ERR_BAD_ARG, "dwconv fwd: empty output");
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(kT), 0, as_stream(stream), x,
+                       ldx, B, H, W, C / 4, w, stride, pad, dil, y, ldy, Ho, Wo);
+    return check_launch("dwconv_fwd_kernel");
+}
+
+int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, int C, const float* w, int stride, int pad,
+                          int dil, float* dx, int64_t lddx, pp_stream_t stream)
+{
+    if (!dy || !w || !dx) return fail(PP_ERR_BAD_ARG, "dwconv bwd_data: null");
+    if (int rc = need_c4(C, "dwconv bwd_data")) return rc;
+    const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(kT), 0, as_stream(stream),
+                       dy, lddy, B, Ho, Wo, C / 4, w, stride, pad, dil, dx, lddx, H, W);
+    return check_launch("dwconv_bwd_data_kernel");
+}
+
+int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
+                            int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!x || !dy || !dw) return fail(PP_ERR_BAD_ARG, "dwconv bwd_weight: null");
+    if (int rc = need_c4(C, "dwconv bwd_weight")) return rc;
+    const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    ColReduceGeom g = col_geom(M, C);
+    if (!workspace || ws_bytes < (size_t)g.nblk_rows * 9 * C * 4) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4, dy,
+                       lddy, Ho, Wo, stride, pad, dil, g, part);
+    if (int rc = check_launch("dwconv_bwd_weight_kernel")) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(9 * C, kT)), dim3(kT), 0, st, part, g.nblk_rows,
+                       (int64_t)9 * C, dw, 1.0f);
+    return check_launch("sum_partials_kernel");
+}
+
+// ---- padding ------------------------------------------------------------------------------------------
+int pp_pad2d(const float* x, int64_t ldx, int B, int H, int W, int C, int pad_top, int pad_left, int Hp, int Wp, float* y,
+             int64_t ldy, pp_stream_t stream)
+{
+    if (!x || !y) return fail(PP_ERR_BAD_ARG, "pad2d: null");
+    if (int rc = need_c4(C, "pad2d")) return rc;
+    hipLaunchKernelGGL(pad_kernel, dim3(grid_for((int64_t)B * Hp * Wp * (C / 4))), dim3(kT), 0, as_stream(stream), x, ldx, B,
+                       H, W, C / 4, pad_top, pad_left, y, ldy, Hp, Wp);
+    return check_launch("pad_kernel");
+}
+
+int pp_crop2d_add(const float* xp, int64_t ldxp, int B, int Hp, int Wp, int C, int pad_top, int pad_left, const float* add,
+                  int64_t ldadd, float* y, int64_t ldy, int H, int W, pp_stream_t stream)
+{
+    if (!xp || !y) return fail(PP_ERR_BAD_ARG, "crop2d_add: null");
+    if (int rc = need_c4(C, "crop2d_add")) return rc;
+    hipLaunchKernelGGL(crop_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(kT), 0, as_stream(stream), xp, ldxp, B,
+                       Hp, Wp, C / 4, pad_top, pad_left, add, ldadd, y, ldy, H, W);
+    return check_launch("crop_kernel");
+}
+
+// ---- bilinear ---------------------------------------------------------------------------------------------
+static void bil_scales(int H, int W, int Ho, int Wo, int align, float scale_h, float scale_w, float& sh, float& sw)
+{
+    if (align) {
+        sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.0f;
+        sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
+    } else {
+        sh = scale_h > 0.0f ? 1.0f / scale_h : (float)H / (float)Ho;
+        sw = scale_w > 0.0f ? 1.0f / scale_w : (float)W / (float)Wo;
+    }
+}
+
+int pp_bilinear_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, float* y, int64_t ldy, int Ho, int Wo,
+                    int align_corners, float scale_h, float scale_w, int out_nchw, pp_stream_t stream)
+{
+    if (!x || !y) return fail(PP_ERR_BAD_ARG, "bilinear fwd: null");
+    float sh, sw;
+    bil_scales(H, W, Ho, Wo, align_corners, scale_h, scale_w, sh, sw);
+    hipStream_t st = as_stream(stream);
+    if (out_nchw) {
+        hipLaunchKernelGGL((bilinear_fwd_kernel<true>), dim3(grid_for((int64_t)B * C * Ho * Wo)), dim3(kT), 0, st, x, ldx, B, H,
+                           W, C, y, ldy, Ho, Wo, sh, sw, align_corners);
+    } else {
+        if (int rc = need_c4(C, "bilinear fwd (NHWC out)")) return rc;
+        hipLaunchKernelGGL((bilinear_fwd_kernel<false>), dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(kT), 0, st, x, ldx,
+                           B, H, W, C, y, ldy, Ho, Wo, sh, sw, align_corners);
+    }
+    return check_launch("bilinear_fwd_kernel");
+}
+
+int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C, float* dx, int64_t lddx, int H, int W,
+                    int align_corners, float scale_h, float scale_w, int dy_nchw, pp_stream_t stream)
+{
+    if (!dy || !dx) return fail(PP_ERR_BAD_ARG, "bilinear bwd: null");
+    float sh, sw;
+    bil_scales(H, W, Ho, Wo, align_corners, scale_h, scale_w, sh, sw);
+    hipStream_t st = as_stream(stream);
+    if (dy_nchw)
+        hipLaunchKernelGGL((bilinear_bwd_kernel<true>), dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, lddy, B, Ho,
+                           Wo, C, dx, lddx, H, W, sh, sw, align_corners);
+    else
+        hipLaunchKernelGGL((bilinear_bwd_kernel<false>), dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, lddy, B, Ho,
+                           Wo, C, dx, lddx, H, W, sh, sw, align_corners);
+    return check_launch("bilinear_bwd_kernel");
+}
+
+// ---- pooling / broadcast -------------------------------------------------------------------------------------
+int pp_image_colsum(const float* x, int64_t ldx, int B, int64_t P, int C, float mul, float* out, int64_t ldo, pp_stream_t stream)
+{
+    if (!x || !out) return fail(PP_ERR_BAD_ARG, "image_colsum: null");
+    hipLaunchKernelGGL(image_colsum_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)B), dim3(kT), 0, as_stream(stream), x, ldx, P,
+                       C, mul, out, ldo);
+    return check_launch("image_colsum_kernel");
+}
+
+int pp_image_broadcast(const float* v, int64_t ldv, int B, int64_t P, int C, float mul, float* y, int64_t ldy, pp_stream_t stream)
+{
+    if (!v || !y) return fail(PP_ERR_BAD_ARG, "image_broadcast: null");
+    if (int rc = need_c4(C, "image_broadcast")) return rc;
+    hipLaunchKernelGGL(image_broadcast_kernel, dim3(grid_for((int64_t)B * P * (C / 4))), dim3(kT), 0, as_stream(stream), v, ldv,
+                       B, P, C / 4, mul, y, ldy);
+    return check_launch("image_broadcast_kernel");
+}
+
+// ---- dropout ---------------------------------------------------------------------------------------------------
+int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed, pp_stream_t stream)
+{
+    if (!x || !y) return fail(PP_ERR_BAD_ARG, "dropout: null");
+    if (p < 0.0f || p >= 1.0f) return fail(PP_ERR_BAD_ARG, "dropout: p=%f outside [0,1)", (double)p);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(M * C)), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C, p,
+                       1.0f / (1.0f - p), seed);
+    return check_launch("dropout_kernel");
+}
+
+// ---- loss ----------------------------------------------------------------------------------------------------------
+size_t pp_sparse_ce_workspace_bytes(void) { return 1024 * 2 * 4 + 256; }
+
+int pp_sparse_ce_fwd_bwd(const float* logits, int B, int C, int64_t HW, int64_t sB, int64_t sC, const int64_t* target,
+                         int ignore_index, float* loss, float* count, const float* grad_out, float* dlogits, void* workspace,
+                         size_t ws_bytes, pp_stream_t stream)
+{
+    if (!logits || !target || !loss || !count) return fail(PP_ERR_BAD_ARG, "sparse_ce: null");
+    if (!workspace || ws_bytes < pp_sparse_ce_workspace_bytes()) return fail(PP_ERR_WORKSPACE, "sparse_ce: workspace");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    int nblk = (int)cdiv((int64_t)B * HW, kT * 8);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(ce_partial_kernel, dim3(nblk), dim3(kT), 0, st, logits, target, B, C, HW, sB, sC, ignore_index, part);
+    if (int rc = check_launch("ce_partial_kernel")) return rc;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblk, loss, count);
+    if (int rc = check_launch("ce_finalize_kernel")) return rc;
+    if (dlogits) {
+        hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid_for((int64_t)B * HW)), dim3(kT), 0, st, logits, target, B, C, HW, sB, sC,
+                           ignore_index, count, grad_out, dlogits);
+        if (int rc = check_launch("ce_bwd_kernel")) return rc;
+    }
+    return PP_OK;
+}
+
+// ---- optimiser ------------------------------------------------------------------------------------------------------
+int pp_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_split,
+                      float lr_a, float lr_b, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                      float grad_scale, pp_stream_t stream)
+{
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(PP_ERR_BAD_ARG, "adam: null");
+    if (n < 1 || step < 1) return fail(PP_ERR_BAD_ARG, "adam: bad n/step");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
+                       n_split, lr_a, lr_b, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return check_launch("adam_kernel");
+}
+
+int pp_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int C, pp_stream_t stream)
+{
+    if (!a || !b || !y) return fail(PP_ERR_BAD_ARG, "add2d: null");
+    hipLaunchKernelGGL(add2d_kernel, dim3(grid_for(M * C)), dim3(kT), 0, as_stream(stream), a, lda, b, ldb, y, ldy, M, C);
+    return check_launch("add2d_kernel");
+}
+
+// ---- layout ------------------------------------------------------------------------------------------------------------
+int pp_nchw_to_nhwc(const float* x, int B, int C, int64_t HW, float* y, int64_t ldy, pp_stream_t stream)
+{
+    if (!x || !y) return fail(PP_ERR_BAD_ARG, "nchw_to_nhwc: null");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)B * HW * C)), dim3(kT), 0, as_stream(stream), x, B, C, HW, y, ldy);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+}  // extern "C"
