@@ -1,0 +1,463 @@
+"""Minimal define-by-run tape over the network-layer entry points of the C ABI.
+
+The reference relies on torch.autograd over ATen ops (model.py:113-121).  Here every forward AND
+backward arithmetic step is a hand-written HIP kernel behind include/pixelpick_hip.h; this module only
+records which kernel produced which tensor so that the reverse sweep can call the matching backward
+kernels, and accumulates gradients of multiply-consumed tensors with pp_add2d.  torch provides device
+memory (caching allocator) and the current stream — no torch arithmetic is used on activations.
+
+Activations are NHWC `torch.Tensor`s [B,H,W,C]; channel slices of a wider buffer are allowed
+(pixel stride `ld` = stride(2)).  Weights are HWIO (dense) / [3,3,C] (depthwise).
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+
+class Var:
+    """A tensor on the tape.  `grad` is filled during Tape.backward()."""
+    __slots__ = ("t", "grad", "needs_grad")
+
+    def __init__(self, t: torch.Tensor, needs_grad: bool = True):
+        self.t = t
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+
+class Tape:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+        self.nodes: List = []          # (backward_fn, ctx_tuple, output Var)
+        self.param_grads = {}          # id(param tensor) -> grad tensor
+        self.param_grad_dst = None     # optional callable(param) -> preallocated grad tensor to write into
+
+    def record(self, fn, ctx, out: Var):
+        if self.enabled:
+            self.nodes.append((fn, ctx, out))
+
+    def grad_buffer_for(self, param: torch.Tensor) -> torch.Tensor:
+        if self.param_grad_dst is not None:
+            g = self.param_grad_dst(param)
+            if g is not None:
+                return g
+        return torch.empty_like(param)
+
+    def set_param_grad(self, param: torch.Tensor, g: torch.Tensor):
+        key = id(param)
+        if key in self.param_grads:   # parameter used twice on the tape: accumulate
+            prev = self.param_grads[key]
+            add2d_(prev.view(1, -1), g.view(1, -1), prev.view(1, -1))
+        else:
+            self.param_grads[key] = g
+
+    def backward(self, out: Var, dout: torch.Tensor):
+        out.grad = dout
+        for fn, ctx, o in reversed(self.nodes):
+            if o.grad is None:
+                continue
+            fn(self, o.grad, *ctx)
+            o.grad = None             # free as we go
+        self.nodes = []
+
+
+# ------------------------------------------------------------------------------------------------- helpers
+def _stream():
+    return _lib.current_stream_ptr()
+
+
+def _geom(t: torch.Tensor):
+    """[B,H,W,C] NHWC (possibly a channel slice of a wider buffer) -> (B,H,W,C,ld)."""
+    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, "NHWC float32 GPU tensor expected"
+    B, H, W, C = t.shape
+    if C > 1 and t.stride(3) != 1:
+        raise ValueError("channel axis must be contiguous")
+    if W > 1:
+        ld = t.stride(2)
+    elif H > 1:
+        ld = t.stride(1)
+    elif B > 1:
+        ld = t.stride(0)
+    else:
+        ld = C
+    if (W > 1 and H > 1 and t.stride(1) != W * ld) or (B > 1 and (H > 1 or W > 1) and t.stride(0) != H * W * ld):
+        raise ValueError(f"tensor is not a pixel-strided NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
+    return B, H, W, C, ld
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _acc(v: Var, g: torch.Tensor):
+    """Accumulate gradient g into v (pp_add2d when v already holds one)."""
+    if not v.needs_grad:
+        return
+    if v.grad is None:
+        v.grad = g
+        return
+    B, H, W, C, lda = _geom(v.grad)
+    _, _, _, _, ldb = _geom(g)
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+    rc = _lib.lib().pp_add2d(v.grad.data_ptr(), lda, g.data_ptr(), ldb, out.data_ptr(), C, B * H * W, C, _stream())
+    _lib.check(rc, "pp_add2d")
+    v.grad = out
+
+
+def add2d_(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor):
+    n = a.numel()
+    rc = _lib.lib().pp_add2d(a.data_ptr(), n, b.data_ptr(), n, out.data_ptr(), n, 1, n, _stream())
+    _lib.check(rc, "pp_add2d")
+
+
+def out_size(n: int, k: int, stride: int, pad: int, dil: int) -> int:
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ------------------------------------------------------------------------------------------------- layout
+def nchw_to_nhwc(x: torch.Tensor) -> Var:
+    """Network input [B,C,H,W] -> NHWC Var (no gradient: the image is a leaf, model.py:105)."""
+    assert x.dim() == 4 and x.is_cuda and x.dtype == torch.float32
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pp_nchw_to_nhwc(x.data_ptr(), B, C, H * W, y.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_nchw_to_nhwc")
+    return Var(y, needs_grad=False)
+
+
+# ------------------------------------------------------------------------------------------------- dense conv
+def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, dil=1,
+           dst: Optional[torch.Tensor] = None) -> Var:
+    """nn.Conv2d (groups=1).  w: HWIO [kh,kw,Cin,Cout].  dst: optional NHWC view to write into."""
+    B, H, W, Cin, ldx = _geom(x.t)
+    kh, kw, wcin, Cout = w.shape
+    assert wcin == Cin, f"conv2d: Cin {Cin} vs weight {tuple(w.shape)}"
+    Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
+    y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.t.device)
+    _, _, _, _, ldy = _geom(y)
+    rc = _lib.lib().pp_conv2d_fwd(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                  kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, _stream())
+    _lib.check(rc, "pp_conv2d_fwd")
+    out = Var(y)
+    tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil), out)
+    return out
+
+
+def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil):
+    L = _lib.lib()
+    B, H, W, Cin, ldx = _geom(x.t)
+    _, Ho, Wo, Cout, lddy = _geom(dy)
+    kh, kw = w.shape[0], w.shape[1]
+    dev = dy.device
+    if w.requires_grad:
+        dw = tape.grad_buffer_for(w)
+        db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
+        ws = _ws(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
+        rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
+                                    dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+                                    _stream())
+        _lib.check(rc, "pp_conv2d_bwd_weight")
+        tape.set_param_grad(w, dw)
+        if db is not None:
+            tape.set_param_grad(bias, db)
+    if x.needs_grad:
+        dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
+                                  dx.data_ptr(), Cin, H, W, Cin, _stream())
+        _lib.check(rc, "pp_conv2d_bwd_data")
+        _acc(x, dx)
+
+
+# ------------------------------------------------------------------------------------------------- depthwise conv
+def dwconv3x3(tape: Tape, x: Var, w: torch.Tensor, stride=1, pad=0, dil=1) -> Var:
+    """Depthwise 3x3 (groups=C).  w: [3,3,C]."""
+    B, H, W, C, ldx = _geom(x.t)
+    Ho, Wo = out_size(H, 3, stride, pad, dil), out_size(W, 3, stride, pad, dil)
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.t.device)
+    rc = _lib.lib().pp_dwconv3x3_fwd(x.t.data_ptr(), ldx, B, H, W, C, w.data_ptr(), stride, pad, dil, y.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_dwconv3x3_fwd")
+    out = Var(y)
+    tape.record(_dwconv_bwd, (x, w, stride, pad, dil), out)
+    return out
+
+
+def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
+    L = _lib.lib()
+    B, H, W, C, ldx = _geom(x.t)
+    _, Ho, Wo, _, lddy = _geom(dy)
+    dev = dy.device
+    if w.requires_grad:
+        dw = tape.grad_buffer_for(w)
+        ws = _ws(L.pp_colreduce_workspace_bytes(B * Ho * Wo, C), dev)
+        rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream())
+        _lib.check(rc, "pp_dwconv3x3_bwd_weight")
+        tape.set_param_grad(w, dw)
+    if x.needs_grad:
+        dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+        rc = L.pp_dwconv3x3_bwd_data(dy.data_ptr(), lddy, B, H, W, C, w.data_ptr(), stride, pad, dil, dx.data_ptr(), C, _stream())
+        _lib.check(rc, "pp_dwconv3x3_bwd_data")
+        _acc(x, dx)
+
+
+# ------------------------------------------------------------------------------------------------- batch norm (+act, +residual)
+def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE,
+                   residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
+                   dst: Optional[torch.Tensor] = None) -> Var:
+    """nn.BatchNorm2d -> (+ residual) -> activation.  Training: batch statistics + running-stat update."""
+    L = _lib.lib()
+    B, H, W, C, ldx = _geom(x.t)
+    M = B * H * W
+    dev = x.t.device
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    shift = torch.empty(C, dtype=torch.float32, device=dev)
+    mean = invstd = None
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = _ws(L.pp_colreduce_workspace_bytes(M, C), dev)
+        rc = L.pp_bn_train_fwd(x.t.data_ptr(), ldx, M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                               running_mean.data_ptr() if running_mean is not None else None,
+                               running_var.data_ptr() if running_var is not None else None,
+                               mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                               ws.data_ptr(), ws.numel(), _stream())
+        _lib.check(rc, "pp_bn_train_fwd")
+    else:
+        rc = L.pp_bn_eval_affine(C, gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), eps,
+                                 scale.data_ptr(), shift.data_ptr(), _stream())
+        _lib.check(rc, "pp_bn_eval_affine")
+    y = dst if dst is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    _, _, _, _, ldy = _geom(y)
+    rptr, ldr = (None, 0)
+    if residual is not None:
+        _, _, _, _, ldr = _geom(residual.t)
+        rptr = residual.t.data_ptr()
+    rc = L.pp_scale_shift_act(x.t.data_ptr(), ldx, M, C, scale.data_ptr(), shift.data_ptr(), rptr, ldr, act, y.data_ptr(), ldy, _stream())
+    _lib.check(rc, "pp_scale_shift_act")
+    out = Var(y)
+    if training:
+        tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out), out)
+    else:
+        tape.record(_bn_eval_bwd, (x, scale, act, residual, out), out)
+    return out
+
+
+def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, out: Var):
+    L = _lib.lib()
+    B, H, W, C, ldx = _geom(x.t)
+    M = B * H * W
+    _, _, _, _, lddy = _geom(dy)
+    _, _, _, _, ldya = _geom(out.t)
+    dev = dy.device
+    dgamma = tape.grad_buffer_for(gamma)
+    dbeta = tape.grad_buffer_for(beta)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
+    ws = _ws(L.pp_colreduce_workspace_bytes(M, C), dev)
+    rc = L.pp_bn_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(), invstd.data_ptr(),
+                     gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
+                     dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "pp_bn_bwd")
+    if gamma.requires_grad:
+        tape.set_param_grad(gamma, dgamma)
+    if beta.requires_grad:
+        tape.set_param_grad(beta, dbeta)
+    _acc(x, dx)
+    if dres is not None:
+        _acc(residual, dres)
+
+
+def _bn_eval_bwd(tape: Tape, dy, x: Var, scale, act, residual, out: Var):
+    raise RuntimeError("backward through eval-mode BatchNorm is not part of the PixelPick path "
+                       "(query.py:148-158 and model.py:176-190 run eval under no_grad)")
+
+
+# ------------------------------------------------------------------------------------------------- padding
+def pad2d(tape: Tape, x: Var, pad_beg: int, pad_end: int) -> Var:
+    """fixed_padding (mobilenet_v2.py:15-21): zero-pad H and W by (pad_beg, pad_end)."""
+    B, H, W, C, ldx = _geom(x.t)
+    Hp, Wp = H + pad_beg + pad_end, W + pad_beg + pad_end
+    y = torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=x.t.device)
+    rc = _lib.lib().pp_pad2d(x.t.data_ptr(), ldx, B, H, W, C, pad_beg, pad_beg, Hp, Wp, y.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_pad2d")
+    out = Var(y)
+    tape.record(_pad_bwd, (x, pad_beg), out)
+    return out
+
+
+def _pad_bwd(tape: Tape, dy, x: Var, pad_beg):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    _, Hp, Wp, _, lddy = _geom(dy)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    # fuse the accumulation with an already-present gradient (the residual branch) into the crop
+    add_ptr, ldadd = (None, 0)
+    if x.grad is not None:
+        _, _, _, _, ldadd = _geom(x.grad)
+        add_ptr = x.grad.data_ptr()
+    rc = _lib.lib().pp_crop2d_add(dy.data_ptr(), lddy, B, Hp, Wp, C, pad_beg, pad_beg, add_ptr, ldadd, dx.data_ptr(), C, H, W, _stream())
+    _lib.check(rc, "pp_crop2d_add")
+    x.grad = dx
+
+
+# ------------------------------------------------------------------------------------------------- bilinear
+def bilinear(tape: Tape, x: Var, size, align_corners: bool, scale_factor: float = 0.0, out_nchw: bool = False,
+             dst: Optional[torch.Tensor] = None) -> Var:
+    """F.interpolate(mode='bilinear').  out_nchw -> returns a [B,C,Ho,Wo] tensor (the model output)."""
+    B, H, W, C, ldx = _geom(x.t)
+    Ho, Wo = int(size[0]), int(size[1])
+    dev = x.t.device
+    if out_nchw:
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=dev)
+        ldy = 0
+    else:
+        y = dst if dst is not None else torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+        _, _, _, _, ldy = _geom(y)
+    rc = _lib.lib().pp_bilinear_fwd(x.t.data_ptr(), ldx, B, H, W, C, y.data_ptr(), ldy, Ho, Wo, int(align_corners),
+                                    float(scale_factor), float(scale_factor), int(out_nchw), _stream())
+    _lib.check(rc, "pp_bilinear_fwd")
+    out = Var(y)
+    tape.record(_bilinear_bwd, (x, (Ho, Wo), align_corners, scale_factor, out_nchw), out)
+    return out
+
+
+def _bilinear_bwd(tape: Tape, dy, x: Var, size, align_corners, scale_factor, out_nchw):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    Ho, Wo = size
+    if out_nchw:
+        dy = dy.contiguous()
+        lddy = 0
+    else:
+        _, _, _, _, lddy = _geom(dy)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pp_bilinear_bwd(dy.data_ptr(), lddy, B, Ho, Wo, C, dx.data_ptr(), C, H, W, int(align_corners),
+                                    float(scale_factor), float(scale_factor), int(out_nchw), _stream())
+    _lib.check(rc, "pp_bilinear_bwd")
+    _acc(x, dx)
+
+
+# ------------------------------------------------------------------------------------------------- pooling / broadcast
+def global_avg_pool(tape: Tape, x: Var) -> Var:
+    """nn.AdaptiveAvgPool2d((1,1)) -> [B,1,1,C]."""
+    B, H, W, C, ldx = _geom(x.t)
+    y = torch.empty((B, 1, 1, C), dtype=torch.float32, device=x.t.device)
+    rc = _lib.lib().pp_image_colsum(x.t.data_ptr(), ldx, B, H * W, C, 1.0 / (H * W), y.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_image_colsum")
+    out = Var(y)
+    tape.record(_gap_bwd, (x,), out)
+    return out
+
+
+def _gap_bwd(tape: Tape, dy, x: Var):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pp_image_broadcast(dy.data_ptr(), C, B, H * W, C, 1.0 / (H * W), dx.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_image_broadcast")
+    _acc(x, dx)
+
+
+def broadcast_hw(tape: Tape, v: Var, H: int, W: int, dst: Optional[torch.Tensor] = None) -> Var:
+    """Bilinear (align_corners=True) upsample of a 1x1 map = broadcast (aspp.py:70)."""
+    B, _, _, C, ldv = _geom(v.t)
+    y = dst if dst is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=v.t.device)
+    _, _, _, _, ldy = _geom(y)
+    rc = _lib.lib().pp_image_broadcast(v.t.data_ptr(), ldv, B, H * W, C, 1.0, y.data_ptr(), ldy, _stream())
+    _lib.check(rc, "pp_image_broadcast")
+    out = Var(y)
+    tape.record(_broadcast_bwd, (v, H, W), out)
+    return out
+
+
+def _broadcast_bwd(tape: Tape, dy, v: Var, H, W):
+    B, _, _, C, _ = _geom(v.t)
+    _, _, _, _, lddy = _geom(dy)
+    dv = torch.empty((B, 1, 1, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pp_image_colsum(dy.data_ptr(), lddy, B, H * W, C, 1.0, dv.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_image_colsum")
+    _acc(v, dv)
+
+
+# ------------------------------------------------------------------------------------------------- dropout
+_dropout_counter = [0]
+
+
+def set_dropout_seed(seed: int):
+    _dropout_counter[0] = int(seed) * 1000003
+
+
+def dropout(tape: Tape, x: Var, p: float, training: bool) -> Var:
+    """nn.Dropout.  Identity in eval mode / p == 0.  The mask is regenerated from the seed in backward."""
+    if not training or p <= 0.0:
+        return x
+    B, H, W, C, ldx = _geom(x.t)
+    _dropout_counter[0] += 1
+    seed = (_dropout_counter[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.t.device)
+    rc = _lib.lib().pp_dropout(x.t.data_ptr(), ldx, y.data_ptr(), C, B * H * W, C, float(p), seed, _stream())
+    _lib.check(rc, "pp_dropout")
+    out = Var(y)
+    tape.record(_dropout_bwd, (x, p, seed), out)
+    return out
+
+
+def _dropout_bwd(tape: Tape, dy, x: Var, p, seed):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    _, _, _, _, lddy = _geom(dy)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pp_dropout(dy.data_ptr(), lddy, dx.data_ptr(), C, B * H * W, C, float(p), seed, _stream())
+    _lib.check(rc, "pp_dropout")
+    _acc(x, dx)
+
+
+# ------------------------------------------------------------------------------------------------- concat (zero-copy)
+def concat_alias(tape: Tape, buf: torch.Tensor, parts: Sequence[Var]) -> Var:
+    """torch.cat(dim=channel) without a copy: every part was produced directly into its channel slice of
+    `buf` (dst= of the producer).  Backward hands each producer its slice of the gradient."""
+    off = 0
+    for p in parts:
+        c = p.t.shape[3]
+        assert p.t.data_ptr() == buf[..., off:off + c].data_ptr(), "concat_alias: part not produced in place"
+        off += c
+    assert off == buf.shape[3]
+    out = Var(buf)
+    tape.record(_concat_bwd, (tuple(parts),), out)
+    return out
+
+
+def _concat_bwd(tape: Tape, dy, parts):
+    off = 0
+    for p in parts:
+        c = p.t.shape[3]
+        _acc(p, dy[..., off:off + c])
+        off += c
+
+
+# ------------------------------------------------------------------------------------------------- loss
+def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index: int, want_grad: bool = True):
+    """F.cross_entropy(logits [B,C,H,W], target [B,H,W] int64, ignore_index) -> (loss [1], dlogits | None)."""
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4
+    B, C, H, W = logits.shape
+    assert logits.stride(3) == 1 and logits.stride(2) == W, "logits planes must be contiguous"
+    target = target.to(logits.device, torch.int64).contiguous()
+    L = _lib.lib()
+    dev = logits.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.float32, device=dev)
+    dl = torch.empty((B, C, H, W), dtype=torch.float32, device=dev) if want_grad else None
+    ws = _ws(L.pp_sparse_ce_workspace_bytes(), dev)
+    rc = L.pp_sparse_ce_fwd_bwd(logits.data_ptr(), B, C, H * W, logits.stride(0), logits.stride(1), target.data_ptr(),
+                                int(ignore_index), loss.data_ptr(), count.data_ptr(), None,
+                                dl.data_ptr() if dl is not None else None, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "pp_sparse_ce_fwd_bwd")
+    return loss, dl

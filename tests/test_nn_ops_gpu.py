@@ -1,0 +1,307 @@
+"""GPU parity tests of the network-layer HIP kernels (through the C ABI / engine tape) against plain
+PyTorch fp32 CPU references of the same ops (the reference's torch.nn calls).  Floating-point kernels:
+tolerance 1e-4 relative to the tensor scale (north_star: logits/grads within 1e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pixelpick_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):   # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):   # NHWC gpu -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def hwio(w):   # OIHW -> HWIO gpu
+    return w.permute(2, 3, 1, 0).contiguous().to(DEV)
+
+
+def oihw(w):
+    return w.permute(3, 2, 0, 1).contiguous().cpu()
+
+
+def close(a, b, tol=1e-4, what=""):
+    a, b = a.double(), b.double()
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def gparam(t):
+    t = t.detach().clone().to(DEV)
+    t.requires_grad_(True)
+    return t
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dil, bias
+    (2, 16, 32, 320, 256, 1, 1, 0, 1, False),     # ASPP 1x1
+    (2, 16, 32, 320, 256, 3, 1, 6, 6, False),     # atrous d=6
+    (2, 16, 32, 64, 96, 3, 1, 18, 18, False),     # atrous d=18: only the centre row of taps is live
+    (1, 24, 20, 304, 256, 3, 1, 1, 1, False),     # SegmentHead 3x3, ragged M
+    (2, 17, 19, 256, 19, 1, 1, 0, 1, True),       # classifier (bias, Cout=19)
+    (2, 18, 34, 16, 96, 1, 1, 0, 1, False),       # MNv2 expand on the padded map
+    (2, 9, 11, 24, 144, 1, 1, 0, 1, False),       # Cin=24 (not a multiple of 16)
+    (2, 10, 12, 960, 160, 1, 1, 0, 1, False),     # MNv2 project
+    (2, 33, 47, 3, 32, 3, 2, 1, 1, False),        # stem 3x3 s2, Cin=3
+    (1, 40, 36, 3, 64, 7, 2, 3, 1, False),        # ResNet stem 7x7 s2
+    (2, 12, 12, 128, 128, 3, 1, 1, 1, True),      # FPN UpsampleBlock conv (bias)
+    (1, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead at Cityscapes-quarter size (128x128 tiles)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv2d_fwd_bwd(case):
+    B, H, W, Cin, Cout, k, stride, pad, dil, has_bias = case
+    torch.manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout) if has_bias else None
+    xr = x.clone().requires_grad_(stride == 1)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+
+    tape = E.Tape()
+    xv = E.Var(nhwc(x), needs_grad=stride == 1)
+    wg = gparam(hwio(w))
+    bg = gparam(b) if has_bias else None
+    yv = E.conv2d(tape, xv, wg, bg, stride, pad, dil)
+    close(nchw(yv.t), yr.detach(), what="conv fwd")
+    tape.backward(yv, nhwc(dy))
+    close(oihw(tape.param_grads[id(wg)]), wr.grad, what="conv dW")
+    if has_bias:
+        close(tape.param_grads[id(bg)].cpu(), br.grad, what="conv dbias")
+    if stride == 1:
+        close(nchw(xv.grad), xr.grad, what="conv dX")
+
+
+def test_conv2d_channel_slices():
+    """Inputs/outputs that are channel slices of wider buffers (the zero-copy concat of aspp.py:73)."""
+    torch.manual_seed(0)
+    B, H, W = 2, 8, 12
+    x = torch.randn(B, 48, H, W)
+    w = torch.randn(32, 48, 1, 1) / 7
+    big_in = torch.zeros(B, H, W, 80, device=DEV)
+    big_in[..., 16:64] = nhwc(x)
+    big_out = torch.full((B, H, W, 96), 7.0, device=DEV)
+    tape = E.Tape(enabled=False)
+    E.conv2d(tape, E.Var(big_in[..., 16:64]), hwio(w), None, dst=big_out[..., 32:64])
+    close(nchw(big_out[..., 32:64]), F.conv2d(x, w), what="sliced conv")
+    assert (big_out[..., :32] == 7.0).all() and (big_out[..., 64:] == 7.0).all()
+
+
+DW_CASES = [(2, 18, 34, 32, 1, 0, 1), (2, 19, 35, 96, 2, 0, 1), (2, 20, 36, 960, 1, 0, 2), (1, 13, 9, 144, 2, 0, 1),
+            (2, 16, 16, 24, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=[str(c) for c in DW_CASES])
+def test_dwconv_fwd_bwd(case):
+    B, H, W, C, stride, pad, dil = case
+    torch.manual_seed(1)
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    w = (torch.randn(C, 1, 3, 3) / 3).requires_grad_(True)
+    yr = F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil, groups=C)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    wg = gparam(w.detach()[:, 0].permute(1, 2, 0).contiguous())
+    yv = E.dwconv3x3(tape, xv, wg, stride, pad, dil)
+    close(nchw(yv.t), yr.detach(), what="dw fwd")
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad, what="dw dX")
+    close(tape.param_grads[id(wg)].permute(2, 0, 1).cpu()[:, None], w.grad, what="dw dW")
+
+
+@pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, False), (0, True), (1, True)])
+@pytest.mark.parametrize("shape", [(4, 18, 34, 96), (2, 7, 5, 16), (4, 16, 32, 960), (3, 1, 1, 256), (2, 6, 10, 2048)])
+def test_batchnorm_train_fwd_bwd(shape, act, with_res):
+    B, H, W, C = shape
+    torch.manual_seed(2)
+    x = (torch.randn(B, C, H, W) * 2 + 0.5).requires_grad_(True)
+    res = torch.randn(B, C, H, W).requires_grad_(True) if with_res else None
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) + 0.5)
+        bn.bias.copy_(torch.randn(C) * 0.3)
+        bn.running_mean.copy_(torch.randn(C) * 0.1)
+        bn.running_var.copy_(torch.rand(C) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train()
+    z = bn(x)
+    if with_res:
+        z = z + res
+    yr = {0: lambda t: t, 1: F.relu, 2: F.relu6}[act](z)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    rv = E.Var(nhwc(res.detach())) if with_res else None
+    g, bta = gparam(bn.weight), gparam(bn.bias)
+    rm, rvv = rm0.to(DEV), rv0.to(DEV)
+    yv = E.batch_norm_act(tape, xv, g, bta, rm, rvv, True, act, rv)
+    close(nchw(yv.t), yr.detach(), what="bn fwd")
+    close(rm.cpu(), bn.running_mean, what="running_mean")
+    close(rvv.cpu(), bn.running_var, what="running_var")
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad, tol=2e-4, what="bn dX")
+    close(tape.param_grads[id(g)].cpu(), bn.weight.grad, tol=2e-4, what="dgamma")
+    close(tape.param_grads[id(bta)].cpu(), bn.bias.grad, tol=2e-4, what="dbeta")
+    if with_res:
+        close(nchw(rv.grad), res.grad, what="dres")
+
+
+def test_batchnorm_eval():
+    torch.manual_seed(3)
+    B, C, H, W = 2, 48, 5, 7
+    x = torch.randn(B, C, H, W)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) + 0.5); bn.bias.copy_(torch.randn(C))
+        bn.running_mean.copy_(torch.randn(C)); bn.running_var.copy_(torch.rand(C) + 0.5)
+    yv = E.batch_norm_act(E.Tape(False), E.Var(nhwc(x)), bn.weight.detach().to(DEV), bn.bias.detach().to(DEV),
+                          bn.running_mean.to(DEV), bn.running_var.to(DEV), False, E.ACT_RELU6)
+    close(nchw(yv.t), F.relu6(bn(x)).detach(), what="bn eval")
+
+
+def test_pad_and_crop_accumulate():
+    torch.manual_seed(4)
+    x = torch.randn(2, 8, 5, 6, requires_grad=True)
+    yr = F.pad(x, (2, 2, 2, 2))
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    yv = E.pad2d(tape, xv, 2, 2)
+    close(nchw(yv.t), yr.detach(), what="pad")
+    extra = torch.randn(2, 8, 5, 6)
+    xv.grad = nhwc(extra)                         # a gradient already present (residual branch)
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad + extra, what="crop+add")
+
+
+BIL_CASES = [((2, 16, 32, 256), (64, 128), True, 0.0), ((2, 23, 30, 16), (90, 120), True, 0.0),
+             ((2, 8, 12, 128), (16, 24), False, 2.0), ((1, 9, 7, 256), (18, 14), False, 0.0),
+             ((2, 5, 6, 8), (11, 17), False, 0.0), ((2, 1, 1, 16), (4, 6), True, 0.0)]
+
+
+@pytest.mark.parametrize("case", BIL_CASES, ids=[str(c) for c in BIL_CASES])
+def test_bilinear_nhwc(case):
+    (B, H, W, C), size, align, sf = case
+    torch.manual_seed(5)
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    if sf > 0:
+        yr = F.interpolate(x, scale_factor=sf, mode="bilinear", align_corners=align)
+    else:
+        yr = F.interpolate(x, size=size, mode="bilinear", align_corners=align)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    yv = E.bilinear(tape, xv, size, align, sf)
+    close(nchw(yv.t), yr.detach(), tol=2e-5, what="bilinear fwd")
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad, tol=2e-5, what="bilinear bwd")
+
+
+@pytest.mark.parametrize("C,size_in,size_out", [(19, (16, 32), (64, 128)), (11, (23, 30), (90, 120)), (21, (9, 13), (33, 50))])
+def test_bilinear_to_nchw(C, size_in, size_out):
+    torch.manual_seed(6)
+    x = torch.randn(2, C, *size_in, requires_grad=True)
+    yr = F.interpolate(x, size=size_out, mode="bilinear", align_corners=True)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    yv = E.bilinear(tape, xv, size_out, True, 0.0, out_nchw=True)
+    assert yv.t.shape == yr.shape
+    close(yv.t.cpu(), yr.detach(), tol=2e-5, what="bilinear->nchw fwd")
+    tape.backward(yv, dy.to(DEV))
+    close(nchw(xv.grad), x.grad, tol=2e-5, what="bilinear->nchw bwd")
+
+
+def test_gap_and_broadcast():
+    torch.manual_seed(7)
+    x = torch.randn(3, 320, 16, 32, requires_grad=True)
+    yr = F.adaptive_avg_pool2d(x, 1)
+    zr = F.interpolate(yr, size=(16, 32), mode="bilinear", align_corners=True)
+    dz = torch.randn_like(zr)
+    zr.backward(dz)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    yv = E.global_avg_pool(tape, xv)
+    zv = E.broadcast_hw(tape, yv, 16, 32)
+    close(nchw(yv.t), yr.detach(), what="gap")
+    close(nchw(zv.t), zr.detach(), what="broadcast")
+    tape.backward(zv, nhwc(dz))
+    close(nchw(xv.grad), x.grad, what="gap/broadcast bwd")
+
+
+def test_dropout_statistics_and_backward():
+    x = torch.ones(2, 32, 64, 256, device=DEV)
+    tape = E.Tape()
+    xv = E.Var(x)
+    yv = E.dropout(tape, xv, 0.5, True)
+    y = yv.t
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    assert torch.all((y == 0) | (y == 2.0))
+    dy = torch.full_like(y, 3.0)
+    tape.backward(yv, dy)
+    assert torch.equal(xv.grad != 0, y != 0) and torch.all((xv.grad == 0) | (xv.grad == 6.0))
+    y2 = E.dropout(E.Tape(False), E.Var(x), 0.5, True).t
+    assert not torch.equal(y2, y)                      # new mask every call
+    assert E.dropout(E.Tape(False), xv, 0.5, False) is xv   # eval: identity
+
+
+@pytest.mark.parametrize("B,C,H,W,n_lab,ign", [(4, 19, 64, 128, 20, 19), (2, 21, 33, 47, 10, 255), (1, 11, 20, 24, 480, 11)])
+def test_cross_entropy(B, C, H, W, n_lab, ign):
+    torch.manual_seed(8)
+    logits = (torch.randn(B, C, H, W) * 3).requires_grad_(True)
+    y = torch.full((B, H, W), ign, dtype=torch.int64)
+    for b in range(B):
+        idx = torch.randperm(H * W)[:n_lab]
+        y[b].view(-1)[idx] = torch.randint(0, C, (n_lab,))
+    lr = F.cross_entropy(logits, y, ignore_index=ign)
+    lr.backward()
+    loss, dl = E.cross_entropy_nchw(logits.detach().to(DEV), y.to(DEV), ign)
+    assert abs(loss.item() - lr.item()) < 1e-5 * max(1.0, abs(lr.item()))
+    close(dl.cpu(), logits.grad, tol=1e-5, what="dlogits")
+    assert (dl.cpu()[(y == ign)[:, None].expand(-1, C, -1, -1)] == 0).all()
+
+
+def test_adam_matches_torch():
+    torch.manual_seed(9)
+    n, n_split = 10007, 4001
+    p0 = torch.randn(n)
+    pa = p0[:n_split].clone().requires_grad_(True)
+    pb = p0[n_split:].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [pa], "lr": 5e-5, "weight_decay": 2e-4},
+                            {"params": [pb], "lr": 5e-4, "weight_decay": 2e-4}], betas=(0.9, 0.999), eps=1e-7)
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    p = p0.clone().to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g = torch.randn(n) * 0.1
+        pa.grad, pb.grad = g[:n_split].clone(), g[n_split:].clone()
+        opt.step()
+        gg = g.to(DEV)
+        rc = L.pp_adam_step_flat(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), n, n_split, 5e-5, 5e-4, 0.9, 0.999,
+                                 1e-7, 2e-4, step, 1.0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = torch.cat([pa.detach(), pb.detach()])
+        assert (p.cpu() - ref).abs().max().item() < 2e-6
