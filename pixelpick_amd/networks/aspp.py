@@ -1,0 +1,67 @@
+"""ASPP — mirror of networks/aspp.py on the HIP engine.
+
+The five branches write straight into their channel slice of one [B,H,W,1280] buffer (the reference's
+torch.cat, aspp.py:73, costs nothing) and the image-pooling branch's bilinear upsample of a 1x1 map
+(aspp.py:69-70) is a broadcast.
+"""
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from .layers import BatchNorm2d, Conv2d, Dropout, ReLU
+
+
+class _ASPPModule(nn.Module):
+    """aspp.py:6-29."""
+
+    def __init__(self, inplanes, planes, kernel_size, padding, dilation, BatchNorm):
+        super().__init__()
+        self.atrous_conv = Conv2d(inplanes, planes, kernel_size, stride=1, padding=padding, dilation=dilation, bias=False)
+        self.bn = BatchNorm(planes)
+        self.relu = ReLU()
+
+    def run(self, tape, x, dst=None):
+        return self.bn.run(tape, self.atrous_conv.run(tape, x), E.ACT_RELU, dst=dst)
+
+
+class ASPP(nn.Module):
+    """aspp.py:32-88."""
+
+    def __init__(self, backbone, output_stride, BatchNorm=None):
+        super().__init__()
+        BatchNorm = BatchNorm or BatchNorm2d
+        inplanes = {"drn": 512, "mobilenet": 320}.get(backbone, 2048)
+        if output_stride == 16:
+            dilations = [1, 6, 12, 18]
+        elif output_stride == 8:
+            dilations = [1, 12, 24, 36]
+        else:
+            raise NotImplementedError
+        self.aspp1 = _ASPPModule(inplanes, 256, 1, padding=0, dilation=dilations[0], BatchNorm=BatchNorm)
+        self.aspp2 = _ASPPModule(inplanes, 256, 3, padding=dilations[1], dilation=dilations[1], BatchNorm=BatchNorm)
+        self.aspp3 = _ASPPModule(inplanes, 256, 3, padding=dilations[2], dilation=dilations[2], BatchNorm=BatchNorm)
+        self.aspp4 = _ASPPModule(inplanes, 256, 3, padding=dilations[3], dilation=dilations[3], BatchNorm=BatchNorm)
+        # nn.Sequential(AdaptiveAvgPool2d, Conv2d, BatchNorm, ReLU): indices 1 and 2 carry the parameters
+        self.global_avg_pool = nn.Sequential(nn.Identity(), Conv2d(inplanes, 256, 1, stride=1, bias=False), BatchNorm(256), ReLU())
+        self.conv1 = Conv2d(1280, 256, 1, bias=False)
+        self.bn1 = BatchNorm(256)
+        self.relu = ReLU()
+        self.dropout = Dropout(0.5)
+
+    def run(self, tape, x):
+        B, H, W, _ = x.t.shape
+        buf = torch.empty((B, H, W, 1280), dtype=torch.float32, device=x.t.device)
+        x1 = self.aspp1.run(tape, x, dst=buf[..., 0:256])
+        x2 = self.aspp2.run(tape, x, dst=buf[..., 256:512])
+        x3 = self.aspp3.run(tape, x, dst=buf[..., 512:768])
+        x4 = self.aspp4.run(tape, x, dst=buf[..., 768:1024])
+        pooled = E.global_avg_pool(tape, x)
+        x5 = self.global_avg_pool[2].run(tape, self.global_avg_pool[1].run(tape, pooled), E.ACT_RELU)
+        x5 = E.broadcast_hw(tape, x5, H, W, dst=buf[..., 1024:1280])
+        cat = E.concat_alias(tape, buf, [x1, x2, x3, x4, x5])
+        y = self.bn1.run(tape, self.conv1.run(tape, cat), E.ACT_RELU)
+        return self.dropout.run(tape, y)
+
+
+def build_aspp(backbone, output_stride, BatchNorm=None):
+    return ASPP(backbone, output_stride, BatchNorm)

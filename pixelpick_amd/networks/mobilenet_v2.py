@@ -1,0 +1,129 @@
+"""MobileNetV2 encoder (output_stride 16) — mirror of networks/mobilenet_v2.py on the HIP engine.
+
+Same constructor arguments, attribute names (`features`, `low_level_features`, `high_level_features`)
+and state_dict keys.  Parity-critical quirk kept: every InvertedResidual zero-pads its
+INPUT (fixed_padding, mobilenet_v2.py:15-21,61) and runs the expand conv + BN + ReLU6 on the padded map,
+then a depthwise 3x3 with padding 0.
+"""
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from .layers import BatchNorm2d, Conv2d, ReLU6
+
+
+def conv_bn(inp, oup, stride, BatchNorm):
+    """mobilenet_v2.py:7-12."""
+    return nn.Sequential(Conv2d(inp, oup, 3, stride, 1, bias=False), BatchNorm(oup), ReLU6(inplace=True))
+
+
+def fixed_padding_amounts(kernel_size, dilation):
+    """mobilenet_v2.py:15-21 -> (pad_beg, pad_end)."""
+    kernel_size_effective = kernel_size + (kernel_size - 1) * (dilation - 1)
+    pad_total = kernel_size_effective - 1
+    pad_beg = pad_total // 2
+    return pad_beg, pad_total - pad_beg
+
+
+def _run_conv_bn_act_chain(tape, seq, x, residual=None):
+    """Execute an nn.Sequential of [Conv2d, BatchNorm2d, (ReLU6)] groups; the last BN may take a residual."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        conv, bn = mods[i], mods[i + 1]
+        has_act = i + 2 < len(mods) and isinstance(mods[i + 2], ReLU6)
+        is_last = (i + (3 if has_act else 2)) >= len(mods)
+        x = conv.run(tape, x)
+        x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None)
+        i += 3 if has_act else 2
+    return x
+
+
+class InvertedResidual(nn.Module):
+    """mobilenet_v2.py:24-66."""
+
+    def __init__(self, inp, oup, stride, dilation, expand_ratio, BatchNorm):
+        super().__init__()
+        self.stride = stride
+        assert stride in [1, 2]
+        hidden_dim = round(inp * expand_ratio)
+        self.use_res_connect = self.stride == 1 and inp == oup
+        self.kernel_size = 3
+        self.dilation = dilation
+        layers = []
+        if expand_ratio != 1:
+            layers += [Conv2d(inp, hidden_dim, 1, 1, 0, 1, bias=False), BatchNorm(hidden_dim), ReLU6(inplace=True)]
+        layers += [Conv2d(hidden_dim, hidden_dim, 3, stride, 0, dilation, groups=hidden_dim, bias=False),
+                   BatchNorm(hidden_dim), ReLU6(inplace=True),
+                   Conv2d(hidden_dim, oup, 1, 1, 0, 1, bias=False), BatchNorm(oup)]
+        self.conv = nn.Sequential(*layers)
+
+    def run(self, tape, x):
+        pad_beg, pad_end = fixed_padding_amounts(self.kernel_size, self.dilation)
+        x_pad = E.pad2d(tape, x, pad_beg, pad_end)
+        return _run_conv_bn_act_chain(tape, self.conv, x_pad, residual=x if self.use_res_connect else None)
+
+
+class MobileNetV2(nn.Module):
+    """mobilenet_v2.py:69-155.  `pretrained=True` in the reference downloads ImageNet weights from a URL
+    (:140); there is no network here, so weights are loaded from $PIXELPICK_MNV2_WEIGHTS when that file
+    exists and left at their random initialisation otherwise."""
+
+    def __init__(self, output_stride=8, BatchNorm=None, width_mult=1., pretrained=True, mc_dropout=False, mc_dropout_p=0.2):
+        super().__init__()
+        BatchNorm = BatchNorm or BatchNorm2d
+        if mc_dropout:
+            raise NotImplementedError("nn.Dropout2d (MC-dropout training variant, mobilenet_v2.py:114-115,133-134) "
+                                      "is not part of the accelerated path")
+        block = InvertedResidual
+        input_channel = 32
+        current_stride = 1
+        rate = 1
+        setting = [[1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]]
+        input_channel = int(input_channel * width_mult)
+        features = [conv_bn(3, input_channel, 2, BatchNorm)]
+        current_stride *= 2
+        for t, c, n, s in setting:
+            if current_stride == output_stride:
+                stride, dilation = 1, rate
+                rate *= s
+            else:
+                stride, dilation = s, 1
+                current_stride *= s
+            output_channel = int(c * width_mult)
+            for i in range(n):
+                features.append(block(input_channel, output_channel, stride if i == 0 else 1, dilation, t, BatchNorm))
+                input_channel = output_channel
+        self.features = nn.Sequential(*features)
+        if pretrained:
+            self._load_pretrained_model()
+        self.low_level_features = self.features[0:4]
+        self.high_level_features = self.features[4:]
+        self.mc_dropout = mc_dropout
+
+    def _load_pretrained_model(self):
+        path = os.environ.get("PIXELPICK_MNV2_WEIGHTS", "")
+        if path and os.path.isfile(path):
+            pretrain_dict = torch.load(path, map_location="cpu")
+            own = self.state_dict()
+            self.load_state_dict({k: v for k, v in pretrain_dict.items() if k in own}, strict=False)
+        else:
+            warnings.warn("MobileNetV2 ImageNet weights unavailable offline (reference downloads them, "
+                          "mobilenet_v2.py:140); keeping the random initialisation")
+
+    @staticmethod
+    def _run_features(tape, seq, x):
+        for m in seq:
+            if isinstance(m, InvertedResidual):
+                x = m.run(tape, x)
+            else:  # stem conv_bn
+                x = m[1].run(tape, m[0].run(tape, x), E.ACT_RELU6)
+        return x
+
+    def run(self, tape, x):
+        low = self._run_features(tape, self.low_level_features, x)
+        high = self._run_features(tape, self.high_level_features, low)
+        return high, low

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Network golden vectors from the IMPORTED reference (authoring container only): DeepLabv3+-MobileNetV2
+forward/backward with formula-initialised weights (tests/formula_init.py).  Fixtures hold logits samples,
+loss, per-parameter gradient summaries and BN running statistics — data only.
+
+Reference entry points exercised: utils/utils.py:15-51 get_model; networks/deeplab.py:43-61;
+model.py:116 F.cross_entropy(ignore_index); autograd backward (model.py:121).
+"""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import networks.mobilenet_v2 as ref_mnv2  # noqa: E402
+ref_mnv2.MobileNetV2._load_pretrained_model = lambda self: None      # needs the network otherwise (:139-147)
+from utils.utils import get_model  # noqa: E402
+import formula_init as fi  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def gen_deeplab(n_classes, ignore_index, B, H, W, tag, n_lab=20, train=True):
+    args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=n_classes, network_name="deeplab",
+                     weight_type="random", use_dilated_resnet=True, n_layers=50, width_multiplier=1.0)
+    torch.manual_seed(0)
+    model = get_model(args)
+    sd = fi.formula_state_dict(model.state_dict())
+    model.load_state_dict(sd)
+    for m in model.modules():                       # dropout RNG cannot be matched: force p = 0 (SURVEY hard part d)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = fi.formula_input(B, H, W, key=f"x{tag}")
+    out = {"shape": np.array([B, H, W, n_classes, ignore_index, n_lab])}
+    # eval forward
+    model.eval()
+    with torch.no_grad():
+        pe = model(x)["pred"]
+    out["eval_pred_samples"] = pe.reshape(-1)[::7].numpy().copy()
+    out["eval_pred_summary"] = fi.summarize(pe)
+    if train:
+        model.train()
+        y = fi.formula_labels(B, H, W, n_classes, ignore_index, n_lab, key=f"y{tag}")
+        d = model(x)
+        pred = d["pred"]
+        loss = F.cross_entropy(pred, y, ignore_index=ignore_index)
+        loss.backward()
+        out["train_pred_samples"] = pred.detach().reshape(-1)[::7].numpy().copy()
+        out["train_pred_summary"] = fi.summarize(pred)
+        out["loss"] = np.float64(loss.item())
+        names, gsum = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            gsum.append(fi.summarize(p.grad))
+        out["grad_names"] = np.array(names)
+        out["grad_summary"] = np.stack(gsum)
+        # a few full gradients (small tensors) incl. the first and last layers and a padded-border BN
+        for k in ["backbone.features.0.0.weight", "backbone.features.2.conv.1.weight", "backbone.features.2.conv.1.bias",
+                  "backbone.features.17.conv.3.weight", "aspp.aspp4.bn.weight", "aspp.global_avg_pool.2.bias",
+                  "low_level_conv.0.weight", "seg_head.classifier.weight", "seg_head.classifier.bias"]:
+            out["g:" + k] = dict(model.named_parameters())[k].grad.numpy().copy()
+        sdn = model.state_dict()
+        for k in ["backbone.features.2.conv.1.running_mean", "backbone.features.2.conv.1.running_var",
+                  "backbone.features.17.conv.4.running_var", "aspp.bn1.running_mean", "seg_head.segment_head.5.running_var"]:
+            out["rs:" + k] = sdn[k].numpy().copy()
+        out["n_state_keys"] = np.int64(len(sdn))
+        out["state_keys_crc"] = np.int64(__import__("zlib").crc32("\n".join(f"{k}:{tuple(v.shape)}" for k, v in sdn.items()).encode()))
+    np.savez_compressed(os.path.join(OUT, f"net_deeplab_{tag}.npz"), **out)
+    print("written", tag, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith("g:")})
+
+
+if __name__ == "__main__":
+    gen_deeplab(19, 19, 2, 64, 96, "cs64x96")
+    gen_deeplab(11, 11, 2, 72, 88, "cv72x88", n_lab=10)
+    gen_deeplab(21, 255, 1, 40, 56, "voc40x56", train=False)
