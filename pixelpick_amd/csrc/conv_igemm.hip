@@ -421,18 +421,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
     dw[(int64_t)taps.widx[ti] * cn + e] = s;
 }
 
-// dbias[n] = sum_m dy[m][n]   (one block per 64 channels, fixed-order tree: deterministic)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dy, int64_t M, int C, int64_t ld, float* dbias)
+// dbias[n] = sum_m dy[m][n]: per-row-block partials (grid.y row blocks), then a fixed-order fp64 combine.
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* dy, int64_t M, int C, int64_t ld,
+                                                               int64_t rows_per_block, float* part /*[gridDim.y][C]*/)
 {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ry = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     float s = 0.0f;
     if (c < C)
-        for (int64_t m = ry; m < M; m += 4) s += dy[m * ld + c];
+        for (int64_t m = r0 + ry; m < r1; m += 4) s += dy[m * ld + c];
     sh[ry][threadIdx.x & 63] = s;
     __syncthreads();
-    if (ry == 0 && c < C) dbias[c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (ry == 0 && c < C)
+        part[(int64_t)blockIdx.y * C + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* part, int nblk, int C, float* dbias)
+{
+    __shared__ double sh[256];
+    const int t = threadIdx.x, lane = t >> 3;
+    const int c = blockIdx.x * 8 + (t & 7);
+    double s = 0.0;
+    if (c < C)
+        for (int b = lane; b < nblk; b += 32) s += (double)part[(int64_t)b * C + c];
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (t < off) sh[t] += sh[t + off];
+        __syncthreads();
+    }
+    if (t < 8 && c < C) dbias[c] = (float)sh[t];
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
@@ -532,7 +553,8 @@ size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Co
     const int64_t M = (int64_t)B * Ho * Wo;
     // splits chosen in pp_conv2d_bwd_weight never exceed 64
     (void)M;
-    return align_up((size_t)64 * kh * kw * Cin * Cout * 4, 256);
+    size_t w = (size_t)64 * kh * kw * Cin * Cout * 4, b = (size_t)256 * Cout * 4;
+    return align_up(w > b ? w : b, 256);
 }
 
 int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
@@ -572,8 +594,18 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
                        (int)splits, p.taps.n, cn, p.taps, dw);
     if (int rc = check_launch("wgrad_reduce_kernel")) return rc;
     if (dbias) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)cdiv(Cout, 64)), dim3(256), 0, st, dy, p.M, Cout, lddy, dbias);
-        if (int rc = check_launch("bias_grad_kernel")) return rc;
+        // partials reuse the (already consumed) head of the workspace: stream order makes that safe
+        int nblk = (int)cdiv(p.M, 512);
+        if (nblk > 256) nblk = 256;
+        const int64_t rpb = cdiv(p.M, nblk);
+        nblk = (int)cdiv(p.M, rpb);
+        if ((size_t)nblk * Cout * 4 > ws_bytes) return fail(PP_ERR_WORKSPACE, "conv bwd_weight: workspace (bias)");
+        float* bpart = reinterpret_cast<float*>(workspace);
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)cdiv(Cout, 64), (unsigned)nblk), dim3(256), 0, st, dy, p.M,
+                           Cout, lddy, rpb, bpart);
+        if (int rc = check_launch("bias_grad_partial_kernel")) return rc;
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)cdiv(Cout, 8)), dim3(256), 0, st, bpart, nblk, Cout, dbias);
+        if (int rc = check_launch("bias_grad_final_kernel")) return rc;
     }
     return PP_OK;
 }

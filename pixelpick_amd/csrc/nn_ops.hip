@@ -118,6 +118,26 @@ __global__ __launch_bounds__(kT) void col_reduce_kernel(const float* x, const fl
     }
 }
 
+// Fixed-order fp64 sum of `nblk` partial values per output, 32 lanes per output (8 outputs per 256-thread
+// block): lane l adds blocks l, l+32, ... then an LDS tree combines the lanes.  Deterministic.
+__device__ __forceinline__ double lanes32_sum(const float* part, int nblk, int64_t stride_b, int64_t idx, bool valid,
+                                              double* sh /*[256]*/)
+{
+    const int t = threadIdx.x, lane = t >> 3;
+    double s = 0.0;
+    if (valid)
+        for (int b = lane; b < nblk; b += 32) s += (double)part[(int64_t)b * stride_b + idx];
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (t < off) sh[t] += sh[t + off];
+        __syncthreads();
+    }
+    const double r = sh[t & 7];
+    __syncthreads();
+    return r;
+}
+
 // BN forward finalize: batch mean / biased var (fp64 combine), running-stat update (momentum, unbiased var),
 // scale = gamma*invstd, shift = beta - mean*scale.   nn.BatchNorm2d training semantics.
 __global__ __launch_bounds__(kT) void bn_finalize_kernel(const float* part, int nblk, int C, double count,
@@ -125,13 +145,11 @@ __global__ __launch_bounds__(kT) void bn_finalize_kernel(const float* part, int 
                                                         float momentum, float* running_mean, float* running_var,
                                                         float* mean, float* invstd, float* scale, float* shift)
 {
-    const int c = blockIdx.x * kT + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((int64_t)b * 2 + 0) * C + c];
-        ss += (double)part[((int64_t)b * 2 + 1) * C + c];
-    }
+    __shared__ double shd[kT];
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    const double s = lanes32_sum(part, nblk, (int64_t)2 * C, c, c < C, shd);
+    const double ss = lanes32_sum(part + C, nblk, (int64_t)2 * C, c, c < C, shd);
+    if (c >= C || threadIdx.x >= 8) return;
     const double mu = s / count;
     double var = ss / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -187,13 +205,11 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const float* x, int64_t ld
 // BN backward finalize: dbeta = sum g, dgamma = sum g*xhat (fixed-order fp64 combine)
 __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta)
 {
-    const int c = blockIdx.x * kT + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((int64_t)b * 2 + 0) * C + c];
-        ss += (double)part[((int64_t)b * 2 + 1) * C + c];
-    }
+    __shared__ double shd[kT];
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    const double s = lanes32_sum(part, nblk, (int64_t)2 * C, c, c < C, shd);
+    const double ss = lanes32_sum(part + C, nblk, (int64_t)2 * C, c, c < C, shd);
+    if (c >= C || threadIdx.x >= 8) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
 }
@@ -359,10 +375,10 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, i
 
 __global__ __launch_bounds__(kT) void sum_partials_kernel(const float* part, int nblk, int64_t n, float* out, float mul)
 {
-    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * n + i];
+    __shared__ double shd[kT];
+    const int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x & 7);
+    const double s = lanes32_sum(part, nblk, n, i, i < n, shd);
+    if (i >= n || threadIdx.x >= 8) return;
     out[i] = (float)(s * (double)mul);
 }
 
@@ -756,7 +772,7 @@ int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* 
                        (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, M, C, ldx, (int64_t)0,
                        (int64_t)0, g, part);
     if (int rc = check_launch("col_reduce_kernel<0>")) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, kT)), dim3(kT), 0, st, part, g.nblk_rows, C, (double)M,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(kT), 0, st, part, g.nblk_rows, C, (double)M,
                        gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     return check_launch("bn_finalize_kernel");
 }
@@ -795,7 +811,7 @@ int pp_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const 
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, dy, y_act, act, mean,
                        invstd, M, C, ldx, lddy, ldya, g, part);
     if (int rc = check_launch("col_reduce_kernel<1>")) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, kT)), dim3(kT), 0, st, part, g.nblk_rows, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(kT), 0, st, part, g.nblk_rows, C, dgamma, dbeta);
     if (int rc = check_launch("bn_bwd_finalize_kernel")) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(kT), 0, st, x, ldx, dy, lddy, y_act, ldya, act,
                        mean, invstd, gamma, dgamma, dbeta, 1.0f / (float)M, dx, lddx, dres, lddr, M, C / 4);
@@ -840,7 +856,7 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4, dy,
                        lddy, Ho, Wo, stride, pad, dil, g, part);
     if (int rc = check_launch("dwconv_bwd_weight_kernel")) return rc;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(9 * C, kT)), dim3(kT), 0, st, part, g.nblk_rows,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(9 * C, 8)), dim3(kT), 0, st, part, g.nblk_rows,
                        (int64_t)9 * C, dw, 1.0f);
     return check_launch("sum_partials_kernel");
 }

@@ -105,6 +105,13 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._nbt_pending:
+            self.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def run(self, tape, x, act=E.ACT_NONE, residual=None, dst=None):
         training = self.training
@@ -112,7 +119,7 @@ class BatchNorm2d(nn.Module):
             B, H, W, _ = x.t.shape
             if B * H * W <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.t.shape)}")
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1        # folded into the num_batches_tracked buffer when it is read
         return E.batch_norm_act(tape, x, self.weight, self.bias, self.running_mean, self.running_var, training, act,
                                 residual, self.eps, self.momentum, dst=dst)
 

@@ -1,0 +1,142 @@
+"""GPU parity of network BLOCKS (InvertedResidual incl. the padded-border quirk, ASPP, decoder) against a
+plain PyTorch fp32 CPU restatement built from torch.nn.functional ops with the same weights."""
+import warnings
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import formula_init as fi
+from pixelpick_amd import engine as E
+from pixelpick_amd.networks.aspp import ASPP
+from pixelpick_amd.networks.layers import BatchNorm2d, Dropout
+from pixelpick_amd.networks.mobilenet_v2 import InvertedResidual
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-12)
+
+
+def _allowed(ref_clean, ref_noisy, tol=1e-3):
+    """1e-3 of the tensor scale + 4x the torch reference's own deviation under a 1e-6 input perturbation
+    (ReLU/ReLU6 mask flips are discrete: one flipped element moves a bias gradient by O(1))."""
+    return tol * ref_clean.double().abs().max().item() + 4 * (ref_noisy.double() - ref_clean.double()).abs().max().item()
+
+
+def _check(name, got, ref_clean, ref_noisy):
+    err = (got.double() - ref_clean.double()).abs().max().item()
+    assert err <= _allowed(ref_clean, ref_noisy), f"{name}: err {err:.3e} > allowed {_allowed(ref_clean, ref_noisy):.3e}"
+
+
+def _formula(mod):
+    mod.load_state_dict(fi.formula_state_dict(mod.state_dict()))
+    for m in mod.modules():
+        if isinstance(m, Dropout):
+            m.p = 0.0
+    return mod
+
+
+def t_bn(x, sd, prefix, training=True):
+    rm, rv = sd[prefix + "running_mean"].clone(), sd[prefix + "running_var"].clone()
+    return F.batch_norm(x, rm, rv, sd[prefix + "weight"], sd[prefix + "bias"], training, 0.1, 1e-5)
+
+
+def _grads_oihw(mod, tape):
+    out = {}
+    for k, p in mod.named_parameters():
+        g = tape.param_grads[id(p)]
+        if g.dim() == 4:
+            g = g.permute(3, 2, 0, 1)
+        elif g.dim() == 3:
+            g = g.permute(2, 0, 1).unsqueeze(1)
+        out[k] = g.cpu()
+    return out
+
+
+@pytest.mark.parametrize("cfg", [(32, 16, 1, 1, 1), (24, 24, 1, 1, 6), (24, 32, 2, 1, 6), (160, 320, 1, 2, 6), (16, 24, 2, 1, 6)],
+                         ids=["t1", "res", "s2", "dil2", "s2-odd"])
+def test_inverted_residual(cfg):
+    inp, oup, stride, dil, t = cfg
+    blk = _formula(InvertedResidual(inp, oup, stride, dil, t, BatchNorm2d)).to(DEV).train()
+    B, H, W = 2, 13, 18
+    x0 = fi.fill((B, inp, H, W), "xb", -1, 1)
+
+    def ref(xin):                                   # torch restatement of mobilenet_v2.py:60-66
+        sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+              for k, v in blk.state_dict().items()}
+        x = xin.clone().requires_grad_(True)
+        h = F.pad(x, (dil, dil, dil, dil))
+        i = 0
+        if t != 1:
+            h = F.relu6(t_bn(F.conv2d(h, sd["conv.0.weight"]), sd, "conv.1."))
+            i = 3
+        h = F.relu6(t_bn(F.conv2d(h, sd[f"conv.{i}.weight"], None, stride, 0, dil, groups=h.shape[1]), sd, f"conv.{i+1}."))
+        h = t_bn(F.conv2d(h, sd[f"conv.{i+3}.weight"]), sd, f"conv.{i+4}.")
+        yr = x + h if (stride == 1 and inp == oup) else h
+        dy = fi.fill(tuple(yr.shape), "dyb", -1, 1)
+        yr.backward(dy)
+        grads = {k: v.grad for k, v in sd.items() if v.requires_grad}
+        grads["input"] = x.grad
+        return yr.detach(), dy, grads
+
+    yr, dy, gr = ref(x0)
+    yn, _, gn = ref(x0 * (1 + 1e-6 * fi.fill(tuple(x0.shape), "nz", -1, 1)))
+    tape = E.Tape()
+    xv = E.Var(nhwc(x0))
+    yv = blk.run(tape, xv)
+    _check("output", nchw(yv.t), yr, yn)
+    tape.backward(yv, nhwc(dy))
+    got = _grads_oihw(blk, tape)
+    got["input"] = nchw(xv.grad)
+    for k in gr:
+        _check(k, got[k], gr[k], gn[k])
+
+
+@pytest.mark.parametrize("hw", [(4, 6), (16, 32), (23, 30)])
+def test_aspp(hw):
+    H, W = hw
+    aspp = _formula(ASPP("mobilenet", 16, BatchNorm2d)).to(DEV).train()
+    B = 2
+    x0 = fi.fill((B, 320, H, W), "xa", -1, 1)
+
+    def ref(xin):                                   # torch restatement of aspp.py:64-79
+        sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+              for k, v in aspp.state_dict().items()}
+        x = xin.clone().requires_grad_(True)
+        brs = [F.relu(t_bn(F.conv2d(x, sd["aspp1.atrous_conv.weight"]), sd, "aspp1.bn."))]
+        for n, d in (("aspp2", 6), ("aspp3", 12), ("aspp4", 18)):
+            brs.append(F.relu(t_bn(F.conv2d(x, sd[f"{n}.atrous_conv.weight"], None, 1, d, d), sd, f"{n}.bn.")))
+        p = F.adaptive_avg_pool2d(x, 1)
+        p = F.relu(t_bn(F.conv2d(p, sd["global_avg_pool.1.weight"]), sd, "global_avg_pool.2."))
+        brs.append(F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True))
+        yr = F.relu(t_bn(F.conv2d(torch.cat(brs, dim=1), sd["conv1.weight"]), sd, "bn1."))
+        dy = fi.fill(tuple(yr.shape), "dya", -1, 1)
+        yr.backward(dy)
+        grads = {k: v.grad for k, v in sd.items() if v.requires_grad}
+        grads["input"] = x.grad
+        return yr.detach(), dy, grads
+
+    yr, dy, gr = ref(x0)
+    yn, _, gn = ref(x0 * (1 + 1e-6 * fi.fill(tuple(x0.shape), "nz", -1, 1)))
+    tape = E.Tape()
+    xv = E.Var(nhwc(x0))
+    yv = aspp.run(tape, xv)
+    _check("output", nchw(yv.t), yr, yn)
+    tape.backward(yv, nhwc(dy))
+    got = _grads_oihw(aspp, tape)
+    got["input"] = nchw(xv.grad)
+    for k in gr:
+        _check(k, got[k], gr[k], gn[k])

@@ -27,7 +27,7 @@ def model():
 
 
 def test_state_dict_keys_and_shapes_match_reference(model, golden_dir):
-    g = np.load(os.path.join(golden_dir, "net_deeplab_cs64x96.npz"))
+    g = np.load(os.path.join(golden_dir, "net_deeplab_cs128x192.npz"))
     sd = model.state_dict()
     assert len(sd) == int(g["n_state_keys"]) == 668          # aliased backbone slices
     crc = zlib.crc32("\n".join(f"{k}:{tuple(v.shape)}" for k, v in sd.items()).encode())

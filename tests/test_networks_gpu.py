@@ -49,7 +49,10 @@ def _to_oihw(name, g):
     return g
 
 
-@pytest.mark.parametrize("tag", ["cs64x96", "cv72x88", "voc40x56"])
+STRIDE = 29   # tools/gen_golden_net.py SAMPLE_STRIDE
+
+
+@pytest.mark.parametrize("tag", ["cs128x192", "cv120x152", "voc40x56"])
 def test_eval_forward_matches_reference(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, f"net_deeplab_{tag}.npz"))
     B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
@@ -59,13 +62,36 @@ def test_eval_forward_matches_reference(golden_dir, tag):
         out = m(x)
     pred = out["pred"]
     assert pred.shape == (B, C, H, W)
-    assert _rel(pred.reshape(-1)[::7].cpu().numpy(), g["eval_pred_samples"]) < TOL
+    assert _rel(pred.reshape(-1)[::STRIDE].cpu().numpy(), g["eval_pred_samples"]) < TOL
     assert _rel(fi.summarize(pred), g["eval_pred_summary"]) < TOL
     emb = out["emb"]                                   # lazy, full resolution like deeplab.py:58-59
     assert emb.shape == (B, 256, H, W)
 
 
-@pytest.mark.parametrize("tag", ["cs64x96", "cv72x88"])
+def _check_grads(g, grads_by_name, full=True):
+    """Every parameter gradient against the reference.  Allowed deviation per tensor: 1e-3 of its scale plus
+    4x the reference's OWN deviation under a 1e-6 relative input perturbation (fixture `grad_noise`): ReLU
+    mask flips and cancelling sums make some gradients of this train-mode-BN network move by up to 2e-2 under
+    such noise in the reference itself, so a flat 1e-3 cannot be met even by the reference vs itself."""
+    worst = 0.0
+    for i, name in enumerate(g["grad_names"]):
+        got = fi.summarize(grads_by_name[str(name)])
+        ref, noise = g["grad_summary"][i], g["grad_noise"][i]
+        for j, scale_j in ((1, 1), (2, 2), (0, 1)):       # abs-sum, max, sum (sum relative to abs-sum)
+            tol = TOL * max(ref[scale_j], 1e-12) + 4 * noise[j]
+            assert abs(got[j] - ref[j]) <= tol, f"{name}[{j}]: {got[j]} vs {ref[j]} (tol {tol:.3e}, noise {noise[j]:.3e})"
+        worst = max(worst, abs(got[1] - ref[1]) / max(ref[1], 1e-12))
+    if full:
+        for k in g.files:
+            if k.startswith("g:"):
+                name = k[2:]
+                got = _to_oihw(name, grads_by_name[name]).cpu().numpy()
+                err = np.abs(got.astype(np.float64) - g[k]).max()
+                assert err <= TOL * np.abs(g[k]).max() + 4 * float(g["gn:" + name]), f"{name}: {err}"
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["cs128x192", "cv120x152"])
 def test_train_step_matches_reference(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, f"net_deeplab_{tag}.npz"))
     B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
@@ -75,42 +101,28 @@ def test_train_step_matches_reference(golden_dir, tag):
     pred = m(x)["pred"]
     loss = F.cross_entropy(pred, y, ignore_index=ign)          # the reference's own call (model.py:116)
     loss.backward()
-    assert _rel(pred.detach().reshape(-1)[::7].cpu().numpy(), g["train_pred_samples"]) < TOL
+    ref_s = g["train_pred_samples"]
+    err = np.abs(pred.detach().reshape(-1)[::STRIDE].cpu().numpy().astype(np.float64) - ref_s).max()
+    assert err <= TOL * np.abs(ref_s).max() + 4 * float(g["train_pred_noise"]), f"logits err {err}"
     assert abs(loss.item() - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
-    named = dict(m.named_parameters())
-    worst = 0.0
-    for i, name in enumerate(g["grad_names"]):
-        got = fi.summarize(named[str(name)].grad)
-        ref = g["grad_summary"][i]
-        # compare |sum|-style quantities relative to the gradient's own scale (abs-sum / max)
-        assert abs(got[1] - ref[1]) <= TOL * max(ref[1], 1e-12), f"{name}: abs-sum {got[1]} vs {ref[1]}"
-        assert abs(got[2] - ref[2]) <= TOL * max(ref[2], 1e-12), f"{name}: max {got[2]} vs {ref[2]}"
-        assert abs(got[0] - ref[0]) <= TOL * max(ref[1], 1e-12), f"{name}: sum {got[0]} vs {ref[0]}"
-        worst = max(worst, abs(got[1] - ref[1]) / max(ref[1], 1e-12))
+    worst = _check_grads(g, {k: p.grad for k, p in m.named_parameters()})
     for k in g.files:
-        if k.startswith("g:"):
-            name = k[2:]
-            assert _rel(_to_oihw(name, named[name].grad).cpu().numpy(), g[k]) < TOL, name
         if k.startswith("rs:"):
             assert _rel(m.state_dict()[k[3:]].cpu().numpy(), g[k]) < TOL, k
-    print(f"worst relative abs-sum gradient deviation: {worst:.2e}")
+    print(f"[{tag}] logits max err {err:.2e}; worst relative abs-sum gradient deviation {worst:.2e}")
 
 
 def test_flat_trainer_matches_autograd_path_and_is_deterministic(golden_dir):
-    g = np.load(os.path.join(golden_dir, "net_deeplab_cs64x96.npz"))
+    g = np.load(os.path.join(golden_dir, "net_deeplab_cs128x192.npz"))
     B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
-    x = fi.formula_input(B, H, W, key="xcs64x96").to(DEV)
-    y = fi.formula_labels(B, H, W, C, ign, n_lab, key="ycs64x96").to(DEV)
+    x = fi.formula_input(B, H, W, key="xcs128x192").to(DEV)
+    y = fi.formula_labels(B, H, W, C, ign, n_lab, key="ycs128x192").to(DEV)
     m = _build(C).train()
     tr = FlatTrainer(m, ignore_index=ign)
     loss = tr.forward_backward(x, y)
     assert abs(loss.item() - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
     g1 = tr.flat_g.clone()
-    for i, name in enumerate(g["grad_names"]):
-        p = dict(m.named_parameters())[str(name)]
-        got = fi.summarize(tr._grad_view[id(p)])
-        ref = g["grad_summary"][i]
-        assert abs(got[1] - ref[1]) <= TOL * max(ref[1], 1e-12), name
+    _check_grads(g, {k: tr._grad_view[id(p)] for k, p in m.named_parameters()})
     # bit-exact repeatability of the whole forward/backward (deterministic reductions, no float atomics)
     m2 = _build(C).train()
     tr2 = FlatTrainer(m2, ignore_index=ign)

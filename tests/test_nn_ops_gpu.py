@@ -55,6 +55,9 @@ CONV_CASES = [
     (1, 40, 36, 3, 64, 7, 2, 3, 1, False),        # ResNet stem 7x7 s2
     (2, 12, 12, 128, 128, 3, 1, 1, 1, True),      # FPN UpsampleBlock conv (bias)
     (1, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead at Cityscapes-quarter size (128x128 tiles)
+    (2, 23, 30, 1280, 256, 1, 1, 0, 1, False),    # ASPP fuse at CamVid size (M = 1380)
+    (2, 23, 30, 320, 256, 3, 1, 12, 12, False),   # atrous d=12 at CamVid size
+    (2, 17, 22, 160, 960, 1, 1, 0, 1, False),
 ]
 
 
@@ -125,7 +128,8 @@ def test_dwconv_fwd_bwd(case):
 
 
 @pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, False), (0, True), (1, True)])
-@pytest.mark.parametrize("shape", [(4, 18, 34, 96), (2, 7, 5, 16), (4, 16, 32, 960), (3, 1, 1, 256), (2, 6, 10, 2048)])
+@pytest.mark.parametrize("shape", [(4, 18, 34, 96), (2, 7, 5, 16), (4, 16, 32, 960), (3, 1, 1, 256), (2, 6, 10, 2048),
+                                   (2, 23, 30, 256), (2, 13, 18, 960), (2, 17, 22, 960)])
 def test_batchnorm_train_fwd_bwd(shape, act, with_res):
     B, H, W, C = shape
     torch.manual_seed(2)
