@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — PixelPick hot path on MI355X: one JSON line per run (driver contract).
+"""bench.py — PixelPick hot path on MI355X: ONE JSON line per run (driver contract).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the acquisition hot path (softmax -> uncertainty -> exclusion -> per-image
-top-k, query.py:190-204,57-61) over one batch of synthetic logits already resident in HBM.
-Workload = BASELINE.json configs[1]: Cityscapes-quarter 256x512, C=19, entropy, top-k=20, batched
-B=256 images per launch per GPU (2.58 GB of logits >> the 256 MiB Infinity Cache), NCHW fp32 as the
-reference model emits.  Images shard over ranks with no data-path collective ("weak" scaling).
+BASELINE.json metric: images/s of a full DeepLabv3+-MobileNetV2 train step + Mpixels/s of acquisition, at
+Cityscapes-quarter 256x512 (configs[1]).  One run measures both on synthetic data resident in HBM:
 
-Extra objects on the line:
-  roofline     HBM roofline of the dominant kernel (acq_kernel): algorithmic bytes per launch
-               = pixels*(4*C+1) / its mean launch duration measured with HIP events
-               recorded around that kernel on its stream (pp_debug_set_kernel_events).
-  cpu_baseline the torch-CPU port of the reference path (oracle/acq.py) timed on this box's host
-               cores on a bounded sample (rank 0, N=1 only).
+  value / ms_per_step   K train steps (model.py:101-122: forward, sparse cross-entropy over 20 labelled
+                        pixels/image, backward, [RCCL all-reduce of the flat gradient], Adam with the backbone
+                        at lr/10), per-GPU batch 4 (args.py:89), BN in train mode, dropout active, fp32.
+                        One process per GPU; value = images of ALL ranks / max-over-ranks time ("weak").
+  acquisition{}         K passes of softmax -> entropy -> exclusion -> per-image top-20 (query.py:190-204,
+                        57-61) over B=256 images of 256x512x19 logits per GPU (2.58 GB >> 256 MiB MALL);
+                        images shard over ranks, no collective.
+  roofline{}            the roofline-graded kernel (north_star): acq_kernel vs HBM.  achieved = algorithmic
+                        bytes per launch pixels*(4C+1) / mean launch duration from HIP events recorded around
+                        that kernel on its stream, inside the timed region.
+  roofline_mfma{}       the dominant train-step kernel (conv_igemm_kernel, SegmentHead 3x3 304->256 at
+                        B*64*128 rows, decoders.py:107) vs the fp32 MFMA peak, same event method.
+  cpu_baseline{}        the plain-PyTorch port of the same train step / acquisition loop (oracle/) timed on
+                        this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
 import ctypes
@@ -24,13 +29,16 @@ import json
 import os
 import sys
 import time
+import warnings
+from argparse import Namespace
 
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
 class HipEvents:
@@ -66,15 +74,44 @@ class HipEvents:
                 self.hip.hipEventDestroy(arr[i])
 
 
-def cpu_baseline(C, H, W, k, strategy, budget_s=12.0):
-    """Reference path on host cores: per-image loop like query.py:159 (B=1), torch CPU ops."""
-    from oracle import acq as orc
+# ------------------------------------------------------------------------------------------------ synthetic inputs
+def synth_train_batch(B, C, H, W, n_lab, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn((B, 3, H, W), device=device, generator=g)
+    y = torch.full((B, H, W), C, dtype=torch.int64, device=device)          # all ignore_index (= C) ...
+    for b in range(B):                                                      # ... except n_lab labelled pixels/img
+        idx = torch.randperm(H * W, device=device, generator=g)[:n_lab]
+        y[b].view(-1)[idx] = torch.randint(0, C, (n_lab,), device=device, generator=g)
+    return x, y
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines (oracle/)
+def cpu_baseline_train(B, C, H, W, n_lab, budget_s=15.0):
+    from oracle import net as onet
     threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    model = onet.OracleDeepLab(C).train()
+    opt = onet.make_optimizer(model)
+    x, y = synth_train_batch(B, C, H, W, n_lab, torch.device("cpu"), 1)
+    onet.train_step(model, opt, x, y, C)                                     # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        onet.train_step(model, opt, x, y, C)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 50:
+            break
+    return round(done * B / el, 3), f"{done} train steps of B={B} {H}x{W} (oracle/net.py, torch CPU ops, {threads} threads, {el:.1f} s)", threads
+
+
+def cpu_baseline_acq(C, H, W, k, strategy, budget_s=8.0):
+    from oracle import acq as orc
     gen = torch.Generator().manual_seed(0)
     n_img = 4
     logits = [torch.randn(1, C, H, W, generator=gen) * 3 for _ in range(n_img)]
     excl = [torch.rand(H, W, generator=gen) < 0.05 for _ in range(n_img)]
-    orc.torch_port_acquire(logits[0], excl[0], strategy, k)  # warm-up
+    orc.torch_port_acquire(logits[0], excl[0], strategy, k)
     t0 = time.perf_counter()
     done = 0
     while True:
@@ -83,9 +120,7 @@ def cpu_baseline(C, H, W, k, strategy, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or done >= 2000:
             break
-    return {"value": round(done * H * W / el / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": f"{done} images {H}x{W}x{C} one at a time (query.py:159 loop), torch CPU ops, "
-                      f"{threads} threads, {el:.1f} s"}
+    return round(done * H * W / el / 1e6, 3), f"{done} images {H}x{W}x{C} one at a time (query.py:159 loop), {el:.1f} s"
 
 
 def main():
@@ -93,13 +128,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="images per launch per GPU")
+    ap.add_argument("--train-batch", type=int, default=4, help="images per GPU per train step (args.py:89)")
+    ap.add_argument("--batch", type=int, default=256, help="acquisition: images per launch per GPU")
     ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--n-labelled", type=int, default=20)
     ap.add_argument("--strategy", default="entropy")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
+    ap.add_argument("--mode", default="both", choices=["both", "train", "acq"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune-occ", type=int, default=0)
     ap.add_argument("--tune-ppt", type=int, default=0)
@@ -127,74 +165,146 @@ def main():
     L.pp_debug_set_acq_tuning(a.tune_occ, a.tune_ppt)
     L.pp_debug_set_reduce_mode(a.reduce_mode)
     L.pp_debug_set_exact_formula(a.exact_formula)
-
-    B, C, H, W, k = a.batch, a.classes, a.height, a.width, a.k
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    logits = torch.randn((B, C, H, W), device=dev, generator=gen) * 3          # resident in HBM before timing
-    if a.layout == "nhwc":
-        logits = logits.contiguous(memory_format=torch.channels_last)
-    excl = (torch.rand((B, H, W), device=dev, generator=gen) < 0.05).to(torch.uint8)
-
-    # pre-allocate everything the step touches: the timed region is kernels only
-    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
-    val = torch.empty((B, k), dtype=torch.float32, device=dev)
-    ws = torch.empty(max(L.pp_acq_workspace_bytes(B, C, H, W, k), 256), dtype=torch.uint8, device=dev)
-    sB, sC, sH, sW = logits.stride()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    sid = acq.STRATEGY_ID[a.strategy]
-
-    def step():
-        rc = L.pp_acq_score_topk(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW, excl.data_ptr(), sid, k,
-                                 idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), stream)
-        _lib.check(rc, "pp_acq_score_topk")
+    C, H, W, k = a.classes, a.height, a.width, a.k
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
-    ev = HipEvents(a.steps)
-    barrier()
-    L.pp_debug_set_kernel_events(ev.starts, ev.stops, a.steps)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    el = time.perf_counter() - t0
-    L.pp_debug_set_kernel_events(None, None, 0)
-    kern_ms = ev.elapsed_ms()
-    ev.destroy()
-
-    if dist is not None:
+    def max_over_ranks(el):
+        if dist is None:
+            return el
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        return float(t.item())
+
+    def timed(step_fn, steps, warmup, events=None):
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        if events is not None:
+            L.pp_debug_set_kernel_events(events.starts, events.stops, events.n)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        barrier()
+        el = time.perf_counter() - t0
+        L.pp_debug_set_kernel_events(None, None, 0)
+        return max_over_ranks(el)
+
+    line = {}
+
+    # ------------------------------------------------------------------------------------ train step
+    train = None
+    if a.mode in ("both", "train"):
+        from pixelpick_amd.trainer import FlatTrainer
+        from pixelpick_amd.utils.utils import get_model
+        from pixelpick_amd import engine as E
+        TB = a.train_batch
+        torch.manual_seed(0)                         # identical replicas on every rank
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).to(dev).train()
+        tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-7, weight_decay=2e-4, ignore_index=C)
+        E.set_dropout_seed(1234 + rank)
+        x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
+        el = timed(lambda: tr.train_step(x, y), a.steps, a.warmup)
+        loss = float(tr.last_loss.item())
+        train = {"img_per_s": world * TB * a.steps / el, "ms_per_step": el / a.steps * 1e3, "loss_after": loss,
+                 "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
+
+        # dominant train kernel vs the fp32 MFMA roofline: SegmentHead conv 3x3 304->256 on [TB,64,128] (decoders.py:107)
+        Hq, Wq = H // 4, W // 4
+        xa = torch.randn((TB, Hq, Wq, 304), device=dev)
+        wa = torch.randn((3, 3, 304, 256), device=dev) * 0.02
+        ya = torch.empty((TB, Hq, Wq, 256), device=dev)
+        nrep = max(a.steps, 10)
+        evc = HipEvents(nrep)
+
+        def conv_once():
+            rc = L.pp_conv2d_fwd(xa.data_ptr(), 304, TB, Hq, Wq, 304, wa.data_ptr(), None, 3, 3, 1, 1, 1, ya.data_ptr(), 256, 256, stream)
+            _lib.check(rc, "pp_conv2d_fwd")
+        timed(conv_once, nrep, 3, evc)
+        cms = evc.elapsed_ms()
+        evc.destroy()
+        flops = 2.0 * TB * Hq * Wq * 256 * 9 * 304
+        cavg = sum(cms) / len(cms)
+        line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<128,128> SegmentHead 3x3 304->256 fwd",
+                                 "achieved": round(flops / (cavg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": round(flops / (cavg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
+        del tr, model, xa, wa, ya
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------------------------ acquisition
+    acqr = None
+    if a.mode in ("both", "acq"):
+        B = a.batch
+        gen = torch.Generator(device=dev).manual_seed(100 + rank)
+        logits = torch.randn((B, C, H, W), device=dev, generator=gen) * 3        # resident in HBM before timing
+        if a.layout == "nhwc":
+            logits = logits.contiguous(memory_format=torch.channels_last)
+        excl = (torch.rand((B, H, W), device=dev, generator=gen) < 0.05).to(torch.uint8)
+        idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+        val = torch.empty((B, k), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(L.pp_acq_workspace_bytes(B, C, H, W, k), 256), dtype=torch.uint8, device=dev)
+        sB, sC, sH, sW = logits.stride()
+        sid = acq.STRATEGY_ID[a.strategy]
+
+        def acq_step():
+            rc = L.pp_acq_score_topk(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW, excl.data_ptr(), sid, k,
+                                     idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), stream)
+            _lib.check(rc, "pp_acq_score_topk")
+        ev = HipEvents(a.steps)
+        el = timed(acq_step, a.steps, a.warmup, ev)
+        kms = ev.elapsed_ms()
+        ev.destroy()
+        alg_bytes = B * H * W * (4 * C + 1)                  # per launch of acq_kernel on ONE GPU
+        kavg = sum(kms) / len(kms)
+        achieved = alg_bytes / (kavg * 1e-3) / 1e9
+        acqr = {"value": round(world * B * H * W * a.steps / el / 1e6, 1), "unit": "Mpixels/s",
+                "ms_per_step": round(el / a.steps * 1e3, 4), "images_per_launch_per_gpu": B, "k": k,
+                "strategy": a.strategy, "layout": a.layout}
+        line["roofline"] = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
+                            "kernel_ms_min": round(min(kms), 4)}
 
     if rank == 0:
-        pixels_per_step = world * B * H * W
-        ms_per_step = el / a.steps * 1e3
-        value = pixels_per_step / (el / a.steps) / 1e6
-        alg_bytes = B * H * W * (4 * C + 1)                 # per launch of acq_kernel on ONE GPU
-        kavg_ms = sum(kern_ms) / len(kern_ms)
-        achieved = alg_bytes / (kavg_ms * 1e-3) / 1e9
-        line = {
-            "metric": "acquisition_throughput", "value": round(value, 1), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: Cityscapes {H}x{W}, C={C}, {a.strategy} acquisition "
-                                   f"top-k={k}, logits of DeepLabv3+-MNv2 shape, {a.layout.upper()} fp32",
-                       "images_per_launch_per_gpu": B, "k": k, "strategy": a.strategy, "layout": a.layout,
-                       "sharding": f"images over {world} rank(s), no collective"},
-            "roofline": {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg_ms, 4),
-                         "kernel_ms_min": round(min(kern_ms), 4)},
-        }
+        head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        wl = (f"BASELINE configs[1]: Cityscapes {H}x{W}, C={C}, DeepLabv3+-MobileNetV2; train step per-GPU batch "
+              f"{a.train_batch} with {a.n_labelled} labelled px/img + Adam; acquisition {a.strategy} top-k={k}, "
+              f"B={a.batch} images/launch/GPU, {a.layout.upper()} fp32 logits")
+        if train is not None:
+            out = {"metric": "train_step_throughput", "value": round(train["img_per_s"], 2), "unit": "images/s",
+                   "ms_per_step": round(train["ms_per_step"], 4)}
+        else:
+            out = {"metric": "acquisition_throughput", "value": acqr["value"], "unit": "Mpixels/s", "ms_per_step": acqr["ms_per_step"]}
+        out.update(head)
+        out["config"] = {"workload": wl, "global_batch": world * a.train_batch,
+                         "sharding": f"images over {world} rank(s); train: one RCCL all-reduce of the flat gradient per step; "
+                                     f"acquisition: no collective"}
+        if train is not None:
+            out["train"] = {k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in train.items()}
+        if acqr is not None:
+            out["acquisition"] = acqr
+        out.update(line)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(C, H, W, k, a.strategy)
-        print(json.dumps(line), flush=True)
+            cb = {"kind": "port", "cores": torch.get_num_threads()}
+            if train is not None:
+                v, sample, thr = cpu_baseline_train(a.train_batch, C, H, W, a.n_labelled)
+                cb.update({"value": v, "unit": "images/s", "sample": sample})
+            if acqr is not None:
+                v, sample = cpu_baseline_acq(C, H, W, k, a.strategy)
+                if train is None:
+                    cb.update({"value": v, "unit": "Mpixels/s", "sample": sample})
+                else:
+                    cb["acquisition"] = {"value": v, "unit": "Mpixels/s", "sample": sample}
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
 
     if dist is not None:
         dist.destroy_process_group()

@@ -211,7 +211,7 @@ void pp_debug_set_exact_formula(int on);
 void pp_debug_set_acq_tuning(int occ, int ppt);
 
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The
- * i-th launch of the dominant acquisition kernel after this call records starts[i] / stops[i] on its
+ * i-th launch of a dominant kernel (acq_kernel, conv_igemm_kernel) after this call records starts[i] / stops[i] on its
  * stream immediately before / after the launch.  Pass (NULL, NULL, 0) to switch off.  The arrays must
  * stay alive until then. */
 void pp_debug_set_kernel_events(void** starts, void** stops, int n);

@@ -19,25 +19,6 @@ static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 d
 static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
 static int g_tune_ppt = 0;
 
-// Optional profiling hook (bench.py): caller-owned hipEvent pairs recorded right around the dominant
-// kernel's launch, pair i for the i-th launch after pp_debug_set_kernel_events().
-static hipEvent_t* g_ev_start = nullptr;
-static hipEvent_t* g_ev_stop = nullptr;
-static int g_ev_n = 0, g_ev_i = 0;
-
-struct EventScope {
-    hipStream_t st;
-    bool on;
-    explicit EventScope(hipStream_t s) : st(s), on(g_ev_i < g_ev_n)
-    {
-        if (on) (void)hipEventRecord(g_ev_start[g_ev_i], st);
-    }
-    ~EventScope()
-    {
-        if (on) (void)hipEventRecord(g_ev_stop[g_ev_i++], st);
-    }
-};
-
 constexpr int kBlock = 256;
 constexpr int kSmallKMax = 64;        // fused per-wave extraction up to this k; beyond: map + radix select
 constexpr int kMergeItems = 16;       // merge kernel: candidates per thread
@@ -654,14 +635,6 @@ void pp_debug_set_acq_tuning(int occ, int ppt)
 {
     g_tune_occ = (occ == 2 || occ == 3 || occ == 4) ? occ : 0;
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
-}
-
-void pp_debug_set_kernel_events(void** starts, void** stops, int n)
-{
-    g_ev_start = reinterpret_cast<hipEvent_t*>(starts);
-    g_ev_stop = reinterpret_cast<hipEvent_t*>(stops);
-    g_ev_n = (starts && stops) ? n : 0;
-    g_ev_i = 0;
 }
 
 size_t pp_topk_workspace_bytes(int64_t B, int64_t N, int64_t k)

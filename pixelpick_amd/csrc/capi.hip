@@ -18,9 +18,24 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+EventHook& event_hook()
+{
+    static EventHook h{nullptr, nullptr, 0, 0};
+    return h;
+}
+
 }  // namespace pp
 
 extern "C" {
+
+void pp_debug_set_kernel_events(void** starts, void** stops, int n)
+{
+    pp::EventHook& h = pp::event_hook();
+    h.start = reinterpret_cast<hipEvent_t*>(starts);
+    h.stop = reinterpret_cast<hipEvent_t*>(stops);
+    h.n = (starts && stops) ? n : 0;
+    h.i = 0;
+}
 
 int pp_version(void) { return 100; }  // 0.1.0
 

@@ -480,6 +480,7 @@ static void build_taps(ConvTaps& t, int kh, int kw, int stride, int pad, int dil
 template <bool BWD>
 static int launch_conv(const ConvParams& p, hipStream_t st)
 {
+    EventScope ev(st);
     const int64_t mt128 = cdiv(p.M, 128), mt64 = cdiv(p.M, 64);
     if (p.Cn <= 32) {
         dim3 grid((unsigned)mt128, 1);

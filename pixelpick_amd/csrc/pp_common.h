@@ -24,6 +24,28 @@ inline int check_launch(const char* what)
     return PP_OK;
 }
 
+// Optional profiling hook (bench.py): caller-owned hipEvent pairs recorded right around a dominant kernel's
+// launch (acq_kernel, conv_igemm_kernel), pair i for the i-th such launch after pp_debug_set_kernel_events().
+struct EventHook {
+    hipEvent_t* start;
+    hipEvent_t* stop;
+    int n, i;
+};
+EventHook& event_hook();
+
+struct EventScope {
+    hipStream_t st;
+    bool on;
+    explicit EventScope(hipStream_t s) : st(s), on(event_hook().i < event_hook().n)
+    {
+        if (on) (void)hipEventRecord(event_hook().start[event_hook().i], st);
+    }
+    ~EventScope()
+    {
+        if (on) (void)hipEventRecord(event_hook().stop[event_hook().i++], st);
+    }
+};
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
