@@ -130,10 +130,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     for (int i = 0; i < A_F4; ++i) {
         const int64_t m = m0 + (tid >> 2) + i * 64;
         if (m < p.M) {
-            const int ow = (int)(m % p.Wo);
-            const int64_t t = m / p.Wo;
-            const int oh = (int)(t % p.Ho);
-            a_b[i] = (int)(t / p.Ho);
+            const unsigned mu = (unsigned)m;                  // M < 2^31 (checked on the host)
+            const unsigned t = mu / (unsigned)p.Wo;
+            const int ow = (int)(mu - t * (unsigned)p.Wo);
+            const unsigned bb = t / (unsigned)p.Ho;
+            const int oh = (int)(t - bb * (unsigned)p.Ho);
+            a_b[i] = (int)bb;
             a_ih[i] = oh * p.stride;
             a_iw[i] = ow * p.stride;
         } else {
@@ -281,6 +283,7 @@ struct WgradParams {
     int B, H, W, Ho, Wo, Cin, Cout, stride;
     int64_t M;
     int64_t m_per_split;
+    int pointwise;      // 1x1, stride 1, pad 0: input pixel == output pixel, no index decode
     ConvTaps taps;
 };
 
@@ -320,13 +323,20 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
             const int c = c0 + cq * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < m_end && c < p.Cin) {
-                const int ow = (int)(m % p.Wo);
-                const int64_t t = m / p.Wo;
-                const int oh = (int)(t % p.Ho);
-                const int b = (int)(t / p.Ho);
-                const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-                    const float* src = p.x + (((int64_t)b * p.H + ih) * p.W + iw) * p.ldx + c;
+                int64_t pix = m;
+                bool inb = true;
+                if (!p.pointwise) {
+                    const unsigned mu = (unsigned)m;          // M < 2^31 (checked on the host)
+                    const unsigned t = mu / (unsigned)p.Wo;
+                    const int ow = (int)(mu - t * (unsigned)p.Wo);
+                    const unsigned b = t / (unsigned)p.Ho;
+                    const int oh = (int)(t - b * (unsigned)p.Ho);
+                    const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+                    inb = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    pix = ((int64_t)b * p.H + ih) * p.W + iw;
+                }
+                if (inb) {
+                    const float* src = p.x + pix * p.ldx + c;
                     if (x_vec) {
                         v = *reinterpret_cast<const float4*>(src);
                     } else {
@@ -526,6 +536,7 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
     p.stride = stride; p.M = (int64_t)B * Ho * Wo;
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
+    if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
     return launch_conv<false>(p, as_stream(stream));
 }
 
@@ -570,6 +581,8 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout; p.stride = stride;
     p.M = (int64_t)B * Ho * Wo;
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+    if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_weight: more than 2^31 output pixels");
+    p.pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
     const bool big = Cin > 64 && Cout > 64;
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;

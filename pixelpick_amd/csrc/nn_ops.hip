@@ -54,7 +54,10 @@ static ColReduceGeom col_geom(int64_t M, int C)
     g.cq_blk = g.cq < kT ? g.cq : kT;
     g.rows_per_pass = kT / g.cq_blk;
     g.nblk_cols = (int)cdiv(g.cq, g.cq_blk);
-    int64_t want_blocks = 1024 / g.nblk_cols;
+    // enough blocks to fill the chip, but at least ~16 float4 rows per thread so that the second-stage combine
+    // (lanes32_sum) stays a handful of iterations for the small 1/16-resolution maps
+    int64_t want_blocks = (M * g.cq) / (kT * 16) / g.nblk_cols;
+    if (want_blocks > 1024 / g.nblk_cols) want_blocks = 1024 / g.nblk_cols;
     if (want_blocks < 1) want_blocks = 1;
     int64_t rpb = cdiv(cdiv(M, want_blocks), g.rows_per_pass) * g.rows_per_pass;
     if (rpb < g.rows_per_pass * 4) rpb = g.rows_per_pass * 4;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const float* x, int64_t ld
 {
     const int64_t total = M * cq;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
-        const int64_t r = e / cq;
+        const int64_t r = total <= 0xFFFFFFFFll ? (int64_t)((unsigned)e / (unsigned)cq) : e / cq;
         const int q = (int)(e - r * cq);
         const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
         const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* x, int64_
 {
     const int64_t total = M * cq;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
-        const int64_t r = e / cq;
+        const int64_t r = total <= 0xFFFFFFFFll ? (int64_t)((unsigned)e / (unsigned)cq) : e / cq;
         const int q = (int)(e - r * cq);
         float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + q * 4);
         if (act != 0) {
