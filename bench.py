@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--tune-ppt", type=int, default=0)
     ap.add_argument("--reduce-mode", type=int, default=0)
     ap.add_argument("--exact-formula", type=int, default=0)
+    ap.add_argument("--conv-variant", type=int, default=0)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +166,7 @@ def main():
     L.pp_debug_set_acq_tuning(a.tune_occ, a.tune_ppt)
     L.pp_debug_set_reduce_mode(a.reduce_mode)
     L.pp_debug_set_exact_formula(a.exact_formula)
+    L.pp_debug_set_conv_variant(a.conv_variant)
     stream = torch.cuda.current_stream(dev).cuda_stream
     C, H, W, k = a.classes, a.height, a.width, a.k
 

@@ -54,10 +54,9 @@ static ColReduceGeom col_geom(int64_t M, int C)
     g.cq_blk = g.cq < kT ? g.cq : kT;
     g.rows_per_pass = kT / g.cq_blk;
     g.nblk_cols = (int)cdiv(g.cq, g.cq_blk);
-    // enough blocks to fill the chip, but at least ~16 float4 rows per thread so that the second-stage combine
-    // (lanes32_sum) stays a handful of iterations for the small 1/16-resolution maps
-    int64_t want_blocks = (M * g.cq) / (kT * 16) / g.nblk_cols;
-    if (want_blocks > 1024 / g.nblk_cols) want_blocks = 1024 / g.nblk_cols;
+    // measured (profiles/r01_train_step_*): these reductions are latency-bound, more row blocks win even
+    // for the small 1/16-resolution maps; the second-stage combine reads the partials with 4 loads in flight
+    int64_t want_blocks = 1024 / g.nblk_cols;
     if (want_blocks < 1) want_blocks = 1;
     int64_t rpb = cdiv(cdiv(M, want_blocks), g.rows_per_pass) * g.rows_per_pass;
     if (rpb < g.rows_per_pass * 4) rpb = g.rows_per_pass * 4;
@@ -128,8 +127,15 @@ __device__ __forceinline__ double lanes32_sum(const float* part, int nblk, int64
 {
     const int t = threadIdx.x, lane = t >> 3;
     double s = 0.0;
-    if (valid)
-        for (int b = lane; b < nblk; b += 32) s += (double)part[(int64_t)b * stride_b + idx];
+    if (valid) {
+        int b = lane;
+        for (; b + 96 < nblk; b += 128) {      // 4 independent loads in flight per lane
+            const float v0 = part[(int64_t)b * stride_b + idx], v1 = part[(int64_t)(b + 32) * stride_b + idx];
+            const float v2 = part[(int64_t)(b + 64) * stride_b + idx], v3 = part[(int64_t)(b + 96) * stride_b + idx];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nblk; b += 32) s += (double)part[(int64_t)b * stride_b + idx];
+    }
     sh[t] = s;
     __syncthreads();
     for (int off = 128; off >= 8; off >>= 1) {

@@ -58,6 +58,8 @@ CONV_CASES = [
     (2, 23, 30, 1280, 256, 1, 1, 0, 1, False),    # ASPP fuse at CamVid size (M = 1380)
     (2, 23, 30, 320, 256, 3, 1, 12, 12, False),   # atrous d=12 at CamVid size
     (2, 17, 22, 160, 960, 1, 1, 0, 1, False),
+    (4, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead conv1 at bench scale: the 128x128 large-tile kernels
+    (3, 50, 100, 256, 304, 3, 1, 1, 1, True),     # large tile, ragged M (15000 rows), Cout=304 (partial N tile)
 ]
 
 
