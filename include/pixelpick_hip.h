@@ -209,7 +209,8 @@ void pp_debug_set_exact_formula(int on);
 /* Tuning knob for the C == 19 flat path: occupancy bound (2/3/4 waves per SIMD, 0 = default) and
  * pixels per thread (4/8, 0 = automatic). */
 void pp_debug_set_acq_tuning(int occ, int ppt);
-/* Large-tile dense conv kernel: 0 = double-buffered K-step 32 (default), 1 = single-buffered K-step 16. */
+/* Large-tile dense conv kernel: 0 = 128x128 tile, single LDS buffer, K-step 16 (default; measured fastest),
+ * 1 = double-buffered K-step 32, 2 = 128x64 tiles. */
 void pp_debug_set_conv_variant(int v);
 
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The

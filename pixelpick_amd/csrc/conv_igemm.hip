@@ -25,17 +25,20 @@ namespace pp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static int g_conv_variant = 0;   // 0: double-buffered K=32 large tile (default), 1: single-buffered K=16
+static int g_conv_xcd_remap = 1;
+static int g_conv_novec = 0;
+static int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
+static int g_conv_variant = 0;   // large-tile kernel: 0 single-buffered K=16 128x128 (default), 1 double-buffered K=32, 2 128x64 tiles
 
 constexpr int kThreads = 256;
 constexpr int BK = 16;
 constexpr int kMaxTaps = 49;
 
 struct ConvTaps {
-    int n;                      // number of live taps
-    short dh[kMaxTaps];         // input row offset of tap (already includes -pad / flip)
-    short dw[kMaxTaps];
-    unsigned char widx[kMaxTaps];  // index of the tap in the weight tensor (kh*KW + kw)
+    int n;                  // number of live taps
+    int dh[kMaxTaps];       // input row offset of tap (already includes -pad / flip); int: wave-uniform s_load
+    int dw[kMaxTaps];
+    int widx[kMaxTaps];     // index of the tap in the weight tensor (kh*KW + kw)
 };
 
 struct ConvParams {
@@ -51,6 +54,8 @@ struct ConvParams {
     int Cin, Cout;    // weight tensor dims (for addressing)
     int stride;
     int64_t M;        // B*Ho*Wo
+    int n_tiles;      // tiles along the output-channel axis (grid is 1-D: m_tiles * n_tiles blocks)
+    int xcd_remap;
     ConvTaps taps;
 };
 
@@ -66,19 +71,23 @@ __device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a
 {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, h = lane >> 5;
+    constexpr int NQ = BKT / 8;
+    // All fragment reads of the K-step are issued up front (the MFMAs of group q only wait for group q's reads
+    // through hipcc's counted lgkmcnt), so no LDS latency sits between MFMAs: measured, reads placed lazily in
+    // front of each group of 4 MFMAs left the matrix pipe idle ~25 % of the MFMA phase at one wave per SIMD.
+    float a[NQ][TM][4], b[NQ][TN][4];
 #pragma unroll
-    for (int q = 0; q < BKT / 8; ++q) {
-        float a[TM][4], b[TN][4];
+    for (int q = 0; q < NQ; ++q) {
         const int k0 = 8 * q + 4 * h;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int r = a_row0 + tm * 32 + l31;
             if constexpr (A_MK) {
                 const float4 v = *reinterpret_cast<const float4*>(As + r * PITCH_A + k0);
-                a[tm][0] = v.x; a[tm][1] = v.y; a[tm][2] = v.z; a[tm][3] = v.w;
+                a[q][tm][0] = v.x; a[q][tm][1] = v.y; a[q][tm][2] = v.z; a[q][tm][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[tm][j] = As[(k0 + j) * PITCH_A + r];
+                for (int j = 0; j < 4; ++j) a[q][tm][j] = As[(k0 + j) * PITCH_A + r];
             }
         }
 #pragma unroll
@@ -86,26 +95,33 @@ __device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a
             const int c = b_col0 + tn * 32 + l31;
             if constexpr (B_NK) {
                 const float4 v = *reinterpret_cast<const float4*>(Bs + c * PITCH_B + k0);
-                b[tn][0] = v.x; b[tn][1] = v.y; b[tn][2] = v.z; b[tn][3] = v.w;
+                b[q][tn][0] = v.x; b[q][tn][1] = v.y; b[q][tn][2] = v.z; b[q][tn][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(k0 + j) * PITCH_B + c];
+                for (int j = 0; j < 4; ++j) b[q][tn][j] = Bs[(k0 + j) * PITCH_B + c];
             }
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
-    }
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][tm][j], b[q][tn][j], acc[tm][tn], 0, 0, 0);
 }
 
 // ---- forward / backward-data kernel ---------------------------------------------------------------------
 // BWD == false: B operand W[t][c][n]  -> KN form (n contiguous in memory)
 // BWD == true : B operand W[t][n'][k'] with k' = conv Cout contiguous -> NK form
-template <int BM, int BN, int WM, int WN, bool BWD>
+// VEC: every channel count / pixel stride is a multiple of 4 and the bases are 16-B aligned.  Then all global
+// loads are UNCONDITIONAL float4 loads from a clamped address and the zero-fill of out-of-range elements happens
+// when the registers are written to LDS — so the loads of step k+1 stay in flight across the MFMAs of step k
+// (conditional loads make hipcc drain vmcnt(0) at the branch joins, serialising memory latency and MFMA work).
+template <int BM, int BN, int WM, int WN, bool BWD, bool VEC>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -122,8 +138,25 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs, each with its own L2): XCD x
+    // works through a contiguous range of M tiles with the N tiles of one M tile back to back, so the A rows
+    // (and the 3x3 halo rows shared with the neighbouring M tile) are re-read from that XCD's L2.
+    int mt, nt;
+    {
+        const int ntn = p.n_tiles, nblk = gridDim.x;
+        const int bid = blockIdx.x;
+        const int per_xcd = nblk / 8;
+        if (p.xcd_remap && per_xcd * 8 == nblk) {
+            const int lin = (bid & 7) * per_xcd + (bid >> 3);
+            mt = lin / ntn;
+            nt = lin - mt * ntn;
+        } else {
+            mt = bid / ntn;
+            nt = bid - mt * ntn;
+        }
+    }
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
 
     // A staging: thread -> (row, k-quad); rows fixed for the whole K loop
     const int a_kq = tid & 3;
@@ -149,13 +182,52 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     const int nk = p.taps.n * nchunk;
     const bool w_vec = BWD ? (p.Cout % 4 == 0) : (p.Cout % 4 == 0);
 
-    float4 ra[A_F4], rb[B_F4];
+    struct Regs {
+        float4 a[A_F4], b[B_F4];
+        unsigned ok;       // VEC: bit i = a[i] valid, bit 8+i = b[i] valid
+    };
+    Regs R0;
 
-    auto load_tiles = [&](int ks) {
+    auto load_tiles = [&](int ks, Regs& R) {
+        float4 (&ra)[A_F4] = R.a;
+        float4 (&rb)[B_F4] = R.b;
+        unsigned& okmask = R.ok;
         const int ti = ks / nchunk;
         const int c0 = (ks - ti * nchunk) * BK;
         const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
         const int wt = p.taps.widx[ti];
+        if constexpr (VEC) {
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+                const int c = c0 + a_kq * 4;
+                const bool ok = a_b[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && c < p.Ck;
+                const int64_t off = ok ? (((int64_t)a_b[i] * p.H + ih) * p.W + iw) * p.ldx + c : 0;
+                ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+                okmask |= ok ? (1u << i) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int e = tid + i * kThreads;
+                bool ok;
+                int64_t off;
+                if constexpr (!BWD) {
+                    const int kr = e / (BN / 4), nq = e % (BN / 4);
+                    const int c = c0 + kr, n = n0 + nq * 4;
+                    ok = e < B_TOTAL && c < p.Cin && n < p.Cout;
+                    off = ((int64_t)wt * p.Cin + c) * p.Cout + n;
+                } else {
+                    const int col = e >> 2, kq = e & 3;
+                    const int cin = n0 + col, k = c0 + kq * 4;
+                    ok = e < B_TOTAL && cin < p.Cin && k < p.Cout;
+                    off = ((int64_t)wt * p.Cin + cin) * p.Cout + k;
+                }
+                rb[i] = *reinterpret_cast<const float4*>(p.w + (ok ? off : 0));
+                okmask |= ok ? (1u << (8 + i)) : 0u;
+            }
+            return;
+        }
         // A: gather BK channels of the tap's input pixel for each row
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
@@ -220,7 +292,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         }
     };
 
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](Regs& R) {
+        float4 (&ra)[A_F4] = R.a;
+        float4 (&rb)[B_F4] = R.b;
+        const unsigned okmask = R.ok;
+        if constexpr (VEC) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i)
+                if (!((okmask >> i) & 1u)) ra[i] = z;
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i)
+                if (!((okmask >> (8 + i)) & 1u)) rb[i] = z;
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i)
             *reinterpret_cast<float4*>(As + ((tid >> 2) + i * 64) * PITCH_A + a_kq * 4) = ra[i];
@@ -248,11 +332,13 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    load_tiles(0);
+    // Prefetch distance 1 (measured: a second register set with the loads of step k+2 in flight as well was 6 %
+    // SLOWER — 90 vs 96 TF on the SegmentHead conv — so global latency is not what limits this kernel).
+    load_tiles(0, R0);
     for (int ks = 0; ks < nk; ++ks) {
-        store_tiles();
+        store_tiles(R0);
         __syncthreads();
-        if (ks + 1 < nk) load_tiles(ks + 1);
+        if (ks + 1 < nk) load_tiles(ks + 1, R0);
         mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
         __syncthreads();
     }
@@ -669,21 +755,27 @@ static void build_taps(ConvTaps& t, int kh, int kw, int stride, int pad, int dil
             for (int oh = 0; oh < Ho && !okh; ++oh) okh = (unsigned)(oh * stride + dh) < (unsigned)H;
             for (int ow = 0; ow < Wo && !okw; ++ow) okw = (unsigned)(ow * stride + dw) < (unsigned)W;
             if (!(okh && okw)) continue;
-            t.dh[t.n] = (short)dh;
-            t.dw[t.n] = (short)dw;
-            t.widx[t.n] = (unsigned char)(th * kw + tw);
+            t.dh[t.n] = dh;
+            t.dw[t.n] = dw;
+            t.widx[t.n] = th * kw + tw;
             ++t.n;
         }
 }
 
 template <bool BWD>
-static int launch_conv(const ConvParams& p, hipStream_t st)
+static int launch_conv(const ConvParams& p_in, hipStream_t st)
 {
     EventScope ev(st);
+    ConvParams p = p_in;
+    p.xcd_remap = g_conv_xcd_remap;
+    const bool vec = g_conv_novec == 0 && p.Ck % 4 == 0 && p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
     const int64_t mt128 = cdiv(p.M, 128), mt64 = cdiv(p.M, 64);
     if (p.Cn <= 32) {
-        dim3 grid((unsigned)mt128, 1);
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD>), grid, dim3(kThreads), 0, st, p);
+        p.n_tiles = 1;
+        dim3 grid((unsigned)mt128);
+        if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, false>), grid, dim3(kThreads), 0, st, p);
     } else if (p.Cn > 64 && mt128 * cdiv(p.Cn, 128) >= 384) {
         dim3 grid((unsigned)mt128, (unsigned)cdiv(p.Cn, 128));
         constexpr size_t lds = conv_db_lds_bytes<128, 128, BWD>();
@@ -693,13 +785,24 @@ static int launch_conv(const ConvParams& p, hipStream_t st)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        if (g_conv_variant == 1)
-            hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD>), grid, dim3(kThreads), 0, st, p);
-        else
+        if (g_conv_variant == 1) {
             hipLaunchKernelGGL((conv_igemm_db_kernel<128, 128, 2, 2, BWD>), grid, dim3(kThreads), lds, st, p);
+        } else if (g_conv_variant == 2) {
+            p.n_tiles = (int)cdiv(p.Cn, 64);
+            dim3 grid2((unsigned)(mt128 * p.n_tiles));
+            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, true>), grid2, dim3(kThreads), 0, st, p);
+            else     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, false>), grid2, dim3(kThreads), 0, st, p);
+        } else {
+            p.n_tiles = (int)cdiv(p.Cn, 128);
+            dim3 grid1((unsigned)(mt128 * p.n_tiles));
+            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid1, dim3(kThreads), g_conv_lds_pad, st, p);
+            else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid1, dim3(kThreads), g_conv_lds_pad, st, p);
+        }
     } else {
-        dim3 grid((unsigned)mt64, (unsigned)cdiv(p.Cn, 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD>), grid, dim3(kThreads), 0, st, p);
+        p.n_tiles = (int)cdiv(p.Cn, 64);
+        dim3 grid((unsigned)(mt64 * p.n_tiles));
+        if (vec) hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
     }
     return check_launch("conv_igemm_kernel");
 }
@@ -722,7 +825,14 @@ using namespace pp;
 
 extern "C" {
 
-void pp_debug_set_conv_variant(int v) { g_conv_variant = v == 1 ? 1 : 0; }
+void pp_debug_set_conv_variant(int v)
+{
+    g_conv_xcd_remap = (v & 4) ? 0 : 1;      // bit 2 switches the XCD-aware tile order off (A/B)
+    g_conv_novec = (v & 8) ? 1 : 0;          // bit 3 forces the conditional-load path (A/B)
+    g_conv_lds_pad = (v & 16) ? 40 * 1024 : ((v & 32) ? 70 * 1024 : 0);   // bits 4/5: at most 2 / 1 blocks per CU
+    v &= 3;
+    g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
+}
 
 int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                   int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, pp_stream_t stream)
