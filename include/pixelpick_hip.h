@@ -104,7 +104,8 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
 int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                   int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, pp_stream_t stream);
 
-/* dL/dx of the above for stride-1 convolutions (what autograd computes at model.py:121). */
+/* dL/dx of the above (what autograd computes at model.py:121); any stride (the stride-2 Bottleneck convs of
+ * backbones/resnet_models.py:63-64,142-144 gather dY rows where (row + pad - tap*dil) is divisible by the stride). */
 int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
                        int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, pp_stream_t stream);
 
@@ -148,6 +149,24 @@ int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, in
                           int dil, float* dx, int64_t lddx, pp_stream_t stream);
 int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
                             int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* nn.GroupNorm(G, C) [+ nn.ReLU] (decoders.py:92-94), x [B,P=H*W,C]: statistics per (image, group) over P*(C/G)
+ * elements, biased variance, eps inside the sqrt.  mean/rstd [B*G] are outputs of fwd and inputs of bwd; y (the
+ * activation output) supplies the ReLU mask in bwd. */
+size_t pp_groupnorm_workspace_bytes(int B, int64_t P, int C);
+int pp_groupnorm_relu_fwd(const float* x, int64_t ldx, int B, int64_t P, int C, int G, const float* gamma, const float* beta,
+                          float eps, int relu, float* y, int64_t ldy, float* mean, float* rstd, void* workspace,
+                          size_t ws_bytes, pp_stream_t stream);
+int pp_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, int B,
+                          int64_t P, int C, int G, const float* mean, const float* rstd, const float* gamma, float* dgamma,
+                          float* dbeta, float* dx, int64_t lddx, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* nn.MaxPool2d(ksize, stride, pad) (resnet_models.py:121), torch's first-maximum rule; argmax u8 [B,Ho,Wo,C] holds the
+ * winning tap (kh*ksize + kw) and drives the deterministic gather in bwd.  H, W are the INPUT size in both calls. */
+int pp_maxpool2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, int ksize, int stride, int pad, float* y,
+                     int64_t ldy, unsigned char* argmax, pp_stream_t stream);
+int pp_maxpool2d_bwd(const float* dy, int64_t lddy, const unsigned char* argmax, int B, int H, int W, int C, int ksize, int stride,
+                     int pad, float* dx, int64_t lddx, pp_stream_t stream);
 
 /* fixed_padding (mobilenet_v2.py:15-21): zero-pad [B,H,W,C] to [B,Hp,Wp,C]; and its adjoint
  * y = crop(xp) (+ add), used for the gradient of the padded block input (+ the residual gradient). */
@@ -197,6 +216,8 @@ int pp_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y,
 
 /* [B,C,H,W] -> [B,H,W,C] (the network input; deeplab.py:43 receives NCHW). */
 int pp_nchw_to_nhwc(const float* x, int B, int C, int64_t HW, float* y, int64_t ldy, pp_stream_t stream);
+/* [B,H,W,C] (pixel stride ldx) -> [B,C,H,W] contiguous: the FPN model's "pred"/"emb" outputs (decoders.py:77). */
+int pp_nhwc_to_nchw(const float* x, int64_t ldx, int B, int C, int64_t HW, float* y, pp_stream_t stream);
 
 /* Debug/bench knobs.
  * reduce mode: 0 = threshold-prefiltered per-wave top-k with DPP reductions (default), 1 = same with

@@ -36,6 +36,11 @@ SIGNATURES = {
     "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p]),
+    "pp_groupnorm_workspace_bytes": (_sz, [_int, _i64, _int]),
+    "pp_groupnorm_relu_fwd": (_int, [_p, _i64, _int, _i64, _int, _int, _p, _p, _f, _int, _p, _i64, _p, _p, _p, _sz, _p]),
+    "pp_groupnorm_relu_bwd": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _sz, _p]),
+    "pp_maxpool2d_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p, _p]),
+    "pp_maxpool2d_bwd": (_int, [_p, _i64, _p, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p]),
     "pp_pad2d": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p]),
     "pp_crop2d_add": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _p, _i64, _p, _i64, _int, _int, _p]),
     "pp_bilinear_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p]),
@@ -47,6 +52,7 @@ SIGNATURES = {
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "pp_adam_step_flat": (_int, [_p, _p, _p, _p, _i64, _i64, _f, _f, _f, _f, _f, _f, _i64, _f, _p]),
     "pp_add2d": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _p]),
+    "pp_nhwc_to_nchw": (_int, [_p, _i64, _int, _int, _i64, _p, _p]),
     "pp_nchw_to_nhwc": (_int, [_p, _int, _int, _i64, _p, _i64, _p]),
     "pp_debug_set_reduce_mode": (None, [_int]),
     "pp_debug_set_exact_formula": (None, [_int]),

@@ -54,6 +54,7 @@ struct ConvParams {
     int Cin, Cout;    // weight tensor dims (for addressing)
     int stride;
     int64_t M;        // B*Ho*Wo
+    int bwd_stride;   // backward-data of a strided conv: source row = (row + dh) / bwd_stride when divisible (else 1)
     int n_tiles;      // tiles along the output-channel axis (grid is 1-D: m_tiles * n_tiles blocks)
     int xcd_remap;
     ConvTaps taps;
@@ -200,9 +201,15 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
             okmask = 0;
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+                int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
                 const int c = c0 + a_kq * 4;
-                const bool ok = a_b[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && c < p.Ck;
+                bool ok = a_b[i] >= 0 && c < p.Ck;
+                if (BWD && p.bwd_stride > 1) {
+                    ok = ok && ih >= 0 && iw >= 0 && (ih % p.bwd_stride) == 0 && (iw % p.bwd_stride) == 0;
+                    ih /= p.bwd_stride;
+                    iw /= p.bwd_stride;
+                }
+                ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const int64_t off = ok ? (((int64_t)a_b[i] * p.H + ih) * p.W + iw) * p.ldx + c : 0;
                 ra[i] = *reinterpret_cast<const float4*>(p.x + off);
                 okmask |= ok ? (1u << i) : 0u;
@@ -232,9 +239,15 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+            int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
             const int c = c0 + a_kq * 4;
-            if (a_b[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && c < p.Ck) {
+            bool sok = true;
+            if (BWD && p.bwd_stride > 1) {
+                sok = ih >= 0 && iw >= 0 && (ih % p.bwd_stride) == 0 && (iw % p.bwd_stride) == 0;
+                ih /= p.bwd_stride;
+                iw /= p.bwd_stride;
+            }
+            if (sok && a_b[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && c < p.Ck) {
                 const float* src = p.x + (((int64_t)a_b[i] * p.H + ih) * p.W + iw) * p.ldx + c;
                 if (c + 3 < p.Ck) {
                     v = *reinterpret_cast<const float4*>(src);
@@ -562,7 +575,7 @@ struct WgradParams {
     ConvTaps taps;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -588,8 +601,44 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
     const bool x_vec = (p.ldx % 4 == 0) && (p.Cin % 4 == 0);
 
     float4 ra[A_F4], rb[B_F4];
+    unsigned okmask = 0;
 
     auto load_tiles = [&](int64_t mb) {
+        if constexpr (VEC) {   // unconditional float4 loads from clamped addresses; zero-fill happens at the LDS write
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int e = tid + i * kThreads;
+                const int kr = e / (BM / 4), cq = e % (BM / 4);
+                const int64_t m = mb + kr;
+                const int c = c0 + cq * 4;
+                bool ok = m < m_end && c < p.Cin;
+                int64_t pix = m;
+                if (!p.pointwise) {
+                    const unsigned mu = (unsigned)(ok ? m : 0);
+                    const unsigned t = mu / (unsigned)p.Wo;
+                    const int ow = (int)(mu - t * (unsigned)p.Wo);
+                    const unsigned b = t / (unsigned)p.Ho;
+                    const int oh = (int)(t - b * (unsigned)p.Ho);
+                    const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+                    ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    pix = ((int64_t)b * p.H + ih) * p.W + iw;
+                }
+                ra[i] = *reinterpret_cast<const float4*>(p.x + (ok ? pix * p.ldx + c : 0));
+                okmask |= ok ? (1u << i) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int e = tid + i * kThreads;
+                const int kr = e / (BN / 4), nq = e % (BN / 4);
+                const int64_t m = mb + kr;
+                const int n = n0 + nq * 4;
+                const bool ok = m < m_end && n < p.Cout;
+                rb[i] = *reinterpret_cast<const float4*>(p.dy + (ok ? m * p.lddy + n : 0));
+                okmask |= ok ? (1u << (8 + i)) : 0u;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * kThreads;
@@ -646,6 +695,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
         }
     };
     auto store_tiles = [&]() {
+        if constexpr (VEC) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i)
+                if (!((okmask >> i) & 1u)) ra[i] = z;
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i)
+                if (!((okmask >> (8 + i)) & 1u)) rb[i] = z;
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * kThreads;
@@ -743,17 +801,26 @@ __global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* part,
 
 // ---- host ---------------------------------------------------------------------------------------------------
 // live taps for forward-style indexing: input row = oh*stride + (th*dil - pad)
-static void build_taps(ConvTaps& t, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho, int Wo, bool flip)
+// Forward (flip == false): rows are output pixels, source row = oh*stride + dh, H/W = input size.
+// Backward-data (flip == true): rows are INPUT pixels (Ho/Wo = input size), source dY row = (ih + dh)/bstride when
+// divisible, H/W = dY size; `stride` is 1 in that call and `bstride` the convolution's stride.
+static void build_taps(ConvTaps& t, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho, int Wo, bool flip,
+                       int bstride = 1)
 {
     t.n = 0;
     for (int th = 0; th < kh; ++th)
         for (int tw = 0; tw < kw; ++tw) {
             const int dh = flip ? pad - th * dil : th * dil - pad;
             const int dw = flip ? pad - tw * dil : tw * dil - pad;
-            // any output row oh in [0,Ho) with 0 <= oh*stride + dh < H ?
             bool okh = false, okw = false;
-            for (int oh = 0; oh < Ho && !okh; ++oh) okh = (unsigned)(oh * stride + dh) < (unsigned)H;
-            for (int ow = 0; ow < Wo && !okw; ++ow) okw = (unsigned)(ow * stride + dw) < (unsigned)W;
+            for (int oh = 0; oh < Ho && !okh; ++oh) {
+                const int v = oh * stride + dh;
+                okh = v >= 0 && v % bstride == 0 && v / bstride < H;
+            }
+            for (int ow = 0; ow < Wo && !okw; ++ow) {
+                const int v = ow * stride + dw;
+                okw = v >= 0 && v % bstride == 0 && v / bstride < W;
+            }
             if (!(okh && okw)) continue;
             t.dh[t.n] = dh;
             t.dw[t.n] = dw;
@@ -844,7 +911,7 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
     ConvParams p{};
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldx = ldx; p.ldy = ldy;
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Ck = Cin; p.Cn = Cout; p.Cin = Cin; p.Cout = Cout;
-    p.stride = stride; p.M = (int64_t)B * Ho * Wo;
+    p.stride = stride; p.M = (int64_t)B * Ho * Wo; p.bwd_stride = 1;
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
@@ -856,15 +923,15 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
                        pp_stream_t stream)
 {
     if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
-    if (stride != 1) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: stride %d (only stride 1 convolutions need dX here)", stride);
-    if (Ho != out_size(H, kh, 1, pad, dil) || Wo != out_size(W, kw, 1, pad, dil))
+    if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
         return fail(PP_ERR_BAD_ARG, "conv bwd_data: inconsistent sizes");
     ConvParams p{};
     p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.ldx = lddy; p.ldy = lddx;
     p.B = B; p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.Ck = Cout; p.Cn = Cin; p.Cin = Cin; p.Cout = Cout;
-    p.stride = 1; p.M = (int64_t)B * H * W;
-    // dX(ih,iw) = sum_t dY(ih + pad - th*dil, iw + pad - tw*dil) W[t]
-    build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true);
+    p.stride = 1; p.M = (int64_t)B * H * W; p.bwd_stride = stride;
+    // dX(ih,iw) = sum_t dY((ih + pad - th*dil)/stride, (iw + pad - tw*dil)/stride) W[t]   (where divisible)
+    build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
+    if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: more than 2^31 pixels");
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv bwd_data: no live tap");
     return launch_conv<true>(p, as_stream(stream));
 }
@@ -911,8 +978,15 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
         if (hipMemsetAsync(dw, 0, (size_t)kh * kw * Cin * Cout * 4, st) != hipSuccess)
             return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
     dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
-    if (big) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(kThreads), 0, st, p);
-    else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(kThreads), 0, st, p);
+    const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    if (big) {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+    }
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
     const int64_t cn = (int64_t)Cin * Cout;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(p.taps.n * cn, 256)), dim3(256), 0, st, p.part,

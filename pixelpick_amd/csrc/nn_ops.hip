@@ -736,6 +736,19 @@ __global__ __launch_bounds__(kT) void add2d_kernel(const float* a, int64_t lda, 
     }
 }
 
+// NHWC (pixel stride ldx) -> NCHW contiguous; consecutive threads walk the pixel axis (coalesced stores)
+__global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_t ldx, int B, int C, int64_t HW, float* y)
+{
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t pix = e % HW;
+        const int64_t t = e / HW;
+        const int c = (int)(t % C);
+        const int64_t b = t / C;
+        y[e] = x[(b * HW + pix) * ldx + c];
+    }
+}
+
 static inline unsigned grid_for(int64_t total)
 {
     int64_t b = cdiv(total, kT);
@@ -1018,6 +1031,13 @@ int pp_nchw_to_nhwc(const float* x, int B, int C, int64_t HW, float* y, int64_t 
     if (!x || !y) return fail(PP_ERR_BAD_ARG, "nchw_to_nhwc: null");
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)B * HW * C)), dim3(kT), 0, as_stream(stream), x, B, C, HW, y, ldy);
     return check_launch("nchw_to_nhwc_kernel");
+}
+
+int pp_nhwc_to_nchw(const float* x, int64_t ldx, int B, int C, int64_t HW, float* y, pp_stream_t stream)
+{
+    if (!x || !y) return fail(PP_ERR_BAD_ARG, "nhwc_to_nchw: null");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * HW * C)), dim3(kT), 0, as_stream(stream), x, ldx, B, C, HW, y);
+    return check_launch("nhwc_to_nchw_kernel");
 }
 
 }  // extern "C"

@@ -129,6 +129,110 @@ def nchw_to_nhwc(x: torch.Tensor) -> Var:
     return Var(y, needs_grad=False)
 
 
+def nhwc_to_nchw(tape: Tape, x: Var) -> Var:
+    """NHWC Var -> [B,C,H,W] tensor (the FPN model's outputs); backward converts the NCHW gradient back."""
+    B, H, W, C, ldx = _geom(x.t)
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.t.device)
+    rc = _lib.lib().pp_nhwc_to_nchw(x.t.data_ptr(), ldx, B, C, H * W, y.data_ptr(), _stream())
+    _lib.check(rc, "pp_nhwc_to_nchw")
+    out = Var(y)
+    tape.record(_to_nchw_bwd, (x,), out)
+    return out
+
+
+def _to_nchw_bwd(tape: Tape, dy, x: Var):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    dy = dy.contiguous()
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pp_nchw_to_nhwc(dy.data_ptr(), B, C, H * W, dx.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_nchw_to_nhwc")
+    _acc(x, dx)
+
+
+# ------------------------------------------------------------------------------------------------- elementwise add
+def add(tape: Tape, a: Var, b: Var) -> Var:
+    """a + b (FPN top-down pathway decoders.py:82, `emb = p2+p3+p4+p5` decoders.py:75)."""
+    B, H, W, C, lda = _geom(a.t)
+    _, _, _, _, ldb = _geom(b.t)
+    assert a.t.shape == b.t.shape
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=a.t.device)
+    rc = _lib.lib().pp_add2d(a.t.data_ptr(), lda, b.t.data_ptr(), ldb, y.data_ptr(), C, B * H * W, C, _stream())
+    _lib.check(rc, "pp_add2d")
+    out = Var(y)
+    tape.record(_add_bwd, (a, b), out)
+    return out
+
+
+def _add_bwd(tape: Tape, dy, a: Var, b: Var):
+    _acc(a, dy)
+    _acc(b, dy)
+
+
+# ------------------------------------------------------------------------------------------------- group norm / max pool
+def group_norm_relu(tape: Tape, x: Var, gamma, beta, groups: int, relu: bool = True, eps: float = 1e-5) -> Var:
+    """nn.GroupNorm(groups, C) [+ nn.ReLU] (decoders.py:92-94)."""
+    L = _lib.lib()
+    B, H, W, C, ldx = _geom(x.t)
+    dev = x.t.device
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    mean = torch.empty(B * groups, dtype=torch.float32, device=dev)
+    rstd = torch.empty(B * groups, dtype=torch.float32, device=dev)
+    ws = _ws(L.pp_groupnorm_workspace_bytes(B, H * W, C), dev)
+    rc = L.pp_groupnorm_relu_fwd(x.t.data_ptr(), ldx, B, H * W, C, groups, gamma.data_ptr(), beta.data_ptr(), eps, int(relu),
+                                 y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "pp_groupnorm_relu_fwd")
+    out = Var(y)
+    tape.record(_gn_bwd, (x, gamma, beta, groups, mean, rstd, relu, out), out)
+    return out
+
+
+def _gn_bwd(tape: Tape, dy, x: Var, gamma, beta, groups, mean, rstd, relu, out: Var):
+    assert relu, "GroupNorm without ReLU does not occur in the reference"
+    L = _lib.lib()
+    B, H, W, C, ldx = _geom(x.t)
+    _, _, _, _, lddy = _geom(dy)
+    dev = dy.device
+    dgamma, dbeta = tape.grad_buffer_for(gamma), tape.grad_buffer_for(beta)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    ws = _ws(L.pp_groupnorm_workspace_bytes(B, H * W, C), dev)
+    rc = L.pp_groupnorm_relu_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), C, B, H * W, C, groups, mean.data_ptr(),
+                                 rstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
+                                 ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "pp_groupnorm_relu_bwd")
+    if gamma.requires_grad:
+        tape.set_param_grad(gamma, dgamma)
+    if beta.requires_grad:
+        tape.set_param_grad(beta, dbeta)
+    _acc(x, dx)
+
+
+def max_pool2d(tape: Tape, x: Var, ksize: int = 3, stride: int = 2, pad: int = 1) -> Var:
+    """nn.MaxPool2d(ksize, stride, pad) (resnet_models.py:121)."""
+    B, H, W, C, ldx = _geom(x.t)
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    dev = x.t.device
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=dev)
+    rc = _lib.lib().pp_maxpool2d_fwd(x.t.data_ptr(), ldx, B, H, W, C, ksize, stride, pad, y.data_ptr(), C, idx.data_ptr(), _stream())
+    _lib.check(rc, "pp_maxpool2d_fwd")
+    out = Var(y)
+    tape.record(_maxpool_bwd, (x, idx, ksize, stride, pad), out)
+    return out
+
+
+def _maxpool_bwd(tape: Tape, dy, x: Var, idx, ksize, stride, pad):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    _, _, _, _, lddy = _geom(dy)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pp_maxpool2d_bwd(dy.data_ptr(), lddy, idx.data_ptr(), B, H, W, C, ksize, stride, pad, dx.data_ptr(), C, _stream())
+    _lib.check(rc, "pp_maxpool2d_bwd")
+    _acc(x, dx)
+
+
 # ------------------------------------------------------------------------------------------------- dense conv
 def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, dil=1,
            dst: Optional[torch.Tensor] = None) -> Var:

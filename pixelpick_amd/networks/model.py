@@ -1,0 +1,76 @@
+"""FPNSeg (dilated ResNet encoder + FPN decoder) — mirror of networks/model.py:6-14 on the HIP engine.
+`forward(x[B,3,H,W]) -> {"emb": [B,128,H,W], "pred": [B,C,H,W]}`; `.encoder` / `.decoder` feed the optimiser groups
+of utils/utils.py:117-123."""
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from .decoders import FPNDecoder
+from .encoder import Encoder
+
+
+class _FpnOutputs(dict):
+    def __init__(self, pred, emb_nhwc):
+        super().__init__(pred=pred)
+        self._emb_nhwc = emb_nhwc
+
+    def __getitem__(self, k):
+        if k == "emb" and not dict.__contains__(self, "emb"):
+            dict.__setitem__(self, "emb", E.nhwc_to_nchw(E.Tape(False), E.Var(self._emb_nhwc)).t)
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k == "emb" or dict.__contains__(self, k)
+
+    def keys(self):
+        return ["emb", "pred"]
+
+
+class _FpnFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, model, *params):
+        tape = E.Tape(enabled=True)
+        pred, emb = model._run(tape, inputs)
+        ctx.tape, ctx.pred_var, ctx.params = tape, pred, params
+        model._last_emb = emb.t
+        return pred.t
+
+    @staticmethod
+    def backward(ctx, dpred):
+        tape = ctx.tape
+        tape.backward(ctx.pred_var, dpred.contiguous())
+        grads = tuple(tape.param_grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        ctx.tape = None
+        return (None, None) + grads
+
+
+class FPNSeg(nn.Module):
+    def __init__(self, args, load_pretrained=True):
+        super().__init__()
+        self.encoder = Encoder(args, load_pretrained)
+        self.decoder = FPNDecoder(args)
+        self._last_emb = None
+
+    def turn_on_dropout(self):      # the FPN model has no nn.Dropout; kept for QuerySelector (query.py:152)
+        pass
+
+    def turn_off_dropout(self):
+        pass
+
+    def _run(self, tape, inputs):
+        x = E.nchw_to_nhwc(inputs)
+        outs = self.decoder.run(tape, self.encoder.run(tape, x))
+        return E.nhwc_to_nchw(tape, outs["pred"]), outs["emb"]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("pixelpick_amd.FPNSeg runs on the GPU only (no CPU fallback)")
+        x = x.to(torch.float32)
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            pred = _FpnFunction.apply(x, self, *params)
+            emb = self._last_emb
+        else:
+            p, e = self._run(E.Tape(enabled=False), x)
+            pred, emb = p.t, e.t
+        return _FpnOutputs(pred, emb)

@@ -25,10 +25,12 @@ def _args(n_classes):
                      weight_type="random", use_dilated_resnet=True, n_layers=50, width_multiplier=1.0)
 
 
-def _build(n_classes):
+def _build(n_classes, network="deeplab"):
+    a = _args(n_classes)
+    a.network_name = network
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = get_model(_args(n_classes))
+        m = get_model(a)
     m.load_state_dict(fi.formula_state_dict(m.state_dict()))
     for mod in m.modules():
         if isinstance(mod, Dropout):
@@ -143,3 +145,35 @@ def test_flat_trainer_matches_autograd_path_and_is_deterministic(golden_dir):
     assert tr.n_split == 1811712 and tr.n == 5815539
     # parameters alias the flat buffer: the module sees the update
     assert m.seg_head.classifier.bias.data_ptr() >= tr.flat_p.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------- FPN-ResNet50 (R1-R4)
+def test_fpn_eval_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "net_fpn_voc40x56.npz"))
+    B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
+    m = _build(C, "FPN").eval()
+    with torch.no_grad():
+        out = m(fi.formula_input(B, H, W, key="xvoc40x56").to(DEV))
+    assert out["pred"].shape == (B, C, H, W) and out["emb"].shape == (B, 128, H, W)
+    assert _rel(out["pred"].reshape(-1)[::STRIDE].cpu().numpy(), g["eval_pred_samples"]) < TOL
+
+
+def test_fpn_train_step_matches_reference(golden_dir):
+    tag = "cs64x96"
+    g = np.load(os.path.join(golden_dir, f"net_fpn_{tag}.npz"))
+    B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
+    m = _build(C, "FPN").train()
+    x = fi.formula_input(B, H, W, key=f"x{tag}").to(DEV)
+    y = fi.formula_labels(B, H, W, C, ign, n_lab, key=f"y{tag}").to(DEV)
+    pred = m(x)["pred"]
+    loss = F.cross_entropy(pred, y, ignore_index=ign)
+    loss.backward()
+    ref_s = g["train_pred_samples"]
+    err = np.abs(pred.detach().reshape(-1)[::STRIDE].cpu().numpy().astype(np.float64) - ref_s).max()
+    assert err <= TOL * np.abs(ref_s).max() + 4 * float(g["train_pred_noise"]), f"logits err {err}"
+    assert abs(loss.item() - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
+    worst = _check_grads(g, {k: p.grad for k, p in m.named_parameters()})
+    for k in g.files:
+        if k.startswith("rs:"):
+            assert _rel(m.state_dict()[k[3:]].cpu().numpy(), g[k]) < TOL, k
+    print(f"[fpn {tag}] logits max err {err:.2e}; worst relative abs-sum gradient deviation {worst:.2e}")

@@ -91,6 +91,81 @@ def test_conv2d_fwd_bwd(case):
         close(nchw(xv.grad), xr.grad, what="conv dX")
 
 
+STRIDED_BWD = [(2, 17, 23, 128, 128, 3, 2, 1, 1), (2, 16, 24, 256, 512, 1, 2, 0, 1), (1, 15, 15, 64, 96, 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("case", STRIDED_BWD, ids=[str(c) for c in STRIDED_BWD])
+def test_conv2d_strided_bwd_data(case):
+    """ResNet layer2.0: 3x3 stride-2 conv2 and 1x1 stride-2 downsample need dL/dx (resnet_models.py:63-64,142-144)."""
+    B, H, W, Cin, Cout, k, stride, pad, dil = case
+    torch.manual_seed(11)
+    x = torch.randn(B, Cin, H, W, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).requires_grad_(True)
+    yr = F.conv2d(x, w, None, stride, pad, dil)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    wg = gparam(hwio(w.detach()))
+    yv = E.conv2d(tape, xv, wg, None, stride, pad, dil)
+    close(nchw(yv.t), yr.detach(), what="strided fwd")
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad, what="strided dX")
+    close(oihw(tape.param_grads[id(wg)]), w.grad, what="strided dW")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 24, 128), (3, 9, 7, 128), (2, 32, 48, 128), (1, 5, 6, 64)])
+def test_groupnorm_relu(shape):
+    B, H, W, C = shape
+    torch.manual_seed(12)
+    x = (torch.randn(B, C, H, W) * 1.5 + 0.3).requires_grad_(True)
+    gn = torch.nn.GroupNorm(32, C)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(C) + 0.5)
+        gn.bias.copy_(torch.randn(C) * 0.3)
+    yr = F.relu(gn(x))
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    g, b = gparam(gn.weight), gparam(gn.bias)
+    yv = E.group_norm_relu(tape, xv, g, b, 32, True)
+    close(nchw(yv.t), yr.detach(), what="gn fwd")
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad, tol=2e-4, what="gn dX")
+    close(tape.param_grads[id(g)].cpu(), gn.weight.grad, tol=2e-4, what="gn dgamma")
+    close(tape.param_grads[id(b)].cpu(), gn.bias.grad, tol=2e-4, what="gn dbeta")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48, 64), (1, 17, 23, 64), (2, 8, 8, 16)])
+def test_maxpool_fwd_bwd_incl_relu_ties(shape):
+    B, H, W, C = shape
+    torch.manual_seed(13)
+    x = F.relu(torch.randn(B, C, H, W)).requires_grad_(True)      # many exact zeros: tie rule must match torch
+    yr = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    tape = E.Tape()
+    xv = E.Var(nhwc(x.detach()))
+    yv = E.max_pool2d(tape, xv, 3, 2, 1)
+    assert torch.equal(nchw(yv.t), yr.detach())
+    tape.backward(yv, nhwc(dy))
+    close(nchw(xv.grad), x.grad, tol=1e-6, what="maxpool bwd")
+
+
+def test_add_and_nchw_roundtrip():
+    torch.manual_seed(14)
+    a, b = torch.randn(2, 12, 5, 7), torch.randn(2, 12, 5, 7)
+    tape = E.Tape()
+    av, bv = E.Var(nhwc(a)), E.Var(nhwc(b))
+    s = E.add(tape, av, bv)
+    o = E.nhwc_to_nchw(tape, s)
+    assert torch.equal(o.t.cpu(), a + b)
+    dy = torch.randn(2, 12, 5, 7)
+    tape.backward(o, dy.to(DEV))
+    assert torch.equal(nchw(av.grad), dy) and torch.equal(nchw(bv.grad), dy)
+
+
 def test_conv2d_channel_slices():
     """Inputs/outputs that are channel slices of wider buffers (the zero-copy concat of aspp.py:73)."""
     torch.manual_seed(0)

@@ -31,16 +31,26 @@ FULL_GRADS = ["backbone.features.0.0.weight", "backbone.features.2.conv.1.weight
               "low_level_conv.0.weight", "seg_head.classifier.weight", "seg_head.classifier.bias"]
 
 
+NETWORK = "deeplab"
+
+
 def _fresh_model(n_classes):
-    args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=n_classes, network_name="deeplab",
+    import contextlib, io
+    args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=n_classes, network_name=NETWORK,
                      weight_type="random", use_dilated_resnet=True, n_layers=50, width_multiplier=1.0)
     torch.manual_seed(0)
-    model = get_model(args)
+    with contextlib.redirect_stdout(io.StringIO()):      # resnet_models.py:124 prints layer1
+        model = get_model(args)
     model.load_state_dict(fi.formula_state_dict(model.state_dict()))
     for m in model.modules():                       # dropout RNG cannot be matched: force p = 0 (SURVEY hard part d)
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     return model
+
+
+FULL_GRADS_FPN = ["encoder.base.prefix.conv1.weight", "encoder.base.layer2.0.bn2.weight", "encoder.base.layer2.0.downsample.1.bias",
+                  "encoder.base.layer4.2.bn3.bias", "decoder.lat_layer_3.bias", "decoder.upsample_blocks_0.0.block.1.weight",
+                  "decoder.upsample_blocks_3.1.block.0.bias", "decoder.classifier.weight", "decoder.classifier.bias"]
 
 
 def _train_once(n_classes, ignore_index, x, y, dtype=torch.float32):
@@ -89,19 +99,29 @@ def gen_deeplab(n_classes, ignore_index, B, H, W, tag, n_lab=20, train=True):
         out["grad_summary"] = np.stack(gsum)
         out["grad_noise"] = np.stack(gnoise)
         # a few full gradients (small tensors) incl. the first and last layers and a padded-border BN
-        for k in FULL_GRADS:
+        for k in (FULL_GRADS if NETWORK == "deeplab" else FULL_GRADS_FPN):
             out["g:" + k] = dict(model.named_parameters())[k].grad.numpy().copy()
             gk = dict(model.named_parameters())[k].grad
             out["gn:" + k] = np.float64(max((pn[k].grad - gk).abs().max().item(), (pd[k].grad - gk).abs().max().item()))
         sdn = model.state_dict()
-        for k in ["backbone.features.2.conv.1.running_mean", "backbone.features.2.conv.1.running_var",
-                  "backbone.features.17.conv.4.running_var", "aspp.bn1.running_mean", "seg_head.segment_head.5.running_var"]:
+        rs_keys = ["backbone.features.2.conv.1.running_mean", "backbone.features.2.conv.1.running_var",
+                   "backbone.features.17.conv.4.running_var", "aspp.bn1.running_mean", "seg_head.segment_head.5.running_var"]
+        if NETWORK != "deeplab":
+            rs_keys = ["encoder.base.prefix.bn1.running_mean", "encoder.base.layer2.0.downsample.1.running_var",
+                       "encoder.base.layer4.2.bn3.running_var"]
+        for k in rs_keys:
             out["rs:" + k] = sdn[k].numpy().copy()
         out["n_state_keys"] = np.int64(len(sdn))
         out["state_keys_crc"] = np.int64(__import__("zlib").crc32("\n".join(f"{k}:{tuple(v.shape)}" for k, v in sdn.items()).encode()))
-    np.savez_compressed(os.path.join(OUT, f"net_deeplab_{tag}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"net_{'deeplab' if NETWORK == 'deeplab' else 'fpn'}_{tag}.npz"), **out)
     print("written", tag, "keys", len(out))
 
+
+if __name__ == "__main__" and "--fpn" in sys.argv:
+    NETWORK = "FPN"
+    gen_deeplab(19, 19, 2, 64, 96, "cs64x96")
+    gen_deeplab(21, 255, 1, 40, 56, "voc40x56", train=False)
+    sys.exit(0)
 
 if __name__ == "__main__":
     gen_deeplab(19, 19, 2, 128, 192, "cs128x192")
