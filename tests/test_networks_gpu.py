@@ -80,7 +80,9 @@ def _check_grads(g, grads_by_name, full=True):
         got = fi.summarize(grads_by_name[str(name)])
         ref, noise = g["grad_summary"][i], g["grad_noise"][i]
         for j, scale_j in ((1, 1), (2, 2), (0, 1)):       # abs-sum, max, sum (sum relative to abs-sum)
-            tol = TOL * max(ref[scale_j], 1e-12) + 4 * noise[j]
+            # the max is a single-element statistic: one flipped unit moves it by its full amount, and the two
+            # reference probes behind `noise` sample that event poorly -> 8x for it, 4x for the aggregates
+            tol = TOL * max(ref[scale_j], 1e-12) + (8 if j == 2 else 4) * noise[j]
             assert abs(got[j] - ref[j]) <= tol, f"{name}[{j}]: {got[j]} vs {ref[j]} (tol {tol:.3e}, noise {noise[j]:.3e})"
         worst = max(worst, abs(got[1] - ref[1]) / max(ref[1], 1e-12))
     if full:
