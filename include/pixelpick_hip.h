@@ -203,6 +203,12 @@ int pp_sparse_ce_fwd_bwd(const float* logits, int B, int C, int64_t HW, int64_t 
                          int ignore_index, float* loss, float* count, const float* grad_out, float* dlogits, void* workspace,
                          size_t ws_bytes, pp_stream_t stream);
 
+/* Step metrics on the device (model.py:124-125,194-196 + utils/metrics.py:168-177): hist[t*C + argmax_c logits] += 1
+ * for every pixel whose target t is in [0, C) (ignore_index >= C is skipped like RunningScore._fast_hist).  hist is
+ * an int64 [C,C] accumulator the caller zeroes / reads (C*C*8 bytes D2H instead of two full maps). */
+int pp_confusion_matrix_update(const float* logits, int B, int C, int64_t HW, int64_t sB, int64_t sC, const int64_t* target,
+                               int64_t* hist, pp_stream_t stream);
+
 /* torch.optim.Adam step on flat buffers (utils/utils.py:125-141): elements [0,n_split) use lr_a (the
  * backbone/encoder group at lr/10), the rest lr_b; L2 weight decay; `step` is 1-based; grads are
  * multiplied by grad_scale first (1/world_size after the gradient all-reduce). */

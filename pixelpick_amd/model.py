@@ -1,0 +1,168 @@
+"""Active-learning driver — the control flow of the reference's model.py:14-264 (`Model(args)()`) on the HIP path.
+
+The reference's `Model` builds its dataloaders from `datasets/` (PIL / torchvision / cv2 file loaders — host I/O,
+out of scope).  Here the three loaders are injected (any iterable yielding the reference's batch
+dicts `{'x','y','queries','p_img'}` whose `.dataset` offers `.queries`, `.label_queries(dict, nth)` and
+`.n_pixels_total`, base_dataset.py:24-45,182-188); `pixelpick_amd.synthetic.SyntheticDataset` is such a dataset.
+Everything between the loaders is the reference's loop:
+
+    for nth_query in range(n_stages):                         model.py:70-84
+        model = self._train()            fresh model, n_epochs x (_train_epoch; _val), best-mIoU checkpoint
+        queries = self.query_selector(nth_query, model)
+        self.dataloader.dataset.label_queries(queries, nth_query + 1)
+
+with the train step on `FlatTrainer` (HIP forward/backward, sparse CE, fused Adam, Poly lr per iteration) and the
+per-step metrics on the device (`RunningScore.update_from_logits`).  PNG dumps (`Visualiser`) are omitted.
+"""
+import os
+from math import ceil
+
+import torch
+import torch.nn.functional as F
+
+from . import acquisition as acq
+from .query import QuerySelector
+from .trainer import FlatTrainer
+from .utils.metrics import AverageMeter, RunningScore
+from .utils.utils import get_model
+
+
+def write_log(fp, list_entities=None, header=None):
+    """utils/utils.py:66-72 CSV logger."""
+    with open(fp, "w" if header else "a") as f:
+        row = header if header else list_entities
+        f.write(",".join(str(e) for e in row) + "\n")
+
+
+class Model:
+    def __init__(self, args, dataloader, dataloader_query, dataloader_val, device=None):
+        self.args = args
+        self.best_miou = -1.0
+        self.dataset_name = args.dataset_name
+        self.debug = args.debug
+        self.device = device or torch.device("cuda:0")
+        self.dir_checkpoints = f"{args.dir_root}/checkpoints/{args.experim_name}"
+        self.experim_name = args.experim_name
+        self.ignore_index = args.ignore_index
+        self.init_n_pixels = args.n_init_pixels
+        self.max_budget = args.max_budget
+        self.n_classes = args.n_classes
+        self.n_epochs = args.n_epochs
+        self.n_pixels_by_us = args.n_pixels_by_us
+        self.network_name = args.network_name
+        self.nth_query = -1
+        self.stride_total = args.stride_total
+        self.dataloader, self.dataloader_query, self.dataloader_val = dataloader, dataloader_query, dataloader_val
+        self.lr_scheduler_type = args.lr_scheduler_type
+        self.query_selector = QuerySelector(args, self.dataloader_query, device=self.device)
+        self.running_loss, self.running_score = AverageMeter(), RunningScore(args.n_classes)
+        self.history = []
+
+    # ------------------------------------------------------------------ model.py:53-86
+    def __call__(self):
+        if self.n_pixels_by_us == 0:
+            d = f"{self.dir_checkpoints}/fully_sup"
+            os.makedirs(d, exist_ok=True)
+            self._open_logs(d)
+            self._train()
+            return
+        n_stages = self.max_budget // self.n_pixels_by_us
+        n_stages += 1 if self.init_n_pixels > 0 else 0
+        print("n_stages:", n_stages)
+        for nth_query in range(n_stages):
+            d = f"{self.dir_checkpoints}/{nth_query}_query"
+            os.makedirs(d, exist_ok=True)
+            self._open_logs(d)
+            self.nth_query = nth_query
+            model = self._train()
+            queries = self.query_selector(nth_query, model)
+            self.dataloader.dataset.label_queries(queries, nth_query + 1)
+            if nth_query == n_stages - 1:
+                break
+        return
+
+    def _open_logs(self, d):
+        self.log_train, self.log_val = f"{d}/log_train.txt", f"{d}/log_val.txt"
+        write_log(self.log_train, header=["epoch", "mIoU", "pixel_acc", "loss"])
+        write_log(self.log_val, header=["epoch", "mIoU", "pixel_acc"])
+
+    # ------------------------------------------------------------------ model.py:88-159
+    def _train_epoch(self, epoch, model, trainer, n_iters_total):
+        model.train()
+        miou = pixel_acc = float("nan")
+        for it, dict_data in enumerate(self.dataloader):
+            x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+            if self.n_pixels_by_us != 0:                                   # model.py:108-110
+                mask = dict_data['queries'].to(self.device, torch.bool)
+                y = y.clone()
+                y.flatten()[~mask.flatten()] = self.ignore_index
+            if self.lr_scheduler_type == "Poly":                           # per-iteration poly decay (lr_scheduler.py:15-17)
+                trainer.set_poly_lr((epoch - 1) * len(self.dataloader) + it, n_iters_total)
+            tape_pred = trainer.train_step(x, y, keep_logits=True)
+            self.running_score.update_from_logits(y, trainer.last_logits)  # device-side confusion matrix (L6)
+            self.running_loss.update(trainer.last_loss)
+            if self.debug:
+                break
+        scores = self.running_score.get_scores()[0]
+        miou, pixel_acc = scores['Mean IoU'], scores['Pixel Acc']
+        avg_loss = float(self.running_loss.avg) if torch.is_tensor(self.running_loss.avg) else self.running_loss.avg
+        write_log(self.log_train, list_entities=[epoch, miou, pixel_acc, avg_loss])
+        self.history.append(("train", self.nth_query, epoch, miou, pixel_acc, avg_loss))
+        self._reset_meters()
+        return model
+
+    def _train(self):
+        print(f"\n({self.experim_name}) training...\n")
+        model = get_model(self.args).to(self.device)
+        op = self.args.optimizer_params
+        trainer = FlatTrainer(model, lr=op['lr'], betas=op.get('betas', (0.9, 0.999)), eps=op.get('eps', 1e-8),
+                              weight_decay=op['weight_decay'], ignore_index=self.ignore_index)
+        n_total = self.n_epochs * len(self.dataloader)
+        for e in range(1, 1 + self.n_epochs):
+            self._train_epoch(e, model, trainer, n_total)
+            self._val(e, model)
+            if self.debug:
+                break
+        self.best_miou = -1.0
+        return model
+
+    # ------------------------------------------------------------------ model.py:175-238
+    @torch.no_grad()
+    def _val(self, epoch, model):
+        model.eval()
+        for dict_data in self.dataloader_val:
+            x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+            if self.dataset_name == "voc":
+                h, w = y.shape[1:]
+                pad_h = ceil(h / self.stride_total) * self.stride_total - x.shape[2]
+                pad_w = ceil(w / self.stride_total) * self.stride_total - x.shape[3]
+                x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
+                logits = model(x)['pred'][:, :, :h, :w].contiguous()
+            else:
+                logits = model(x)['pred']
+            self.running_score.update_from_logits(y, logits)
+            if self.debug:
+                break
+        scores = self.running_score.get_scores()[0]
+        miou, pixel_acc = scores['Mean IoU'], scores['Pixel Acc']
+        if miou > self.best_miou:
+            sub = f"{self.nth_query}_query" if self.n_pixels_by_us != 0 else "fully_sup"
+            torch.save({"model": model.state_dict()}, f"{self.dir_checkpoints}/{sub}/best_miou_model.pt")
+            self.best_miou = miou
+        write_log(self.log_val, list_entities=[epoch, miou, pixel_acc])
+        self.history.append(("val", self.nth_query, epoch, miou, pixel_acc))
+        self._reset_meters()
+
+    @staticmethod
+    def _query(prob, query_strategy):
+        """model.py:241-260: uncertainty map from probabilities (HIP)."""
+        if query_strategy == "random":
+            b, _, h, w = prob.shape
+            return torch.rand((b, h, w))
+        if query_strategy not in ("least_confidence", "margin_sampling", "entropy"):
+            raise ValueError
+        return acq.uncertainty_from_prob(prob, query_strategy)
+
+    def _reset_meters(self):
+        self.running_loss.reset()
+        self.running_score.reset()

@@ -54,14 +54,16 @@ class FlatTrainer:
         self.step_count = 0
         self.lr_factor = 1.0
         self.last_loss: Optional[torch.Tensor] = None
+        self.last_logits: Optional[torch.Tensor] = None
 
     # -----------------------------------------------------------------------------------------------
-    def forward_backward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    def forward_backward(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
         """x [B,3,H,W] f32, y [B,H,W] int64 with ignore_index at unlabelled pixels (model.py:108-110)."""
         tape = E.Tape(enabled=True)
         tape.param_grad_dst = lambda p: self._grad_view.get(id(p))
         pred, _ = self.model._run(tape, x)
         loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index)
+        self.last_logits = pred.t if keep_logits else None
         tape.backward(pred, dlogits)
         self.last_loss = loss
         return loss
@@ -79,9 +81,9 @@ class FlatTrainer:
                                  self.step_count, 1.0 / self.world, _lib.current_stream_ptr())
         _lib.check(rc, "pp_adam_step_flat")
 
-    def train_step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    def train_step(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
         self.model.train()
-        loss = self.forward_backward(x, y)
+        loss = self.forward_backward(x, y, keep_logits)
         self.all_reduce_grads()
         self.optimizer_step()
         return loss

@@ -1,0 +1,72 @@
+"""GPU: device-side metrics vs the numpy restatement of RunningScore, and the active-learning driver end to end
+on a synthetic dataset (model.py:53-86 control flow: train -> query -> label, twice)."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from pixelpick_amd.model import Model
+from pixelpick_amd.synthetic import SyntheticDataset
+from pixelpick_amd.utils.metrics import RunningScore
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_confusion_matrix_matches_numpy_bincount():
+    torch.manual_seed(0)
+    B, C, H, W = 3, 19, 37, 53
+    logits = torch.randn(B, C, H, W, device=DEV)
+    y = torch.randint(0, C + 1, (B, H, W), device=DEV)        # C == ignore_index
+    y[0, :5] = 255
+    rs = RunningScore(C)
+    rs.update_from_logits(y, logits)
+    rs.update_from_logits(y, logits)
+    got = rs.get_scores()
+    ref = RunningScore(C)
+    pred = logits.argmax(dim=1).cpu().numpy()
+    for _ in range(2):
+        ref.update(y.cpu().numpy(), pred)
+    np.testing.assert_array_equal(rs.confusion_matrix, ref.confusion_matrix)
+    exp = ref.get_scores()
+    for k in exp[0]:
+        assert np.isclose(got[0][k], exp[0][k], equal_nan=True)
+
+
+def _args(td, **kw):
+    base = dict(dataset_name="cs", debug=False, dir_root=td, experim_name="synthetic", ignore_index=5, mc_n_steps=20,
+                n_classes=5, n_pixels_by_us=10, network_name="deeplab", query_strategy="margin_sampling", reverse_order=False,
+                stride_total=16, top_n_percent=0.0, use_mc_dropout=False, vote_type="hard", mc_dropout_p=0.2,
+                n_init_pixels=10, max_budget=20, n_epochs=2, lr_scheduler_type="Poly",
+                optimizer_params={"lr": 5e-4, "betas": (0.9, 0.999), "weight_decay": 2e-4, "eps": 1e-7})
+    base.update(kw)
+    return Namespace(**base)
+
+
+def test_active_learning_rounds_on_synthetic_data(tmp_path):
+    import warnings
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ds = SyntheticDataset(8, 64, 96, 5, 5, n_init_pixels=10, seed=1)
+    ds_val = SyntheticDataset(4, 64, 96, 5, 5, seed=2)
+    mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
+    args = _args(str(tmp_path))
+    m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device(DEV))
+    before = [q.copy() for q in ds.queries]
+    m()
+    # 3 stages (1 initial + max_budget/n_pixels_by_us = 2): each adds exactly 10 new, previously unlabelled, non-void pixels per image
+    assert ds.labelled_rounds == [0, 1, 1, 2, 2, 3][:len(ds.labelled_rounds)] or len(ds.labelled_rounds) >= 3
+    for i in range(len(ds)):
+        assert ds.queries[i].sum() == 10 + 3 * 10
+        assert (ds.queries[i] & before[i]).sum() == 10
+        assert not (ds.queries[i] & (ds.ys[i].numpy() == 5)).any()
+    for nth in range(3):
+        d = tmp_path / "checkpoints" / "synthetic" / f"{nth}_query"
+        assert (d / "log_train.txt").exists() and (d / "best_miou_model.pt").exists() and (d / "query_stats.pkl").exists()
+    losses = [h[5] for h in m.history if h[0] == "train"]
+    assert all(np.isfinite(l) for l in losses)
+    sd = torch.load(tmp_path / "checkpoints" / "synthetic" / "2_query" / "best_miou_model.pt")["model"]
+    assert len(sd) == 668
