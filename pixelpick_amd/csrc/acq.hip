@@ -298,6 +298,66 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
     }
 }
 
+
+// ---- dense NHWC (channels-last) input ----------------------------------------------------------------
+// Pixel-major storage: one pixel's C logits are contiguous (76 B at C=19).  A per-lane strided read touches 38
+// cache lines per wave-instruction; instead the block streams its pixel range as flat coalesced float4 loads
+// into LDS and every lane then reads its own pixel's class vector back (stride C floats: conflict-free for odd C).
+// Measured (B=256 x 256x512x19, entropy, k=20): 4.02 TB/s vs 3.17 TB/s for the per-lane strided path and
+// 5.98 TB/s for NCHW planes; issuing the next group's loads into registers ahead of the compute was slower (2.6).
+template <int CMAX, bool EXACT, int G, int MATH>
+__global__ __launch_bounds__(kBlock, 3) void acq_nhwc_kernel(AcqParams p)
+{
+    __shared__ __attribute__((aligned(16))) float s_x[kBlock * CMAX];
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
+    const int img = blockIdx.x / p.blocks_per_image;
+    const int blk = blockIdx.x - img * p.blocks_per_image;
+    const int tid = threadIdx.x;
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const int C = EXACT ? CMAX : p.C;
+    const float* base = p.logits + (int64_t)img * p.sB;
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+    float* omap = p.out_map ? p.out_map + (int64_t)img * p.N : nullptr;
+    uint32_t kh[G], kl[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t pix_blk = ((int64_t)blk * G + g) * kBlock;          // first pixel of this group
+        const int64_t npix = p.N - pix_blk < kBlock ? p.N - pix_blk : kBlock;
+        if (npix > 0) {
+            const int64_t nfl = npix * C;                                 // floats to stage (multiple of 4: N % 4 == 0)
+            const float4* src = reinterpret_cast<const float4*>(base + pix_blk * C);
+            for (int64_t i = tid; i < nfl / 4; i += kBlock) reinterpret_cast<float4*>(s_x)[i] = src[i];
+        }
+        __syncthreads();
+        const int64_t pix = pix_blk + tid;
+        if (pix < p.N) {
+            float x[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C) x[c] = s_x[tid * C + c];
+            float sc;
+            if constexpr (MATH == 0) sc = pixel_score_fast<CMAX, EXACT>(x, p.C, p.strategy);
+            else sc = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, MATH == 2);
+            if (excl && excl[pix]) sc = fill;
+            if (omap) omap[pix] = sc;
+            kh[g] = order_key(sc, largest);
+            kl[g] = 0xFFFFFFFFu - (uint32_t)pix;
+        } else {
+            kh[g] = 0u; kl[g] = 0u;
+        }
+        __syncthreads();
+    }
+    if (p.cand) {
+        const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
+        const int waves_per_image = p.blocks_per_image * (kBlock / kWave);
+        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
+        if (p.reduce_mode == 2) wave_extract_topk<G>(kh, kl, p.k, dst, 0);
+        else wave_extract_topk_prefilter<G>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
+    }
+}
+
 // ---- small-k selection straight from a score map (pp_topk_select) ------------------------------------
 template <int G>
 __global__ __launch_bounds__(kBlock) void topk_small_from_scores_kernel(const float* scores, int64_t N,
@@ -479,6 +539,7 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* 
 static int next_pow2(int64_t v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct Plan {
+    bool nhwc = false;    // dense channels-last input: LDS-transposed path
     bool vec4;            // flat float4 path
     int ppt;              // pixels per thread
     int blocks_per_image;
@@ -492,6 +553,12 @@ static bool is_flat_vec4(const float* logits, const uint8_t* exclude, const floa
     return sW == 1 && (sH == W || H == 1) && N % 4 == 0 && sC % 4 == 0 && sB % 4 == 0 &&
            (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(exclude) & 3) == 0 &&
            (reinterpret_cast<uintptr_t>(out_map) & 15) == 0;
+}
+
+static bool is_dense_nhwc(const float* logits, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC, int64_t sH, int64_t sW)
+{
+    return C > 1 && C <= 32 && sC == 1 && sW == C && (sH == W * C || H == 1) && (H * W) % 4 == 0 && sB % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
 }
 
 // Deterministic in (B, N, vec4) so that pp_acq_workspace_bytes can size the candidate buffer.
@@ -564,6 +631,15 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
     dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
     // the non-default scorers (reference-order, from-prob) are only built for the 4-pixel tile
     const bool alt = p.from_prob || g_exact_formula;
+    if (pl.nhwc) {
+        if constexpr (CMAX <= 32) {
+            if (p.from_prob)          hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 2>), grid, block, 0, st, p);
+            else if (g_exact_formula) hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 1>), grid, block, 0, st, p);
+            else if (pl.ppt == 8)     hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 8, 0>), grid, block, 0, st, p);
+            else                      hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 0>), grid, block, 0, st, p);
+            return check_launch("acq_nhwc_kernel");
+        }
+    }
 #define PP_LAUNCH_ACQ4(VEC, G)                                                                                    \
     do {                                                                                                          \
         if (p.from_prob)          hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 2>), grid, block, 0, st, p); \
@@ -600,6 +676,9 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
 static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
 {
     if (p.C > 32) pl.vec4 = false;  // 64-class bucket only on the scalar path (register budget)
+    if (!pl.vec4 && g_tune_occ != 9)   // (tuning value 9 forces the generic strided path for A/B)
+        pl.nhwc = is_dense_nhwc(p.logits, p.C, p.N / p.W, p.W, p.sB, p.sC, p.sH, p.sW);
+    if (pl.nhwc && (g_exact_formula || p.from_prob) && pl.ppt != 4) pl.nhwc = false;
     switch (p.C) {
         case 11: return launch_acq<11, true>(p, pl, B, st);   // CamVid      (args.py:109-116)
         case 19: return launch_acq<19, true>(p, pl, B, st);   // Cityscapes  (args.py:89-94)
@@ -633,7 +712,7 @@ void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
 
 void pp_debug_set_acq_tuning(int occ, int ppt)
 {
-    g_tune_occ = (occ == 2 || occ == 3 || occ == 4) ? occ : 0;
+    g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 9) ? occ : 0;
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
 }
 
