@@ -236,8 +236,9 @@ void pp_debug_set_exact_formula(int on);
 /* Tuning knob for the C == 19 flat path: occupancy bound (2/3/4 waves per SIMD, 0 = default) and
  * pixels per thread (4/8, 0 = automatic). */
 void pp_debug_set_acq_tuning(int occ, int ppt);
-/* Large-tile dense conv kernel: 0 = 128x128 tile, single LDS buffer, K-step 16 (default; measured fastest),
- * 1 = double-buffered K-step 32, 2 = 128x64 tiles. */
+/* Dense conv kernel A/B knobs: low 2 bits 0 = 128x128 large tile (default; measured fastest), 2 = 128x64 tiles;
+ * bit 2 = linear instead of XCD-aware tile order; bit 3 = conditional (non-vector) loads; bits 4/5 = cap the large
+ * tile at 2 / 1 blocks per CU.  Findings: profiles/r01_conv_ablation.txt. */
 void pp_debug_set_conv_variant(int v);
 
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The

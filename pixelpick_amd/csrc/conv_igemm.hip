@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static int g_conv_xcd_remap = 1;
 static int g_conv_novec = 0;
 static int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
-static int g_conv_variant = 0;   // large-tile kernel: 0 single-buffered K=16 128x128 (default), 1 double-buffered K=32, 2 128x64 tiles
+static int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
 
 constexpr int kThreads = 256;
 constexpr int BK = 16;
@@ -375,192 +375,6 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 }
 
 
-// ---- large-tile variant: K step 32, two LDS buffers, ONE barrier per step ---------------------------------
-// Same operand forms as conv_igemm_kernel.  Step ks: issue the global loads of step ks+1 into registers,
-// run the 64 MFMAs of step ks from buffer `cur`, write the registers to the other buffer, barrier.
-template <int BM, int BN, int WM, int WN, bool BWD>
-__global__ __launch_bounds__(kThreads) void conv_igemm_db_kernel(ConvParams p)
-{
-    constexpr int BKT = 32;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PITCH_A = BKT + 4;
-    constexpr int PITCH_B = BWD ? BKT + 4 : BN + 4;
-    constexpr int KQ = BKT / 4;                                   // float4 per A row
-    constexpr int A_ROWS_PASS = kThreads / KQ;                    // rows covered per pass
-    constexpr int A_F4 = BM / A_ROWS_PASS;
-    constexpr int B_TOTAL = BN * BKT / 4;
-    constexpr int B_F4 = B_TOTAL / kThreads;
-    constexpr int A_TILE = BM * PITCH_A;
-    constexpr int B_TILE = BWD ? BN * PITCH_B : BKT * PITCH_B;
-    static_assert(B_TOTAL % kThreads == 0 && BM % A_ROWS_PASS == 0, "tile/threads mismatch");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                    // [2][A_TILE]
-    float* Bs = smem + 2 * A_TILE;       // [2][B_TILE]
-
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-
-    const int a_kq = tid % KQ, a_r = tid / KQ;
-    int a_b[A_F4], a_ih[A_F4], a_iw[A_F4];
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-        const int64_t m = m0 + a_r + i * A_ROWS_PASS;
-        if (m < p.M) {
-            const unsigned mu = (unsigned)m;
-            const unsigned t = mu / (unsigned)p.Wo;
-            const int ow = (int)(mu - t * (unsigned)p.Wo);
-            const unsigned bb = t / (unsigned)p.Ho;
-            const int oh = (int)(t - bb * (unsigned)p.Ho);
-            a_b[i] = (int)bb;
-            a_ih[i] = oh * p.stride;
-            a_iw[i] = ow * p.stride;
-        } else {
-            a_b[i] = -1; a_ih[i] = 0; a_iw[i] = 0;
-        }
-    }
-
-    const int nchunk = (p.Ck + BKT - 1) / BKT;
-    const int nk = p.taps.n * nchunk;
-    const bool w_vec = p.Cout % 4 == 0;
-    const bool x_vec = p.ldx % 4 == 0;
-
-    float4 ra[A_F4], rb[B_F4];
-
-    auto load_tiles = [&](int ks) {
-        const int ti = ks / nchunk;
-        const int c0 = (ks - ti * nchunk) * BKT;
-        const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
-        const int wt = p.taps.widx[ti];
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
-            const int c = c0 + a_kq * 4;
-            if (a_b[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && c < p.Ck) {
-                const float* src = p.x + (((int64_t)a_b[i] * p.H + ih) * p.W + iw) * p.ldx + c;
-                if (x_vec && c + 3 < p.Ck) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v.x = src[0];
-                    if (c + 1 < p.Ck) v.y = src[1];
-                    if (c + 2 < p.Ck) v.z = src[2];
-                    if (c + 3 < p.Ck) v.w = src[3];
-                }
-            }
-            ra[i] = v;
-        }
-        if constexpr (!BWD) {
-#pragma unroll
-            for (int i = 0; i < B_F4; ++i) {
-                const int e = tid + i * kThreads;
-                const int kr = e / (BN / 4), nq = e % (BN / 4);
-                const int c = c0 + kr, n = n0 + nq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < p.Cin && n < p.Cout) {
-                    const float* src = p.w + ((int64_t)wt * p.Cin + c) * p.Cout + n;
-                    if (w_vec) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (n + 1 < p.Cout) v.y = src[1];
-                        if (n + 2 < p.Cout) v.z = src[2];
-                        if (n + 3 < p.Cout) v.w = src[3];
-                    }
-                }
-                rb[i] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_F4; ++i) {
-                const int e = tid + i * kThreads;
-                const int col = e / KQ, kq = e % KQ;
-                const int cin = n0 + col, k = c0 + kq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cin < p.Cin && k < p.Cout) {
-                    const float* src = p.w + ((int64_t)wt * p.Cin + cin) * p.Cout + k;
-                    if (w_vec && k + 3 < p.Cout) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (k + 1 < p.Cout) v.y = src[1];
-                        if (k + 2 < p.Cout) v.z = src[2];
-                        if (k + 3 < p.Cout) v.w = src[3];
-                    }
-                }
-                rb[i] = v;
-            }
-        }
-    };
-
-    auto store_tiles = [&](int buf) {
-        float* A = As + buf * A_TILE;
-        float* B = Bs + buf * B_TILE;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i)
-            *reinterpret_cast<float4*>(A + (a_r + i * A_ROWS_PASS) * PITCH_A + a_kq * 4) = ra[i];
-        if constexpr (!BWD) {
-#pragma unroll
-            for (int i = 0; i < B_F4; ++i) {
-                const int e = tid + i * kThreads;
-                *reinterpret_cast<float4*>(B + (e / (BN / 4)) * PITCH_B + (e % (BN / 4)) * 4) = rb[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_F4; ++i) {
-                const int e = tid + i * kThreads;
-                *reinterpret_cast<float4*>(B + (e / KQ) * PITCH_B + (e % KQ) * 4) = rb[i];
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        const bool more = ks + 1 < nk;
-        if (more) load_tiles(ks + 1);
-        mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B, BKT>(As + cur * A_TILE, Bs + cur * B_TILE, wm * TM * 32, wn * TN * 32, acc);
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wn * TN + tn) * 32 + l31;
-        if (n >= p.Cn) continue;
-        const float bv = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m < p.M) p.y[m * p.ldy + n] = acc[tm][tn][r] + bv;
-            }
-        }
-    }
-}
-
-template <int BM, int BN, bool BWD>
-constexpr size_t conv_db_lds_bytes()
-{
-    return (size_t)(2 * BM * (32 + 4) + 2 * (BWD ? BN * (32 + 4) : 32 * (BN + 4))) * 4;
-}
-
 // ---- weight gradient ---------------------------------------------------------------------------------------
 // GEMM rows = Cin (c), cols = Cout (n), reduction = output pixels m of one split; one tap per blockIdx.z/..
 struct WgradParams {
@@ -844,17 +658,7 @@ static int launch_conv(const ConvParams& p_in, hipStream_t st)
         if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, false>), grid, dim3(kThreads), 0, st, p);
     } else if (p.Cn > 64 && mt128 * cdiv(p.Cn, 128) >= 384) {
-        dim3 grid((unsigned)mt128, (unsigned)cdiv(p.Cn, 128));
-        constexpr size_t lds = conv_db_lds_bytes<128, 128, BWD>();
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_db_kernel<128, 128, 2, 2, BWD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        if (g_conv_variant == 1) {
-            hipLaunchKernelGGL((conv_igemm_db_kernel<128, 128, 2, 2, BWD>), grid, dim3(kThreads), lds, st, p);
-        } else if (g_conv_variant == 2) {
+        if (g_conv_variant == 2) {
             p.n_tiles = (int)cdiv(p.Cn, 64);
             dim3 grid2((unsigned)(mt128 * p.n_tiles));
             if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, true>), grid2, dim3(kThreads), 0, st, p);
