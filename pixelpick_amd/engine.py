@@ -9,6 +9,7 @@ memory (caching allocator) and the current stream — no torch arithmetic is use
 Activations are NHWC `torch.Tensor`s [B,H,W,C]; channel slices of a wider buffer are allowed
 (pixel stride `ld` = stride(2)).  Weights are HWIO (dense) / [3,3,C] (depthwise).
 """
+import contextlib
 from typing import List, Optional, Sequence
 
 import torch
@@ -28,12 +29,30 @@ class Var:
         self.needs_grad = needs_grad
 
 
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
 class Tape:
+    # Weight-gradient kernels have no consumer until the optimiser step, and most layers of this network are too
+    # small to fill 256 CUs on their own: in backward() they run on a second HIP stream, concurrently with the
+    # data-gradient chain on the main stream (joined at the end of backward()).
+    overlap_wgrad = True
+
     def __init__(self, enabled: bool = True):
         self.enabled = enabled
         self.nodes: List = []          # (backward_fn, ctx_tuple, output Var)
         self.param_grads = {}          # id(param tensor) -> grad tensor
         self.param_grad_dst = None     # optional callable(param) -> preallocated grad tensor to write into
+        self._side = None
 
     def record(self, fn, ctx, out: Var):
         if self.enabled:
@@ -54,6 +73,20 @@ class Tape:
         else:
             self.param_grads[key] = g
 
+    def side_stream_for(self, *tensors):
+        """Context manager: run the enclosed launches on the side stream, after everything queued so far on the
+        main stream; `tensors` are kept alive for the side stream (caching-allocator bookkeeping)."""
+        if not Tape.overlap_wgrad:
+            return contextlib.nullcontext()
+        dev = tensors[0].device
+        side = _side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+        self._side = side
+        return torch.cuda.stream(side)
+
     def backward(self, out: Var, dout: torch.Tensor):
         out.grad = dout
         for fn, ctx, o in reversed(self.nodes):
@@ -62,6 +95,9 @@ class Tape:
             fn(self, o.grad, *ctx)
             o.grad = None             # free as we go
         self.nodes = []
+        if self._side is not None:    # join: the optimiser / all-reduce must see every weight gradient
+            torch.cuda.current_stream(dout.device).wait_stream(self._side)
+            self._side = None
 
 
 # ------------------------------------------------------------------------------------------------- helpers
@@ -260,10 +296,11 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
     if w.requires_grad:
         dw = tape.grad_buffer_for(w)
         db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
-        ws = _ws(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
-        rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
-                                    dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
-                                    _stream())
+        with tape.side_stream_for(x.t, dy, dw, db):
+            ws = _ws(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
+            rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
+                                        dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+                                        _stream())
         _lib.check(rc, "pp_conv2d_bwd_weight")
         tape.set_param_grad(w, dw)
         if db is not None:
@@ -296,9 +333,10 @@ def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
     dev = dy.device
     if w.requires_grad:
         dw = tape.grad_buffer_for(w)
-        ws = _ws(L.pp_colreduce_workspace_bytes(B * Ho * Wo, C), dev)
-        rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), _stream())
+        with tape.side_stream_for(x.t, dy, dw):
+            ws = _ws(L.pp_colreduce_workspace_bytes(B * Ho * Wo, C), dev)
+            rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream())
         _lib.check(rc, "pp_dwconv3x3_bwd_weight")
         tape.set_param_grad(w, dw)
     if x.needs_grad:
