@@ -513,6 +513,56 @@ __device__ __forceinline__ void out_window(int i, int in, int out, float scale, 
     if (scale == 0.0f) { lo = 0; hi = out - 1; }
 }
 
+// NHWC, C % 4 == 0: one thread per (input pixel, 4 channels); the row / column weights of the candidate window are
+// separable, so they are evaluated once per thread (<= 2*kMaxWin lerp evaluations) instead of once per tap.
+constexpr int kMaxWin = 24;
+__global__ __launch_bounds__(kT) void bilinear_bwd4_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq,
+                                                          float* dx, int64_t lddx, int H, int W, float sh, float sw, int align)
+{
+    const int64_t total = (int64_t)B * H * W * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        int h0, h1, w0, w1;
+        out_window(ih, H, Ho, sh, align, h0, h1);
+        out_window(iw, W, Wo, sw, align, w0, w1);
+        float ww[kMaxWin];               // statically indexed everywhere (fully unrolled loops): stays in registers
+        const int nw = w1 - w0 + 1;
+#pragma unroll
+        for (int k = 0; k < kMaxWin; ++k) {
+            float v = 0.0f;
+            if (k < nw) {
+                const Lerp lw = lerp_src(w0 + k, W, sw, align);
+                if (lw.i0 == iw) v += lw.l0;
+                if (lw.i1 == iw) v += lw.l1;
+            }
+            ww[k] = v;
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = h0; oh <= h1; ++oh) {
+            const Lerp lh = lerp_src(oh, H, sh, align);
+            float wh = 0.0f;
+            if (lh.i0 == ih) wh += lh.l0;
+            if (lh.i1 == ih) wh += lh.l1;
+            if (wh == 0.0f) continue;
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* base = dy + (((int64_t)b * Ho + oh) * Wo + w0) * lddy + q * 4;
+#pragma unroll
+            for (int k = 0; k < kMaxWin; ++k) {
+                const float wk = ww[k];
+                if (wk == 0.0f) continue;    // also covers k >= nw
+                const float4 g = *reinterpret_cast<const float4*>(base + (int64_t)k * lddy);
+                row.x = fmaf(wk, g.x, row.x); row.y = fmaf(wk, g.y, row.y); row.z = fmaf(wk, g.z, row.z); row.w = fmaf(wk, g.w, row.w);
+            }
+            acc.x = fmaf(wh, row.x, acc.x); acc.y = fmaf(wh, row.y, acc.y); acc.z = fmaf(wh, row.z, acc.z); acc.w = fmaf(wh, row.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4) = acc;
+    }
+}
+
 template <bool DY_NCHW>
 __global__ __launch_bounds__(kT) void bilinear_bwd_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C,
                                                          float* dx, int64_t lddx, int H, int W, float sh, float sw,
@@ -602,6 +652,26 @@ __device__ __forceinline__ uint32_t hash_rng(uint64_t seed, uint64_t idx)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
     return (uint32_t)(z >> 32);
+}
+
+// float4 variant (C % 4 == 0): same per-element hash stream as the scalar kernel (mask = f(seed, flat index))
+__global__ __launch_bounds__(kT) void dropout4_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int cq,
+                                                     float p, float inv_keep, uint64_t seed)
+{
+    const int64_t total = M * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t r = total <= 0xFFFFFFFFll ? (int64_t)((unsigned)e / (unsigned)cq) : e / cq;
+        const int q = (int)(e - r * cq);
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
+        const uint64_t i0 = (uint64_t)(r * cq + q) * 4;
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = (float)(hash_rng(seed, i0 + j) >> 8) * (1.0f / 16777216.0f);
+            o[j] = u >= p ? o[j] * inv_keep : 0.0f;
+        }
+        *reinterpret_cast<float4*>(y + r * ldy + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 __global__ __launch_bounds__(kT) void dropout_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C,
@@ -944,6 +1014,10 @@ int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C,
     if (dy_nchw)
         hipLaunchKernelGGL((bilinear_bwd_kernel<true>), dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, lddy, B, Ho,
                            Wo, C, dx, lddx, H, W, sh, sw, align_corners);
+    else if (C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && sh > 0.0f && sw > 0.0f &&
+             (int)(2.0f / sw) + 6 <= kMaxWin)   // window of candidate output columns fits the per-thread weight table
+        hipLaunchKernelGGL(bilinear_bwd4_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(kT), 0, st, dy, lddy, B, Ho, Wo,
+                           C / 4, dx, lddx, H, W, sh, sw, align_corners);
     else
         hipLaunchKernelGGL((bilinear_bwd_kernel<false>), dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, lddy, B, Ho,
                            Wo, C, dx, lddx, H, W, sh, sw, align_corners);
@@ -973,8 +1047,12 @@ int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, in
 {
     if (!x || !y) return fail(PP_ERR_BAD_ARG, "dropout: null");
     if (p < 0.0f || p >= 1.0f) return fail(PP_ERR_BAD_ARG, "dropout: p=%f outside [0,1)", (double)p);
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(M * C)), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C, p,
-                       1.0f / (1.0f - p), seed);
+    if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0)
+        hipLaunchKernelGGL(dropout4_kernel, dim3(grid_for(M * (C / 4))), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C / 4,
+                           p, 1.0f / (1.0f - p), seed);
+    else
+        hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(M * C)), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C, p,
+                           1.0f / (1.0f - p), seed);
     return check_launch("dropout_kernel");
 }
 
