@@ -192,7 +192,10 @@ int pp_image_broadcast(const float* v, int64_t ldv, int B, int64_t P, int C, flo
 
 /* nn.Dropout (aspp.py:61; decoders.py:110,114): y = x * keep / (1-p), keep from a counter-based hash of
  * (seed, element index) — the backward pass calls this again on dy with the same seed. */
-int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed, pp_stream_t stream);
+/* seed_dev (NULL or a device u64): added (hashed) to `seed` when the kernel RUNS, so a launch captured in a hipGraph
+ * draws a fresh mask on every replay once the host bumps that word. */
+int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed,
+               const uint64_t* seed_dev, pp_stream_t stream);
 
 /* F.cross_entropy(logits, target, ignore_index) (model.py:116) on NCHW logits (plane stride 1 within a
  * class: element (b,c,pix) at b*sB + c*sC + pix): *loss = mean over labelled pixels, *count = their
@@ -212,9 +215,11 @@ int pp_confusion_matrix_update(const float* logits, int B, int C, int64_t HW, in
 /* torch.optim.Adam step on flat buffers (utils/utils.py:125-141): elements [0,n_split) use lr_a (the
  * backbone/encoder group at lr/10), the rest lr_b; L2 weight decay; `step` is 1-based; grads are
  * multiplied by grad_scale first (1/world_size after the gradient all-reduce). */
+/* hyper_dev (NULL or device f32[4] = {lr_a, lr_b, 1-beta1^step, sqrt(1-beta2^step)}): when given, these four
+ * replace the by-value arguments at RUN time, so the launch can be replayed from a hipGraph with a moving step. */
 int pp_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_split,
                       float lr_a, float lr_b, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                      float grad_scale, pp_stream_t stream);
+                      float grad_scale, const float* hyper_dev, pp_stream_t stream);
 
 /* y = a + b on [M,C] matrices with pixel strides (gradient accumulation for tensors with several
  * consumers: the residual input of mobilenet_v2.py:62, the ASPP input of aspp.py:64-69). */

@@ -47,11 +47,11 @@ SIGNATURES = {
     "pp_bilinear_bwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p]),
     "pp_image_colsum": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
     "pp_image_broadcast": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
-    "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p]),
+    "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p, _p]),
     "pp_sparse_ce_workspace_bytes": (_sz, []),
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "pp_confusion_matrix_update": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _p, _p]),
-    "pp_adam_step_flat": (_int, [_p, _p, _p, _p, _i64, _i64, _f, _f, _f, _f, _f, _f, _i64, _f, _p]),
+    "pp_adam_step_flat": (_int, [_p, _p, _p, _p, _i64, _i64, _f, _f, _f, _f, _f, _f, _i64, _f, _p, _p]),
     "pp_add2d": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _p]),
     "pp_nhwc_to_nchw": (_int, [_p, _i64, _int, _int, _i64, _p, _p]),
     "pp_nchw_to_nhwc": (_int, [_p, _int, _int, _i64, _p, _i64, _p]),

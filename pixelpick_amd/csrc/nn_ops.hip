@@ -656,8 +656,9 @@ __device__ __forceinline__ uint32_t hash_rng(uint64_t seed, uint64_t idx)
 
 // float4 variant (C % 4 == 0): same per-element hash stream as the scalar kernel (mask = f(seed, flat index))
 __global__ __launch_bounds__(kT) void dropout4_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int cq,
-                                                     float p, float inv_keep, uint64_t seed)
+                                                     float p, float inv_keep, uint64_t seed, const uint64_t* seed_dev)
 {
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;   // per-step base seed read at run time (hipGraph replay)
     const int64_t total = M * cq;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
         const int64_t r = total <= 0xFFFFFFFFll ? (int64_t)((unsigned)e / (unsigned)cq) : e / cq;
@@ -675,8 +676,9 @@ __global__ __launch_bounds__(kT) void dropout4_kernel(const float* x, int64_t ld
 }
 
 __global__ __launch_bounds__(kT) void dropout_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C,
-                                                    float p, float inv_keep, uint64_t seed)
+                                                    float p, float inv_keep, uint64_t seed, const uint64_t* seed_dev)
 {
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
     const int64_t total = M * C;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
         const int64_t r = e / C;
@@ -766,8 +768,11 @@ __global__ __launch_bounds__(kT) void ce_bwd_kernel(const float* logits, const i
 // ================================================================================================
 __global__ __launch_bounds__(kT) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_split,
                                                  float lr_a, float lr_b, float beta1, float beta2, float eps, float wd,
-                                                 float bc1, float bc2_sqrt, float grad_scale)
+                                                 float bc1, float bc2_sqrt, float grad_scale, const float* hyper_dev)
 {
+    if (hyper_dev) {   // [lr_a, lr_b, bc1, bc2_sqrt] read at run time: the launch can sit in a replayed hipGraph
+        lr_a = hyper_dev[0]; lr_b = hyper_dev[1]; bc1 = hyper_dev[2]; bc2_sqrt = hyper_dev[3];
+    }
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) {
         const float lr = i < n_split ? lr_a : lr_b;
         float grad = g[i] * grad_scale;
@@ -1043,16 +1048,17 @@ int pp_image_broadcast(const float* v, int64_t ldv, int B, int64_t P, int C, flo
 }
 
 // ---- dropout ---------------------------------------------------------------------------------------------------
-int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed, pp_stream_t stream)
+int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed,
+               const uint64_t* seed_dev, pp_stream_t stream)
 {
     if (!x || !y) return fail(PP_ERR_BAD_ARG, "dropout: null");
     if (p < 0.0f || p >= 1.0f) return fail(PP_ERR_BAD_ARG, "dropout: p=%f outside [0,1)", (double)p);
     if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0)
         hipLaunchKernelGGL(dropout4_kernel, dim3(grid_for(M * (C / 4))), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C / 4,
-                           p, 1.0f / (1.0f - p), seed);
+                           p, 1.0f / (1.0f - p), seed, seed_dev);
     else
         hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(M * C)), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C, p,
-                           1.0f / (1.0f - p), seed);
+                           1.0f / (1.0f - p), seed, seed_dev);
     return check_launch("dropout_kernel");
 }
 
@@ -1085,14 +1091,14 @@ int pp_sparse_ce_fwd_bwd(const float* logits, int B, int C, int64_t HW, int64_t 
 // ---- optimiser ------------------------------------------------------------------------------------------------------
 int pp_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_split,
                       float lr_a, float lr_b, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                      float grad_scale, pp_stream_t stream)
+                      float grad_scale, const float* hyper_dev, pp_stream_t stream)
 {
     if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(PP_ERR_BAD_ARG, "adam: null");
     if (n < 1 || step < 1) return fail(PP_ERR_BAD_ARG, "adam: bad n/step");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
-                       n_split, lr_a, lr_b, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       n_split, lr_a, lr_b, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, hyper_dev);
     return check_launch("adam_kernel");
 }
 

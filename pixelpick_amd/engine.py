@@ -53,6 +53,7 @@ class Tape:
         self.param_grads = {}          # id(param tensor) -> grad tensor
         self.param_grad_dst = None     # optional callable(param) -> preallocated grad tensor to write into
         self._side = None
+        self._keepalive = []
 
     def record(self, fn, ctx, out: Var):
         if self.enabled:
@@ -81,9 +82,12 @@ class Tape:
         dev = tensors[0].device
         side = _side_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        capturing = torch.cuda.is_current_stream_capturing()
         for t in tensors:
             if t is not None:
-                t.record_stream(side)
+                self._keepalive.append(t)       # not recycled by the allocator before the join (needed under graph capture)
+                if not capturing:
+                    t.record_stream(side)
         self._side = side
         return torch.cuda.stream(side)
 
@@ -98,6 +102,7 @@ class Tape:
         if self._side is not None:    # join: the optimiser / all-reduce must see every weight gradient
             torch.cuda.current_stream(dout.device).wait_stream(self._side)
             self._side = None
+        self._keepalive = []
 
 
 # ------------------------------------------------------------------------------------------------- helpers
@@ -298,6 +303,7 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
         db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
         with tape.side_stream_for(x.t, dy, dw, db):
             ws = _ws(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
+            tape._keepalive.append(ws)
             rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
                                         dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
                                         _stream())
@@ -335,6 +341,7 @@ def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
         dw = tape.grad_buffer_for(w)
         with tape.side_stream_for(x.t, dy, dw):
             ws = _ws(L.pp_colreduce_workspace_bytes(B * Ho * Wo, C), dev)
+            tape._keepalive.append(ws)
             rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
                                            ws.data_ptr(), ws.numel(), _stream())
         _lib.check(rc, "pp_dwconv3x3_bwd_weight")
@@ -530,10 +537,22 @@ def _broadcast_bwd(tape: Tape, dy, v: Var, H, W):
 
 # ------------------------------------------------------------------------------------------------- dropout
 _dropout_counter = [0]
+_dropout_seed_dev = [None]     # optional device int64[1]: per-step base seed read by the kernels at run time
 
 
 def set_dropout_seed(seed: int):
     _dropout_counter[0] = int(seed) * 1000003
+
+
+def set_dropout_device_seed(t: Optional[torch.Tensor]):
+    """With a device seed word installed, the per-call salts restart at 0 every step (begin_step()) so that a captured
+    graph and eager execution draw identical masks for the same word; the trainer bumps the word once per step."""
+    _dropout_seed_dev[0] = t
+
+
+def begin_step():
+    if _dropout_seed_dev[0] is not None:
+        _dropout_counter[0] = 0
 
 
 def dropout(tape: Tape, x: Var, p: float, training: bool) -> Var:
@@ -544,7 +563,9 @@ def dropout(tape: Tape, x: Var, p: float, training: bool) -> Var:
     _dropout_counter[0] += 1
     seed = (_dropout_counter[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
     y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.t.device)
-    rc = _lib.lib().pp_dropout(x.t.data_ptr(), ldx, y.data_ptr(), C, B * H * W, C, float(p), seed, _stream())
+    sd = _dropout_seed_dev[0]
+    rc = _lib.lib().pp_dropout(x.t.data_ptr(), ldx, y.data_ptr(), C, B * H * W, C, float(p), seed,
+                               sd.data_ptr() if sd is not None else None, _stream())
     _lib.check(rc, "pp_dropout")
     out = Var(y)
     tape.record(_dropout_bwd, (x, p, seed), out)
@@ -557,7 +578,9 @@ def _dropout_bwd(tape: Tape, dy, x: Var, p, seed):
     B, H, W, C, _ = _geom(x.t)
     _, _, _, _, lddy = _geom(dy)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
-    rc = _lib.lib().pp_dropout(dy.data_ptr(), lddy, dx.data_ptr(), C, B * H * W, C, float(p), seed, _stream())
+    sd = _dropout_seed_dev[0]
+    rc = _lib.lib().pp_dropout(dy.data_ptr(), lddy, dx.data_ptr(), C, B * H * W, C, float(p), seed,
+                               sd.data_ptr() if sd is not None else None, _stream())
     _lib.check(rc, "pp_dropout")
     _acc(x, dx)
 

@@ -55,6 +55,14 @@ class FlatTrainer:
         self.lr_factor = 1.0
         self.last_loss: Optional[torch.Tensor] = None
         self.last_logits: Optional[torch.Tensor] = None
+        # run-time hyper-parameters live in device memory so that the whole step can be a replayed hipGraph:
+        # hyper = [lr_backbone, lr_head, 1-beta1^t, sqrt(1-beta2^t)], seed = per-step dropout base seed
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._graph = None
+        self._gx = self._gy = None
 
     # -----------------------------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
@@ -72,21 +80,68 @@ class FlatTrainer:
         if self.world > 1:
             torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
-    def optimizer_step(self):
-        self.step_count += 1
+    def _stage_hyper(self):
+        """Host -> pinned -> device copies of the per-step scalars (enqueued on the current stream)."""
+        t = self.step_count
+        self._hyper_host[0] = self.lr / 10 * self.lr_factor
+        self._hyper_host[1] = self.lr * self.lr_factor
+        self._hyper_host[2] = 1.0 - self.betas[0] ** t
+        self._hyper_host[3] = (1.0 - self.betas[1] ** t) ** 0.5
+        self._seed_host[0] = 0x5DEECE66D * t + 11
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        self._seed_dev.copy_(self._seed_host, non_blocking=True)
+
+    def optimizer_step(self, use_device_hyper: bool = False):
         L = _lib.lib()
         rc = L.pp_adam_step_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                  self.exp_avg_sq.data_ptr(), self.n, self.n_split, self.lr / 10 * self.lr_factor,
                                  self.lr * self.lr_factor, self.betas[0], self.betas[1], self.eps, self.wd,
-                                 self.step_count, 1.0 / self.world, _lib.current_stream_ptr())
+                                 max(self.step_count, 1), 1.0 / self.world,
+                                 self._hyper_dev.data_ptr() if use_device_hyper else None, _lib.current_stream_ptr())
         _lib.check(rc, "pp_adam_step_flat")
 
-    def train_step(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
-        self.model.train()
+    def _step_body(self, x, y, keep_logits, device_hyper):
+        E.begin_step()
         loss = self.forward_backward(x, y, keep_logits)
         self.all_reduce_grads()
-        self.optimizer_step()
+        self.optimizer_step(device_hyper)
         return loss
+
+    def train_step(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
+        """One optimisation step (model.py:101-122).  After enable_graph() the step is a hipGraph replay."""
+        self.model.train()
+        self.step_count += 1
+        if self._graph is not None:
+            self._gx.copy_(x, non_blocking=True)
+            self._gy.copy_(y, non_blocking=True)
+            self._stage_hyper()
+            self._graph.replay()
+            return self.last_loss
+        return self._step_body(x, y, keep_logits, False)
+
+    def enable_graph(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2):
+        """Capture forward + loss + backward (+ all-reduce) + Adam for this input shape into ONE hipGraph (~700 kernel
+        launches per step otherwise go through Python/ctypes one by one and the step becomes host-bound below ~9 ms).
+        Per-step scalars (learning rates, Adam bias corrections, dropout seed) are read from device memory at run time.
+        `warmup` eager steps run first (they are real optimisation steps)."""
+        assert self._graph is None
+        self.model.train()
+        E.set_dropout_device_seed(self._seed_dev)
+        self._gx, self._gy = x.clone(), y.clone()
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):                      # warm-up on a side stream, as torch's capture recipe asks
+            for _ in range(warmup):
+                self.step_count += 1
+                self._stage_hyper()
+                self._step_body(self._gx, self._gy, True, True)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_body(self._gx, self._gy, True, True)
+        self._graph = g
+        return self
 
     def set_poly_lr(self, T: int, N: int, power: float = 0.9):
         """utils/lr_scheduler.py:15-17 applied to both segments."""

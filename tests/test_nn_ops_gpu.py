@@ -382,7 +382,7 @@ def test_adam_matches_torch():
         opt.step()
         gg = g.to(DEV)
         rc = L.pp_adam_step_flat(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), n, n_split, 5e-5, 5e-4, 0.9, 0.999,
-                                 1e-7, 2e-4, step, 1.0, torch.cuda.current_stream().cuda_stream)
+                                 1e-7, 2e-4, step, 1.0, None, torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         ref = torch.cat([pa.detach(), pb.detach()])
         assert (p.cpu() - ref).abs().max().item() < 2e-6
