@@ -144,7 +144,9 @@ def main():
     ap.add_argument("--reduce-mode", type=int, default=0)
     ap.add_argument("--exact-formula", type=int, default=0)
     ap.add_argument("--conv-variant", type=int, default=0)
-    ap.add_argument("--no-graph", action="store_true", help="launch the train step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the train step as one hipGraph (FlatTrainer.enable_graph).  Measured on ROCm 7.2: 10.3 ms vs "
+                         "9.1-10.0 ms eager — the replay serialises the weight-gradient side stream — so eager is the default")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -213,12 +215,12 @@ def main():
         tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-7, weight_decay=2e-4, ignore_index=C)
         E.set_dropout_seed(1234 + rank)
         x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
-        if not a.no_graph:
+        if a.graph:
             tr.enable_graph(x, y)                    # whole step (fwd, CE, bwd, all-reduce, Adam) = one hipGraph replay
         el = timed(lambda: tr.train_step(x, y), a.steps, a.warmup)
         loss = float(tr.last_loss.item())
         train = {"img_per_s": world * TB * a.steps / el, "ms_per_step": el / a.steps * 1e3, "loss_after": loss,
-                 "launch": "eager" if a.no_graph else "hipGraph replay",
+                 "launch": "hipGraph replay" if a.graph else "eager, weight gradients on a second stream",
                  "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
 
         # dominant train kernel vs the fp32 MFMA roofline: SegmentHead conv 3x3 304->256 on [TB,64,128] (decoders.py:107)
