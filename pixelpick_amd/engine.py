@@ -48,6 +48,7 @@ class Tape:
     overlap_wgrad = True
 
     def __init__(self, enabled: bool = True):
+        refresh_stream()
         self.enabled = enabled
         self.nodes: List = []          # (backward_fn, ctx_tuple, output Var)
         self.param_grads = {}          # id(param tensor) -> grad tensor
@@ -89,9 +90,10 @@ class Tape:
                 if not capturing:
                     t.record_stream(side)
         self._side = side
-        return torch.cuda.stream(side)
+        return _SideStreamCtx(side)
 
     def backward(self, out: Var, dout: torch.Tensor):
+        refresh_stream()               # autograd may call this from its own thread / stream
         out.grad = dout
         for fn, ctx, o in reversed(self.nodes):
             if o.grad is None:
@@ -106,8 +108,34 @@ class Tape:
 
 
 # ------------------------------------------------------------------------------------------------- helpers
+# torch.cuda.current_stream() costs ~7 us per call and a train step issues ~550 launches: the raw stream handle is
+# cached (refreshed whenever a Tape is created / replayed and swapped by the side-stream context).
+_stream_cache = [None]
+
+
+def refresh_stream():
+    _stream_cache[0] = _lib.current_stream_ptr()
+
+
 def _stream():
-    return _lib.current_stream_ptr()
+    if _stream_cache[0] is None:
+        refresh_stream()
+    return _stream_cache[0]
+
+
+class _SideStreamCtx:
+    def __init__(self, side):
+        self.side = side
+        self.ctx = torch.cuda.stream(side)
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        self.prev = _stream_cache[0]
+        _stream_cache[0] = self.side.cuda_stream
+
+    def __exit__(self, *exc):
+        _stream_cache[0] = self.prev
+        return self.ctx.__exit__(*exc)
 
 
 def _geom(t: torch.Tensor):

@@ -98,6 +98,7 @@ class FlatTrainer:
                                  self.lr * self.lr_factor, self.betas[0], self.betas[1], self.eps, self.wd,
                                  max(self.step_count, 1), 1.0 / self.world,
                                  self._hyper_dev.data_ptr() if use_device_hyper else None, _lib.current_stream_ptr())
+        E.refresh_stream()
         _lib.check(rc, "pp_adam_step_flat")
 
     def _step_body(self, x, y, keep_logits, device_hyper):
