@@ -275,8 +275,15 @@ def main():
         acqr = {"value": round(world * B * H * W * a.steps / el / 1e6, 1), "unit": "Mpixels/s",
                 "ms_per_step": round(el / a.steps * 1e3, 4), "images_per_launch_per_gpu": B, "k": k,
                 "strategy": a.strategy, "layout": a.layout}
+        # HBM traffic per launch from the PMC passes of this very configuration (profiles/r01_acq_pmc.txt: rocprofv3
+        # --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
+        # gfx950).  A counter pass cannot run inside this process, so the figure is quoted only for the profiled config.
+        traffic = None
+        if (B, C, H, W, k, a.strategy, a.layout) == (256, 19, 256, 512, 20, "entropy", "nchw"):
+            traffic = 2 * 1261741.69 * 1024 + 10841.89 * 1024
         line["roofline"] = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                            "traffic_source": "profiles/r01_acq_pmc.txt (rocprofv3 PMC, round 1)" if traffic else None,
                             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
                             "kernel_ms_min": round(min(kms), 4)}
 
