@@ -198,7 +198,7 @@ def test_errors():
     with pytest.raises(ValueError):
         acq.score_topk(t, None, "entropy", 0)
     with pytest.raises(ValueError):
-        acq.score_topk(t, None, "entropy", 65)
+        acq.score_topk(t, None, "entropy", 65)   # k > H*W
     with pytest.raises(_lib.PixelPickHipError):
         acq.score_topk(torch.zeros(1, 65, 8, 8, device=DEV), None, "entropy", 2)
     # k == H*W is legal
