@@ -50,6 +50,9 @@ class QuerySelector:
         self.uncertainty_sampler = UncertaintySampler(args.query_strategy)
         self.use_mc_dropout = args.use_mc_dropout
         self.vote_type = args.vote_type
+        # not in the reference: images of equal size are forwarded `query_batch_size` at a time (the reference's
+        # query loader has batch_size 1, model.py:36-37; in eval mode the per-image results do not depend on the batch)
+        self.query_batch_size = int(getattr(args, "query_batch_size", 1))
 
     # ------------------------------------------------------------------ selection (query.py:33-69)
     @property
@@ -150,6 +153,45 @@ class QuerySelector:
         dict_queries: dict = dict()
         y = None
 
+        pending = []      # (x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w))
+
+        def flush():
+            nonlocal n_pixels
+            if not pending:
+                return
+            xs = torch.cat([it[0] for it in pending], dim=0)
+            logits_b = None
+            if not self.use_mc_dropout:
+                logits_b = model(xs)["pred"]
+            for j, (x1, yj, exclude, p_img, (h, w)) in enumerate(pending):
+                if self.use_mc_dropout:
+                    # mean uncertainty / mean probability over mc_n_steps stochastic passes
+                    uc_map = torch.zeros((h, w), device=self.device)
+                    prob = torch.zeros((1, self.n_classes, h, w), device=self.device)
+                    for _ in range(self.mc_n_steps):
+                        logits = self._forward_logits(model, x1, h, w)
+                        uc_map += acq.score_map(logits, None, self.query_strategy)[0]
+                        prob += F.softmax(logits, dim=1)
+                    uc_map /= self.mc_n_steps
+                    prob /= self.mc_n_steps
+                    uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0
+                    query = self._select_queries(uc_map)
+                    logits_for_stats = None
+                else:
+                    logits = logits_b[j:j + 1, :, :h, :w]
+                    prob = None
+                    logits_for_stats = logits
+                    query = self._select_from_logits(logits, exclude)
+                list_queries.append(query)
+                n_pixels += query.sum()
+                if not human_labels and yj is not None:
+                    if logits_for_stats is not None:
+                        self.query_stats.update_from_logits(query, yj, logits_for_stats)
+                    else:
+                        self.query_stats.update(query, yj, prob)
+                dict_queries.update(self.encode_query(p_img, size=(h, w), query=query))
+            pending.clear()
+
         with torch.no_grad():
             for batch_ind, dict_data in enumerate(self.dataloader):
                 x = dict_data['x'].to(self.device)
@@ -167,37 +209,15 @@ class QuerySelector:
                     pad_w = ceil(w / self.stride_total) * self.stride_total - w
                     x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
 
-                if self.use_mc_dropout:
-                    # mean uncertainty / mean probability over mc_n_steps stochastic passes
-                    uc_map = torch.zeros((h, w), device=self.device)
-                    logits_for_stats = None
-                    prob = torch.zeros((x.shape[0], self.n_classes, h, w), device=self.device)
-                    for _ in range(self.mc_n_steps):
-                        logits = self._forward_logits(model, x, h, w)
-                        uc_map += acq.score_map(logits, None, self.query_strategy)[0]
-                        prob += F.softmax(logits, dim=1)
-                    uc_map /= self.mc_n_steps
-                    prob /= self.mc_n_steps
-                    uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0
-                    query = self._select_queries(uc_map)
-                else:
-                    logits = self._forward_logits(model, x, h, w)
-                    prob = None
-                    logits_for_stats = logits
-                    query = self._select_from_logits(logits, exclude)
-
-                list_queries.append(query)
-                n_pixels += query.sum()
-
-                if not human_labels and y is not None:
-                    if logits_for_stats is not None:
-                        self.query_stats.update_from_logits(query, y, logits_for_stats)
-                    else:
-                        self.query_stats.update(query, y, prob)
-                dict_queries.update(self.encode_query(dict_data["p_img"][0], size=(h, w), query=query))
+                if pending and (pending[0][0].shape != x.shape or len(pending) >= self.query_batch_size):
+                    flush()
+                pending.append((x, y, exclude, dict_data["p_img"][0], (h, w)))
+                if len(pending) >= self.query_batch_size:
+                    flush()
 
                 if self.debug:
                     break
+            flush()
 
         assert len(list_queries) > 0, f"no queries are chosen!"
         if not human_labels and y is not None:

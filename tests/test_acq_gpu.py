@@ -307,3 +307,22 @@ def test_full_size_properties(st, shape):
     sub = logits[0, :, :8, :64].contiguous().cpu().numpy()[None]
     np.testing.assert_allclose(acq.score_map(logits[:1, :, :8, :64], None, st).cpu().numpy(), orc.score_map(sub, st),
                                rtol=RTOL, atol=ATOL)
+
+
+def test_query_selector_batched_forward_gives_identical_queries(golden_dir):
+    """query_batch_size > 1 (several equal-sized images per forward) must not change a single coordinate."""
+    g4 = np.load(os.path.join(golden_dir, "acq_end_to_end.npz"))
+    st = "entropy"
+    names = [str(n) for n in g4["names"]]
+    model = _OneConv(torch.from_numpy(g4[f"{st}_W"]).to(DEV), torch.from_numpy(g4[f"{st}_b"]).to(DEV))
+    outs = []
+    for bs in (1, 2, 3):
+        ds = _DS(torch.from_numpy(g4[f"{st}_xs"]), torch.from_numpy(g4[f"{st}_ys"]), list(g4[f"{st}_prev"]), names)
+        with tempfile.TemporaryDirectory() as td:
+            qs = ppq.QuerySelector(_args(query_strategy=st, dir_root=td, query_batch_size=bs), _DL(ds), device=torch.device(DEV))
+            outs.append(qs(nth_query=1, model=model))
+    for n in names:
+        for o in outs[1:]:
+            np.testing.assert_array_equal(o[n]["x_coords"], outs[0][n]["x_coords"])
+            np.testing.assert_array_equal(o[n]["y_coords"], outs[0][n]["y_coords"])
+        np.testing.assert_array_equal(outs[0][n]["x_coords"], g4[f"{st}_x_{names.index(n)}"])
