@@ -326,3 +326,102 @@ def test_query_selector_batched_forward_gives_identical_queries(golden_dir):
             np.testing.assert_array_equal(o[n]["x_coords"], outs[0][n]["x_coords"])
             np.testing.assert_array_equal(o[n]["y_coords"], outs[0][n]["y_coords"])
         np.testing.assert_array_equal(outs[0][n]["x_coords"], g4[f"{st}_x_{names.index(n)}"])
+
+
+# ---------------------------------------------------------------- the other __call__ branches, pinned on the reference
+class _Conv3(torch.nn.Module):
+    def __init__(self, w, b):
+        super().__init__()
+        self.w, self.b = w, b
+
+    def forward(self, x):
+        return {"pred": torch.nn.functional.conv2d(x, self.w, self.b, padding=1)}
+
+
+class _DLNoY(_DL):
+    def __iter__(self):
+        for i in range(len(self.dataset.xs)):
+            yield {"x": self.dataset.xs[i][None], "p_img": [self.dataset.names[i]]}
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_query_selector_voc_reflect_pad_branch(golden_dir, bs):
+    """query.py:171-174,190: voc images are reflect-padded to a multiple of stride_total, logits cropped back."""
+    gb = np.load(os.path.join(golden_dir, "acq_branches.npz"))
+    names = [f"/voc/img_{i}.jpg" for i in range(2)]
+    ds = _DS(torch.from_numpy(gb["voc_xs"]), torch.from_numpy(gb["voc_ys"]), list(gb["voc_prev"]), names)
+    model = _Conv3(torch.from_numpy(gb["voc_W"]).to(DEV), torch.from_numpy(gb["voc_b"]).to(DEV))
+    with tempfile.TemporaryDirectory() as td:
+        a = _args(query_strategy="margin_sampling", dir_root=td, dataset_name="voc", n_classes=21, ignore_index=255,
+                  n_pixels_by_us=10, query_batch_size=bs)
+        dq = ppq.QuerySelector(a, _DL(ds), device=torch.device(DEV))(nth_query=1, model=model)
+    for i, n in enumerate(names):
+        assert dq[n]["height"] == 37 and dq[n]["width"] == 53
+        np.testing.assert_array_equal(dq[n]["x_coords"], gb[f"voc_x_{i}"])
+        np.testing.assert_array_equal(dq[n]["y_coords"], gb[f"voc_y_{i}"])
+
+
+def test_query_selector_human_labels_branch(golden_dir):
+    """query.py:145-146,196-197,215: previous labels are int64 maps (labelled where != ignore_index); no 'y', no
+    stats, and dataset.label_queries is NOT called."""
+    gb = np.load(os.path.join(golden_dir, "acq_branches.npz"))
+    names = [f"/cv/img_{i}.png" for i in range(2)]
+    ds = _DS(torch.from_numpy(gb["hl_xs"]), None, None, names)
+    ds.list_labelled_queries = list(gb["hl_labelled"])
+    model = _OneConv(torch.from_numpy(gb["hl_W"]).to(DEV), torch.from_numpy(gb["hl_b"]).to(DEV))
+    with tempfile.TemporaryDirectory() as td:
+        a = _args(query_strategy="least_confidence", dir_root=td, dataset_name="cv", n_classes=11, ignore_index=11,
+                  n_pixels_by_us=12)
+        dq = ppq.QuerySelector(a, _DLNoY(ds), device=torch.device(DEV))(nth_query=2, model=model, human_labels=True)
+        assert not os.path.exists(f"{td}/checkpoints/golden/2_query/query_stats.pkl")
+    for i, n in enumerate(names):
+        np.testing.assert_array_equal(dq[n]["x_coords"], gb[f"hl_x_{i}"])
+        np.testing.assert_array_equal(dq[n]["y_coords"], gb[f"hl_y_{i}"])
+        picked = np.zeros((24, 40), bool)
+        picked[dq[n]["y_coords"], dq[n]["x_coords"]] = True
+        assert not (picked & (gb["hl_labelled"][i] != 11)).any()
+    assert ds.labelled is None
+
+
+class _DropModel(torch.nn.Module):
+    """1x1 classifier with an element dropout in front; turn_on_dropout as networks/deeplab.py:41-46."""
+    def __init__(self, w, b):
+        super().__init__()
+        self.w, self.b, self.drop = w, b, torch.nn.Dropout(0.3)
+
+    def turn_on_dropout(self):
+        self.drop.train()
+
+    def forward(self, x):
+        return {"pred": torch.nn.functional.conv2d(self.drop(x), self.w, self.b)}
+
+
+def test_query_selector_mc_dropout_mean_of_maps():
+    """MC-dropout branch (query.py:176-188 as intended — upstream's version crashes): the selector must
+    pick top-k of the MEAN uncertainty map over mc_n_steps stochastic passes.  Re-derive it with the same torch RNG."""
+    torch.manual_seed(5)
+    C, h, w, steps, k = 7, 24, 40, 4, 9
+    W, b = (torch.randn(C, 3, 1, 1) * 2).to(DEV), (torch.randn(C) * .5).to(DEV)
+    xs, ys = torch.randn(2, 3, h, w), torch.randint(0, C, (2, h, w))
+    prev = [np.zeros((h, w), bool) for _ in range(2)]
+    prev[0][3, 4] = True
+    names = ["/a.png", "/b.png"]
+    model = _DropModel(W, b)
+    with tempfile.TemporaryDirectory() as td:
+        a = _args(query_strategy="entropy", dir_root=td, n_classes=C, ignore_index=C, n_pixels_by_us=k,
+                  use_mc_dropout=True, mc_n_steps=steps)
+        torch.manual_seed(11); torch.cuda.manual_seed(11)
+        dq = ppq.QuerySelector(a, _DL(_DS(xs, ys, prev, names)), device=torch.device(DEV))(nth_query=1, model=model)
+    torch.manual_seed(11); torch.cuda.manual_seed(11)
+    model.eval(); model.turn_on_dropout()
+    for i, n in enumerate(names):
+        uc = torch.zeros(h, w, device=DEV)
+        with torch.no_grad():
+            for _ in range(steps):
+                lg = model(xs[i:i + 1].to(DEV))["pred"]
+                uc += acq.score_map(lg, None, "entropy")[0]
+        uc /= steps
+        uc[torch.from_numpy(prev[i]).to(DEV)] = 0.0
+        want = uc.flatten().topk(k).indices.cpu().numpy()
+        got = dq[n]["y_coords"].astype(np.int64) * w + dq[n]["x_coords"]
+        assert set(got.tolist()) == set(want.tolist())

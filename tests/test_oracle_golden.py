@@ -92,3 +92,33 @@ def test_tiebreak_and_signed_zero():
     assert idx.tolist() == [6, 1, 2, 5, 0, 3, 4]
     idx, _ = orc.topk(s, 7, False)
     assert idx.tolist() == [3, 4, 0, 1, 2, 5, 6]
+
+
+def test_oracle_reproduces_voc_pad_and_human_label_branches(golden_dir):
+    """query.py:171-174,190 and :145-146,196-197 — the oracle (score + exclude + top-k) on logits made the way the
+    reference makes them (reflect pad -> net -> crop) lands on the reference QuerySelector's own coordinates."""
+    import torch
+    import torch.nn.functional as F
+    gb = np.load(os.path.join(golden_dir, "acq_branches.npz"))
+    W, b = torch.from_numpy(gb["voc_W"]), torch.from_numpy(gb["voc_b"])
+    for i in range(2):
+        x = torch.from_numpy(gb["voc_xs"][i:i + 1])
+        xp = F.pad(x, (0, 56 - 53, 0, 40 - 37), mode="reflect")
+        logits = F.conv2d(xp, W, b, padding=1)[:, :, :37, :53].contiguous().numpy()
+        excl = (gb["voc_prev"][i] | (gb["voc_ys"][i] == 255)).astype(np.uint8)[None]
+        idx, _ = orc.score_topk(logits, excl, "margin_sampling", 10)
+        q = np.zeros(37 * 53, bool)
+        q[idx[0]] = True
+        ys, xs = np.where(q.reshape(37, 53))
+        np.testing.assert_array_equal(xs, gb[f"voc_x_{i}"])
+        np.testing.assert_array_equal(ys, gb[f"voc_y_{i}"])
+    W, b = torch.from_numpy(gb["hl_W"]), torch.from_numpy(gb["hl_b"])
+    for i in range(2):
+        logits = F.conv2d(torch.from_numpy(gb["hl_xs"][i:i + 1]), W, b).numpy()
+        excl = (gb["hl_labelled"][i] != 11).astype(np.uint8)[None]
+        idx, _ = orc.score_topk(logits, excl, "least_confidence", 12)
+        q = np.zeros(24 * 40, bool)
+        q[idx[0]] = True
+        ys, xs = np.where(q.reshape(24, 40))
+        np.testing.assert_array_equal(xs, gb[f"hl_x_{i}"])
+        np.testing.assert_array_equal(ys, gb[f"hl_y_{i}"])

@@ -329,7 +329,109 @@ def gen_codec():
     print("G5 written")
 
 
+class Conv3(torch.nn.Module):
+    def __init__(self, w, b):
+        super().__init__()
+        self.w, self.b = w, b
+
+    def forward(self, x):
+        return {"pred": F.conv2d(x, self.w, self.b, padding=1)}
+
+
+class FakeLoaderNoY(FakeLoader):
+    def __iter__(self):
+        for i in range(len(self.dataset.xs)):
+            yield {"x": self.dataset.xs[i][None], "p_img": [self.dataset.names[i]]}
+
+
+def gen_branches():
+    """query.py:171-174,190 (voc: reflect-pad to a multiple of stride_total, crop the logits) and
+    query.py:145-146,196-197 (human_labels: previous labels are int64 maps, excluded where != ignore_index, no 'y')."""
+    out = {}
+    C, h, w, n_img = 21, 37, 53, 2
+    seed = 77
+    while True:
+        torch.manual_seed(seed)
+        rng = np.random.RandomState(seed)
+        W3 = torch.randn(C, 3, 3, 3) * 0.8
+        b3 = torch.randn(C) * 0.3
+        xs = [torch.randn(3, h, w) * 1.5 for _ in range(n_img)]
+        ys = [torch.from_numpy(rng.randint(0, C, size=(h, w)).astype(np.int64)) for _ in range(n_img)]
+        for y in ys:
+            y[torch.from_numpy(rng.rand(h, w) < 0.05)] = 255
+        prev = []
+        for _ in range(n_img):
+            q = np.zeros((h, w), dtype=bool)
+            q.reshape(-1)[rng.choice(h * w, 25, replace=False)] = True
+            prev.append(q)
+        names = [f"/voc/img_{i}.jpg" for i in range(n_img)]
+        model = Conv3(W3, b3)
+        ok = True
+        with torch.no_grad():
+            for i in range(n_img):
+                xp = F.pad(xs[i][None], (0, 56 - w, 0, 40 - h), mode="reflect")
+                prob = F.softmax(model(xp)["pred"][:, :, :h, :w], dim=1)
+                uc = refq.UncertaintySampler("margin_sampling")(prob)[0]
+                uc[torch.from_numpy(prev[i])] = 1.0
+                uc[ys[i] == 255] = 1.0
+                if not all_gaps_ok(torch.sort(uc.flatten()).values.numpy()[:11]):
+                    ok = False
+        if ok:
+            break
+        seed += 1
+    ds = FakeDataset(xs, ys, prev, names)
+    with tempfile.TemporaryDirectory() as td:
+        args = mk_args("margin_sampling", C, k=10, dataset_name="voc", ignore_index=255, dir_root=td)
+        dq = refq.QuerySelector(args, FakeLoader(ds), device=torch.device("cpu"))(nth_query=1, model=model)
+    out["voc_W"], out["voc_b"] = W3.numpy(), b3.numpy()
+    out["voc_xs"], out["voc_ys"], out["voc_prev"] = torch.stack(xs).numpy(), torch.stack(ys).numpy(), np.stack(prev)
+    for i, nme in enumerate(names):
+        out[f"voc_x_{i}"], out[f"voc_y_{i}"] = np.asarray(dq[nme]["x_coords"]), np.asarray(dq[nme]["y_coords"])
+    # human labels
+    C, h, w = 11, 24, 40
+    seed = 91
+    while True:
+        torch.manual_seed(seed)
+        rng = np.random.RandomState(seed)
+        W1 = torch.randn(C, 3, 1, 1) * 2.0
+        b1 = torch.randn(C) * 0.5
+        xs = [torch.randn(3, h, w) * 1.5 for _ in range(n_img)]
+        labelled = []
+        for _ in range(n_img):
+            m = np.full((h, w), 11, dtype=np.int64)
+            idx = rng.choice(h * w, 30, replace=False)
+            m.reshape(-1)[idx] = rng.randint(0, C, size=30)
+            labelled.append(m)
+        ok = True
+        with torch.no_grad():
+            for i in range(n_img):
+                prob = F.softmax(OneConv(W1, b1)(xs[i][None])["pred"], dim=1)
+                uc = refq.UncertaintySampler("least_confidence")(prob)[0]
+                uc[torch.from_numpy(labelled[i] != 11)] = 0.0
+                if not all_gaps_ok(torch.sort(uc.flatten(), descending=True).values.numpy()[:13]):
+                    ok = False
+        if ok:
+            break
+        seed += 1
+    names = [f"/cv/img_{i}.png" for i in range(n_img)]
+    ds = FakeDataset(xs, [None] * n_img, None, names)
+    ds.list_labelled_queries = labelled
+    with tempfile.TemporaryDirectory() as td:
+        args = mk_args("least_confidence", C, k=12, dataset_name="cv", ignore_index=11, dir_root=td)
+        dq = refq.QuerySelector(args, FakeLoaderNoY(ds), device=torch.device("cpu"))(nth_query=2, model=OneConv(W1, b1), human_labels=True)
+    out["hl_W"], out["hl_b"] = W1.numpy(), b1.numpy()
+    out["hl_xs"], out["hl_labelled"] = torch.stack(xs).numpy(), np.stack(labelled)
+    for i, nme in enumerate(names):
+        out[f"hl_x_{i}"], out[f"hl_y_{i}"] = np.asarray(dq[nme]["x_coords"]), np.asarray(dq[nme]["y_coords"])
+    assert ds.labelled is None        # human_labels: label_queries is NOT called (query.py:215)
+    np.savez_compressed(os.path.join(OUT, "acq_branches.npz"), **out)
+    print("branches written")
+
+
 if __name__ == "__main__":
+    if "--branches" in sys.argv:
+        gen_branches()
+        sys.exit(0)
     gen_scores_and_topk()
     gen_select_modes()
     gen_edges()
