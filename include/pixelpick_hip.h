@@ -126,6 +126,23 @@ int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* 
                     float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                     float* shift, void* workspace, size_t ws_bytes, pp_stream_t stream);
 
+/* The same BatchNorm2d training forward INCLUDING the apply (+ residual, + activation) in ONE launch
+ * (column strips x row chunks, a per-strip arrival counter instead of two more launches; see nn_ops.hip).
+ * `sync` is an int32 array of pp_bn_fused_sync_ints(C) zeros: every launch leaves it zeroed again, and it
+ * must not be shared by launches that can run concurrently.  Results are deterministic. */
+size_t pp_bn_fused_workspace_bytes(int64_t M, int C);
+size_t pp_bn_fused_sync_ints(int C);
+int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                          const float* residual, int64_t ldr, int act, float* y, int64_t ldy, void* workspace,
+                          size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
+
+/* Single-launch form of pp_bn_bwd (same arguments + sync). */
+int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+                    int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, void* workspace, size_t ws_bytes,
+                    int32_t* sync, size_t sync_ints, pp_stream_t stream);
+
 /* nn.BatchNorm2d, eval mode: scale/shift from the running statistics. */
 int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, pp_stream_t stream);

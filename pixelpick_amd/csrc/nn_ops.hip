@@ -257,6 +257,332 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* x, int64_
 }
 
 // ================================================================================================
+// Single-launch BatchNorm (training) forward and backward.
+//
+// The three-launch form above (column partials -> finalize -> apply) costs ~17 us forward / ~23 us backward per
+// layer on the 1/16-resolution maps where each launch is latency-bound, and DeepLabv3+-MNv2 has 60 BN layers.
+// Here one launch does all three: the grid is (channel strip) x (row chunk); a block reduces its chunk of its
+// strip, publishes the partial, waits on a per-strip arrival counter (agent-scope release/acquire: the XCD L2s
+// are not coherent with each other), then EVERY block of the strip combines the strip's partials in the same
+// fixed order in fp64 (bit-identical in all of them, deterministic) and applies the normalisation to its own
+// rows, which it re-reads from L2.  All blocks of a launch are co-resident (<= 1024 blocks of 256 threads on
+// 256 CUs), so the wait cannot deadlock; R == 1 skips it.  The last block through a strip's counters zeroes them,
+// so the caller's `sync` array stays zero between launches (it must not be shared by launches that can overlap).
+// ================================================================================================
+struct BnFusedGeom {
+    int cq;        // C/4
+    int bq;        // float4 columns per strip (4..8)
+    int nrl;       // row lanes = 256 / bq
+    int nstrips;   // cdiv(cq, bq)
+    int R;         // row chunks per strip
+    int64_t rows_per_chunk;
+};
+
+static BnFusedGeom bn_fused_geom(int64_t M, int C)
+{
+    BnFusedGeom g;
+    g.cq = C / 4;
+    g.bq = g.cq < 8 ? g.cq : 8;
+    if (g.cq > 8 && g.cq % 8 != 0) {
+        for (int b = 7; b >= 4; --b)
+            if (g.cq % b == 0) { g.bq = b; break; }
+    }
+    g.nrl = kT / g.bq;
+    g.nstrips = (int)cdiv(g.cq, g.bq);
+    int64_t R = 512 / g.nstrips;
+    if (R > 256) R = 256;
+    if (R < 1 || (int64_t)g.nstrips * R > 1024) R = 1;
+    int64_t rpc = cdiv(cdiv(M, R), g.nrl) * g.nrl;
+    g.rows_per_chunk = rpc;
+    g.R = (int)cdiv(M, rpc);
+    return g;
+}
+
+// tree-sum the per-thread (s0,s1) over the row lanes of each column; result valid in row lane 0
+__device__ __forceinline__ void rowlane_tree(float4& s0, float4& s1, float4 (*sh)[kT], int rl, int nrl, int bq)
+{
+    const int t = threadIdx.x;
+    sh[0][t] = s0;
+    sh[1][t] = s1;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (rl < off && rl + off < nrl) {
+            const float4 a = sh[0][t + off * bq], b = sh[1][t + off * bq];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            sh[0][t] = s0;
+            sh[1][t] = s1;
+        }
+        __syncthreads();
+    }
+}
+
+// Partials cross XCDs (non-coherent L2s).  They are written and read with agent-scope atomic accesses (sc1: served
+// at the device coherence point), so the arrival counter needs no L2 write-back (a release fence costs a full
+// `buffer_wbl2` per block, measured ~0.09 us x blocks serialised) — only the block's own stores must have completed.
+__device__ __forceinline__ void st_agent(float* p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p)
+{
+    return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void publish_partial(float* p, int nch, const float4& s0, const float4& s1)
+{
+    st_agent(p + 0, s0.x); st_agent(p + 1, s0.y); st_agent(p + 2, s0.z); st_agent(p + 3, s0.w);
+    st_agent(p + nch + 0, s1.x); st_agent(p + nch + 1, s1.y); st_agent(p + nch + 2, s1.z); st_agent(p + nch + 3, s1.w);
+}
+
+constexpr int kSyncStride = 32;   // one 128-byte line per strip: arrivals of different strips do not contend
+
+// publish this block's partial and wait until all R blocks of the strip have published theirs
+__device__ __forceinline__ void strip_barrier(int* sync, int strip, int R)
+{
+    if (R > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial stores have completed
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(sync + kSyncStride * strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(sync + kSyncStride * strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < R)
+                __builtin_amdgcn_s_sleep(8);
+            const int gone = __hip_atomic_fetch_add(sync + kSyncStride * strip + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone == R - 1) {   // every sibling has left the wait: rearm for the next launch
+                __hip_atomic_store(sync + kSyncStride * strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync + kSyncStride * strip + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fixed-order fp64 sum over the strip's R partial rows; tot[o] for o < nout = 8*bq (stat-major: [2][bq*4])
+__device__ __forceinline__ void strip_combine(const float* part, int strip, int R, int nout, double* shd /*[256]*/,
+                                              double* tot /*[64]*/)
+{
+    const int t = threadIdx.x;
+    const int nsub = kT / nout;
+    const int o = t % nout, sub = t / nout;
+    double s = 0.0;
+    if (sub < nsub) {
+        const float* p = part + (int64_t)strip * R * nout + o;
+        int c = sub;
+        for (; c + 3 * nsub < R; c += 4 * nsub) {
+            const float v0 = ld_agent(p + (int64_t)c * nout), v1 = ld_agent(p + (int64_t)(c + nsub) * nout);
+            const float v2 = ld_agent(p + (int64_t)(c + 2 * nsub) * nout), v3 = ld_agent(p + (int64_t)(c + 3 * nsub) * nout);
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; c < R; c += nsub) s += (double)ld_agent(p + (int64_t)c * nout);
+    }
+    shd[t] = s;
+    __syncthreads();
+    if (t < nout) {
+        double a = shd[t];
+        for (int k = 1; k < nsub; ++k) a += shd[k * nout + t];
+        tot[t] = a;
+    }
+    __syncthreads();
+}
+
+struct BnFwdArgs {
+    const float* x; int64_t ldx; int64_t M; int C;
+    const float* gamma; const float* beta; float eps; float momentum;
+    float* running_mean; float* running_var; float* mean; float* invstd;
+    const float* res; int64_t ldr; int act; float* y; int64_t ldy;
+    float* part; int* sync; BnFusedGeom g;
+};
+
+__global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
+{
+    __shared__ float4 sh[2][kT];
+    __shared__ double shd[kT];
+    __shared__ double tot[64];
+    __shared__ float aff[2][32];
+    const BnFusedGeom g = a.g;
+    const int t = threadIdx.x;
+    const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
+    const int ql = t % g.bq, rl = t / g.bq;
+    const int q = strip * g.bq + ql;
+    const bool active = rl < g.nrl && q < g.cq;
+    const int64_t r0 = (int64_t)chunk * g.rows_per_chunk;
+    const int64_t r1 = r0 + g.rows_per_chunk < a.M ? r0 + g.rows_per_chunk : a.M;
+    const float* xq = a.x + q * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (active) {
+        for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
+            float4 v[4];
+            float w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t rr = r + (int64_t)j * g.nrl;
+                w[j] = rr < r1 ? 1.0f : 0.0f;
+                v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 u = make_float4(v[j].x * w[j], v[j].y * w[j], v[j].z * w[j], v[j].w * w[j]);
+                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                s1.x = fmaf(u.x, u.x, s1.x); s1.y = fmaf(u.y, u.y, s1.y);
+                s1.z = fmaf(u.z, u.z, s1.z); s1.w = fmaf(u.w, u.w, s1.w);
+            }
+        }
+    }
+    rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
+    const int nch = g.bq * 4, nout = nch * 2;
+    if (rl == 0) {
+        publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1);
+    }
+    strip_barrier(a.sync, strip, g.R);
+    strip_combine(a.part, strip, g.R, nout, shd, tot);
+    if (t < nch) {
+        const int c = strip * nch + t;
+        if (c < a.C) {
+            const double count = (double)a.M;
+            const double mu = tot[t] / count;
+            double var = tot[nch + t] / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)a.eps));
+            const float sc = a.gamma[c] * is;
+            aff[0][t] = sc;
+            aff[1][t] = a.beta[c] - (float)mu * sc;
+            if (chunk == 0) {
+                a.mean[c] = (float)mu;
+                a.invstd[c] = is;
+                if (a.running_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mu;
+                    a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float4 sc = *reinterpret_cast<const float4*>(&aff[0][ql * 4]);
+    const float4 sf = *reinterpret_cast<const float4*>(&aff[1][ql * 4]);
+    float* yq = a.y + q * 4;
+    const float* rq = a.res ? a.res + q * 4 : nullptr;
+    const int act = a.act;
+    for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
+        const int64_t rb = r + g.nrl;
+        const bool two = rb < r1;
+        const float4 va = *reinterpret_cast<const float4*>(xq + r * a.ldx);
+        const float4 vb = *reinterpret_cast<const float4*>(xq + (two ? rb : r) * a.ldx);
+        float4 oa, ob;
+        oa.x = fmaf(va.x, sc.x, sf.x); oa.y = fmaf(va.y, sc.y, sf.y); oa.z = fmaf(va.z, sc.z, sf.z); oa.w = fmaf(va.w, sc.w, sf.w);
+        ob.x = fmaf(vb.x, sc.x, sf.x); ob.y = fmaf(vb.y, sc.y, sf.y); ob.z = fmaf(vb.z, sc.z, sf.z); ob.w = fmaf(vb.w, sc.w, sf.w);
+        if (rq) {
+            const float4 ra = *reinterpret_cast<const float4*>(rq + r * a.ldr);
+            const float4 rbv = *reinterpret_cast<const float4*>(rq + (two ? rb : r) * a.ldr);
+            oa.x += ra.x; oa.y += ra.y; oa.z += ra.z; oa.w += ra.w;
+            ob.x += rbv.x; ob.y += rbv.y; ob.z += rbv.z; ob.w += rbv.w;
+        }
+        oa.x = act_fwd(oa.x, act); oa.y = act_fwd(oa.y, act); oa.z = act_fwd(oa.z, act); oa.w = act_fwd(oa.w, act);
+        *reinterpret_cast<float4*>(yq + r * a.ldy) = oa;
+        if (two) {
+            ob.x = act_fwd(ob.x, act); ob.y = act_fwd(ob.y, act); ob.z = act_fwd(ob.z, act); ob.w = act_fwd(ob.w, act);
+            *reinterpret_cast<float4*>(yq + rb * a.ldy) = ob;
+        }
+    }
+}
+
+struct BnBwdArgs {
+    const float* x; int64_t ldx; const float* dy; int64_t lddy; const float* yact; int64_t ldya; int act;
+    int64_t M; int C; const float* mean; const float* invstd; const float* gamma; float* dgamma; float* dbeta;
+    float* dx; int64_t lddx; float* dres; int64_t lddr; float* part; int* sync; BnFusedGeom g;
+};
+
+__global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
+{
+    __shared__ float4 sh[2][kT];
+    __shared__ double shd[kT];
+    __shared__ double tot[64];
+    __shared__ float red[2][32];
+    const BnFusedGeom g = a.g;
+    const int t = threadIdx.x;
+    const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
+    const int ql = t % g.bq, rl = t / g.bq;
+    const int q = strip * g.bq + ql;
+    const bool active = rl < g.nrl && q < g.cq;
+    const int64_t r0 = (int64_t)chunk * g.rows_per_chunk;
+    const int64_t r1 = r0 + g.rows_per_chunk < a.M ? r0 + g.rows_per_chunk : a.M;
+    const float* xq = a.x + q * 4;
+    const float* gq = a.dy + q * 4;
+    const float* aq = a.yact ? a.yact + q * 4 : nullptr;
+    const int act = aq ? a.act : 0;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0, is = s0;
+    if (active) {
+        mu = *reinterpret_cast<const float4*>(a.mean + q * 4);
+        is = *reinterpret_cast<const float4*>(a.invstd + q * 4);
+        for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
+            float4 v[2], gg[2], ya[2];
+            float w[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t rr = r + (int64_t)j * g.nrl;
+                w[j] = rr < r1 ? 1.0f : 0.0f;
+                const int64_t rc = rr < r1 ? rr : r1 - 1;
+                v[j] = *reinterpret_cast<const float4*>(xq + rc * a.ldx);
+                gg[j] = *reinterpret_cast<const float4*>(gq + rc * a.lddy);
+                if (act != 0) ya[j] = *reinterpret_cast<const float4*>(aq + rc * a.ldya);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float4 u = gg[j];
+                if (act != 0) {
+                    u.x *= act_mask(ya[j].x, act); u.y *= act_mask(ya[j].y, act);
+                    u.z *= act_mask(ya[j].z, act); u.w *= act_mask(ya[j].w, act);
+                }
+                u.x *= w[j]; u.y *= w[j]; u.z *= w[j]; u.w *= w[j];
+                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                s1.x = fmaf(u.x, (v[j].x - mu.x) * is.x, s1.x); s1.y = fmaf(u.y, (v[j].y - mu.y) * is.y, s1.y);
+                s1.z = fmaf(u.z, (v[j].z - mu.z) * is.z, s1.z); s1.w = fmaf(u.w, (v[j].w - mu.w) * is.w, s1.w);
+            }
+        }
+    }
+    rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
+    const int nch = g.bq * 4, nout = nch * 2;
+    if (rl == 0) {
+        publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1);
+    }
+    strip_barrier(a.sync, strip, g.R);
+    strip_combine(a.part, strip, g.R, nout, shd, tot);
+    if (t < nch) {
+        const int c = strip * nch + t;
+        const float db = (float)tot[t], dg = (float)tot[nch + t];
+        red[0][t] = db;
+        red[1][t] = dg;
+        if (c < a.C && chunk == 0) {
+            a.dbeta[c] = db;
+            a.dgamma[c] = dg;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float inv_count = 1.0f / (float)a.M;
+    const float4 db = *reinterpret_cast<const float4*>(&red[0][ql * 4]);
+    const float4 dg = *reinterpret_cast<const float4*>(&red[1][ql * 4]);
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + q * 4);
+    float* dxq = a.dx + q * 4;
+    float* drq = a.dres ? a.dres + q * 4 : nullptr;
+    for (int64_t r = r0 + rl; r < r1; r += g.nrl) {
+        float4 u = *reinterpret_cast<const float4*>(gq + r * a.lddy);
+        const float4 v = *reinterpret_cast<const float4*>(xq + r * a.ldx);
+        if (act != 0) {
+            const float4 ya = *reinterpret_cast<const float4*>(aq + r * a.ldya);
+            u.x *= act_mask(ya.x, act); u.y *= act_mask(ya.y, act); u.z *= act_mask(ya.z, act); u.w *= act_mask(ya.w, act);
+        }
+        if (drq) *reinterpret_cast<float4*>(drq + r * a.lddr) = u;
+        float4 o;
+        o.x = ga.x * is.x * (u.x - db.x * inv_count - (v.x - mu.x) * is.x * dg.x * inv_count);
+        o.y = ga.y * is.y * (u.y - db.y * inv_count - (v.y - mu.y) * is.y * dg.y * inv_count);
+        o.z = ga.z * is.z * (u.z - db.z * inv_count - (v.z - mu.z) * is.z * dg.z * inv_count);
+        o.w = ga.w * is.w * (u.w - db.w * inv_count - (v.w - mu.w) * is.w * dg.w * inv_count);
+        *reinterpret_cast<float4*>(dxq + r * a.lddx) = o;
+    }
+}
+
+// ================================================================================================
 // depthwise 3x3 (weights [3][3][C]); generic stride / dilation / padding.
 // ================================================================================================
 __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
@@ -872,6 +1198,60 @@ int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(kT), 0, st, part, g.nblk_rows, C, (double)M,
                        gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     return check_launch("bn_finalize_kernel");
+}
+
+size_t pp_bn_fused_workspace_bytes(int64_t M, int C)
+{
+    if (M < 1 || C < 4) return 256;
+    BnFusedGeom g = bn_fused_geom(M, C);
+    return align_up((size_t)g.nstrips * g.R * g.bq * 8 * 4, 256);
+}
+
+size_t pp_bn_fused_sync_ints(int C) { return C < 4 ? kSyncStride : (size_t)kSyncStride * cdiv(C / 4, 4); }
+
+static int bn_fused_check(const char* what, int64_t M, int C, const BnFusedGeom& g, const void* workspace, size_t ws_bytes,
+                          const int32_t* sync, size_t sync_ints)
+{
+    if (M < 1) return fail(PP_ERR_BAD_ARG, "%s: M < 1", what);
+    if (!workspace || ws_bytes < (size_t)g.nstrips * g.R * g.bq * 8 * 4) return fail(PP_ERR_WORKSPACE, "%s: workspace", what);
+    if (!sync || sync_ints < (size_t)kSyncStride * g.nstrips)
+        return fail(PP_ERR_WORKSPACE, "%s: sync array needs %d ints", what, kSyncStride * g.nstrips);
+    (void)C;
+    return PP_OK;
+}
+
+int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                          const float* residual, int64_t ldr, int act, float* y, int64_t ldy, void* workspace,
+                          size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
+{
+    if (!x || !gamma || !beta || !mean || !invstd || !y) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_fused: null");
+    if (int rc = need_c4(C, "bn_train_fwd_fused")) return rc;
+    if (ldx % 4 || ldy % 4 || (residual && ldr % 4)) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_fused: ld must be multiples of 4");
+    BnFusedGeom g = bn_fused_geom(M, C);
+    if (int rc = bn_fused_check("bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
+    BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
+                reinterpret_cast<float*>(workspace), sync, g};
+    hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    return check_launch("bn_fused_fwd_kernel");
+}
+
+int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+                    int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, void* workspace, size_t ws_bytes,
+                    int32_t* sync, size_t sync_ints, pp_stream_t stream)
+{
+    if (!x || !dy || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: null");
+    if (act != 0 && !y_act) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: activation output needed for the mask");
+    if (int rc = need_c4(C, "bn_bwd_fused")) return rc;
+    if (ldx % 4 || lddy % 4 || lddx % 4 || (y_act && ldya % 4) || (dres && lddr % 4))
+        return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: ld must be multiples of 4");
+    BnFusedGeom g = bn_fused_geom(M, C);
+    if (int rc = bn_fused_check("bn_bwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
+    BnBwdArgs a{x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr,
+                reinterpret_cast<float*>(workspace), sync, g};
+    hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    return check_launch("bn_fused_bwd_kernel");
 }
 
 int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,

@@ -10,6 +10,7 @@ Activations are NHWC `torch.Tensor`s [B,H,W,C]; channel slices of a wider buffer
 (pixel stride `ld` = stride(2)).  Weights are HWIO (dense) / [3,3,C] (depthwise).
 """
 import contextlib
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -159,6 +160,23 @@ def _geom(t: torch.Tensor):
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# Single-launch BatchNorm (pp_bn_train_fwd_fused / pp_bn_bwd_fused).  PIXELPICK_BN_FUSED=0 selects the
+# three-launch form (partials -> finalize -> apply) for A/B timing.
+_BN_FUSED = os.environ.get("PIXELPICK_BN_FUSED", "1") != "0"
+_BN_SYNC = {}
+
+
+def _bn_sync(device, C: int) -> torch.Tensor:
+    """Zeroed arrival counters for the fused BN launches on the main stream (each launch re-zeroes them)."""
+    key = (device.type, device.index)
+    t = _BN_SYNC.get(key)
+    need = int(_lib.lib().pp_bn_fused_sync_ints(C))
+    if t is None or t.numel() < need:
+        t = torch.zeros(max(16384, need), dtype=torch.int32, device=device)
+        _BN_SYNC[key] = t
+    return t
 
 
 def _acc(v: Var, g: torch.Tensor):
@@ -390,6 +408,27 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
     dev = x.t.device
+    if training and _BN_FUSED:
+        # one launch: statistics + running-stat update + affine + residual + activation
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        y = dst if dst is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+        _, _, _, _, ldy = _geom(y)
+        rptr, ldr = (None, 0)
+        if residual is not None:
+            _, _, _, _, ldr = _geom(residual.t)
+            rptr = residual.t.data_ptr()
+        ws = _ws(L.pp_bn_fused_workspace_bytes(M, C), dev)
+        sync = _bn_sync(dev, C)
+        rc = L.pp_bn_train_fwd_fused(x.t.data_ptr(), ldx, M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                     running_mean.data_ptr() if running_mean is not None else None,
+                                     running_var.data_ptr() if running_var is not None else None,
+                                     mean.data_ptr(), invstd.data_ptr(), rptr, ldr, act, y.data_ptr(), ldy,
+                                     ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
+        _lib.check(rc, "pp_bn_train_fwd_fused")
+        out = Var(y)
+        tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out), out)
+        return out
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     shift = torch.empty(C, dtype=torch.float32, device=dev)
     mean = invstd = None
@@ -434,11 +473,20 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     dbeta = tape.grad_buffer_for(beta)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
     dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
-    ws = _ws(L.pp_colreduce_workspace_bytes(M, C), dev)
-    rc = L.pp_bn_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(), invstd.data_ptr(),
-                     gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
-                     dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(), _stream())
-    _lib.check(rc, "pp_bn_bwd")
+    if _BN_FUSED:
+        ws = _ws(L.pp_bn_fused_workspace_bytes(M, C), dev)
+        sync = _bn_sync(dev, C)
+        rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(),
+                               invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
+                               dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(),
+                               sync.data_ptr(), sync.numel(), _stream())
+        _lib.check(rc, "pp_bn_bwd_fused")
+    else:
+        ws = _ws(L.pp_colreduce_workspace_bytes(M, C), dev)
+        rc = L.pp_bn_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(), invstd.data_ptr(),
+                         gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
+                         dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(), _stream())
+        _lib.check(rc, "pp_bn_bwd")
     if gamma.requires_grad:
         tape.set_param_grad(gamma, dgamma)
     if beta.requires_grad:

@@ -80,10 +80,9 @@ def _check_grads(g, grads_by_name, full=True):
         got = fi.summarize(grads_by_name[str(name)])
         ref, noise = g["grad_summary"][i], g["grad_noise"][i]
         for j, scale_j in ((1, 1), (2, 2), (0, 1)):       # abs-sum, max, sum (sum relative to abs-sum)
-            # `noise` comes from only two reference probes (perturbed fp32, fp64) and under-samples a heavy-tailed
-            # event (unit flips): over the 213 FPN tensors the observed deviation/band ratio has median 0.18 and a
-            # tail up to 1.6 at 4x.  Aggregates get 6x, the single-element max 10x; a wrong kernel is off by >>10x.
-            tol = TOL * max(ref[scale_j], 1e-12) + (10 if j == 2 else 6) * noise[j]
+            # `noise` = largest deviation over 7 reference probes (6 perturbed fp32 + fp64, tools/gen_golden_net.py).
+            # Unit flips are heavy-tailed, so the band is 4x that floor; a wrong kernel is off by orders of magnitude.
+            tol = TOL * max(ref[scale_j], 1e-12) + 4 * noise[j]
             assert abs(got[j] - ref[j]) <= tol, f"{name}[{j}]: {got[j]} vs {ref[j]} (tol {tol:.3e}, noise {noise[j]:.3e})"
         worst = max(worst, abs(got[1] - ref[1]) / max(ref[1], 1e-12))
     if full:

@@ -204,10 +204,21 @@ def test_dwconv_fwd_bwd(case):
     close(tape.param_grads[id(wg)].permute(2, 0, 1).cpu()[:, None], w.grad, what="dw dW")
 
 
+@pytest.fixture(params=[True, False], ids=["bn-1launch", "bn-3launch"])
+def bn_fused(request):
+    old = E._BN_FUSED
+    E._BN_FUSED = request.param
+    yield request.param
+    E._BN_FUSED = old
+
+
 @pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, False), (0, True), (1, True)])
 @pytest.mark.parametrize("shape", [(4, 18, 34, 96), (2, 7, 5, 16), (4, 16, 32, 960), (3, 1, 1, 256), (2, 6, 10, 2048),
-                                   (2, 23, 30, 256), (2, 13, 18, 960), (2, 17, 22, 960)])
-def test_batchnorm_train_fwd_bwd(shape, act, with_res):
+                                   (2, 23, 30, 256), (2, 13, 18, 960), (2, 17, 22, 960),
+                                   # strip widths 6/4/5/7/8-with-a-ragged-last-strip/1/2/3, and a many-chunk map
+                                   (2, 9, 11, 24), (2, 9, 11, 144), (2, 9, 11, 304), (2, 9, 11, 100), (2, 9, 11, 28),
+                                   (2, 9, 11, 44), (2, 33, 9, 4), (2, 9, 11, 8), (2, 9, 11, 12), (2, 128, 160, 32)])
+def test_batchnorm_train_fwd_bwd(shape, act, with_res, bn_fused):
     B, H, W, C = shape
     torch.manual_seed(2)
     x = (torch.randn(B, C, H, W) * 2 + 0.5).requires_grad_(True)
@@ -242,6 +253,45 @@ def test_batchnorm_train_fwd_bwd(shape, act, with_res):
     close(tape.param_grads[id(bta)].cpu(), bn.bias.grad, tol=2e-4, what="dbeta")
     if with_res:
         close(nchw(rv.grad), res.grad, what="dres")
+
+
+def test_batchnorm_single_launch_is_deterministic_and_rearms_its_counters():
+    """pp_bn_train_fwd_fused / pp_bn_bwd_fused: 50 back-to-back launches on one sync array are bit-identical
+    (fixed-order fp64 combine) and leave the arrival counters at zero."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(9)
+    for (M, C) in [(2048, 960), (8192, 192), (32768, 24), (100, 304)]:
+        x = torch.randn(M, C, device=DEV) * 2 + 1
+        dy = torch.randn(M, C, device=DEV)
+        gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+        ws = torch.empty(L.pp_bn_fused_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
+        sync = torch.zeros(L.pp_bn_fused_sync_ints(C), dtype=torch.int32, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for it in range(50):
+            mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+            y, dx = torch.empty_like(x), torch.empty_like(x)
+            dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+            _lib.check(L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                                               mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
+                                               ws.numel(), sync.data_ptr(), sync.numel(), st), "fwd")
+            _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
+                                         invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
+                                         None, 0, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
+            if it in (0, 49):
+                outs.append((y.clone(), dx.clone(), dg.clone(), db.clone(), mean.clone()))
+        torch.cuda.synchronize()
+        assert int(sync.abs().sum()) == 0
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        # too-small sync array / workspace are refused, not overrun
+        assert L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                                       mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
+                                       ws.numel(), sync.data_ptr(), 1, st) != 0
+        assert L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
+                                 invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
+                                 None, 0, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
 
 
 def test_batchnorm_eval():

@@ -48,6 +48,8 @@ def _fresh_model(n_classes):
     return model
 
 
+N_PROBES = 6
+
 FULL_GRADS_FPN = ["encoder.base.prefix.conv1.weight", "encoder.base.layer2.0.bn2.weight", "encoder.base.layer2.0.downsample.1.bias",
                   "encoder.base.layer4.2.bn3.bias", "decoder.lat_layer_3.bias", "decoder.upsample_blocks_0.0.block.1.weight",
                   "decoder.upsample_blocks_3.1.block.0.bias", "decoder.classifier.weight", "decoder.classifier.bias"]
@@ -77,24 +79,27 @@ def gen_deeplab(n_classes, ignore_index, B, H, W, tag, n_lab=20, train=True):
         # the reference's OWN fp32 conditioning: same step with the input perturbed by 1e-6 relative (a few ulp).
         # ReLU/ReLU6 mask flips and cancelling sums (gradients of a BN-input are zero-mean) make some tensors
         # move by far more than 1e-3 under such noise; the tests allow 1e-3 + 4x this noise floor per tensor.
-        xn = x * (1 + 1e-6 * fi.fill(tuple(x.shape), f"noise{tag}", -1, 1))
-        model_n, pred_n, loss_n = _train_once(n_classes, ignore_index, xn, y)
-        # second probe: the same reference code evaluated in float64.  Where a ReLU pre-activation sits within an
-        # fp32 ulp of 0 the fp32 and fp64 evaluations take different branches; both are "the reference".
-        model_d, pred_d, loss_d = _train_once(n_classes, ignore_index, x, y, torch.float64)
+        # N_PROBES perturbed fp32 probes (the first keeps the original key) + one float64 probe (where a ReLU
+        # pre-activation sits within an fp32 ulp of 0 the fp32 and fp64 evaluations take different branches; all of
+        # them are "the reference").  The floor is the largest deviation any probe shows: unit flips are heavy-tailed,
+        # two probes under-sampled them (an equally accurate BN kernel with a different summation order landed
+        # outside the two-probe band on one tensor).
+        probes = []
+        for pi in range(N_PROBES):
+            xn = x * (1 + 1e-6 * fi.fill(tuple(x.shape), f"noise{tag}" + ("" if pi == 0 else f"#{pi}"), -1, 1))
+            probes.append(_train_once(n_classes, ignore_index, xn, y))
+        probes.append(_train_once(n_classes, ignore_index, x, y, torch.float64))
         out["train_pred_samples"] = pred.reshape(-1)[::SAMPLE_STRIDE].numpy().copy()
         out["train_pred_summary"] = fi.summarize(pred)
-        out["train_pred_noise"] = np.float64(max((pred_n - pred).abs().max().item(), (pred_d - pred).abs().max().item()))
+        out["train_pred_noise"] = np.float64(max((pp - pred).abs().max().item() for _, pp, _ in probes))
         out["loss"] = np.float64(loss)
-        out["loss_noise"] = np.float64(max(abs(loss_n - loss), abs(loss_d - loss)))
+        out["loss_noise"] = np.float64(max(abs(lp - loss) for _, _, lp in probes))
         names, gsum, gnoise = [], [], []
-        pn = dict(model_n.named_parameters())
-        pd = dict(model_d.named_parameters())
+        pgs = [dict(m.named_parameters()) for m, _, _ in probes]
         for k, p in model.named_parameters():
             names.append(k)
             gsum.append(fi.summarize(p.grad))
-            gnoise.append(np.maximum(np.abs(fi.summarize(pn[k].grad) - fi.summarize(p.grad)),
-                                     np.abs(fi.summarize(pd[k].grad) - fi.summarize(p.grad))))
+            gnoise.append(np.max(np.stack([np.abs(fi.summarize(pg[k].grad) - fi.summarize(p.grad)) for pg in pgs]), axis=0))
         out["grad_names"] = np.array(names)
         out["grad_summary"] = np.stack(gsum)
         out["grad_noise"] = np.stack(gnoise)
@@ -102,7 +107,7 @@ def gen_deeplab(n_classes, ignore_index, B, H, W, tag, n_lab=20, train=True):
         for k in (FULL_GRADS if NETWORK == "deeplab" else FULL_GRADS_FPN):
             out["g:" + k] = dict(model.named_parameters())[k].grad.numpy().copy()
             gk = dict(model.named_parameters())[k].grad
-            out["gn:" + k] = np.float64(max((pn[k].grad - gk).abs().max().item(), (pd[k].grad - gk).abs().max().item()))
+            out["gn:" + k] = np.float64(max((pg[k].grad - gk).abs().max().item() for pg in pgs))
         sdn = model.state_dict()
         rs_keys = ["backbone.features.2.conv.1.running_mean", "backbone.features.2.conv.1.running_var",
                    "backbone.features.17.conv.4.running_var", "aspp.bn1.running_mean", "seg_head.segment_head.5.running_var"]
