@@ -232,7 +232,7 @@ def main():
         evc = HipEvents(nrep)
 
         def conv_once():
-            rc = L.pp_conv2d_fwd(xa.data_ptr(), 304, TB, Hq, Wq, 304, wa.data_ptr(), None, 3, 3, 1, 1, 1, ya.data_ptr(), 256, 256, stream)
+            rc = L.pp_conv2d_fwd(xa.data_ptr(), 304, TB, Hq, Wq, 304, wa.data_ptr(), None, 3, 3, 1, 1, 1, ya.data_ptr(), 256, 256, None, 0, stream)
             _lib.check(rc, "pp_conv2d_fwd")
         timed(conv_once, nrep, 3, evc)
         cms = evc.elapsed_ms()

@@ -101,13 +101,21 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
  * networks/mobilenet_v2.py:9,42,48,56; aspp.py:9-10,55,58; deeplab.py:24; decoders.py:107,111,116;
  * backbones/resnet_models.py Bottleneck convs; decoders.py:25-28,92 (bias != NULL).
  * y[b,oh,ow,n] = bias[n] + sum x[b, oh*stride - pad + th*dil, ow*stride - pad + tw*dil, c] * w[th,tw,c,n] */
+/* `workspace` (optional, may be NULL / 0): scratch for the split-K form used when the output has too few tiles to
+ * fill the 256 CUs (partial sums [splits][M][Cout], reduced in fixed order: deterministic).  Size it with
+ * pp_conv2d_fwd_workspace_bytes (0 = this shape never splits); with less, the single-pass form runs. */
+size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
-                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, pp_stream_t stream);
+                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                  size_t ws_bytes, pp_stream_t stream);
 
 /* dL/dx of the above (what autograd computes at model.py:121); any stride (the stride-2 Bottleneck convs of
- * backbones/resnet_models.py:63-64,142-144 gather dY rows where (row + pad - tap*dil) is divisible by the stride). */
+ * backbones/resnet_models.py:63-64,142-144 gather dY rows where (row + pad - tap*dil) is divisible by the stride).
+ * B,H,W,Cin describe the conv INPUT for the workspace query. */
+size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
-                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, pp_stream_t stream);
+                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, void* workspace,
+                       size_t ws_bytes, pp_stream_t stream);
 
 /* dL/dw (HWIO) and optionally dL/dbias [Cout]; workspace holds the split-M partial sums. */
 size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);

@@ -55,8 +55,11 @@ struct ConvParams {
     int stride;
     int64_t M;        // B*Ho*Wo
     int bwd_stride;   // backward-data of a strided conv: source row = (row + dh) / bwd_stride when divisible (else 1)
-    int n_tiles;      // tiles along the output-channel axis (grid is 1-D: m_tiles * n_tiles blocks)
+    int n_tiles;      // tiles along the output-channel axis (grid.x is 1-D: m_tiles * n_tiles blocks)
     int xcd_remap;
+    int splits;       // split-K: grid.y slices of the (tap, channel-chunk) loop; > 1 -> partial sums go to `part`
+    int ks_per_split;
+    float* part;      // [splits][M][Cn] partial outputs (no bias)
     ConvTaps taps;
 };
 
@@ -347,11 +350,13 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 
     // Prefetch distance 1 (measured: a second register set with the loads of step k+2 in flight as well was 6 %
     // SLOWER — 90 vs 96 TF on the SegmentHead conv — so global latency is not what limits this kernel).
-    load_tiles(0, R0);
-    for (int ks = 0; ks < nk; ++ks) {
+    const int ks_beg = p.splits > 1 ? (int)blockIdx.y * p.ks_per_split : 0;
+    const int ks_end = p.splits > 1 ? (ks_beg + p.ks_per_split < nk ? ks_beg + p.ks_per_split : nk) : nk;
+    load_tiles(ks_beg, R0);
+    for (int ks = ks_beg; ks < ks_end; ++ks) {
         store_tiles(R0);
         __syncthreads();
-        if (ks + 1 < nk) load_tiles(ks + 1, R0);
+        if (ks + 1 < ks_end) load_tiles(ks + 1, R0);
         mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
         __syncthreads();
     }
@@ -362,14 +367,46 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + (wn * TN + tn) * 32 + l31;
         if (n >= p.Cn) continue;
-        const float bv = p.bias ? p.bias[n] : 0.0f;
+        const float bv = (p.bias && p.splits <= 1) ? p.bias[n] : 0.0f;
+        float* out = p.splits > 1 ? p.part + (int64_t)blockIdx.y * p.M * p.Cn : p.y;
+        const int64_t ldo = p.splits > 1 ? (int64_t)p.Cn : p.ldy;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m < p.M) p.y[m * p.ldy + n] = acc[tm][tn][r] + bv;
+                if (m < p.M) out[m * ldo + n] = acc[tm][tn][r] + bv;
             }
+        }
+    }
+}
+
+// split-K second stage: y[m][n] = bias[n] + sum_z part[z][m][n], z in fixed order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int splits, int64_t M, int Cn,
+                                                            const float* bias, float* y, int64_t ldy)
+{
+    const int64_t MN = M * Cn;
+    if ((Cn & 3) == 0 && (ldy & 3) == 0) {
+        const int cq = Cn >> 2;
+        const int64_t total = M * cq;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int64_t m = e / cq;
+            const int q = (int)(e - m * cq);
+            float4 s = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = part + m * Cn + q * 4;
+            for (int z = 0; z < splits; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)z * MN);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4*>(y + m * ldy + q * 4) = s;
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < MN; e += (int64_t)gridDim.x * 256) {
+            const int64_t m = e / Cn;
+            const int n = (int)(e - m * Cn);
+            float s = bias ? bias[n] : 0.0f;
+            for (int z = 0; z < splits; ++z) s += part[(int64_t)z * MN + e];
+            y[m * ldy + n] = s;
         }
     }
 }
@@ -643,39 +680,88 @@ static void build_taps(ConvTaps& t, int kh, int kw, int stride, int pad, int dil
         }
 }
 
+// Tile configuration + split-K factor for an (M x Cn x K) implicit GEMM.  Layers whose output has fewer than ~192
+// tiles (every 1/16-resolution conv of MobileNetV2/ASPP at the BASELINE batch) leave most of the 256 CUs idle and
+// run their whole K loop at one block per CU, exposing the full global-load latency every K-step; slicing the
+// (tap, channel-chunk) loop over grid.y fills the chip, at the price of one [splits][M][Cn] round trip.
+struct ConvPlan {
+    int cfg;            // 0: 128x32, 1: 128x128 (or 128x64 under the A/B knob), 2: 64x64
+    int64_t tiles;
+    int n_tiles;
+    int splits, ks_per_split;
+};
+
+static int g_conv_splitk = 1;
+
+static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps)
+{
+    ConvPlan pl{};
+    const int64_t mt128 = cdiv(M, 128), mt64 = cdiv(M, 64);
+    if (Cn <= 32) {
+        pl.cfg = 0; pl.n_tiles = 1; pl.tiles = mt128;
+    } else if (Cn > 64 && mt128 * cdiv(Cn, 128) >= 384) {
+        pl.cfg = 1;
+        pl.n_tiles = (int)cdiv(Cn, g_conv_variant == 2 ? 64 : 128);
+        pl.tiles = mt128 * pl.n_tiles;
+    } else {
+        pl.cfg = 2; pl.n_tiles = (int)cdiv(Cn, 64); pl.tiles = mt64 * pl.n_tiles;
+    }
+    const int nk = ntaps * (int)cdiv(Ck, BK);
+    pl.splits = 1;
+    pl.ks_per_split = nk;
+    if (g_conv_splitk && pl.tiles < 192 && nk >= 12) {
+        int64_t s = cdiv(512, pl.tiles);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 32) s = 32;
+        if (s > 1) {
+            pl.ks_per_split = (int)cdiv(nk, s);
+            pl.splits = (int)cdiv(nk, pl.ks_per_split);
+        }
+    }
+    return pl;
+}
+
 template <bool BWD>
-static int launch_conv(const ConvParams& p_in, hipStream_t st)
+static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes, hipStream_t st)
 {
     EventScope ev(st);
     ConvParams p = p_in;
     p.xcd_remap = g_conv_xcd_remap;
     const bool vec = g_conv_novec == 0 && p.Ck % 4 == 0 && p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
-    const int64_t mt128 = cdiv(p.M, 128), mt64 = cdiv(p.M, 64);
-    if (p.Cn <= 32) {
-        p.n_tiles = 1;
-        dim3 grid((unsigned)mt128);
+    ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n);
+    if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
+        pl.splits = 1;                   // no (or too small a) workspace: single pass
+    }
+    p.n_tiles = pl.n_tiles;
+    p.splits = pl.splits;
+    p.ks_per_split = pl.ks_per_split;
+    p.part = reinterpret_cast<float*>(workspace);
+    dim3 grid((unsigned)pl.tiles, (unsigned)pl.splits);
+    if (pl.cfg == 0) {
         if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, false>), grid, dim3(kThreads), 0, st, p);
-    } else if (p.Cn > 64 && mt128 * cdiv(p.Cn, 128) >= 384) {
+    } else if (pl.cfg == 1) {
         if (g_conv_variant == 2) {
-            p.n_tiles = (int)cdiv(p.Cn, 64);
-            dim3 grid2((unsigned)(mt128 * p.n_tiles));
-            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, true>), grid2, dim3(kThreads), 0, st, p);
-            else     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, false>), grid2, dim3(kThreads), 0, st, p);
+            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
+            else     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
         } else {
-            p.n_tiles = (int)cdiv(p.Cn, 128);
-            dim3 grid1((unsigned)(mt128 * p.n_tiles));
-            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid1, dim3(kThreads), g_conv_lds_pad, st, p);
-            else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid1, dim3(kThreads), g_conv_lds_pad, st, p);
+            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
+            else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
         }
     } else {
-        p.n_tiles = (int)cdiv(p.Cn, 64);
-        dim3 grid((unsigned)(mt64 * p.n_tiles));
         if (vec) hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
     }
-    return check_launch("conv_igemm_kernel");
+    if (int rc = check_launch("conv_igemm_kernel")) return rc;
+    if (pl.splits > 1) {
+        int64_t nb = cdiv(p.M * cdiv(p.Cn, 4), 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p.part, pl.splits, p.M, p.Cn, p.bias,
+                           p.y, p.ldy);
+        return check_launch("splitk_reduce_kernel");
+    }
+    return PP_OK;
 }
 
 static int conv_common_check(const void* a, const void* b, const void* c, int B, int H, int W, int Cin, int Cout,
@@ -701,12 +787,38 @@ void pp_debug_set_conv_variant(int v)
     g_conv_xcd_remap = (v & 4) ? 0 : 1;      // bit 2 switches the XCD-aware tile order off (A/B)
     g_conv_novec = (v & 8) ? 1 : 0;          // bit 3 forces the conditional-load path (A/B)
     g_conv_lds_pad = (v & 16) ? 40 * 1024 : ((v & 32) ? 70 * 1024 : 0);   // bits 4/5: at most 2 / 1 blocks per CU
+    g_conv_splitk = (v & 64) ? 0 : 1;        // bit 6 switches split-K off (A/B)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
 }
 
+size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return 0;
+    ConvTaps t;
+    build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n);
+    return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cout * 4, 256) : 0;
+}
+
+size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return 0;
+    ConvTaps t;
+    build_taps(t, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
+    const int64_t M = (int64_t)B * H * W;
+    const ConvPlan pl = plan_conv(M, Cin, Cout, t.n);
+    return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
+}
+
 int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
-                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, pp_stream_t stream)
+                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                  size_t ws_bytes, pp_stream_t stream)
 {
     if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
@@ -719,12 +831,12 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
-    return launch_conv<false>(p, as_stream(stream));
+    return launch_conv<false>(p, workspace, ws_bytes, as_stream(stream));
 }
 
 int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
                        int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin,
-                       pp_stream_t stream)
+                       void* workspace, size_t ws_bytes, pp_stream_t stream)
 {
     if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
@@ -737,7 +849,7 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
     build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: more than 2^31 pixels");
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv bwd_data: no live tap");
-    return launch_conv<true>(p, as_stream(stream));
+    return launch_conv<true>(p, workspace, ws_bytes, as_stream(stream));
 }
 
 size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,

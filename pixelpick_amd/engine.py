@@ -78,20 +78,21 @@ class Tape:
 
     def side_stream_for(self, *tensors):
         """Context manager: run the enclosed launches on the side stream, after everything queued so far on the
-        main stream; `tensors` are kept alive for the side stream (caching-allocator bookkeeping)."""
+        main stream.  `tensors` are kept alive until the join (they were allocated for the main stream; the caching
+        allocator must not recycle them while the side stream reads them).  No torch stream context is entered:
+        the enclosed code takes its stream handle from _stream() and its scratch from _ws(), both switched here
+        (the torch context manager + wait_stream + record_stream cost ~30 us of host time per weight gradient)."""
         if not Tape.overlap_wgrad:
-            return contextlib.nullcontext()
+            return _NULL_CTX
         dev = tensors[0].device
         side = _side_stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        capturing = torch.cuda.is_current_stream_capturing()
-        for t in tensors:
-            if t is not None:
-                self._keepalive.append(t)       # not recycled by the allocator before the join (needed under graph capture)
-                if not capturing:
-                    t.record_stream(side)
+        ev = _fork_event(dev)
+        ev.record(_main_stream_obj())
+        side.wait_event(ev)
+        self._keepalive.extend(tensors)
         self._side = side
-        return _SideStreamCtx(side)
+        _SIDE_CTX.handle = side.cuda_stream
+        return _SIDE_CTX
 
     def backward(self, out: Var, dout: torch.Tensor):
         refresh_stream()               # autograd may call this from its own thread / stream
@@ -112,10 +113,16 @@ class Tape:
 # torch.cuda.current_stream() costs ~7 us per call and a train step issues ~550 launches: the raw stream handle is
 # cached (refreshed whenever a Tape is created / replayed and swapped by the side-stream context).
 _stream_cache = [None]
+_stream_obj_cache = [None]
+_role = [0]                 # 0: launches go to the main stream, 1: to the side stream (selects the scratch buffer)
+_fork_events = {}
+_NULL_CTX = contextlib.nullcontext()
 
 
 def refresh_stream():
-    _stream_cache[0] = _lib.current_stream_ptr()
+    st = torch.cuda.current_stream()
+    _stream_obj_cache[0] = st
+    _stream_cache[0] = st.cuda_stream
 
 
 def _stream():
@@ -124,25 +131,47 @@ def _stream():
     return _stream_cache[0]
 
 
-class _SideStreamCtx:
-    def __init__(self, side):
-        self.side = side
-        self.ctx = torch.cuda.stream(side)
+def _main_stream_obj():
+    if _stream_obj_cache[0] is None:
+        refresh_stream()
+    return _stream_obj_cache[0]
+
+
+def _fork_event(device):
+    key = (device.type, device.index)
+    ev = _fork_events.get(key)
+    if ev is None:
+        ev = torch.cuda.Event()
+        _fork_events[key] = ev
+    return ev
+
+
+class _SideCtx:
+    """Switches _stream() / _ws() to the side stream for the enclosed launches (re-entrant use is not needed)."""
+    __slots__ = ("handle", "prev")
 
     def __enter__(self):
-        self.ctx.__enter__()
         self.prev = _stream_cache[0]
-        _stream_cache[0] = self.side.cuda_stream
+        _stream_cache[0] = self.handle
+        _role[0] = 1
 
     def __exit__(self, *exc):
         _stream_cache[0] = self.prev
-        return self.ctx.__exit__(*exc)
+        _role[0] = 0
+        return False
+
+
+_SIDE_CTX = _SideCtx()
 
 
 def _geom(t: torch.Tensor):
     """[B,H,W,C] NHWC (possibly a channel slice of a wider buffer) -> (B,H,W,C,ld)."""
-    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, "NHWC float32 GPU tensor expected"
     B, H, W, C = t.shape
+    if t.is_contiguous():
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise AssertionError("NHWC float32 GPU tensor expected")
+        return B, H, W, C, C
+    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, "NHWC float32 GPU tensor expected"
     if C > 1 and t.stride(3) != 1:
         raise ValueError("channel axis must be contiguous")
     if W > 1:
@@ -158,13 +187,39 @@ def _geom(t: torch.Tensor):
     return B, H, W, C, ld
 
 
+# Kernel scratch (reduction partials, split-K partials): one grow-only buffer per (device, stream role).  Launches
+# on one stream are serialised, so consecutive layers share it; a buffer that is outgrown is retired, never freed
+# (the side stream may still be reading it and the allocator would hand it to the main stream).
+_SCRATCH = {}
+_SCRATCH_RETIRED = []
+_WS_BYTES = {}
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    key = (device.type, device.index, _role[0])
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _SCRATCH_RETIRED.append(buf)
+        buf = torch.empty(max(int(nbytes), 2 * (buf.numel() if buf is not None else 0), 8 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def _wsbytes(fn_name: str, *args) -> int:
+    """Memoised pp_*_workspace_bytes query (a ctypes round trip per layer per step otherwise)."""
+    key = (fn_name,) + args
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = int(getattr(_lib.lib(), fn_name)(*args))
+        _WS_BYTES[key] = n
+    return n
 
 
 # Single-launch BatchNorm (pp_bn_train_fwd_fused / pp_bn_bwd_fused).  PIXELPICK_BN_FUSED=0 selects the
 # three-launch form (partials -> finalize -> apply) for A/B timing.
 _BN_FUSED = os.environ.get("PIXELPICK_BN_FUSED", "1") != "0"
+_BN_FUSED_MAXM = int(os.environ.get("PIXELPICK_BN_FUSED_MAXM", str(1 << 62)))
 _BN_SYNC = {}
 
 
@@ -172,7 +227,7 @@ def _bn_sync(device, C: int) -> torch.Tensor:
     """Zeroed arrival counters for the fused BN launches on the main stream (each launch re-zeroes them)."""
     key = (device.type, device.index)
     t = _BN_SYNC.get(key)
-    need = int(_lib.lib().pp_bn_fused_sync_ints(C))
+    need = _wsbytes("pp_bn_fused_sync_ints", C)
     if t is None or t.numel() < need:
         t = torch.zeros(max(16384, need), dtype=torch.int32, device=device)
         _BN_SYNC[key] = t
@@ -266,7 +321,7 @@ def group_norm_relu(tape: Tape, x: Var, gamma, beta, groups: int, relu: bool = T
     y = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
     mean = torch.empty(B * groups, dtype=torch.float32, device=dev)
     rstd = torch.empty(B * groups, dtype=torch.float32, device=dev)
-    ws = _ws(L.pp_groupnorm_workspace_bytes(B, H * W, C), dev)
+    ws = _ws(_wsbytes("pp_groupnorm_workspace_bytes", B, H * W, C), dev)
     rc = L.pp_groupnorm_relu_fwd(x.t.data_ptr(), ldx, B, H * W, C, groups, gamma.data_ptr(), beta.data_ptr(), eps, int(relu),
                                  y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "pp_groupnorm_relu_fwd")
@@ -283,7 +338,7 @@ def _gn_bwd(tape: Tape, dy, x: Var, gamma, beta, groups, mean, rstd, relu, out: 
     dev = dy.device
     dgamma, dbeta = tape.grad_buffer_for(gamma), tape.grad_buffer_for(beta)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
-    ws = _ws(L.pp_groupnorm_workspace_bytes(B, H * W, C), dev)
+    ws = _ws(_wsbytes("pp_groupnorm_workspace_bytes", B, H * W, C), dev)
     rc = L.pp_groupnorm_relu_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), C, B, H * W, C, groups, mean.data_ptr(),
                                  rstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
                                  ws.data_ptr(), ws.numel(), _stream())
@@ -321,6 +376,28 @@ def _maxpool_bwd(tape: Tape, dy, x: Var, idx, ksize, stride, pad):
 
 
 # ------------------------------------------------------------------------------------------------- dense conv
+_CONV_WS_BYTES = {}      # (bwd, shape...) -> split-K workspace bytes (0: never splits)
+_CONV_WS_BUF = {}        # device -> one grow-only scratch buffer; forward / backward-data run on the main stream only
+
+
+def _conv_ws(bwd: bool, device, *shape):
+    """(pointer, bytes) of the split-K scratch for this conv shape, or (None, 0)."""
+    key = (bwd,) + shape
+    need = _CONV_WS_BYTES.get(key)
+    if need is None:
+        L = _lib.lib()
+        need = int((L.pp_conv2d_bwd_data_workspace_bytes if bwd else L.pp_conv2d_fwd_workspace_bytes)(*shape))
+        _CONV_WS_BYTES[key] = need
+    if need == 0:
+        return None, 0
+    dk = (device.type, device.index)
+    buf = _CONV_WS_BUF.get(dk)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device)
+        _CONV_WS_BUF[dk] = buf
+    return buf.data_ptr(), buf.numel()
+
+
 def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, dil=1,
            dst: Optional[torch.Tensor] = None) -> Var:
     """nn.Conv2d (groups=1).  w: HWIO [kh,kw,Cin,Cout].  dst: optional NHWC view to write into."""
@@ -330,8 +407,9 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
     Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
     y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.t.device)
     _, _, _, _, ldy = _geom(y)
+    ws, wsn = _conv_ws(False, x.t.device, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
     rc = _lib.lib().pp_conv2d_fwd(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                  kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, _stream())
+                                  kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, _stream())
     _lib.check(rc, "pp_conv2d_fwd")
     out = Var(y)
     tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil), out)
@@ -348,8 +426,7 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
         dw = tape.grad_buffer_for(w)
         db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
         with tape.side_stream_for(x.t, dy, dw, db):
-            ws = _ws(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
-            tape._keepalive.append(ws)
+            ws = _ws(_wsbytes("pp_conv2d_bwd_weight_workspace_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
             rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
                                         dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
                                         _stream())
@@ -359,8 +436,9 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
             tape.set_param_grad(bias, db)
     if x.needs_grad:
         dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
         rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                  dx.data_ptr(), Cin, H, W, Cin, _stream())
+                                  dx.data_ptr(), Cin, H, W, Cin, ws, wsn, _stream())
         _lib.check(rc, "pp_conv2d_bwd_data")
         _acc(x, dx)
 
@@ -386,8 +464,7 @@ def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
     if w.requires_grad:
         dw = tape.grad_buffer_for(w)
         with tape.side_stream_for(x.t, dy, dw):
-            ws = _ws(L.pp_colreduce_workspace_bytes(B * Ho * Wo, C), dev)
-            tape._keepalive.append(ws)
+            ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", B * Ho * Wo, C), dev)
             rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
                                            ws.data_ptr(), ws.numel(), _stream())
         _lib.check(rc, "pp_dwconv3x3_bwd_weight")
@@ -408,7 +485,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
     dev = x.t.device
-    if training and _BN_FUSED:
+    if training and _BN_FUSED and M <= _BN_FUSED_MAXM:
         # one launch: statistics + running-stat update + affine + residual + activation
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -418,7 +495,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         if residual is not None:
             _, _, _, _, ldr = _geom(residual.t)
             rptr = residual.t.data_ptr()
-        ws = _ws(L.pp_bn_fused_workspace_bytes(M, C), dev)
+        ws = _ws(_wsbytes("pp_bn_fused_workspace_bytes", M, C), dev)
         sync = _bn_sync(dev, C)
         rc = L.pp_bn_train_fwd_fused(x.t.data_ptr(), ldx, M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                      running_mean.data_ptr() if running_mean is not None else None,
@@ -435,7 +512,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
     if training:
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = _ws(L.pp_colreduce_workspace_bytes(M, C), dev)
+        ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", M, C), dev)
         rc = L.pp_bn_train_fwd(x.t.data_ptr(), ldx, M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                running_mean.data_ptr() if running_mean is not None else None,
                                running_var.data_ptr() if running_var is not None else None,
@@ -473,8 +550,8 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     dbeta = tape.grad_buffer_for(beta)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
     dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
-    if _BN_FUSED:
-        ws = _ws(L.pp_bn_fused_workspace_bytes(M, C), dev)
+    if _BN_FUSED and M <= _BN_FUSED_MAXM:
+        ws = _ws(_wsbytes("pp_bn_fused_workspace_bytes", M, C), dev)
         sync = _bn_sync(dev, C)
         rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(),
                                invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
@@ -482,7 +559,7 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
                                sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_bn_bwd_fused")
     else:
-        ws = _ws(L.pp_colreduce_workspace_bytes(M, C), dev)
+        ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", M, C), dev)
         rc = L.pp_bn_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(), invstd.data_ptr(),
                          gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
                          dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(), _stream())
@@ -696,7 +773,7 @@ def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index:
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     count = torch.empty(1, dtype=torch.float32, device=dev)
     dl = torch.empty((B, C, H, W), dtype=torch.float32, device=dev) if want_grad else None
-    ws = _ws(L.pp_sparse_ce_workspace_bytes(), dev)
+    ws = _ws(_wsbytes("pp_sparse_ce_workspace_bytes"), dev)
     rc = L.pp_sparse_ce_fwd_bwd(logits.data_ptr(), B, C, H * W, logits.stride(0), logits.stride(1), target.data_ptr(),
                                 int(ignore_index), loss.data_ptr(), count.data_ptr(), None,
                                 dl.data_ptr() if dl is not None else None, ws.data_ptr(), ws.numel(), _stream())

@@ -65,6 +65,16 @@ class FlatTrainer:
         self._gx = self._gy = None
 
     # -----------------------------------------------------------------------------------------------
+    def _ensure_train_mode(self):
+        """model.train() (model.py:104) without its ~400 setattr calls when every module already is in train mode."""
+        mods = self.__dict__.get("_all_modules")
+        if mods is None:
+            mods = self.__dict__["_all_modules"] = list(self.model.modules())
+        for m in mods:
+            if not m.training:
+                self.model.train()
+                return
+
     def forward_backward(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
         """x [B,3,H,W] f32, y [B,H,W] int64 with ignore_index at unlabelled pixels (model.py:108-110)."""
         tape = E.Tape(enabled=True)
@@ -110,7 +120,7 @@ class FlatTrainer:
 
     def train_step(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
         """One optimisation step (model.py:101-122).  After enable_graph() the step is a hipGraph replay."""
-        self.model.train()
+        self._ensure_train_mode()
         self.step_count += 1
         if self._graph is not None:
             self._gx.copy_(x, non_blocking=True)

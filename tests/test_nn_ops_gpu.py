@@ -166,6 +166,50 @@ def test_add_and_nchw_roundtrip():
     assert torch.equal(nchw(av.grad), dy) and torch.equal(nchw(bv.grad), dy)
 
 
+@pytest.mark.parametrize("case", [(4, 16, 32, 320, 256, 3, 1, 6, 6), (4, 16, 32, 960, 320, 1, 1, 0, 1), (2, 16, 32, 1280, 256, 1, 1, 0, 1),
+                                  (2, 9, 13, 576, 96, 1, 1, 0, 1), (2, 8, 8, 144, 19, 3, 1, 1, 1), (1, 20, 18, 3, 64, 7, 2, 3, 1)])
+def test_conv2d_split_k_matches_single_pass(case):
+    """Few-tile layers slice their K loop over grid.y (partials + fixed-order reduce).  Same numbers (to fp32
+    summation-order noise) as the single-pass kernel, bit-identical run to run, correct into a channel slice."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    B, H, W, Cin, Cout, k, stride, pad, dil = case
+    assert L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad, dil) > 0, "case does not split"
+    torch.manual_seed(3)
+    x = torch.randn(B, H, W, Cin, device=DEV)
+    w = torch.randn(k, k, Cin, Cout, device=DEV) / np.sqrt(Cin * k * k)
+    bias = torch.randn(Cout, device=DEV)
+    Ho, Wo = E.out_size(H, k, stride, pad, dil), E.out_size(W, k, stride, pad, dil)
+    dy = torch.randn(B, Ho, Wo, Cout, device=DEV)
+
+    def run():
+        tape = E.Tape()
+        xv = E.Var(x.clone()); xv.needs_grad = True
+        wide = torch.full((B, Ho, Wo, Cout + 8), 5.0, device=DEV)
+        yv = E.conv2d(tape, xv, w, bias, stride, pad, dil, dst=wide[..., 4:4 + Cout])
+        assert (wide[..., :4] == 5.0).all() and (wide[..., 4 + Cout:] == 5.0).all()
+        y = yv.t.clone()
+        dx = None
+        if stride == 1:
+            tape.backward(yv, dy)
+            dx = xv.grad.clone()
+        return y, dx
+
+    y1, dx1 = run()
+    y2, dx2 = run()
+    assert torch.equal(y1, y2) and (dx1 is None or torch.equal(dx1, dx2))
+    L.pp_debug_set_conv_variant(64)          # split-K off
+    try:
+        y0, dx0 = run()
+    finally:
+        L.pp_debug_set_conv_variant(0)
+    close(y1, y0, tol=2e-5, what="split-K fwd vs single pass")
+    if dx1 is not None:
+        close(dx1, dx0, tol=2e-5, what="split-K bwd-data vs single pass")
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.permute(3, 2, 0, 1).cpu(), bias.cpu(), stride, pad, dil)
+    close(nchw(y1), ref, what="split-K fwd vs torch")
+
+
 def test_conv2d_channel_slices():
     """Inputs/outputs that are channel slices of wider buffers (the zero-copy concat of aspp.py:73)."""
     torch.manual_seed(0)

@@ -20,4 +20,4 @@ print(f"enqueue {1e3*(t1-t0)/20:.2f} ms/step, total {1e3*(t2-t0)/20:.2f} ms/step
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): tr.train_step(x, y)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(50)
