@@ -31,10 +31,11 @@ class Var:
 
 
 _side_streams = {}
+N_SIDE_STREAMS = int(os.environ.get("PIXELPICK_SIDE_STREAMS", "1"))
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+def _side_stream(device, i: int = 0) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), i)
     st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=device)
@@ -47,6 +48,7 @@ class Tape:
     # small to fill 256 CUs on their own: in backward() they run on a second HIP stream, concurrently with the
     # data-gradient chain on the main stream (joined at the end of backward()).
     overlap_wgrad = True
+    trace = None                       # debugging: a list collects (label, torch.cuda.Event) phase marks (tools/phase_times.py)
 
     def __init__(self, enabled: bool = True):
         refresh_stream()
@@ -55,6 +57,7 @@ class Tape:
         self.param_grads = {}          # id(param tensor) -> grad tensor
         self.param_grad_dst = None     # optional callable(param) -> preallocated grad tensor to write into
         self._side = None
+        self._side_rr = 0
         self._keepalive = []
 
     def record(self, fn, ctx, out: Var):
@@ -85,17 +88,24 @@ class Tape:
         if not Tape.overlap_wgrad:
             return _NULL_CTX
         dev = tensors[0].device
-        side = _side_stream(dev)
+        i = self._side_rr
+        self._side_rr = (i + 1) % N_SIDE_STREAMS
+        side = _side_stream(dev, i)
         ev = _fork_event(dev)
         ev.record(_main_stream_obj())
         side.wait_event(ev)
         self._keepalive.extend(tensors)
-        self._side = side
+        if self._side is None:
+            self._side = {}
+        self._side[i] = side
         _SIDE_CTX.handle = side.cuda_stream
+        _SIDE_CTX.role = 1 + i
         return _SIDE_CTX
 
     def backward(self, out: Var, dout: torch.Tensor):
         refresh_stream()               # autograd may call this from its own thread / stream
+        if Tape.trace is not None:
+            Tape.trace.append(("bwd_begin", _mark()))
         out.grad = dout
         for fn, ctx, o in reversed(self.nodes):
             if o.grad is None:
@@ -103,9 +113,14 @@ class Tape:
             fn(self, o.grad, *ctx)
             o.grad = None             # free as we go
         self.nodes = []
+        if Tape.trace is not None:
+            Tape.trace.append(("bwd_main_end", _mark()))
         if self._side is not None:    # join: the optimiser / all-reduce must see every weight gradient
-            torch.cuda.current_stream(dout.device).wait_stream(self._side)
+            for side in self._side.values():
+                _main_stream_obj().wait_stream(side)
             self._side = None
+        if Tape.trace is not None:
+            Tape.trace.append(("joined", _mark()))
         self._keepalive = []
 
 
@@ -137,6 +152,12 @@ def _main_stream_obj():
     return _stream_obj_cache[0]
 
 
+def _mark():
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(_main_stream_obj())
+    return ev
+
+
 def _fork_event(device):
     key = (device.type, device.index)
     ev = _fork_events.get(key)
@@ -148,12 +169,12 @@ def _fork_event(device):
 
 class _SideCtx:
     """Switches _stream() / _ws() to the side stream for the enclosed launches (re-entrant use is not needed)."""
-    __slots__ = ("handle", "prev")
+    __slots__ = ("handle", "prev", "role")
 
     def __enter__(self):
         self.prev = _stream_cache[0]
         _stream_cache[0] = self.handle
-        _role[0] = 1
+        _role[0] = self.role
 
     def __exit__(self, *exc):
         _stream_cache[0] = self.prev
