@@ -20,6 +20,8 @@ Cityscapes-quarter 256x512 (configs[1]).  One run measures both on synthetic dat
                         that kernel on its stream, inside the timed region.
   roofline_mfma{}       the dominant train-step kernel (conv_igemm_kernel, SegmentHead 3x3 304->256 at
                         B*64*128 rows, decoders.py:107) vs the fp32 MFMA peak, same event method.
+  roofline_mfma_1x1{}   the SURVEY 8(d) graded 1x1 (pointwise) shapes at the BASELINE batch, each vs the fp32 MFMA peak
+                        and vs its own HBM-limited ceiling.
   cpu_baseline{}        the plain-PyTorch port of the same train step / acquisition loop (oracle/) timed on
                         this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -243,6 +245,41 @@ def main():
                                  "achieved": round(flops / (cavg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": round(flops / (cavg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
                                  "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
+        # SURVEY 8(d) graded 1x1 shapes at the BASELINE batch: op time (split-K launch + its reduce where the plan
+        # splits) from HIP events; ceiling = min(MFMA peak, arithmetic intensity x HBM peak) for ONE pass over x, w, y.
+        graded = [("ASPP fuse 1280->256 @16x32 (aspp.py:73-75)", 16, 32, 1280, 256),
+                  ("MNv2 expand 160->960 @18x34 (mobilenet_v2.py:42)", 18, 34, 160, 960),
+                  ("MNv2 project 960->160 @16x32 (mobilenet_v2.py:56)", 16, 32, 960, 160),
+                  ("MNv2 project 960->320 @16x32 (mobilenet_v2.py:56)", 16, 32, 960, 320),
+                  ("R50 Bottleneck 256->1024 @32x64 (resnet_models.py:66)", 32, 64, 256, 1024),
+                  ("R50 Bottleneck 1024->256 @32x64 (resnet_models.py:60)", 32, 64, 1024, 256),
+                  ("R50 Bottleneck 2048->512 @32x64 (resnet_models.py:60)", 32, 64, 2048, 512),
+                  ("R50 Bottleneck 64->256 @64x128 (resnet_models.py:66)", 64, 128, 64, 256)]
+        rows1 = []
+        for name, h1, w1, ci, co in graded:
+            xg = torch.randn((TB, h1, w1, ci), device=dev)
+            wg = torch.randn((1, 1, ci, co), device=dev) * 0.05
+            yg = torch.empty((TB, h1, w1, co), device=dev)
+            wsb = int(L.pp_conv2d_fwd_workspace_bytes(TB, h1, w1, ci, co, 1, 1, 1, 0, 1))
+            wsg = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+            evg = HipEvents(10)
+
+            def one():
+                rc = L.pp_conv2d_fwd(xg.data_ptr(), ci, TB, h1, w1, ci, wg.data_ptr(), None, 1, 1, 1, 0, 1, yg.data_ptr(), co, co,
+                                     wsg.data_ptr() if wsb else None, wsb, stream)
+                _lib.check(rc, "pp_conv2d_fwd")
+            timed(one, 10, 3, evg)
+            ms1 = sum(evg.elapsed_ms()) / 10
+            evg.destroy()
+            m1 = TB * h1 * w1
+            fl = 2.0 * m1 * ci * co
+            by = 4.0 * (m1 * ci + ci * co + m1 * co)
+            ceil_tf = min(MFMA_F32_PEAK_TF, fl / by * HBM_PEAK_GBS / 1e3)
+            rows1.append({"shape": name, "rows": m1, "split_k": bool(wsb), "us": round(ms1 * 1e3, 2),
+                          "achieved": round(fl / (ms1 * 1e-3) / 1e12, 2), "ceiling": round(ceil_tf, 1),
+                          "frac_of_mfma_peak": round(fl / (ms1 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)})
+            del xg, wg, yg, wsg
+        line["roofline_mfma_1x1"] = {"unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "batch": TB, "shapes": rows1}
         del tr, model, xa, wa, ya
         torch.cuda.empty_cache()
 

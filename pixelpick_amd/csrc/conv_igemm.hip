@@ -66,7 +66,6 @@ struct ConvParams {
 // ---- LDS tiles ---------------------------------------------------------------------------------------
 // "MK" form: tile[rows][BK + 4]   (K contiguous, 80-B row pitch: conflict-free ds_read_b128)
 // "KM" form: tile[BK][rows + 4]   (rows contiguous: conflict-free ds_read_b32)
-constexpr int kPitchMK = BK + 4;
 
 // One K-step (16) of MFMAs for a wave tile of TM x TN 32x32 blocks.
 //   A_MK: A tile in MK form, else KM form.   B_NK: B tile in "NK" (= MK-like) form, else KN form.
@@ -125,19 +124,22 @@ __device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a
 // loads are UNCONDITIONAL float4 loads from a clamped address and the zero-fill of out-of-range elements happens
 // when the registers are written to LDS — so the loads of step k+1 stay in flight across the MFMAs of step k
 // (conditional loads make hipcc drain vmcnt(0) at the branch joins, serialising memory latency and MFMA work).
-template <int BM, int BN, int WM, int WN, bool BWD, bool VEC>
+template <int BM, int BN, int WM, int WN, bool BWD, bool VEC, int BKT = BK>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PITCH_A = kPitchMK;
-    constexpr int PITCH_B = BWD ? kPitchMK : BN + 4;
-    constexpr int A_F4 = BM * BK / 4 / kThreads;                 // float4 per thread for the A tile
-    constexpr int B_TOTAL = BN * BK / 4;
+    constexpr int KQ = BKT / 4;                                   // float4 per tile row along K
+    constexpr int RPP = kThreads / KQ;                            // A rows staged per pass
+    constexpr int PITCH_MK = BKT + 4;                             // 16 -> 20, 64 -> 68 floats: conflict-free ds_read_b128
+    constexpr int PITCH_A = PITCH_MK;
+    constexpr int PITCH_B = BWD ? PITCH_MK : BN + 4;
+    constexpr int A_F4 = BM * BKT / 4 / kThreads;                // float4 per thread for the A tile
+    constexpr int B_TOTAL = BN * BKT / 4;
     constexpr int B_F4 = (B_TOTAL + kThreads - 1) / kThreads;
     static_assert(A_F4 >= 1, "tile too small for 256 threads");
 
     __shared__ __attribute__((aligned(16))) float As[BM * PITCH_A];
-    __shared__ __attribute__((aligned(16))) float Bs[BWD ? BN * kPitchMK : BK * (BN + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[BWD ? BN * PITCH_MK : BKT * (BN + 4)];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -163,11 +165,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     const int n0 = nt * BN;
 
     // A staging: thread -> (row, k-quad); rows fixed for the whole K loop
-    const int a_kq = tid & 3;
+    const int a_kq = tid % KQ;
     int a_b[A_F4], a_ih[A_F4], a_iw[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        const int64_t m = m0 + (tid >> 2) + i * 64;
+        const int64_t m = m0 + tid / KQ + i * RPP;
         if (m < p.M) {
             const unsigned mu = (unsigned)m;                  // M < 2^31 (checked on the host)
             const unsigned t = mu / (unsigned)p.Wo;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         }
     }
 
-    const int nchunk = (p.Ck + BK - 1) / BK;
+    const int nchunk = (p.Ck + BKT - 1) / BKT;
     const int nk = p.taps.n * nchunk;
     const bool w_vec = BWD ? (p.Cout % 4 == 0) : (p.Cout % 4 == 0);
 
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         float4 (&rb)[B_F4] = R.b;
         unsigned& okmask = R.ok;
         const int ti = ks / nchunk;
-        const int c0 = (ks - ti * nchunk) * BK;
+        const int c0 = (ks - ti * nchunk) * BKT;
         const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
         const int wt = p.taps.widx[ti];
         if constexpr (VEC) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
                     ok = e < B_TOTAL && c < p.Cin && n < p.Cout;
                     off = ((int64_t)wt * p.Cin + c) * p.Cout + n;
                 } else {
-                    const int col = e >> 2, kq = e & 3;
+                    const int col = e / KQ, kq = e % KQ;
                     const int cin = n0 + col, k = c0 + kq * 4;
                     ok = e < B_TOTAL && cin < p.Cin && k < p.Cout;
                     off = ((int64_t)wt * p.Cin + cin) * p.Cout + k;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int e = tid + i * kThreads;
-                const int col = e >> 2, kq = e & 3;
+                const int col = e / KQ, kq = e % KQ;
                 const int cin = n0 + col, k = c0 + kq * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < B_TOTAL && cin < p.Cin && k < p.Cout) {
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i)
-            *reinterpret_cast<float4*>(As + ((tid >> 2) + i * 64) * PITCH_A + a_kq * 4) = ra[i];
+            *reinterpret_cast<float4*>(As + (tid / KQ + i * RPP) * PITCH_A + a_kq * 4) = ra[i];
         if constexpr (!BWD) {
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int e = tid + i * kThreads;
-                if (e < B_TOTAL) *reinterpret_cast<float4*>(Bs + (e >> 2) * PITCH_B + (e & 3) * 4) = rb[i];
+                if (e < B_TOTAL) *reinterpret_cast<float4*>(Bs + (e / KQ) * PITCH_B + (e % KQ) * 4) = rb[i];
             }
         }
     };
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         store_tiles(R0);
         __syncthreads();
         if (ks + 1 < ks_end) load_tiles(ks + 1, R0);
-        mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
+        mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B, BKT>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
         __syncthreads();
     }
 
@@ -693,7 +695,9 @@ struct ConvPlan {
 
 static int g_conv_splitk = 1;
 
-static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps)
+static int g_conv_deepk = 1;
+
+static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
 {
     ConvPlan pl{};
     const int64_t mt128 = cdiv(M, 128), mt64 = cdiv(M, 64);
@@ -705,13 +709,18 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps)
         pl.tiles = mt128 * pl.n_tiles;
     } else {
         pl.cfg = 2; pl.n_tiles = (int)cdiv(Cn, 64); pl.tiles = mt64 * pl.n_tiles;
+        // Deep-K variant: at one or two 64x64 blocks per CU the 16-deep K step has 512 MFMA cycles per wave to hide
+        // ~2000 cycles of global-load latency behind; a 64-deep step has 2048 (and 4x the bytes in flight).
+        if (g_conv_deepk && vec && Ck >= 64) pl.cfg = 3;
     }
-    const int nk = ntaps * (int)cdiv(Ck, BK);
+    const int bk = pl.cfg == 3 ? 64 : BK;
+    const int nk = ntaps * (int)cdiv(Ck, bk);
     pl.splits = 1;
     pl.ks_per_split = nk;
-    if (g_conv_splitk && pl.tiles < 192 && nk >= 12) {
+    if (g_conv_splitk && pl.tiles < 192 && nk >= (pl.cfg == 3 ? 4 : 12)) {
         int64_t s = cdiv(512, pl.tiles);
-        if (s > nk / 4) s = nk / 4;
+        const int min_iters = pl.cfg == 3 ? 2 : 4;
+        if (s > nk / min_iters) s = nk / min_iters;
         if (s > 32) s = 32;
         if (s > 1) {
             pl.ks_per_split = (int)cdiv(nk, s);
@@ -729,7 +738,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     p.xcd_remap = g_conv_xcd_remap;
     const bool vec = g_conv_novec == 0 && p.Ck % 4 == 0 && p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
-    ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n);
+    ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n, vec);
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
     }
@@ -749,6 +758,8 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
             if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
             else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
         }
+    } else if (pl.cfg == 3) {
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true, 64>), grid, dim3(kThreads), 0, st, p);
     } else {
         if (vec) hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
@@ -788,6 +799,7 @@ void pp_debug_set_conv_variant(int v)
     g_conv_novec = (v & 8) ? 1 : 0;          // bit 3 forces the conditional-load path (A/B)
     g_conv_lds_pad = (v & 16) ? 40 * 1024 : ((v & 32) ? 70 * 1024 : 0);   // bits 4/5: at most 2 / 1 blocks per CU
     g_conv_splitk = (v & 64) ? 0 : 1;        // bit 6 switches split-K off (A/B)
+    g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
 }
@@ -800,7 +812,7 @@ size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int
     ConvTaps t;
     build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     const int64_t M = (int64_t)B * Ho * Wo;
-    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n);
+    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cout * 4, 256) : 0;
 }
 
@@ -812,7 +824,7 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
     ConvTaps t;
     build_taps(t, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
     const int64_t M = (int64_t)B * H * W;
-    const ConvPlan pl = plan_conv(M, Cin, Cout, t.n);
+    const ConvPlan pl = plan_conv(M, Cin, Cout, t.n, Cin % 4 == 0 && Cout % 4 == 0);
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
 }
 

@@ -889,6 +889,120 @@ __global__ __launch_bounds__(kT) void bilinear_bwd4_kernel(const float* dy, int6
     }
 }
 
+// Same gather with the window ROWS spread over the block: block = (input pixel, group of QB float4 columns),
+// thread (r, ql) accumulates window rows h0+r, h0+r+NR, ..; the NR row sums are combined in fixed order through LDS.
+// The one-thread-per-pixel form above walks ~49 taps serially with only B*H*W*C/4 threads (131 K for the ASPP
+// upsample: 144 us for 33 MB); this form has ~8x the loads in flight.
+__global__ __launch_bounds__(kT) void bilinear_bwd4r_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq,
+                                                           float* dx, int64_t lddx, int H, int W, float sh, float sw,
+                                                           int align, int QB, int NR)
+{
+    __shared__ float4 red[kT];
+    const int t = threadIdx.x;
+    const int ql = t % QB, r = t / QB;
+    const int nqb = (cq + QB - 1) / QB;
+    const int qb = blockIdx.x % nqb;
+    int64_t pix = blockIdx.x / nqb;
+    const int iw = (int)(pix % W); pix /= W;
+    const int ih = (int)(pix % H);
+    const int b = (int)(pix / H);
+    const int q = qb * QB + ql;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < NR && q < cq) {
+        int h0, h1, w0, w1;
+        out_window(ih, H, Ho, sh, align, h0, h1);
+        out_window(iw, W, Wo, sw, align, w0, w1);
+        float ww[kMaxWin];
+        const int nw = w1 - w0 + 1;
+#pragma unroll
+        for (int k = 0; k < kMaxWin; ++k) {
+            float v = 0.0f;
+            if (k < nw) {
+                const Lerp lw = lerp_src(w0 + k, W, sw, align);
+                if (lw.i0 == iw) v += lw.l0;
+                if (lw.i1 == iw) v += lw.l1;
+            }
+            ww[k] = v;
+        }
+        for (int oh = h0 + r; oh <= h1; oh += NR) {
+            const Lerp lh = lerp_src(oh, H, sh, align);
+            float wh = 0.0f;
+            if (lh.i0 == ih) wh += lh.l0;
+            if (lh.i1 == ih) wh += lh.l1;
+            if (wh == 0.0f) continue;
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* base = dy + (((int64_t)b * Ho + oh) * Wo + w0) * lddy + q * 4;
+#pragma unroll
+            for (int k = 0; k < kMaxWin; ++k) {
+                const float wk = ww[k];
+                if (wk == 0.0f) continue;
+                const float4 g = *reinterpret_cast<const float4*>(base + (int64_t)k * lddy);
+                row.x = fmaf(wk, g.x, row.x); row.y = fmaf(wk, g.y, row.y); row.z = fmaf(wk, g.z, row.z); row.w = fmaf(wk, g.w, row.w);
+            }
+            acc.x = fmaf(wh, row.x, acc.x); acc.y = fmaf(wh, row.y, acc.y); acc.z = fmaf(wh, row.z, acc.z); acc.w = fmaf(wh, row.w, acc.w);
+        }
+    }
+    red[t] = acc;
+    __syncthreads();
+    if (r == 0 && q < cq) {
+        for (int k = 1; k < NR; ++k) {
+            const float4 a = red[k * QB + ql];
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4) = acc;
+    }
+}
+
+// dY in NCHW (the logits gradient, deeplab.py:55 / model.py:116) -> dX NHWC: one thread per (b, c, ih, iw) with iw
+// fastest, so neighbouring lanes read neighbouring windows of the SAME dY plane (the per-element form below walks
+// c fastest: every lane in a different plane, 4-byte accesses 512 KB apart).
+__global__ __launch_bounds__(kT) void bilinear_bwd_planes_kernel(const float* dy, int B, int Ho, int Wo, int C, float* dx,
+                                                                int64_t lddx, int H, int W, float sh, float sw, int align)
+{
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int iw = (int)(e % W);
+        int64_t t = e / W;
+        const int ih = (int)(t % H); t /= H;
+        const int c = (int)(t % C);
+        const int b = (int)(t / C);
+        int h0, h1, w0, w1;
+        out_window(ih, H, Ho, sh, align, h0, h1);
+        out_window(iw, W, Wo, sw, align, w0, w1);
+        float ww[kMaxWin];
+        const int nw = w1 - w0 + 1;
+#pragma unroll
+        for (int k = 0; k < kMaxWin; ++k) {
+            float v = 0.0f;
+            if (k < nw) {
+                const Lerp lw = lerp_src(w0 + k, W, sw, align);
+                if (lw.i0 == iw) v += lw.l0;
+                if (lw.i1 == iw) v += lw.l1;
+            }
+            ww[k] = v;
+        }
+        const float* plane = dy + ((int64_t)b * C + c) * Ho * Wo;
+        float acc = 0.0f;
+        for (int oh = h0; oh <= h1; ++oh) {
+            const Lerp lh = lerp_src(oh, H, sh, align);
+            float wh = 0.0f;
+            if (lh.i0 == ih) wh += lh.l0;
+            if (lh.i1 == ih) wh += lh.l1;
+            if (wh == 0.0f) continue;
+            const float* base = plane + (int64_t)oh * Wo + w0;
+            float row = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMaxWin; ++k) {
+                const float wk = ww[k];
+                if (wk == 0.0f) continue;
+                row = fmaf(wk, base[k], row);
+            }
+            acc = fmaf(wh, row, acc);
+        }
+        dx[(((int64_t)b * H + ih) * W + iw) * lddx + c] = acc;
+    }
+}
+
 template <bool DY_NCHW>
 __global__ __launch_bounds__(kT) void bilinear_bwd_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C,
                                                          float* dx, int64_t lddx, int H, int W, float sh, float sw,
@@ -1396,16 +1510,29 @@ int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C,
     float sh, sw;
     bil_scales(H, W, Ho, Wo, align_corners, scale_h, scale_w, sh, sw);
     hipStream_t st = as_stream(stream);
-    if (dy_nchw)
+    const bool win_ok = sh > 0.0f && sw > 0.0f && (int)(2.0f / sw) + 6 <= kMaxWin;   // candidate columns fit the weight table
+    if (dy_nchw && win_ok) {
+        hipLaunchKernelGGL(bilinear_bwd_planes_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, B, Ho, Wo, C,
+                           dx, lddx, H, W, sh, sw, align_corners);
+    } else if (dy_nchw) {
         hipLaunchKernelGGL((bilinear_bwd_kernel<true>), dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, lddy, B, Ho,
                            Wo, C, dx, lddx, H, W, sh, sw, align_corners);
-    else if (C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && sh > 0.0f && sw > 0.0f &&
-             (int)(2.0f / sw) + 6 <= kMaxWin)   // window of candidate output columns fits the per-thread weight table
-        hipLaunchKernelGGL(bilinear_bwd4_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(kT), 0, st, dy, lddy, B, Ho, Wo,
-                           C / 4, dx, lddx, H, W, sh, sw, align_corners);
-    else
+    } else if (C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && win_ok) {
+        const int cq = C / 4;
+        const int QB = cq >= 32 ? 32 : (cq >= 16 ? 16 : (cq >= 8 ? 8 : cq));
+        const int NR = kT / QB;
+        const int64_t nblk = (int64_t)B * H * W * cdiv(cq, QB);
+        const int hwin = (int)(2.0f / sh) + 6;
+        if (hwin >= 4 && nblk <= 0x7FFFFFFFll)
+            hipLaunchKernelGGL(bilinear_bwd4r_kernel, dim3((unsigned)nblk), dim3(kT), 0, st, dy, lddy, B, Ho, Wo, cq, dx, lddx, H, W,
+                               sh, sw, align_corners, QB, NR);
+        else
+            hipLaunchKernelGGL(bilinear_bwd4_kernel, dim3(grid_for((int64_t)B * H * W * cq)), dim3(kT), 0, st, dy, lddy, B, Ho, Wo,
+                               cq, dx, lddx, H, W, sh, sw, align_corners);
+    } else {
         hipLaunchKernelGGL((bilinear_bwd_kernel<false>), dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, lddy, B, Ho,
                            Wo, C, dx, lddx, H, W, sh, sw, align_corners);
+    }
     return check_launch("bilinear_bwd_kernel");
 }
 

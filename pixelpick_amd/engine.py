@@ -47,7 +47,7 @@ class Tape:
     # Weight-gradient kernels have no consumer until the optimiser step, and most layers of this network are too
     # small to fill 256 CUs on their own: in backward() they run on a second HIP stream, concurrently with the
     # data-gradient chain on the main stream (joined at the end of backward()).
-    overlap_wgrad = True
+    overlap_wgrad = os.environ.get("PIXELPICK_OVERLAP_WGRAD", "1") != "0"
     trace = None                       # debugging: a list collects (label, torch.cuda.Event) phase marks (tools/phase_times.py)
 
     def __init__(self, enabled: bool = True):
