@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--strategy", default="entropy")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "acq"])
+    ap.add_argument("--network", default="deeplab", choices=["deeplab", "FPN"],
+                    help="train leg: deeplab = DeepLabv3+-MobileNetV2 (BASELINE configs[1], the default line); FPN = the "
+                         "reference's ResNet50 model (networks/model.py FPNSeg, configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune-occ", type=int, default=0)
     ap.add_argument("--tune-ppt", type=int, default=0)
@@ -213,7 +216,9 @@ def main():
         torch.manual_seed(0)                         # identical replicas on every rank
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).to(dev).train()
+            model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=a.network,
+                                        weight_type="random", n_layers=50, use_softmax=True, use_dilated_resnet=True,
+                                        width_multiplier=1.0)).to(dev).train()
         tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-7, weight_decay=2e-4, ignore_index=C)
         E.set_dropout_seed(1234 + rank)
         x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
@@ -327,7 +332,9 @@ def main():
     if rank == 0:
         head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
-        wl = (f"BASELINE configs[1]: Cityscapes {H}x{W}, C={C}, DeepLabv3+-MobileNetV2; train step per-GPU batch "
+        net_desc = ("BASELINE configs[1]: Cityscapes {}x{}, C={}, DeepLabv3+-MobileNetV2" if a.network == "deeplab" else
+                    "BASELINE configs[2] (per GPU): Cityscapes {}x{}, C={}, ResNet50 model of the reference (FPNSeg)").format(H, W, C)
+        wl = (f"{net_desc}; train step per-GPU batch "
               f"{a.train_batch} with {a.n_labelled} labelled px/img + Adam; acquisition {a.strategy} top-k={k}, "
               f"B={a.batch} images/launch/GPU, {a.layout.upper()} fp32 logits")
         if train is not None:

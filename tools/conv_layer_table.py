@@ -15,7 +15,7 @@ def main():
     net = os.environ.get("NET", "deeplab")
     B, H, W, C = int(os.environ.get("B", 4)), 256, 512, 19
     args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=net, weight_type="random",
-                     n_layers=50, use_softmax=True)
+                     n_layers=50, use_softmax=True, use_dilated_resnet=True, width_multiplier=1.0)
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
