@@ -81,10 +81,12 @@ class Conv2d(nn.Module):
         elif bkey in state_dict and strict:
             unexpected_keys.append(bkey)
 
-    def run(self, tape, x, dst=None):
+    def run(self, tape, x, dst=None, extra_pad: int = 0):
+        """extra_pad: zero padding applied to x in front of this convolution (F.pad(x, extra_pad) then conv), folded
+        into the kernel's own bounds handling instead of materialising the padded tensor."""
         if self.depthwise:
-            return E.dwconv3x3(tape, x, self.weight, self.stride, self.padding, self.dilation)
-        return E.conv2d(tape, x, self.weight, self.bias, self.stride, self.padding, self.dilation, dst=dst)
+            return E.dwconv3x3(tape, x, self.weight, self.stride, self.padding + extra_pad, self.dilation)
+        return E.conv2d(tape, x, self.weight, self.bias, self.stride, self.padding + extra_pad, self.dilation, dst=dst)
 
     def forward(self, x):
         raise RuntimeError("pixelpick_amd layers execute through run(tape, x); call the network's forward()")

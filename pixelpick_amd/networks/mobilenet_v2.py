@@ -15,6 +15,9 @@ from .. import engine as E
 from .layers import BatchNorm2d, Conv2d, ReLU6
 
 
+FOLD_FIXED_PADDING = os.environ.get("PIXELPICK_FOLD_PAD", "1") != "0"
+
+
 def conv_bn(inp, oup, stride, BatchNorm):
     """mobilenet_v2.py:7-12."""
     return nn.Sequential(Conv2d(inp, oup, 3, stride, 1, bias=False), BatchNorm(oup), ReLU6(inplace=True))
@@ -28,15 +31,16 @@ def fixed_padding_amounts(kernel_size, dilation):
     return pad_beg, pad_total - pad_beg
 
 
-def _run_conv_bn_act_chain(tape, seq, x, residual=None):
-    """Execute an nn.Sequential of [Conv2d, BatchNorm2d, (ReLU6)] groups; the last BN may take a residual."""
+def _run_conv_bn_act_chain(tape, seq, x, residual=None, first_pad=0):
+    """Execute an nn.Sequential of [Conv2d, BatchNorm2d, (ReLU6)] groups; the last BN may take a residual.
+    first_pad: zero padding of x folded into the first convolution."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         conv, bn = mods[i], mods[i + 1]
         has_act = i + 2 < len(mods) and isinstance(mods[i + 2], ReLU6)
         is_last = (i + (3 if has_act else 2)) >= len(mods)
-        x = conv.run(tape, x)
+        x = conv.run(tape, x, extra_pad=first_pad if i == 0 else 0)
         x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None)
         i += 3 if has_act else 2
     return x
@@ -63,8 +67,14 @@ class InvertedResidual(nn.Module):
 
     def run(self, tape, x):
         pad_beg, pad_end = fixed_padding_amounts(self.kernel_size, self.dilation)
+        res = x if self.use_res_connect else None
+        if FOLD_FIXED_PADDING and pad_beg == pad_end:
+            # F.pad(x) followed by a bias-free 1x1 conv (or the depthwise 3x3 of the t=1 block) is that convolution
+            # with padding=pad: the border outputs are the same zeros, the BN statistics over the padded map too,
+            # and neither the padded copy (forward) nor its cropped gradient (backward) is materialised.
+            return _run_conv_bn_act_chain(tape, self.conv, x, residual=res, first_pad=pad_beg)
         x_pad = E.pad2d(tape, x, pad_beg, pad_end)
-        return _run_conv_bn_act_chain(tape, self.conv, x_pad, residual=x if self.use_res_connect else None)
+        return _run_conv_bn_act_chain(tape, self.conv, x_pad, residual=res)
 
 
 class MobileNetV2(nn.Module):
