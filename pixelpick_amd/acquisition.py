@@ -5,6 +5,7 @@ include/pixelpick_hip.h calls; all arithmetic runs in the hand-written HIP kerne
 """
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -26,11 +27,15 @@ def _require_cuda_f32(t: torch.Tensor, name: str, ndim: int):
 def _exclude_u8(exclude, B, H, W, device):
     if exclude is None:
         return None
+    if isinstance(exclude, np.ndarray):
+        exclude = np.ascontiguousarray(exclude)       # also resolves negative strides (flipped views)
     ex = torch.as_tensor(exclude)
     if ex.dtype == torch.bool:
-        ex = ex.to(torch.uint8)
+        # reinterpret, do not convert: a torch CPU op on a 131 K-element mask costs milliseconds on a many-core host
+        # (OpenMP fork/join per op) - it was 90 % of the per-image time of an acquisition round
+        ex = ex.contiguous().view(torch.uint8)
     elif ex.dtype != torch.uint8:
-        ex = (ex != 0).to(torch.uint8)
+        ex = (ex != 0).contiguous().view(torch.uint8)
     ex = ex.to(device, non_blocking=True).reshape(B, H, W).contiguous()
     return ex
 

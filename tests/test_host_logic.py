@@ -137,3 +137,17 @@ def test_query_stats_host_part_matches_reference(golden_dir):
     np.testing.assert_array_equal(cnt, g[f"{st}_stats_label_cnt"])
     assert np.isclose(np.mean(qs.list_n_unique_labels), float(g[f"{st}_stats_avg_n_unique"]))
     assert np.isclose(np.mean(qs.list_spatial_coverage), float(g[f"{st}_stats_avg_cov"]))
+
+
+def test_exclusion_mask_is_reinterpreted_not_converted():
+    """acquisition._exclude_u8: bool masks (numpy or torch) become uint8 by a zero-copy view; other dtypes by != 0."""
+    import torch
+    from pixelpick_amd import acquisition as acq
+    rng = np.random.RandomState(0)
+    m = rng.rand(2, 5, 7) < 0.3
+    for src in (m, torch.from_numpy(m), torch.from_numpy(m.astype(np.int64) * 3), m[:, ::-1, :], torch.from_numpy(m.astype(np.uint8))):
+        want = np.asarray(src if isinstance(src, np.ndarray) else src.numpy()) != 0
+        got = acq._exclude_u8(src, 2, 5, 7, torch.device("cpu"))
+        assert got.dtype == torch.uint8 and tuple(got.shape) == (2, 5, 7)
+        np.testing.assert_array_equal(got.numpy(), want.astype(np.uint8))
+    assert acq._exclude_u8(None, 2, 5, 7, torch.device("cpu")) is None
