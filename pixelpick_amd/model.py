@@ -36,6 +36,12 @@ def write_log(fp, list_entities=None, header=None):
 
 class Model:
     def __init__(self, args, dataloader, dataloader_query, dataloader_val, device=None):
+        # Host threads: every remaining torch CPU op in the loop (DataLoader collate = torch.stack of 11 MB per batch)
+        # forks torch's intra-op pool, whose workers then spin; with the default of one thread per core (128 on the
+        # MI355X hosts) the main thread that feeds the GPU is starved: measured 98 images/s through this driver vs
+        # 496 with <= 8 threads (tools/driver_bench.py).  The GPU path needs no CPU parallelism; OMP_NUM_THREADS wins.
+        if "OMP_NUM_THREADS" not in os.environ and torch.get_num_threads() > 8:
+            torch.set_num_threads(8)
         self.args = args
         self.best_miou = -1.0
         self.dataset_name = args.dataset_name
@@ -93,9 +99,10 @@ class Model:
         for it, dict_data in enumerate(self.dataloader):
             x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
             if self.n_pixels_by_us != 0:                                   # model.py:108-110
-                mask = dict_data['queries'].to(self.device, torch.bool)
-                y = y.clone()
-                y.flatten()[~mask.flatten()] = self.ignore_index
+                mask = dict_data['queries'].to(self.device).view(y.shape)
+                # same values as `y.flatten()[~mask.flatten()] = ignore_index`, without the nonzero() + host sync
+                # that boolean-index assignment performs on every step
+                y = torch.where(mask != 0, y, torch.full_like(y, self.ignore_index))
             if self.lr_scheduler_type == "Poly":                           # per-iteration poly decay (lr_scheduler.py:15-17)
                 trainer.set_poly_lr((epoch - 1) * len(self.dataloader) + it, n_iters_total)
             tape_pred = trainer.train_step(x, y, keep_logits=True)
