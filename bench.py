@@ -352,16 +352,32 @@ def main():
             out["acquisition"] = acqr
         out.update(line)
         if world == 1 and not a.no_cpu_baseline:
-            cb = {"kind": "port", "cores": torch.get_num_threads()}
+            # torch's default of one intra-op thread per core (128 here) is the WORST setting for these ops on this
+            # host (fork/join dominates: 0.96 img/s and 15 Mpix/s vs 5.7 and 146 at 16 threads, measured round 1), so the
+            # port is timed at a few thread counts and the best one is the baseline; `cores` = the threads it used.
+            default_threads = torch.get_num_threads()
+            cands = sorted({t for t in (8, 16, 32) if t <= default_threads} | {min(default_threads, 16)})
+            cb = {"kind": "port", "threads_tried": cands, "torch_default_threads": default_threads}
             if train is not None:
-                v, sample, thr = cpu_baseline_train(a.train_batch, C, H, W, a.n_labelled)
-                cb.update({"value": v, "unit": "images/s", "sample": sample})
+                best = None
+                for t in cands:
+                    torch.set_num_threads(t)
+                    v, sample, thr = cpu_baseline_train(a.train_batch, C, H, W, a.n_labelled, budget_s=5.0)
+                    if best is None or v > best[0]:
+                        best = (v, sample, t)
+                cb.update({"value": best[0], "unit": "images/s", "sample": best[1], "cores": best[2]})
             if acqr is not None:
-                v, sample = cpu_baseline_acq(C, H, W, k, a.strategy)
+                best = None
+                for t in cands:
+                    torch.set_num_threads(t)
+                    v, sample = cpu_baseline_acq(C, H, W, k, a.strategy, budget_s=2.5)
+                    if best is None or v > best[0]:
+                        best = (v, sample + f", {t} threads", t)
                 if train is None:
-                    cb.update({"value": v, "unit": "Mpixels/s", "sample": sample})
+                    cb.update({"value": best[0], "unit": "Mpixels/s", "sample": best[1], "cores": best[2]})
                 else:
-                    cb["acquisition"] = {"value": v, "unit": "Mpixels/s", "sample": sample}
+                    cb["acquisition"] = {"value": best[0], "unit": "Mpixels/s", "sample": best[1], "cores": best[2]}
+            torch.set_num_threads(default_threads)
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
 

@@ -52,7 +52,8 @@ class QuerySelector:
         self.vote_type = args.vote_type
         # not in the reference: images of equal size are forwarded `query_batch_size` at a time (the reference's
         # query loader has batch_size 1, model.py:36-37; in eval mode the per-image results do not depend on the batch)
-        self.query_batch_size = int(getattr(args, "query_batch_size", 1))
+        # Default 8: identical picks (tested), 385 -> ~1500 images/s for an acquisition round on MI355X (tools/query_bench.py)
+        self.query_batch_size = int(getattr(args, "query_batch_size", 8))
 
     # ------------------------------------------------------------------ selection (query.py:33-69)
     @property
@@ -71,12 +72,16 @@ class QuerySelector:
         sampling_mask[ind] = True
         return sampling_mask
 
-    def _finish_selection(self, ind_sorted: np.ndarray, h: int, w: int) -> np.ndarray:
-        """query.py:63-68: optional random subsample of the value-sorted top-k, then bool mask."""
+    def _choose(self, ind_sorted: np.ndarray) -> np.ndarray:
+        """query.py:63-64: optional random subsample (numpy global RNG) of the value-sorted top-k -> flat indices."""
         if (not self.reverse_order) and self.top_n_percent > 0.:
             ind_sorted = np.random.choice(ind_sorted, self.n_pixels_by_us, False)
+        return ind_sorted
+
+    def _finish_selection(self, ind_sorted: np.ndarray, h: int, w: int) -> np.ndarray:
+        """query.py:63-68: optional random subsample of the value-sorted top-k, then bool mask."""
         query = np.zeros(h * w, dtype=np.bool_)
-        query[ind_sorted] = True
+        query[self._choose(ind_sorted)] = True
         return query.reshape(h, w)
 
     def _select_queries(self, uc_map) -> np.ndarray:
@@ -163,6 +168,44 @@ class QuerySelector:
             logits_b = None
             if not self.use_mc_dropout:
                 logits_b = model(xs)["pred"]
+            sizes = {it[4] for it in pending}
+            if not self.use_mc_dropout and len(sizes) == 1:
+                # one scoring launch, one index read-back and one entropy read-back for the whole batch
+                (h, w), = sizes
+                excl = np.stack([it[2] for it in pending])
+                if self.reverse_order:
+                    for j in range(len(pending)):           # RNG draws in image order, as the per-image loop
+                        excl[j] |= ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
+                    k = self.n_pixels_by_us
+                else:
+                    k = self._k_topk(h, w)
+                lg = logits_b[:, :, :h, :w]
+                idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, k)
+                idx_h = idx.cpu().numpy().astype(np.int64)
+                chosen = [np.sort(self._choose(idx_h[j])) for j in range(len(pending))]
+                want_stats = (not human_labels) and all(it[1] is not None for it in pending)
+                ent_all = None
+                if want_stats:
+                    flat = np.concatenate(chosen)
+                    img = np.repeat(np.arange(len(pending)), [len(c) for c in chosen])
+                    dev = lg.device
+                    picked = lg[torch.from_numpy(img).to(dev), :, torch.from_numpy(flat // w).to(dev), torch.from_numpy(flat % w).to(dev)]
+                    ent_all = acq.score_map(picked.t().reshape(1, picked.shape[1], 1, -1).contiguous(), None, "entropy").reshape(-1).cpu().numpy()
+                off = 0
+                for j, (x1, yj, exclude, p_img, _) in enumerate(pending):
+                    sel = chosen[j]
+                    query = np.zeros(h * w, dtype=np.bool_)
+                    query[sel] = True
+                    query = query.reshape(h, w)
+                    list_queries.append(query)
+                    n_pixels += len(sel)
+                    if want_stats:
+                        self.query_stats.update_from_picked(query, yj, ent_all[off:off + len(sel)].tolist(), coords=(sel // w, sel % w))
+                        off += len(sel)
+                    # encode_query(p_img, size, query) without re-scanning the mask: the sorted flat indices ARE np.nonzero order
+                    dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
+                pending.clear()
+                return
             for j, (x1, yj, exclude, p_img, (h, w)) in enumerate(pending):
                 if self.use_mc_dropout:
                     # mean uncertainty / mean probability over mc_n_steps stochastic passes
@@ -263,8 +306,8 @@ class QueryStats:
         self.list_entropy, self.list_n_unique_labels, self.list_spatial_coverage = list(), list(), list()
         self.dict_label_cnt = {l: 0 for l in range(args.n_classes)}
 
-    def _count_labels(self, query, y):
-        for l in y.flatten()[query.flatten()]:
+    def _count_labels(self, query, y, coords=None):
+        for l in (y[coords] if coords is not None else y.flatten()[query.flatten()]):
             self.dict_label_cnt[l] += 1
 
     @staticmethod
@@ -284,12 +327,12 @@ class QueryStats:
         return ent.reshape(-1).cpu().numpy().tolist()
 
     @staticmethod
-    def _n_unique_labels(query, y):
-        return len(set(y.flatten()[query.flatten()]))
+    def _n_unique_labels(query, y, coords=None):
+        return len(set(y[coords] if coords is not None else y.flatten()[query.flatten()]))
 
     @staticmethod
-    def _spatial_coverage(query):
-        a, b = np.nonzero(query)
+    def _spatial_coverage(query, coords=None):
+        a, b = coords if coords is not None else np.nonzero(query)
         n = a.shape[0]
         if n < 2:
             return np.nan
@@ -310,12 +353,13 @@ class QueryStats:
         with open(f"{self.dir_checkpoints}/{nth_query}_query/query_stats.pkl", "wb") as f:
             pkl.dump(dict_stats, f)
 
-    def update_from_picked(self, query, y, pixel_entropy):
-        """Host-only part of update(): everything except the entropy evaluation."""
-        self._count_labels(query, y)
+    def update_from_picked(self, query, y, pixel_entropy, coords=None):
+        """Host-only part of update(): everything except the entropy evaluation.  coords = (rows, cols) of the picked
+        pixels in row-major order, when the caller already has them (saves three scans of the mask)."""
+        self._count_labels(query, y, coords)
         self.list_entropy.extend(pixel_entropy)
-        self.list_n_unique_labels.append(self._n_unique_labels(query, y))
-        self.list_spatial_coverage.append(self._spatial_coverage(query))
+        self.list_n_unique_labels.append(self._n_unique_labels(query, y, coords))
+        self.list_spatial_coverage.append(self._spatial_coverage(query, coords))
 
     def update(self, query, y, prob):
         self.update_from_picked(query, y, self._get_entropy(query, prob))
