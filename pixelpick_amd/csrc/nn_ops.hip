@@ -1523,7 +1523,9 @@ int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C,
         const int NR = kT / QB;
         const int64_t nblk = (int64_t)B * H * W * cdiv(cq, QB);
         const int hwin = (int)(2.0f / sh) + 6;
-        if (hwin >= 4 && nblk <= 0x7FFFFFFFll)
+        // row-split pays when the one-thread-per-(pixel, 4 channels) grid cannot fill the chip (ASPP x4 upsample: 131 K
+        // threads); on the FPN decoder's x2 upsamples at 128x256 (1 M+ threads, 4-row windows) it is 3x slower
+        if (hwin >= 4 && (int64_t)B * H * W * cq <= (1 << 19))
             hipLaunchKernelGGL(bilinear_bwd4r_kernel, dim3((unsigned)nblk), dim3(kT), 0, st, dy, lddy, B, Ho, Wo, cq, dx, lddx, H, W,
                                sh, sw, align_corners, QB, NR);
         else

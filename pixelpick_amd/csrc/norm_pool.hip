@@ -92,6 +92,36 @@ __global__ __launch_bounds__(kTN) void gn_partial_kernel(const float* x, int64_t
     }
 }
 
+// Row-block partials [B][nblk][2][C] -> [B][1][2][C]: 32 lanes per output add blocks l, l+32, .. in fp64, then a fixed
+// LDS tree (deterministic).  The per-(image, group) / per-channel combines below then see nblk == 1; walking up to
+// 256 row blocks serially in ONE thread per group made them the slowest kernels of the FPN step (305 / 112 us).
+__global__ __launch_bounds__(kTN) void gn_reduce_blocks_kernel(const float* part, int nblk, int C2 /* 2*C */, int64_t nout,
+                                                               float* red)
+{
+    __shared__ double sh[kTN];
+    const int t = threadIdx.x, lane = t >> 3;
+    const int64_t o = (int64_t)blockIdx.x * 8 + (t & 7);          // output index in [B][2C]
+    double s = 0.0;
+    if (o < nout) {
+        const int64_t b = o / C2, j = o - b * C2;
+        const float* p = part + b * nblk * C2 + j;
+        int k = lane;
+        for (; k + 96 < nblk; k += 128) {
+            const float v0 = p[(int64_t)k * C2], v1 = p[(int64_t)(k + 32) * C2];
+            const float v2 = p[(int64_t)(k + 64) * C2], v3 = p[(int64_t)(k + 96) * C2];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; k < nblk; k += 32) s += (double)p[(int64_t)k * C2];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (t < off) sh[t] += sh[t + off];
+        __syncthreads();
+    }
+    if (t < 8 && o < nout) red[o] = (float)sh[t];
+}
+
 // one thread per (image, group): fixed-order fp64 combine over row blocks and the group's channels
 __global__ __launch_bounds__(kTN) void gn_stats_kernel(const float* part, int B, int nblk, int C, int G, double count,
                                                        float eps, float* mean, float* rstd)
@@ -291,7 +321,7 @@ size_t pp_groupnorm_workspace_bytes(int B, int64_t P, int C)
 {
     if (B < 1 || P < 1 || C < 4) return 256;
     GnGeom g = gn_geom(P, C, B);
-    return align_up((size_t)B * g.nblk_rows * 2 * C * 4 + (size_t)2 * B * C * 4, 256);
+    return align_up((size_t)B * g.nblk_rows * 2 * C * 4 + (size_t)2 * B * C * 4 + (size_t)2 * B * C * 4, 256);
 }
 
 int pp_groupnorm_relu_fwd(const float* x, int64_t ldx, int B, int64_t P, int C, int G, const float* gamma, const float* beta,
@@ -307,7 +337,11 @@ int pp_groupnorm_relu_fwd(const float* x, int64_t ldx, int B, int64_t P, int C, 
     hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(g.nblk_rows, g.nblk_cols, B), dim3(kTN), 0, st, x, ldx, (const float*)nullptr,
                        (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, P, C, G, g, part);
     if (int rc = check_launch("gn_partial_kernel<0>")) return rc;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)cdiv(B * G, kTN)), dim3(kTN), 0, st, part, B, g.nblk_rows, C, G,
+    float* red = part + (size_t)B * g.nblk_rows * 2 * C + (size_t)2 * B * C;
+    const int64_t nout = (int64_t)B * 2 * C;
+    hipLaunchKernelGGL(gn_reduce_blocks_kernel, dim3((unsigned)cdiv(nout, 8)), dim3(kTN), 0, st, part, g.nblk_rows, 2 * C, nout, red);
+    if (int rc = check_launch("gn_reduce_blocks_kernel")) return rc;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)cdiv(B * G, kTN)), dim3(kTN), 0, st, red, B, 1, C, G,
                        (double)P * (C / G), eps, mean, rstd);
     if (int rc = check_launch("gn_stats_kernel")) return rc;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gridn((int64_t)B * P * (C / 4))), dim3(kTN), 0, st, x, ldx, mean, rstd, gamma, beta,
@@ -330,8 +364,12 @@ int pp_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
     hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(g.nblk_rows, g.nblk_cols, B), dim3(kTN), 0, st, x, ldx, dy, lddy, y, ldy, mean,
                        rstd, P, C, G, g, part);
     if (int rc = check_launch("gn_partial_kernel<1>")) return rc;
+    float* red = s2 + (size_t)B * C;
+    const int64_t nout = (int64_t)B * 2 * C;
+    hipLaunchKernelGGL(gn_reduce_blocks_kernel, dim3((unsigned)cdiv(nout, 8)), dim3(kTN), 0, st, part, g.nblk_rows, 2 * C, nout, red);
+    if (int rc = check_launch("gn_reduce_blocks_kernel")) return rc;
     const int n = C > B * G ? C : B * G;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((unsigned)cdiv(n, kTN)), dim3(kTN), 0, st, part, B, g.nblk_rows, C, G, gamma,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((unsigned)cdiv(n, kTN)), dim3(kTN), 0, st, red, B, 1, C, G, gamma,
                        dgamma, dbeta, s1, s2);
     if (int rc = check_launch("gn_bwd_stats_kernel")) return rc;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gridn((int64_t)B * P * (C / 4))), dim3(kTN), 0, st, x, ldx, dy, lddy, y, ldy, mean,
