@@ -137,19 +137,38 @@ class Model:
     @torch.no_grad()
     def _val(self, epoch, model):
         model.eval()
+        # The reference validates one image per forward (val loader batch_size 1, model.py:36-37).  In eval mode the
+        # result per image does not depend on the batch, and at B=1 the forward is launch-bound (1.9 ms for ~200
+        # launches), so consecutive images of equal size are forwarded `val_batch_size` at a time (default 8).
+        vbs = int(getattr(self.args, "val_batch_size", 8))
+        pend_x, pend_y = [], []
+
+        def flush():
+            if not pend_x:
+                return
+            xs, ys = torch.cat(pend_x, dim=0), torch.cat(pend_y, dim=0)
+            if self.dataset_name == "voc":
+                h, w = ys.shape[1:]
+                pad_h = ceil(h / self.stride_total) * self.stride_total - xs.shape[2]
+                pad_w = ceil(w / self.stride_total) * self.stride_total - xs.shape[3]
+                xs = F.pad(xs, pad=(0, pad_w, 0, pad_h), mode='reflect')
+                logits = model(xs)['pred'][:, :, :h, :w].contiguous()
+            else:
+                logits = model(xs)['pred']
+            self.running_score.update_from_logits(ys, logits)
+            pend_x.clear()
+            pend_y.clear()
+
         for dict_data in self.dataloader_val:
             x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
-            if self.dataset_name == "voc":
-                h, w = y.shape[1:]
-                pad_h = ceil(h / self.stride_total) * self.stride_total - x.shape[2]
-                pad_w = ceil(w / self.stride_total) * self.stride_total - x.shape[3]
-                x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
-                logits = model(x)['pred'][:, :, :h, :w].contiguous()
-            else:
-                logits = model(x)['pred']
-            self.running_score.update_from_logits(y, logits)
+            if pend_x and (pend_x[0].shape[1:] != x.shape[1:] or pend_y[0].shape[1:] != y.shape[1:]
+                           or sum(t.shape[0] for t in pend_x) + x.shape[0] > vbs):
+                flush()
+            pend_x.append(x)
+            pend_y.append(y)
             if self.debug:
                 break
+        flush()
         scores = self.running_score.get_scores()[0]
         miou, pixel_acc = scores['Mean IoU'], scores['Pixel Acc']
         if miou > self.best_miou:

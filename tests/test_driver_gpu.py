@@ -70,3 +70,39 @@ def test_active_learning_rounds_on_synthetic_data(tmp_path):
     assert all(np.isfinite(l) for l in losses)
     sd = torch.load(tmp_path / "checkpoints" / "synthetic" / "2_query" / "best_miou_model.pt")["model"]
     assert len(sd) == 668
+
+
+def test_validation_batched_equals_per_image(tmp_path):
+    """Model._val forwards equal-sized images val_batch_size at a time; eval-mode results per image do not depend on
+    the batch, so the confusion matrix (and mIoU) match the reference's one-image-per-forward loop."""
+    import warnings
+    from pixelpick_amd.utils.utils import get_model
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    ds = SyntheticDataset(4, 64, 96, 5, 5, n_init_pixels=10, seed=1)
+    ds_val = SyntheticDataset(11, 64, 96, 5, 5, seed=2)
+    mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
+    res = []
+    model = None
+    for vbs in (1, 4, 8):
+        args = _args(str(tmp_path / f"v{vbs}"), val_batch_size=vbs)
+        m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device(DEV))
+        m.nth_query = 0
+        os.makedirs(f"{m.dir_checkpoints}/0_query", exist_ok=True)
+        m._open_logs(f"{m.dir_checkpoints}/0_query")
+        if model is None:
+            model = get_model(args).to(DEV)
+        cm = []
+        orig = m.running_score.get_scores
+
+        def spy():
+            out = orig()                                   # pulls the device-side matrix to the host
+            cm.append(np.array(m.running_score.confusion_matrix, copy=True))
+            return out
+        m.running_score.get_scores = spy
+        m._val(1, model)
+        res.append((cm[0], m.history[-1][3], m.history[-1][4]))
+    for cmx, miou, acc in res[1:]:
+        assert cmx.sum() == res[0][0].sum() == 11 * 64 * 96 - int(sum((y == 5).sum() for y in ds_val.ys))
+        assert np.abs(cmx - res[0][0]).sum() <= 4          # a near-tie argmax may flip with the summation order
+        assert abs(miou - res[0][1]) < 1e-3 and abs(acc - res[0][2]) < 1e-3
