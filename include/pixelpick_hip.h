@@ -109,6 +109,16 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
                   int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
                   size_t ws_bytes, pp_stream_t stream);
 
+/* Inference form of Conv2d -> BatchNorm2d(eval) [-> + residual] -> ReLU/ReLU6 in ONE launch (mobilenet_v2.py:7-12,
+ * 36-57; aspp.py:9-20; decoders.py:107-113; resnet_models.py:71-92): the epilogue folds scale = gamma/sqrt(running_var+eps),
+ * shift = beta - running_mean*scale with the arithmetic of pp_bn_eval_affine + pp_scale_shift_act (bit-identical results).
+ * gamma == NULL: no BatchNorm (bias / residual / activation only).  act: 0 none, 1 ReLU, 2 ReLU6. */
+int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                         int kh, int kw, int stride, int pad, int dil, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps, const float* residual,
+                         int64_t ldr, int act, float* y, int64_t ldy, int Cout, void* workspace, size_t ws_bytes,
+                         pp_stream_t stream);
+
 /* dL/dx of the above (what autograd computes at model.py:121); any stride (the stride-2 Bottleneck convs of
  * backbones/resnet_models.py:63-64,142-144 gather dY rows where (row + pad - tap*dil) is divisible by the stride).
  * B,H,W,Cin describe the conv INPUT for the workspace query. */
@@ -137,7 +147,11 @@ int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* 
 /* The same BatchNorm2d training forward INCLUDING the apply (+ residual, + activation) in ONE launch
  * (column strips x row chunks, a per-strip arrival counter instead of two more launches; see nn_ops.hip).
  * `sync` is an int32 array of pp_bn_fused_sync_ints(C) zeros: every launch leaves it zeroed again, and it
- * must not be shared by launches that can run concurrently.  Results are deterministic. */
+ * must not be shared by launches that can run concurrently.  Results are deterministic.
+ * BOTH `workspace` and `sync` MUST be FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)):
+ * blocks on different XCDs exchange partial sums through them inside one launch, and the XCD L2s are not coherent
+ * with each other for ordinary allocations (a stale partial was observed with ordinary memory; pixelpick_amd/engine.py
+ * `_bn_exchange` allocates the area once per device). */
 size_t pp_bn_fused_workspace_bytes(int64_t M, int C);
 size_t pp_bn_fused_sync_ints(int C);
 int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
@@ -170,6 +184,13 @@ int pp_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const 
  * H, W are always the INPUT spatial size. */
 int pp_dwconv3x3_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
                      float* y, int64_t ldy, pp_stream_t stream);
+
+/* Inference form of the depthwise 3x3 -> BatchNorm2d(eval) -> ReLU6 (mobilenet_v2.py:38-40,52-54) in one launch;
+ * same epilogue contract as pp_conv2d_fwd_bn_act. */
+int pp_dwconv3x3_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad,
+                            int dil, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, const float* residual, int64_t ldr, int act, float* y,
+                            int64_t ldy, pp_stream_t stream);
 int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, int C, const float* w, int stride, int pad,
                           int dil, float* dx, int64_t lddx, pp_stream_t stream);
 int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,

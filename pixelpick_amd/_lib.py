@@ -27,6 +27,9 @@ SIGNATURES = {
     "pp_conv2d_fwd_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_data_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p]),
+    "pp_conv2d_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int,
+                                    _p, _i64, _int, _p, _sz, _p]),
+    "pp_dwconv3x3_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int, _p, _i64, _p]),
     "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_weight_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p]),

@@ -60,6 +60,7 @@ struct ConvParams {
     int splits;       // split-K: grid.y slices of the (tap, channel-chunk) loop; > 1 -> partial sums go to `part`
     int ks_per_split;
     float* part;      // [splits][M][Cn] partial outputs (no bias)
+    Epilogue epi;     // inference only: folded BatchNorm + residual + activation (all NULL / 0 in training)
     ConvTaps taps;
 };
 
@@ -369,7 +370,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + (wn * TN + tn) * 32 + l31;
         if (n >= p.Cn) continue;
-        const float bv = (p.bias && p.splits <= 1) ? p.bias[n] : 0.0f;
+        const bool final_pass = p.splits <= 1;
+        const float bv = (p.bias && final_pass) ? p.bias[n] : 0.0f;
+        const bool affine = final_pass && p.epi.gamma != nullptr;
+        float sc = 1.0f, sf = 0.0f;
+        if (affine) {
+            const float is = 1.0f / sqrtf(p.epi.var[n] + p.epi.eps);
+            sc = p.epi.gamma[n] * is;
+            sf = p.epi.beta[n] - p.epi.mean[n] * sc;
+        }
+        const float* res = final_pass ? p.epi.res : nullptr;
+        const int act = final_pass ? p.epi.act : 0;
         float* out = p.splits > 1 ? p.part + (int64_t)blockIdx.y * p.M * p.Cn : p.y;
         const int64_t ldo = p.splits > 1 ? (int64_t)p.Cn : p.ldy;
 #pragma unroll
@@ -377,18 +388,24 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m < p.M) out[m * ldo + n] = acc[tm][tn][r] + bv;
+                if (m < p.M) {
+                    float o = acc[tm][tn][r] + bv;
+                    if (affine) o = fmaf(o, sc, sf);
+                    if (res) o += res[m * p.epi.ldr + n];
+                    out[m * ldo + n] = epi_act(o, act);
+                }
             }
         }
     }
 }
 
-// split-K second stage: y[m][n] = bias[n] + sum_z part[z][m][n], z in fixed order (deterministic)
+// split-K second stage: y[m][n] = epilogue(bias[n] + sum_z part[z][m][n]), z in fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int splits, int64_t M, int Cn,
-                                                            const float* bias, float* y, int64_t ldy)
+                                                            const float* bias, float* y, int64_t ldy, Epilogue epi)
 {
     const int64_t MN = M * Cn;
-    if ((Cn & 3) == 0 && (ldy & 3) == 0) {
+    if ((Cn & 3) == 0 && (ldy & 3) == 0 && epi.gamma == nullptr && epi.res == nullptr && epi.act == 0) {
+        // training form (bias only): 16-byte accesses
         const int cq = Cn >> 2;
         const int64_t total = M * cq;
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -396,23 +413,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
             const int q = (int)(e - m * cq);
             float4 s = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float* src = part + m * Cn + q * 4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int z = 0; z < splits; ++z) {
                 const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)z * MN);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             *reinterpret_cast<float4*>(y + m * ldy + q * 4) = s;
         }
-    } else {
-        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < MN; e += (int64_t)gridDim.x * 256) {
-            const int64_t m = e / Cn;
-            const int n = (int)(e - m * Cn);
-            float s = bias ? bias[n] : 0.0f;
-            for (int z = 0; z < splits; ++z) s += part[(int64_t)z * MN + e];
-            y[m * ldy + n] = s;
+        return;
+    }
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < MN; e += (int64_t)gridDim.x * 256) {
+        const int64_t m = e / Cn;
+        const int n = (int)(e - m * Cn);
+        float s = 0.0f;
+        for (int z = 0; z < splits; ++z) s += part[(int64_t)z * MN + e];
+        if (bias) s += bias[n];
+        if (epi.gamma) {
+            const float is = 1.0f / sqrtf(epi.var[n] + epi.eps);
+            const float sc = epi.gamma[n] * is;
+            s = fmaf(s, sc, epi.beta[n] - epi.mean[n] * sc);
         }
+        if (epi.res) s += epi.res[m * epi.ldr + n];
+        y[m * ldy + n] = epi_act(s, epi.act);
     }
 }
-
 
 // ---- weight gradient ---------------------------------------------------------------------------------------
 // GEMM rows = Cin (c), cols = Cout (n), reduction = output pixels m of one split; one tap per blockIdx.z/..
@@ -766,10 +791,11 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     }
     if (int rc = check_launch("conv_igemm_kernel")) return rc;
     if (pl.splits > 1) {
-        int64_t nb = cdiv(p.M * cdiv(p.Cn, 4), 256);
-        if (nb > 4096) nb = 4096;
+        const bool plain = p.epi.gamma == nullptr && p.epi.res == nullptr && p.epi.act == 0 && p.Cn % 4 == 0 && p.ldy % 4 == 0;
+        int64_t nb = cdiv(plain ? p.M * (p.Cn / 4) : p.M * p.Cn, 256);
+        if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p.part, pl.splits, p.M, p.Cn, p.bias,
-                           p.y, p.ldy);
+                           p.y, p.ldy, p.epi);
         return check_launch("splitk_reduce_kernel");
     }
     return PP_OK;
@@ -828,9 +854,9 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
 }
 
-int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
-                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
-                  size_t ws_bytes, pp_stream_t stream)
+static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                           int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, const Epilogue& epi,
+                           void* workspace, size_t ws_bytes, pp_stream_t stream)
 {
     if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
@@ -840,10 +866,31 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldx = ldx; p.ldy = ldy;
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Ck = Cin; p.Cn = Cout; p.Cin = Cin; p.Cout = Cout;
     p.stride = stride; p.M = (int64_t)B * Ho * Wo; p.bwd_stride = 1;
+    p.epi = epi;
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
     return launch_conv<false>(p, workspace, ws_bytes, as_stream(stream));
+}
+
+int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                  int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                  size_t ws_bytes, pp_stream_t stream)
+{
+    return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
+                           ws_bytes, stream);
+}
+
+int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                         int kh, int kw, int stride, int pad, int dil, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps, const float* residual,
+                         int64_t ldr, int act, float* y, int64_t ldy, int Cout, void* workspace, size_t ws_bytes,
+                         pp_stream_t stream)
+{
+    if (gamma && (!beta || !running_mean || !running_var)) return fail(PP_ERR_BAD_ARG, "conv fwd_bn_act: incomplete BatchNorm");
+    if (act < 0 || act > 2) return fail(PP_ERR_BAD_ARG, "conv fwd_bn_act: act %d", act);
+    Epilogue e{gamma, beta, running_mean, running_var, eps, residual, ldr, act};
+    return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, e, workspace, ws_bytes, stream);
 }
 
 int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
 // ================================================================================================
 __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
                                                        const float* w, int stride, int pad, int dil, float* y,
-                                                       int64_t ldy, int Ho, int Wo)
+                                                       int64_t ldy, int Ho, int Wo, Epilogue epi)
 {
     const int C = cq * 4;
     const int64_t total = (int64_t)B * Ho * Wo * cq;
@@ -612,7 +612,22 @@ __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t 
                 acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
             }
         }
-        *reinterpret_cast<float4*>(y + (((int64_t)b * Ho + oh) * Wo + ow) * ldy + q * 4) = acc;
+        const int64_t row = ((int64_t)b * Ho + oh) * Wo + ow;
+        if (epi.gamma) {       // inference: folded eval-mode BatchNorm (same arithmetic as bn_eval_affine + bn_apply)
+            const float4 g = *reinterpret_cast<const float4*>(epi.gamma + q * 4), be = *reinterpret_cast<const float4*>(epi.beta + q * 4);
+            const float4 mu = *reinterpret_cast<const float4*>(epi.mean + q * 4), va = *reinterpret_cast<const float4*>(epi.var + q * 4);
+            float sc;
+            sc = g.x * (1.0f / sqrtf(va.x + epi.eps)); acc.x = fmaf(acc.x, sc, be.x - mu.x * sc);
+            sc = g.y * (1.0f / sqrtf(va.y + epi.eps)); acc.y = fmaf(acc.y, sc, be.y - mu.y * sc);
+            sc = g.z * (1.0f / sqrtf(va.z + epi.eps)); acc.z = fmaf(acc.z, sc, be.z - mu.z * sc);
+            sc = g.w * (1.0f / sqrtf(va.w + epi.eps)); acc.w = fmaf(acc.w, sc, be.w - mu.w * sc);
+        }
+        if (epi.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(epi.res + row * epi.ldr + q * 4);
+            acc.x += rr.x; acc.y += rr.y; acc.z += rr.z; acc.w += rr.w;
+        }
+        acc.x = epi_act(acc.x, epi.act); acc.y = epi_act(acc.y, epi.act); acc.z = epi_act(acc.z, epi.act); acc.w = epi_act(acc.w, epi.act);
+        *reinterpret_cast<float4*>(y + row * ldy + q * 4) = acc;
     }
 }
 
@@ -1462,16 +1477,34 @@ int pp_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const 
 }
 
 // ---- depthwise 3x3 ---------------------------------------------------------------------------------
-int pp_dwconv3x3_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
-                     float* y, int64_t ldy, pp_stream_t stream)
+static int dwconv_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
+                           float* y, int64_t ldy, const Epilogue& epi, pp_stream_t stream)
 {
     if (!x || !w || !y) return fail(PP_ERR_BAD_ARG, "dwconv fwd: null");
     if (int rc = need_c4(C, "dwconv fwd")) return rc;
     const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
     if (Ho < 1 || Wo < 1) return fail(PP_ERR_BAD_ARG, "dwconv fwd: empty output");
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(kT), 0, as_stream(stream), x,
-                       ldx, B, H, W, C / 4, w, stride, pad, dil, y, ldy, Ho, Wo);
+                       ldx, B, H, W, C / 4, w, stride, pad, dil, y, ldy, Ho, Wo, epi);
     return check_launch("dwconv_fwd_kernel");
+}
+
+int pp_dwconv3x3_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
+                     float* y, int64_t ldy, pp_stream_t stream)
+{
+    return dwconv_fwd_impl(x, ldx, B, H, W, C, w, stride, pad, dil, y, ldy, Epilogue{}, stream);
+}
+
+int pp_dwconv3x3_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad,
+                            int dil, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, const float* residual, int64_t ldr, int act, float* y,
+                            int64_t ldy, pp_stream_t stream)
+{
+    if (gamma && (!beta || !running_mean || !running_var)) return fail(PP_ERR_BAD_ARG, "dwconv fwd_bn_act: incomplete BatchNorm");
+    if (act < 0 || act > 2) return fail(PP_ERR_BAD_ARG, "dwconv fwd_bn_act: act %d", act);
+    if (ldy % 4 || (residual && ldr % 4)) return fail(PP_ERR_BAD_ARG, "dwconv fwd_bn_act: ld must be multiples of 4");
+    Epilogue e{gamma, beta, running_mean, running_var, eps, residual, ldr, act};
+    return dwconv_fwd_impl(x, ldx, B, H, W, C, w, stride, pad, dil, y, ldy, e, stream);
 }
 
 int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, int C, const float* w, int stride, int pad,

@@ -49,7 +49,27 @@ struct EventScope {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Inference epilogue shared by the dense and depthwise convolutions: eval-mode BatchNorm folded per output channel
+// (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale: the arithmetic of pp_bn_eval_affine +
+// pp_scale_shift_act, so the fused and the three-launch forms agree bit for bit), optional residual, activation.
+struct Epilogue {
+    const float* gamma;        // NULL: no BatchNorm (plain bias / identity)
+    const float* beta;
+    const float* mean;
+    const float* var;
+    float eps;
+    const float* res;          // NULL: no residual
+    int64_t ldr;
+    int act;                   // 0 none, 1 ReLU, 2 ReLU6
+};
+
 #ifdef __HIPCC__
+__device__ __forceinline__ float epi_act(float z, int act)
+{
+    if (act == 1) return fmaxf(z, 0.0f);
+    if (act == 2) return fminf(fmaxf(z, 0.0f), 6.0f);
+    return z;
+}
 // ---- wave64 reductions -------------------------------------------------------------------------
 // DPP row_shr 1/2/4/8 builds the row maximum in lane 15 of each 16-lane row, row_bcast15/31 carry it
 // to lane 63 (canonical GFX9 reduction); result broadcast with readlane.  No LDS traffic.

@@ -21,13 +21,68 @@ ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
 
 class Var:
-    """A tensor on the tape.  `grad` is filled during Tape.backward()."""
-    __slots__ = ("t", "grad", "needs_grad")
+    """A tensor on the tape.  `grad` is filled during Tape.backward().
 
-    def __init__(self, t: torch.Tensor, needs_grad: bool = True):
-        self.t = t
+    In inference (tape disabled) a convolution's output may be DEFERRED: `_pending` holds the launch arguments and the
+    tensor does not exist yet.  If the next consumer is an eval-mode BatchNorm, conv + BN (+ residual) + activation go
+    out as ONE launch (pp_conv2d_fwd_bn_act / pp_dwconv3x3_fwd_bn_act); any other consumer reads `.t`, which launches
+    the plain convolution first."""
+    __slots__ = ("_t", "grad", "needs_grad", "_pending")
+
+    def __init__(self, t: Optional[torch.Tensor], needs_grad: bool = True):
+        self._t = t
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
+        self._pending = None
+
+    @property
+    def t(self) -> torch.Tensor:
+        if self._pending is not None:
+            _launch_deferred(self, None)
+        return self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = value
+
+
+# PIXELPICK_FUSE_EVAL=0 keeps the three-launch inference form (conv, bn_eval_affine, scale_shift_act) for A/B.
+_FUSE_EVAL = os.environ.get("PIXELPICK_FUSE_EVAL", "1") != "0"
+
+
+def _launch_deferred(v: "Var", bn):
+    """Launch the convolution held in v._pending; bn = None (plain) or (gamma, beta, mean, var, eps, act, residual, dst)."""
+    kind, x, w, bias, stride, pad, dil = v._pending
+    v._pending = None
+    L = _lib.lib()
+    B, H, W, Cin, ldx = _geom(x.t)
+    dev = x.t.device
+    g = be = rm = rv = rptr = None
+    eps, act, ldr, dst = 0.0, 0, 0, None
+    if bn is not None:
+        gamma, beta, mean, var, eps, act, residual, dst = bn
+        g, be, rm, rv = gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr()
+        if residual is not None:
+            _, _, _, _, ldr = _geom(residual.t)
+            rptr = residual.t.data_ptr()
+    if kind == "conv":
+        kh, kw, _, Cout = w.shape
+        Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
+        y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+        _, _, _, _, ldy = _geom(y)
+        ws, wsn = _conv_ws(False, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+        rc = L.pp_conv2d_fwd_bn_act(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    kh, kw, stride, pad, dil, g, be, rm, rv, eps, rptr, ldr, act, y.data_ptr(), ldy, Cout,
+                                    ws, wsn, _stream())
+        _lib.check(rc, "pp_conv2d_fwd_bn_act")
+    else:
+        Ho, Wo = out_size(H, 3, stride, pad, dil), out_size(W, 3, stride, pad, dil)
+        y = dst if dst is not None else torch.empty((B, Ho, Wo, Cin), dtype=torch.float32, device=dev)
+        _, _, _, _, ldy = _geom(y)
+        rc = L.pp_dwconv3x3_fwd_bn_act(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), stride, pad, dil, g, be, rm, rv, eps,
+                                       rptr, ldr, act, y.data_ptr(), ldy, _stream())
+        _lib.check(rc, "pp_dwconv3x3_fwd_bn_act")
+    v._t = y
 
 
 _side_streams = {}
@@ -241,18 +296,55 @@ def _wsbytes(fn_name: str, *args) -> int:
 # three-launch form (partials -> finalize -> apply) for A/B timing.
 _BN_FUSED = os.environ.get("PIXELPICK_BN_FUSED", "1") != "0"
 _BN_FUSED_MAXM = int(os.environ.get("PIXELPICK_BN_FUSED_MAXM", str(1 << 62)))
-_BN_SYNC = {}
+_BN_XCHG = {}
+_BN_XCHG_SYNC_INTS = 1 << 14          # 64 KiB of arrival counters (2048 strips: C <= 65536)
+_BN_XCHG_PART_BYTES = 1 << 20         # partial-sum exchange area (<= 1024 blocks x 64 floats = 256 KiB needed)
 
 
-def _bn_sync(device, C: int) -> torch.Tensor:
-    """Zeroed arrival counters for the fused BN launches on the main stream (each launch re-zeroes them)."""
-    key = (device.type, device.index)
-    t = _BN_SYNC.get(key)
-    need = _wsbytes("pp_bn_fused_sync_ints", C)
-    if t is None or t.numel() < need:
-        t = torch.zeros(max(16384, need), dtype=torch.int32, device=device)
-        _BN_SYNC[key] = t
-    return t
+class _Raw:
+    """data_ptr()/numel() view of a raw device allocation."""
+    __slots__ = ("ptr", "n")
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numel(self):
+        return self.n
+
+
+def _bn_exchange(device):
+    """(sync, part): the arrival counters and the partial-sum area of the single-launch BatchNorm, in FINE-GRAINED device
+    memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)), allocated once per device and never freed.
+
+    The blocks of one launch sit on different XCDs, whose L2s are not coherent with each other for ordinary
+    (coarse-grained) allocations: a partial written on one XCD can be served stale from another XCD's L2 even through
+    agent-scope (sc1) loads - observed as run-to-run differences of a whole train step once the scratch became a
+    persistent buffer (same addresses every launch).  Fine-grained memory is kept coherent by the hardware, so the
+    exchange needs neither the L2 write-back nor the invalidate that a release/acquire pair on ordinary memory costs
+    (11.9 vs 8.5 ms per step)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ex = _BN_XCHG.get(key)
+    if ex is None:
+        import ctypes
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        nbytes = _BN_XCHG_SYNC_INTS * 4 + _BN_XCHG_PART_BYTES
+        ptr = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = hip.hipExtMallocWithFlags(ctypes.byref(ptr), nbytes, 1)          # hipDeviceMallocFinegrained
+            if rc != 0 or not ptr.value:
+                raise _lib.PixelPickHipError(f"hipExtMallocWithFlags(finegrained, {nbytes}) -> {rc}")
+            rc = hip.hipMemset(ptr, 0, nbytes)
+            if rc != 0:
+                raise _lib.PixelPickHipError(f"hipMemset -> {rc}")
+            torch.cuda.synchronize(device)
+        ex = (_Raw(ptr.value, _BN_XCHG_SYNC_INTS), _Raw(ptr.value + _BN_XCHG_SYNC_INTS * 4, _BN_XCHG_PART_BYTES))
+        _BN_XCHG[key] = ex
+    return ex
 
 
 def _acc(v: Var, g: torch.Tensor):
@@ -425,6 +517,10 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
     B, H, W, Cin, ldx = _geom(x.t)
     kh, kw, wcin, Cout = w.shape
     assert wcin == Cin, f"conv2d: Cin {Cin} vs weight {tuple(w.shape)}"
+    if _FUSE_EVAL and not tape.enabled and dst is None:
+        out = Var(None, needs_grad=False)
+        out._pending = ("conv", x, w, bias, stride, pad, dil)
+        return out
     Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
     y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.t.device)
     _, _, _, _, ldy = _geom(y)
@@ -467,6 +563,10 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
 # ------------------------------------------------------------------------------------------------- depthwise conv
 def dwconv3x3(tape: Tape, x: Var, w: torch.Tensor, stride=1, pad=0, dil=1) -> Var:
     """Depthwise 3x3 (groups=C).  w: [3,3,C]."""
+    if _FUSE_EVAL and not tape.enabled:
+        out = Var(None, needs_grad=False)
+        out._pending = ("dw", x, w, None, stride, pad, dil)
+        return out
     B, H, W, C, ldx = _geom(x.t)
     Ho, Wo = out_size(H, 3, stride, pad, dil), out_size(W, 3, stride, pad, dil)
     y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.t.device)
@@ -502,11 +602,14 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
                    residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
                    dst: Optional[torch.Tensor] = None) -> Var:
     """nn.BatchNorm2d -> (+ residual) -> activation.  Training: batch statistics + running-stat update."""
+    if not training and x._pending is not None and not tape.enabled:
+        _launch_deferred(x, (gamma, beta, running_mean, running_var, eps, act, residual, dst))
+        return Var(x._t, needs_grad=False)
     L = _lib.lib()
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
     dev = x.t.device
-    if training and _BN_FUSED and M <= _BN_FUSED_MAXM:
+    if training and _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536:
         # one launch: statistics + running-stat update + affine + residual + activation
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -516,8 +619,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         if residual is not None:
             _, _, _, _, ldr = _geom(residual.t)
             rptr = residual.t.data_ptr()
-        ws = _ws(_wsbytes("pp_bn_fused_workspace_bytes", M, C), dev)
-        sync = _bn_sync(dev, C)
+        sync, ws = _bn_exchange(dev)
         rc = L.pp_bn_train_fwd_fused(x.t.data_ptr(), ldx, M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                      running_mean.data_ptr() if running_mean is not None else None,
                                      running_var.data_ptr() if running_var is not None else None,
@@ -571,9 +673,8 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     dbeta = tape.grad_buffer_for(beta)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
     dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
-    if _BN_FUSED and M <= _BN_FUSED_MAXM:
-        ws = _ws(_wsbytes("pp_bn_fused_workspace_bytes", M, C), dev)
-        sync = _bn_sync(dev, C)
+    if _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536:
+        sync, ws = _bn_exchange(dev)
         rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(),
                                invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
                                dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(),

@@ -216,3 +216,56 @@ def test_graph_replay_matches_eager_steps():
     p_graph, l_graph = run(True)
     assert l_eager == l_graph
     assert torch.equal(p_eager, p_graph)
+
+
+@pytest.mark.parametrize("network,shape", [("deeplab", (2, 72, 88)), ("deeplab", (1, 128, 192)), ("FPN", (2, 64, 96))])
+def test_inference_with_fused_conv_bn_act_is_bit_identical(network, shape):
+    """Inference folds eval-mode BatchNorm (+ residual + activation) into the producing convolution's epilogue
+    (pp_conv2d_fwd_bn_act / pp_dwconv3x3_fwd_bn_act): same arithmetic as conv -> bn_eval_affine -> scale_shift_act,
+    so the logits are bit-identical; MC-dropout inference (dropout on in eval mode) takes the same path."""
+    from pixelpick_amd import engine as E
+    B, H, W = shape
+    m = _build(19, network).eval()
+    # non-trivial running statistics
+    g = torch.Generator().manual_seed(3)
+    for mod in m.modules():
+        if hasattr(mod, "running_var"):
+            mod.running_mean.copy_((torch.randn(mod.running_mean.shape, generator=g) * 0.2).to(DEV))
+            mod.running_var.copy_((torch.rand(mod.running_var.shape, generator=g) + 0.5).to(DEV))
+    x = fi.formula_input(B, H, W, key="fuse").to(DEV)
+    outs = []
+    for fuse in (True, False, True):
+        E._FUSE_EVAL = fuse
+        try:
+            with torch.no_grad():
+                outs.append(m(x)["pred"].clone())
+        finally:
+            E._FUSE_EVAL = True
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+
+
+def test_baseline_size_train_steps_are_bitwise_reproducible():
+    """Three runs of 8 optimisation steps at the BASELINE shape (B=4, 256x512, 19 classes) from identical state end in
+    bit-identical parameters: no atomics on floats, fixed-order reductions, and the cross-XCD exchange of the
+    single-launch BatchNorm is coherent (a stale partial showed up here as run-to-run differences)."""
+    from pixelpick_amd import engine as E
+    sys_path_bench = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    import sys
+    sys.path.insert(0, sys_path_bench)
+    from bench import synth_train_batch
+    x, y = synth_train_batch(4, 19, 256, 512, 20, torch.device(DEV), 1)
+    sigs = []
+    for _ in range(3):
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = get_model(_args(19)).to(DEV).train()
+        tr = FlatTrainer(m, ignore_index=19)
+        E.set_dropout_seed(1234)
+        losses = [tr.train_step(x, y) for _ in range(8)]
+        torch.cuda.synchronize()
+        sigs.append((tr.flat_p.clone(), torch.stack([l.reshape(()) for l in losses])))
+    for p, l in sigs[1:]:
+        assert torch.equal(l, sigs[0][1]), "loss trajectory differs between identical runs"
+        assert torch.equal(p, sigs[0][0]), "parameters differ between identical runs"

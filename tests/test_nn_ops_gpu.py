@@ -1,6 +1,8 @@
 """GPU parity tests of the network-layer HIP kernels (through the C ABI / engine tape) against plain
 PyTorch fp32 CPU references of the same ops (the reference's torch.nn calls).  Floating-point kernels:
 tolerance 1e-4 relative to the tensor scale (north_star: logits/grads within 1e-3)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -299,37 +301,61 @@ def test_batchnorm_train_fwd_bwd(shape, act, with_res, bn_fused):
         close(nchw(rv.grad), res.grad, what="dres")
 
 
-def test_batchnorm_single_launch_is_deterministic_and_rearms_its_counters():
-    """pp_bn_train_fwd_fused / pp_bn_bwd_fused: 50 back-to-back launches on one sync array are bit-identical
-    (fixed-order fp64 combine) and leave the arrival counters at zero."""
+def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms():
+    """pp_bn_train_fwd_fused / pp_bn_bwd_fused exchange partial sums between blocks on different XCDs through the
+    fine-grained area of engine._bn_exchange.  With DIFFERENT data in every launch (a stale partial from the previous
+    launch would show), 60 back-to-back launches agree with the three-launch path, a repeat of the whole sequence is
+    bit-identical, and the arrival counters are zero afterwards."""
     from pixelpick_amd import _lib
     L = _lib.lib()
-    torch.manual_seed(9)
+    dev = torch.device(DEV)
+    sync, ws = E._bn_exchange(dev)
+    st = torch.cuda.current_stream().cuda_stream
     for (M, C) in [(2048, 960), (8192, 192), (32768, 24), (100, 304)]:
-        x = torch.randn(M, C, device=DEV) * 2 + 1
-        dy = torch.randn(M, C, device=DEV)
-        gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
-        ws = torch.empty(L.pp_bn_fused_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
-        sync = torch.zeros(L.pp_bn_fused_sync_ints(C), dtype=torch.int32, device=DEV)
-        st = torch.cuda.current_stream().cuda_stream
-        outs = []
-        for it in range(50):
-            mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-            y, dx = torch.empty_like(x), torch.empty_like(x)
-            dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-            _lib.check(L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
-                                               mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
-                                               ws.numel(), sync.data_ptr(), sync.numel(), st), "fwd")
-            _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
-                                         invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
-                                         None, 0, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
-            if it in (0, 49):
-                outs.append((y.clone(), dx.clone(), dg.clone(), db.clone(), mean.clone()))
+        assert L.pp_bn_fused_workspace_bytes(M, C) <= ws.numel() and L.pp_bn_fused_sync_ints(C) <= sync.numel()
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        xs = [torch.randn(M, C, device=DEV, generator=gen) * (1 + i % 3) + i for i in range(6)]
+        dy = torch.randn(M, C, device=DEV, generator=gen)
+        gamma, beta = torch.rand(C, device=DEV, generator=gen) + 0.5, torch.randn(C, device=DEV, generator=gen)
+        ws3 = torch.empty(L.pp_colreduce_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
+
+        def sequence():
+            outs = []
+            for it in range(60):
+                x = xs[it % 6]
+                mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+                y, dx = torch.empty_like(x), torch.empty_like(x)
+                dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+                _lib.check(L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                                                   mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
+                                                   ws.numel(), sync.data_ptr(), sync.numel(), st), "fwd")
+                _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
+                                             invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
+                                             None, 0, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
+                outs.append((mean, invstd, dg, db, y if it % 20 == 0 else None, dx if it % 20 == 0 else None))
+            return outs
+        a, b = sequence(), sequence()
         torch.cuda.synchronize()
-        assert int(sync.abs().sum()) == 0
-        for a, b in zip(outs[0], outs[1]):
-            assert torch.equal(a, b)
+        for (ta, tb) in zip(a, b):
+            for u, v in zip(ta, tb):
+                assert (u is None and v is None) or torch.equal(u, v)
+        # against the three-launch kernels (other summation grouping: not bitwise)
+        for it in (0, 1, 2, 3, 4, 5, 59):
+            x = xs[it % 6]
+            mean3, inv3, sc, sf = (torch.empty(C, device=DEV) for _ in range(4))
+            _lib.check(L.pp_bn_train_fwd(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                                         mean3.data_ptr(), inv3.data_ptr(), sc.data_ptr(), sf.data_ptr(), ws3.data_ptr(), ws3.numel(), st), "fwd3")
+            close(a[it][0], mean3, tol=1e-5, what=f"mean it {it}")
+            close(a[it][1], inv3, tol=1e-5, what=f"invstd it {it}")
+        probe = torch.empty(64, dtype=torch.int32, device=DEV)
+        hip = __import__("ctypes").CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipMemcpy.argtypes = [__import__("ctypes").c_void_p] * 2 + [__import__("ctypes").c_size_t, __import__("ctypes").c_int]
+        assert hip.hipMemcpy(probe.data_ptr(), sync.data_ptr(), 256, 3) == 0          # D2D
+        assert int(probe.abs().sum()) == 0
         # too-small sync array / workspace are refused, not overrun
+        x = xs[0]
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        mean, invstd, dg, db = (torch.empty(C, device=DEV) for _ in range(4))
         assert L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
                                        mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
                                        ws.numel(), sync.data_ptr(), 1, st) != 0
