@@ -145,13 +145,13 @@ int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* 
                     float* shift, void* workspace, size_t ws_bytes, pp_stream_t stream);
 
 /* The same BatchNorm2d training forward INCLUDING the apply (+ residual, + activation) in ONE launch
- * (column strips x row chunks, a per-strip arrival counter instead of two more launches; see nn_ops.hip).
- * `sync` is an int32 array of pp_bn_fused_sync_ints(C) zeros: every launch leaves it zeroed again, and it
- * must not be shared by launches that can run concurrently.  Results are deterministic.
- * BOTH `workspace` and `sync` MUST be FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)):
- * blocks on different XCDs exchange partial sums through them inside one launch, and the XCD L2s are not coherent
- * with each other for ordinary allocations (a stale partial was observed with ordinary memory; pixelpick_amd/engine.py
- * `_bn_exchange` allocates the area once per device). */
+ * (column strips x row chunks; blocks exchange their partial sums inside the launch; see nn_ops.hip).
+ * `workspace` (pp_bn_fused_workspace_bytes, 8-byte aligned) holds one 64-bit {launch tag, value} word per partial and
+ * `sync` (pp_bn_fused_sync_ints ints) the launch epoch and a done-counter.  BOTH MUST be FINE-GRAINED device memory
+ * (hipExtMallocWithFlags(hipDeviceMallocFinegrained)), zero-filled ONCE before first use and then left alone: the
+ * blocks of a launch sit on different XCDs whose L2s are not coherent for ordinary allocations (stale partials and
+ * run-to-run differences were observed with ordinary memory; pixelpick_amd/engine.py `_bn_exchange` allocates the area
+ * once per device).  They must not be shared by launches that can run concurrently.  Results are deterministic. */
 size_t pp_bn_fused_workspace_bytes(int64_t M, int C);
 size_t pp_bn_fused_sync_ints(int C);
 int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,

@@ -642,6 +642,156 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
     dw[(int64_t)taps.widx[ti] * cn + e] = s;
 }
 
+// ---- weight gradient of the narrow layers ----------------------------------------------------------------------
+// The first layers of both encoders and the classifier have 3..32 channels on one side (stem 3->32 / 3->64, MNv2
+// 32->16, 16->96, 24->144, 96->24, 144->24/32, 192->32, classifier 256->19 / 128->19) and 33 K..524 K pixels.  As 64-
+// or 128-wide MFMA tiles they run at 1-8 TF (3 of 64 rows live) and they are the LAST weight gradients of the backward
+// pass, i.e. on the critical path of the join.  They are bandwidth problems: one read of x and dy.
+//   lanes-over-Cout form: thread = output channel n, registers = the NTAPS*CIN input taps (x values are wave-uniform
+//   loads), rows split over row lanes and blocks; partials [split][tap][c][n] feed the common fixed-order reduce.
+// (row, column, image) of output pixel m, advanced incrementally: no integer division in the row loops
+struct RowIter {
+    int ow, oh, bb;
+    __device__ __forceinline__ void init(int64_t m, int Wo, int Ho)
+    {
+        const unsigned mu = (unsigned)m;
+        const unsigned q = mu / (unsigned)Wo;
+        ow = (int)(mu - q * (unsigned)Wo);
+        bb = (int)(q / (unsigned)Ho);
+        oh = (int)(q - (unsigned)bb * (unsigned)Ho);
+    }
+    __device__ __forceinline__ void next(int Wo, int Ho)
+    {
+        if (++ow == Wo) { ow = 0; if (++oh == Ho) { oh = 0; ++bb; } }
+    }
+};
+
+template <int CIN, int NTAPS, int U>
+__global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int NL, int RL, int64_t rows_per_split)
+{
+    const int t = threadIdx.x;
+    const int n = t % NL, rl = t / NL;
+    if (rl >= RL) return;
+    const int64_t split = (int64_t)blockIdx.x * RL + rl;
+    const int64_t m0 = split * rows_per_split;
+    const int64_t m1 = m0 + rows_per_split < p.M ? m0 + rows_per_split : p.M;
+    float acc[NTAPS * CIN];
+#pragma unroll
+    for (int j = 0; j < NTAPS * CIN; ++j) acc[j] = 0.0f;
+    const bool live = n < p.Cout;
+    const float* __restrict__ xg = p.x;
+    const float* __restrict__ dyg = p.dy;
+    RowIter it;
+    it.init(m0 < p.M ? m0 : 0, p.Wo, p.Ho);
+    // U rows per trip: all their loads are issued before the first FMA (the rows are independent; one row at a time
+    // exposes a full memory latency per row)
+    for (int64_t m = m0; m < m1; m += U) {
+        float g[U];
+        float xv[U][NTAPS * CIN];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rv = m + u < m1;
+            g[u] = (live && rv) ? dyg[(m + u) * p.lddy + n] : 0.0f;
+#pragma unroll
+            for (int ti = 0; ti < NTAPS; ++ti) {
+                const int ih = it.oh * p.stride + p.taps.dh[ti], iw = it.ow * p.stride + p.taps.dw[ti];
+                const bool ok = rv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const float* xr = xg + (ok ? (((int64_t)it.bb * p.H + ih) * p.W + iw) * p.ldx : 0);
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    const float v = xr[c];
+                    xv[u][ti * CIN + c] = ok ? v : 0.0f;
+                }
+            }
+            it.next(p.Wo, p.Ho);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < NTAPS * CIN; ++j) acc[j] = fmaf(xv[u][j], g[u], acc[j]);
+    }
+    if (live) {
+        float* out = p.part + split * (int64_t)(NTAPS * CIN) * p.Cout + n;
+#pragma unroll
+        for (int j = 0; j < NTAPS * CIN; ++j) out[(int64_t)j * p.Cout] = acc[j];
+    }
+}
+
+//   lanes-over-Cin form (1x1 convolutions with a narrow OUTPUT): thread = input channel c, registers = the COUT
+//   outputs (dy values are wave-uniform loads).
+template <int COUT, int U>
+__global__ __launch_bounds__(256) void wgrad_narrow_out_kernel(WgradParams p, int NL, int RL, int64_t rows_per_split)
+{
+    const int t = threadIdx.x;
+    const int c = t % NL, rl = t / NL;
+    if (rl >= RL) return;
+    const int64_t split = (int64_t)blockIdx.x * RL + rl;
+    const int64_t m0 = split * rows_per_split;
+    const int64_t m1 = m0 + rows_per_split < p.M ? m0 + rows_per_split : p.M;
+    float acc[COUT];
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) acc[j] = 0.0f;
+    const bool live = c < p.Cin;
+    const int dh = p.taps.dh[0], dw = p.taps.dw[0];
+    const float* __restrict__ xg = p.x;
+    const float* __restrict__ dyg = p.dy;
+    RowIter it;
+    it.init(m0 < p.M ? m0 : 0, p.Wo, p.Ho);
+    for (int64_t m = m0; m < m1; m += U) {
+        float xv[U];
+        float g[U][COUT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rv = m + u < m1;
+            const int ih = it.oh * p.stride + dh, iw = it.ow * p.stride + dw;
+            const bool ok = rv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const float v = xg[(ok ? (((int64_t)it.bb * p.H + ih) * p.W + iw) * p.ldx : 0) + (live ? c : 0)];
+            xv[u] = (ok && live) ? v : 0.0f;
+            const float* gr = dyg + (rv ? m + u : m0) * p.lddy;
+#pragma unroll
+            for (int j = 0; j < COUT; ++j) g[u][j] = gr[j];
+            it.next(p.Wo, p.Ho);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < COUT; ++j) acc[j] = fmaf(xv[u], g[u][j], acc[j]);
+    }
+    if (live) {
+        float* out = p.part + split * (int64_t)p.Cin * COUT + (int64_t)c * COUT;
+#pragma unroll
+        for (int j = 0; j < COUT; ++j) out[j] = acc[j];
+    }
+}
+
+// Many-split reduce: 32 lanes per output add splits l, l+32, .. then a fixed LDS tree (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* part, int splits, int ntaps, int64_t cn,
+                                                               ConvTaps taps, float* dw)
+{
+    __shared__ float sh[256];
+    const int t = threadIdx.x, lane = t >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 8 + (t & 7);
+    const int64_t total = (int64_t)ntaps * cn;
+    float s = 0.0f;
+    if (i < total) {
+        const float* p0 = part + i;
+        int k = lane;
+        for (; k + 96 < splits; k += 128)
+            s += (p0[(int64_t)k * total] + p0[(int64_t)(k + 32) * total]) + (p0[(int64_t)(k + 64) * total] + p0[(int64_t)(k + 96) * total]);
+        for (; k < splits; k += 32) s += p0[(int64_t)k * total];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (t < off) sh[t] += sh[t + off];
+        __syncthreads();
+    }
+    if (t < 8 && i < total) {
+        const int ti = (int)(i / cn);
+        dw[(int64_t)taps.widx[ti] * cn + (i - (int64_t)ti * cn)] = sh[t];
+    }
+}
+
 // dbias[n] = sum_m dy[m][n]: per-row-block partials (grid.y row blocks), then a fixed-order fp64 combine.
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* dy, int64_t M, int C, int64_t ld,
                                                                int64_t rows_per_block, float* part /*[gridDim.y][C]*/)
@@ -801,6 +951,51 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     return PP_OK;
 }
 
+static int g_wgrad_narrow = 1;
+
+// returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
+static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, void* workspace, size_t ws_bytes, hipStream_t st)
+{
+    const int nt = p.taps.n;
+    int form = 0;            // 1: lanes over Cout (narrow input), 2: lanes over Cin (narrow output)
+    // measured against the MFMA path (tools/conv_layer_table.py, B=4 256x512): wins for 3->32 3x3 (182 -> 136 us), 32->16
+    // (78 -> 48), 16->96 (82 -> 44), 96->24 (35 -> 25), 144->24 (35 -> 31), 128->19 at full resolution (416 -> 214); loses
+    // for 24->144, 32->192, the 7x7 stem (147 accumulators per thread) and everything below 32 K pixels.
+    if ((p.Cin == 3 && nt == 9) || (nt == 1 && (p.Cin == 16 || p.Cin == 32) && p.Cout <= 128)) form = 1;
+    else if (nt == 1 && kh == 1 && kw == 1 && (p.Cout == 16 || p.Cout == 19 || p.Cout == 24 || p.Cout == 32) && p.Cin <= 256) form = 2;
+    if (form == 0 || p.M < 32768) return 1;
+    const int lanes_dim = form == 1 ? p.Cout : p.Cin;
+    const int NL = lanes_dim >= 256 ? 256 : (int)(cdiv(lanes_dim, 16) * 16);
+    const int RL = 256 / NL;
+    int64_t splits = cdiv(p.M, 64);                       // >= 64 rows per split
+    if (splits > 1024) splits = 1024;
+    const int64_t nblk = cdiv(splits, RL);
+    splits = nblk * RL;
+    const int64_t rows_per_split = cdiv(p.M, splits);
+    const int64_t cn = (int64_t)p.Cin * p.Cout;
+    const size_t need = (size_t)splits * nt * cn * 4;
+    if (!workspace || ws_bytes < need) return 1;           // caller sized the workspace for the MFMA path: use that
+    p.part = reinterpret_cast<float*>(workspace);
+    if (nt != kh * kw)
+        if (hipMemsetAsync(dw, 0, (size_t)kh * kw * cn * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
+    dim3 grid((unsigned)nblk), blk(256);
+    if (form == 1) {
+        if (p.Cin == 3 && nt == 9)        hipLaunchKernelGGL((wgrad_narrow_in_kernel<3, 9, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+        else if (p.Cin == 16)             hipLaunchKernelGGL((wgrad_narrow_in_kernel<16, 1, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+        else                              hipLaunchKernelGGL((wgrad_narrow_in_kernel<32, 1, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+    } else {
+        if (p.Cout == 16)       hipLaunchKernelGGL((wgrad_narrow_out_kernel<16, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+        else if (p.Cout == 19)  hipLaunchKernelGGL((wgrad_narrow_out_kernel<19, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+        else if (p.Cout == 24)  hipLaunchKernelGGL((wgrad_narrow_out_kernel<24, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+        else                    hipLaunchKernelGGL((wgrad_narrow_out_kernel<32, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+    }
+    if (int rc = check_launch("wgrad_narrow_kernel")) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)cdiv((int64_t)nt * cn, 8)), dim3(256), 0, st, p.part, (int)splits,
+                       nt, cn, p.taps, dw);
+    if (int rc = check_launch("wgrad_reduce_wide_kernel")) return rc;
+    return 0;
+}
+
 static int conv_common_check(const void* a, const void* b, const void* c, int B, int H, int W, int Cin, int Cout,
                              int kh, int kw, int stride, int pad, int dil)
 {
@@ -825,6 +1020,7 @@ void pp_debug_set_conv_variant(int v)
     g_conv_novec = (v & 8) ? 1 : 0;          // bit 3 forces the conditional-load path (A/B)
     g_conv_lds_pad = (v & 16) ? 40 * 1024 : ((v & 32) ? 70 * 1024 : 0);   // bits 4/5: at most 2 / 1 blocks per CU
     g_conv_splitk = (v & 64) ? 0 : 1;        // bit 6 switches split-K off (A/B)
+    g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
@@ -919,6 +1115,11 @@ size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Co
     // splits chosen in pp_conv2d_bwd_weight never exceed 64
     (void)M;
     size_t w = (size_t)64 * kh * kw * Cin * Cout * 4, b = (size_t)256 * Cout * 4;
+    const bool narrow = Cin == 3 || ((kh == 1 && kw == 1) && (Cin <= 32 || Cout <= 32) && Cin <= 256 && Cout <= 256);
+    if (narrow) {               // wgrad_narrow_*: up to 1024 (+ one block of row lanes) splits
+        const size_t n = (size_t)(1024 + 16) * kh * kw * Cin * Cout * 4;
+        if (n > w) w = n;
+    }
     return align_up(w > b ? w : b, 256);
 }
 
@@ -936,6 +1137,14 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_weight: more than 2^31 output pixels");
     p.pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    if (g_wgrad_narrow) {
+        const int rc = launch_wgrad_narrow(p, kh, kw, dw, workspace, ws_bytes, st);
+        if (rc != 1) {                       // 0: handled, < 0: error, 1: not a narrow layer
+            if (rc < 0) return rc;
+            goto bias_part;
+        }
+    }
+    {
     const bool big = Cin > 64 && Cout > 64;
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
@@ -967,6 +1176,8 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(p.taps.n * cn, 256)), dim3(256), 0, st, p.part,
                        (int)splits, p.taps.n, cn, p.taps, dw);
     if (int rc = check_launch("wgrad_reduce_kernel")) return rc;
+    }
+bias_part:
     if (dbias) {
         // partials reuse the (already consumed) head of the workspace: stream order makes that safe
         int nblk = (int)cdiv(p.M, 512);

@@ -317,47 +317,56 @@ __device__ __forceinline__ void rowlane_tree(float4& s0, float4& s1, float4 (*sh
     }
 }
 
-// Partials cross XCDs (non-coherent L2s).  They are written and read with agent-scope atomic accesses (sc1: served
-// at the device coherence point), so the arrival counter needs no L2 write-back (a release fence costs a full
-// `buffer_wbl2` per block, measured ~0.09 us x blocks serialised) — only the block's own stores must have completed.
-__device__ __forceinline__ void st_agent(float* p, float v)
+// Partials cross XCDs.  Every partial is ONE 64-bit word {launch tag, value} written and read with agent-scope
+// atomic accesses in FINE-GRAINED device memory: the value carries its own "ready" flag, so no ordering between a
+// data store and a separate arrival counter is needed (that ordering needs a release fence = a `buffer_wbl2` per
+// block, 0.09 us x blocks serialised; without the fence a counter can be seen before the data - observed as a
+// run-to-run difference in ~1 of 10 twelve-step runs).  A reader spins until the tag of the word equals this
+// launch's tag.  The tag is epoch+1, the epoch lives in sync[0] and is advanced by the last block of the launch to
+// finish reading (counted in sync[1]), so consecutive launches - also replays of a captured graph - never share one.
+typedef unsigned long long xword;
+
+__device__ __forceinline__ void xchg_put(xword* p, float v, unsigned tag)
 {
-    __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, ((xword)tag << 32) | (xword)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float ld_agent(const float* p)
+__device__ __forceinline__ float xchg_get(const xword* p, unsigned tag)
 {
-    return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    xword w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((unsigned)(w >> 32) != tag) {
+        __builtin_amdgcn_s_sleep(2);
+        w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __uint_as_float((unsigned)w);
 }
-__device__ __forceinline__ void publish_partial(float* p, int nch, const float4& s0, const float4& s1)
+__device__ __forceinline__ void publish_partial(xword* p, int nch, const float4& s0, const float4& s1, unsigned tag)
 {
-    st_agent(p + 0, s0.x); st_agent(p + 1, s0.y); st_agent(p + 2, s0.z); st_agent(p + 3, s0.w);
-    st_agent(p + nch + 0, s1.x); st_agent(p + nch + 1, s1.y); st_agent(p + nch + 2, s1.z); st_agent(p + nch + 3, s1.w);
+    xchg_put(p + 0, s0.x, tag); xchg_put(p + 1, s0.y, tag); xchg_put(p + 2, s0.z, tag); xchg_put(p + 3, s0.w, tag);
+    xchg_put(p + nch + 0, s1.x, tag); xchg_put(p + nch + 1, s1.y, tag); xchg_put(p + nch + 2, s1.z, tag); xchg_put(p + nch + 3, s1.w, tag);
 }
 
-constexpr int kSyncStride = 32;   // one 128-byte line per strip: arrivals of different strips do not contend
-
-// publish this block's partial and wait until all R blocks of the strip have published theirs
-__device__ __forceinline__ void strip_barrier(int* sync, int strip, int R)
+// this launch's tag, read once per block (before any block of the launch can have advanced the epoch)
+__device__ __forceinline__ unsigned launch_tag(const int* sync, unsigned* sh_tag)
 {
-    if (R > 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial stores have completed
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(sync + kSyncStride * strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(sync + kSyncStride * strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < R)
-                __builtin_amdgcn_s_sleep(8);
-            const int gone = __hip_atomic_fetch_add(sync + kSyncStride * strip + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gone == R - 1) {   // every sibling has left the wait: rearm for the next launch
-                __hip_atomic_store(sync + kSyncStride * strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sync + kSyncStride * strip + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+    if (threadIdx.x == 0) *sh_tag = (unsigned)__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __syncthreads();
+    return *sh_tag;
+}
+
+// called by every block after its last xchg_get: the last one through advances the epoch and re-arms the counter
+__device__ __forceinline__ void launch_done(int* sync)
+{
+    if (threadIdx.x == 0) {
+        const int gone = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == (int)gridDim.x - 1) {
+            __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();
     }
 }
 
 // fixed-order fp64 sum over the strip's R partial rows; tot[o] for o < nout = 8*bq (stat-major: [2][bq*4])
-__device__ __forceinline__ void strip_combine(const float* part, int strip, int R, int nout, double* shd /*[256]*/,
+__device__ __forceinline__ void strip_combine(const xword* part, int strip, int R, int nout, unsigned tag, double* shd /*[256]*/,
                                               double* tot /*[64]*/)
 {
     const int t = threadIdx.x;
@@ -365,14 +374,25 @@ __device__ __forceinline__ void strip_combine(const float* part, int strip, int 
     const int o = t % nout, sub = t / nout;
     double s = 0.0;
     if (sub < nsub) {
-        const float* p = part + (int64_t)strip * R * nout + o;
+        const xword* p = part + (int64_t)strip * R * nout + o;
         int c = sub;
         for (; c + 3 * nsub < R; c += 4 * nsub) {
-            const float v0 = ld_agent(p + (int64_t)c * nout), v1 = ld_agent(p + (int64_t)(c + nsub) * nout);
-            const float v2 = ld_agent(p + (int64_t)(c + 2 * nsub) * nout), v3 = ld_agent(p + (int64_t)(c + 3 * nsub) * nout);
+            // four words in flight; a word whose tag is not this launch's yet is re-read by xchg_get
+            const xword* p0 = p + (int64_t)c * nout;
+            const xword* p1 = p + (int64_t)(c + nsub) * nout;
+            const xword* p2 = p + (int64_t)(c + 2 * nsub) * nout;
+            const xword* p3 = p + (int64_t)(c + 3 * nsub) * nout;
+            const xword w0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const xword w1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const xword w2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const xword w3 = __hip_atomic_load(p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v0 = (unsigned)(w0 >> 32) == tag ? __uint_as_float((unsigned)w0) : xchg_get(p0, tag);
+            const float v1 = (unsigned)(w1 >> 32) == tag ? __uint_as_float((unsigned)w1) : xchg_get(p1, tag);
+            const float v2 = (unsigned)(w2 >> 32) == tag ? __uint_as_float((unsigned)w2) : xchg_get(p2, tag);
+            const float v3 = (unsigned)(w3 >> 32) == tag ? __uint_as_float((unsigned)w3) : xchg_get(p3, tag);
             s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
         }
-        for (; c < R; c += nsub) s += (double)ld_agent(p + (int64_t)c * nout);
+        for (; c < R; c += nsub) s += (double)xchg_get(p + (int64_t)c * nout, tag);
     }
     shd[t] = s;
     __syncthreads();
@@ -389,16 +409,18 @@ struct BnFwdArgs {
     const float* gamma; const float* beta; float eps; float momentum;
     float* running_mean; float* running_var; float* mean; float* invstd;
     const float* res; int64_t ldr; int act; float* y; int64_t ldy;
-    float* part; int* sync; BnFusedGeom g;
+    xword* part; int* sync; BnFusedGeom g;
 };
 
 __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 {
+    __shared__ unsigned sh_tag;
     __shared__ float4 sh[2][kT];
     __shared__ double shd[kT];
     __shared__ double tot[64];
     __shared__ float aff[2][32];
     const BnFusedGeom g = a.g;
+    const unsigned tag = launch_tag(a.sync, &sh_tag);
     const int t = threadIdx.x;
     const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
     const int ql = t % g.bq, rl = t / g.bq;
@@ -430,10 +452,10 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
     rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
     const int nch = g.bq * 4, nout = nch * 2;
     if (rl == 0) {
-        publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1);
+        publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1, tag);
     }
-    strip_barrier(a.sync, strip, g.R);
-    strip_combine(a.part, strip, g.R, nout, shd, tot);
+    strip_combine(a.part, strip, g.R, nout, tag, shd, tot);
+    launch_done(a.sync);
     if (t < nch) {
         const int c = strip * nch + t;
         if (c < a.C) {
@@ -489,16 +511,18 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 struct BnBwdArgs {
     const float* x; int64_t ldx; const float* dy; int64_t lddy; const float* yact; int64_t ldya; int act;
     int64_t M; int C; const float* mean; const float* invstd; const float* gamma; float* dgamma; float* dbeta;
-    float* dx; int64_t lddx; float* dres; int64_t lddr; float* part; int* sync; BnFusedGeom g;
+    float* dx; int64_t lddx; float* dres; int64_t lddr; xword* part; int* sync; BnFusedGeom g;
 };
 
 __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
 {
+    __shared__ unsigned sh_tag;
     __shared__ float4 sh[2][kT];
     __shared__ double shd[kT];
     __shared__ double tot[64];
     __shared__ float red[2][32];
     const BnFusedGeom g = a.g;
+    const unsigned tag = launch_tag(a.sync, &sh_tag);
     const int t = threadIdx.x;
     const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
     const int ql = t % g.bq, rl = t / g.bq;
@@ -543,10 +567,10 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
     rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
     const int nch = g.bq * 4, nout = nch * 2;
     if (rl == 0) {
-        publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1);
+        publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1, tag);
     }
-    strip_barrier(a.sync, strip, g.R);
-    strip_combine(a.part, strip, g.R, nout, shd, tot);
+    strip_combine(a.part, strip, g.R, nout, tag, shd, tot);
+    launch_done(a.sync);
     if (t < nch) {
         const int c = strip * nch + t;
         const float db = (float)tot[t], dg = (float)tot[nch + t];
@@ -1385,18 +1409,18 @@ size_t pp_bn_fused_workspace_bytes(int64_t M, int C)
 {
     if (M < 1 || C < 4) return 256;
     BnFusedGeom g = bn_fused_geom(M, C);
-    return align_up((size_t)g.nstrips * g.R * g.bq * 8 * 4, 256);
+    return align_up((size_t)g.nstrips * g.R * g.bq * 8 * 8, 256);     // one 64-bit {tag, value} word per partial
 }
 
-size_t pp_bn_fused_sync_ints(int C) { return C < 4 ? kSyncStride : (size_t)kSyncStride * cdiv(C / 4, 4); }
+size_t pp_bn_fused_sync_ints(int C) { (void)C; return 64; }      // [0] launch epoch, [1] blocks done; one 256-byte line
 
 static int bn_fused_check(const char* what, int64_t M, int C, const BnFusedGeom& g, const void* workspace, size_t ws_bytes,
                           const int32_t* sync, size_t sync_ints)
 {
     if (M < 1) return fail(PP_ERR_BAD_ARG, "%s: M < 1", what);
-    if (!workspace || ws_bytes < (size_t)g.nstrips * g.R * g.bq * 8 * 4) return fail(PP_ERR_WORKSPACE, "%s: workspace", what);
-    if (!sync || sync_ints < (size_t)kSyncStride * g.nstrips)
-        return fail(PP_ERR_WORKSPACE, "%s: sync array needs %d ints", what, kSyncStride * g.nstrips);
+    if (!workspace || ws_bytes < (size_t)g.nstrips * g.R * g.bq * 8 * 8) return fail(PP_ERR_WORKSPACE, "%s: workspace", what);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return fail(PP_ERR_BAD_ARG, "%s: workspace must be 8-byte aligned", what);
+    if (!sync || sync_ints < 2) return fail(PP_ERR_WORKSPACE, "%s: sync array needs 2 ints", what);
     (void)C;
     return PP_OK;
 }
@@ -1412,7 +1436,7 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
-                reinterpret_cast<float*>(workspace), sync, g};
+                reinterpret_cast<xword*>(workspace), sync, g};
     hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel");
 }
@@ -1430,7 +1454,7 @@ int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_bwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnBwdArgs a{x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr,
-                reinterpret_cast<float*>(workspace), sync, g};
+                reinterpret_cast<xword*>(workspace), sync, g};
     hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_bwd_kernel");
 }

@@ -56,6 +56,14 @@ CONV_CASES = [
     (2, 33, 47, 3, 32, 3, 2, 1, 1, False),        # stem 3x3 s2, Cin=3
     (1, 40, 36, 3, 64, 7, 2, 3, 1, False),        # ResNet stem 7x7 s2
     (2, 12, 12, 128, 128, 3, 1, 1, 1, True),      # FPN UpsampleBlock conv (bias)
+    # >= 32768 output pixels with 3..32 channels on one side: the narrow-layer weight-gradient kernels
+    (2, 256, 264, 3, 32, 3, 2, 1, 1, False),      # MNv2 stem
+    (2, 128, 160, 32, 16, 1, 1, 0, 1, False),     # MNv2 block 1 project
+    (2, 128, 130, 16, 96, 1, 1, 1, 1, False),     # expand with the folded fixed_padding (1x1, padding 1)
+    (2, 128, 136, 96, 24, 1, 1, 0, 1, False),     # narrow output
+    (2, 128, 132, 144, 32, 1, 1, 0, 1, False),
+    (1, 128, 160, 3, 64, 7, 2, 3, 1, False),      # ResNet stem (stays on the MFMA path)
+    (3, 96, 128, 256, 19, 1, 1, 0, 1, True),      # classifier (bias), 36864 pixels
     (1, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead at Cityscapes-quarter size (128x128 tiles)
     (2, 23, 30, 1280, 256, 1, 1, 0, 1, False),    # ASPP fuse at CamVid size (M = 1380)
     (2, 23, 30, 320, 256, 3, 1, 12, 12, False),   # atrous d=12 at CamVid size
@@ -301,11 +309,22 @@ def test_batchnorm_train_fwd_bwd(shape, act, with_res, bn_fused):
         close(nchw(rv.grad), res.grad, what="dres")
 
 
+def _read_sync(sync):
+    import ctypes
+    probe = torch.empty(2, dtype=torch.int32, device=DEV)
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(probe.data_ptr(), sync.data_ptr(), 8, 3) == 0          # D2D
+    e, d = probe.cpu().tolist()
+    return e, d
+
+
 def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms():
     """pp_bn_train_fwd_fused / pp_bn_bwd_fused exchange partial sums between blocks on different XCDs through the
     fine-grained area of engine._bn_exchange.  With DIFFERENT data in every launch (a stale partial from the previous
     launch would show), 60 back-to-back launches agree with the three-launch path, a repeat of the whole sequence is
-    bit-identical, and the arrival counters are zero afterwards."""
+    bit-identical, and every launch advances the launch epoch once and leaves the done-counter at zero."""
     from pixelpick_amd import _lib
     L = _lib.lib()
     dev = torch.device(DEV)
@@ -318,6 +337,9 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
         dy = torch.randn(M, C, device=DEV, generator=gen)
         gamma, beta = torch.rand(C, device=DEV, generator=gen) + 0.5, torch.randn(C, device=DEV, generator=gen)
         ws3 = torch.empty(L.pp_colreduce_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
+
+        epoch0, done0 = _read_sync(sync)
+        assert done0 == 0
 
         def sequence():
             outs = []
@@ -347,11 +369,8 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
                                          mean3.data_ptr(), inv3.data_ptr(), sc.data_ptr(), sf.data_ptr(), ws3.data_ptr(), ws3.numel(), st), "fwd3")
             close(a[it][0], mean3, tol=1e-5, what=f"mean it {it}")
             close(a[it][1], inv3, tol=1e-5, what=f"invstd it {it}")
-        probe = torch.empty(64, dtype=torch.int32, device=DEV)
-        hip = __import__("ctypes").CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-        hip.hipMemcpy.argtypes = [__import__("ctypes").c_void_p] * 2 + [__import__("ctypes").c_size_t, __import__("ctypes").c_int]
-        assert hip.hipMemcpy(probe.data_ptr(), sync.data_ptr(), 256, 3) == 0          # D2D
-        assert int(probe.abs().sum()) == 0
+        epoch1, done1 = _read_sync(sync)
+        assert done1 == 0 and epoch1 - epoch0 == 2 * 60 * 2      # every launch advanced the epoch once and re-armed
         # too-small sync array / workspace are refused, not overrun
         x = xs[0]
         y, dx = torch.empty_like(x), torch.empty_like(x)
