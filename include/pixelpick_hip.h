@@ -121,11 +121,12 @@ int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int C
 
 /* dL/dx of the above (what autograd computes at model.py:121); any stride (the stride-2 Bottleneck convs of
  * backbones/resnet_models.py:63-64,142-144 gather dY rows where (row + pad - tap*dil) is divisible by the stride).
- * B,H,W,Cin describe the conv INPUT for the workspace query. */
+ * B,H,W,Cin describe the conv INPUT for the workspace query.  accumulate != 0: dx += result (the tensor already holds
+ * the gradient of another consumer of x, e.g. the residual branch of mobilenet_v2.py:62-63). */
 size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
-                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, void* workspace,
-                       size_t ws_bytes, pp_stream_t stream);
+                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                       void* workspace, size_t ws_bytes, pp_stream_t stream);
 
 /* dL/dw (HWIO) and optionally dL/dbias [Cout]; workspace holds the split-M partial sums. */
 size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
@@ -156,14 +157,18 @@ size_t pp_bn_fused_workspace_bytes(int64_t M, int C);
 size_t pp_bn_fused_sync_ints(int C);
 int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                          const float* residual, int64_t ldr, int act, float* y, int64_t ldy, void* workspace,
+                          const float* residual, int64_t ldr, int act, float drop_p, uint64_t drop_seed,
+                          const uint64_t* drop_seed_dev, float* y, int64_t ldy, void* workspace,
                           size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
+/* drop_p > 0: the nn.Dropout(p) that follows BN -> ReLU (aspp.py:60-61, decoders.py:108-114) is applied in the same pass
+ * with pp_dropout's mask stream (same seed / seed_dev -> same mask), act must be 0 or 1. */
 
-/* Single-launch form of pp_bn_bwd (same arguments + sync). */
+/* Single-launch form of pp_bn_bwd (same arguments + sync).  grad_scale = 1/(1-p) when a dropout was fused into the
+ * forward (its mask is recovered from y_act == 0), else 1. */
 int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
                     int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, void* workspace, size_t ws_bytes,
-                    int32_t* sync, size_t sync_ints, pp_stream_t stream);
+                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, void* workspace,
+                    size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
 
 /* nn.BatchNorm2d, eval mode: scale/shift from the running statistics. */
 int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,

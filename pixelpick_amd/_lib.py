@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpixelpick_hip.so")
 
 _i64, _p, _int, _sz, _f = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/pixelpick_hip.h declares
 SIGNATURES = {
@@ -30,7 +31,7 @@ SIGNATURES = {
     "pp_conv2d_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int,
                                     _p, _i64, _int, _p, _sz, _p]),
     "pp_dwconv3x3_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int, _p, _i64, _p]),
-    "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _sz, _p]),
+    "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_weight_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p]),
     "pp_colreduce_workspace_bytes": (_sz, [_i64, _int]),
@@ -40,8 +41,8 @@ SIGNATURES = {
     "pp_bn_bwd": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "pp_bn_fused_workspace_bytes": (_sz, [_i64, _int]),
     "pp_bn_fused_sync_ints": (_sz, [_int]),
-    "pp_bn_train_fwd_fused": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _int, _p, _i64, _p, _sz, _p, _sz, _p]),
-    "pp_bn_bwd_fused": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p, _sz, _p]),
+    "pp_bn_train_fwd_fused": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _int, _f, _u64, _p, _p, _i64, _p, _sz, _p, _sz, _p]),
+    "pp_bn_bwd_fused": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _sz, _p, _sz, _p]),
     "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p]),

@@ -61,6 +61,7 @@ struct ConvParams {
     int ks_per_split;
     float* part;      // [splits][M][Cn] partial outputs (no bias)
     Epilogue epi;     // inference only: folded BatchNorm + residual + activation (all NULL / 0 in training)
+    int accumulate;   // y += result (backward-data into a gradient that already holds the residual branch's part)
     ConvTaps taps;
 };
 
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
                     float o = acc[tm][tn][r] + bv;
                     if (affine) o = fmaf(o, sc, sf);
                     if (res) o += res[m * p.epi.ldr + n];
+                    if (final_pass && p.accumulate) o += out[m * ldo + n];
                     out[m * ldo + n] = epi_act(o, act);
                 }
             }
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 
 // split-K second stage: y[m][n] = epilogue(bias[n] + sum_z part[z][m][n]), z in fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int splits, int64_t M, int Cn,
-                                                            const float* bias, float* y, int64_t ldy, Epilogue epi)
+                                                            const float* bias, float* y, int64_t ldy, Epilogue epi, int accumulate)
 {
     const int64_t MN = M * Cn;
     if ((Cn & 3) == 0 && (ldy & 3) == 0 && epi.gamma == nullptr && epi.res == nullptr && epi.act == 0) {
@@ -419,6 +421,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(y + m * ldy + q * 4);
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
             *reinterpret_cast<float4*>(y + m * ldy + q * 4) = s;
         }
         return;
@@ -435,6 +441,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
             s = fmaf(s, sc, epi.beta[n] - epi.mean[n] * sc);
         }
         if (epi.res) s += epi.res[m * epi.ldr + n];
+        if (accumulate) s += y[m * ldy + n];
         y[m * ldy + n] = epi_act(s, epi.act);
     }
 }
@@ -945,7 +952,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         int64_t nb = cdiv(plain ? p.M * (p.Cn / 4) : p.M * p.Cn, 256);
         if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p.part, pl.splits, p.M, p.Cn, p.bias,
-                           p.y, p.ldy, p.epi);
+                           p.y, p.ldy, p.epi, p.accumulate);
         return check_launch("splitk_reduce_kernel");
     }
     return PP_OK;
@@ -1090,7 +1097,7 @@ int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int C
 }
 
 int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
-                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin,
+                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
                        void* workspace, size_t ws_bytes, pp_stream_t stream)
 {
     if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
@@ -1099,7 +1106,7 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
     ConvParams p{};
     p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.ldx = lddy; p.ldy = lddx;
     p.B = B; p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.Ck = Cout; p.Cn = Cin; p.Cin = Cin; p.Cout = Cout;
-    p.stride = 1; p.M = (int64_t)B * H * W; p.bwd_stride = stride;
+    p.stride = 1; p.M = (int64_t)B * H * W; p.bwd_stride = stride; p.accumulate = accumulate ? 1 : 0;
     // dX(ih,iw) = sum_t dY((ih + pad - th*dil)/stride, (iw + pad - tw*dil)/stride) W[t]   (where divisible)
     build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: more than 2^31 pixels");

@@ -269,6 +269,16 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* x, int64_
 // 256 CUs), so the wait cannot deadlock; R == 1 skips it.  The last block through a strip's counters zeroes them,
 // so the caller's `sync` array stays zero between launches (it must not be shared by launches that can overlap).
 // ================================================================================================
+// counter-based RNG of the dropout kernels (mask = f(seed, flat element index)); also used by the BatchNorm epilogue
+__device__ __forceinline__ uint32_t hash_rng(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
 struct BnFusedGeom {
     int cq;        // C/4
     int bq;        // float4 columns per strip (4..8)
@@ -404,12 +414,22 @@ __device__ __forceinline__ void strip_combine(const xword* part, int strip, int 
     __syncthreads();
 }
 
+// the element-wise dropout of dropout4_kernel on one float4 (same hash stream: flat index i0 .. i0+3)
+__device__ __forceinline__ void drop4(float4& o, uint64_t i0, uint64_t seed, float p, float inv_keep)
+{
+    o.x = (float)(hash_rng(seed, i0 + 0) >> 8) * (1.0f / 16777216.0f) >= p ? o.x * inv_keep : 0.0f;
+    o.y = (float)(hash_rng(seed, i0 + 1) >> 8) * (1.0f / 16777216.0f) >= p ? o.y * inv_keep : 0.0f;
+    o.z = (float)(hash_rng(seed, i0 + 2) >> 8) * (1.0f / 16777216.0f) >= p ? o.z * inv_keep : 0.0f;
+    o.w = (float)(hash_rng(seed, i0 + 3) >> 8) * (1.0f / 16777216.0f) >= p ? o.w * inv_keep : 0.0f;
+}
+
 struct BnFwdArgs {
     const float* x; int64_t ldx; int64_t M; int C;
     const float* gamma; const float* beta; float eps; float momentum;
     float* running_mean; float* running_var; float* mean; float* invstd;
     const float* res; int64_t ldr; int act; float* y; int64_t ldy;
     xword* part; int* sync; BnFusedGeom g;
+    float drop_p, drop_inv_keep; uint64_t drop_seed; const uint64_t* drop_seed_dev;   // nn.Dropout after the activation (p = 0: none)
 };
 
 __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
@@ -485,6 +505,9 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
     float* yq = a.y + q * 4;
     const float* rq = a.res ? a.res + q * 4 : nullptr;
     const int act = a.act;
+    const bool drop = a.drop_p > 0.0f;
+    uint64_t dseed = a.drop_seed;
+    if (drop && a.drop_seed_dev) dseed += *a.drop_seed_dev * 0x9E3779B97F4A7C15ull;      // as dropout4_kernel
     for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
         const int64_t rb = r + g.nrl;
         const bool two = rb < r1;
@@ -500,9 +523,11 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
             ob.x += rbv.x; ob.y += rbv.y; ob.z += rbv.z; ob.w += rbv.w;
         }
         oa.x = act_fwd(oa.x, act); oa.y = act_fwd(oa.y, act); oa.z = act_fwd(oa.z, act); oa.w = act_fwd(oa.w, act);
+        if (drop) drop4(oa, (uint64_t)(r * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
         *reinterpret_cast<float4*>(yq + r * a.ldy) = oa;
         if (two) {
             ob.x = act_fwd(ob.x, act); ob.y = act_fwd(ob.y, act); ob.z = act_fwd(ob.z, act); ob.w = act_fwd(ob.w, act);
+            if (drop) drop4(ob, (uint64_t)(rb * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
             *reinterpret_cast<float4*>(yq + rb * a.ldy) = ob;
         }
     }
@@ -512,6 +537,7 @@ struct BnBwdArgs {
     const float* x; int64_t ldx; const float* dy; int64_t lddy; const float* yact; int64_t ldya; int act;
     int64_t M; int C; const float* mean; const float* invstd; const float* gamma; float* dgamma; float* dbeta;
     float* dx; int64_t lddx; float* dres; int64_t lddr; xword* part; int* sync; BnFusedGeom g;
+    float gscale;     // 1/(1-p) of a dropout fused after the activation (its mask is y_act == 0), else 1
 };
 
 __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
@@ -557,7 +583,8 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
                     u.x *= act_mask(ya[j].x, act); u.y *= act_mask(ya[j].y, act);
                     u.z *= act_mask(ya[j].z, act); u.w *= act_mask(ya[j].w, act);
                 }
-                u.x *= w[j]; u.y *= w[j]; u.z *= w[j]; u.w *= w[j];
+                const float ws_ = w[j] * a.gscale;
+                u.x *= ws_; u.y *= ws_; u.z *= ws_; u.w *= ws_;
                 s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
                 s1.x = fmaf(u.x, (v[j].x - mu.x) * is.x, s1.x); s1.y = fmaf(u.y, (v[j].y - mu.y) * is.y, s1.y);
                 s1.z = fmaf(u.z, (v[j].z - mu.z) * is.z, s1.z); s1.w = fmaf(u.w, (v[j].w - mu.w) * is.w, s1.w);
@@ -596,6 +623,7 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
             const float4 ya = *reinterpret_cast<const float4*>(aq + r * a.ldya);
             u.x *= act_mask(ya.x, act); u.y *= act_mask(ya.y, act); u.z *= act_mask(ya.z, act); u.w *= act_mask(ya.w, act);
         }
+        u.x *= a.gscale; u.y *= a.gscale; u.z *= a.gscale; u.w *= a.gscale;
         if (drq) *reinterpret_cast<float4*>(drq + r * a.lddr) = u;
         float4 o;
         o.x = ga.x * is.x * (u.x - db.x * inv_count - (v.x - mu.x) * is.x * dg.x * inv_count);
@@ -1147,7 +1175,16 @@ __global__ __launch_bounds__(kT) void image_colsum_kernel(const float* x, int64_
     float s = 0.0f;
     if (c < C) {
         const float* base = x + (int64_t)b * P * ldx + c;
-        for (int64_t p = ry; p < P; p += 4) s += base[p * ldx];
+        int64_t p = ry;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; p + 28 < P; p += 32) {          // 8 rows in flight per lane (one row per trip exposes a full load latency)
+            const float v0 = base[p * ldx], v1 = base[(p + 4) * ldx], v2 = base[(p + 8) * ldx], v3 = base[(p + 12) * ldx];
+            const float v4 = base[(p + 16) * ldx], v5 = base[(p + 20) * ldx], v6 = base[(p + 24) * ldx], v7 = base[(p + 28) * ldx];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        s = (s0 + s1) + (s2 + s3);
+        for (; p < P; p += 4) s += base[p * ldx];
     }
     sh[ry][threadIdx.x & 63] = s;
     __syncthreads();
@@ -1176,15 +1213,6 @@ __global__ __launch_bounds__(kT) void image_broadcast_kernel(const float* v, int
 // dropout: counter-based RNG (SplitMix64-style hash of (seed, flat element index)); the mask is regenerated
 // in the backward pass from the same seed, never stored.
 // ================================================================================================
-__device__ __forceinline__ uint32_t hash_rng(uint64_t seed, uint64_t idx)
-{
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
-}
-
 // float4 variant (C % 4 == 0): same per-element hash stream as the scalar kernel (mask = f(seed, flat index))
 __global__ __launch_bounds__(kT) void dropout4_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int cq,
                                                      float p, float inv_keep, uint64_t seed, const uint64_t* seed_dev)
@@ -1427,24 +1455,27 @@ static int bn_fused_check(const char* what, int64_t M, int C, const BnFusedGeom&
 
 int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                          const float* residual, int64_t ldr, int act, float* y, int64_t ldy, void* workspace,
+                          const float* residual, int64_t ldr, int act, float drop_p, uint64_t drop_seed,
+                          const uint64_t* drop_seed_dev, float* y, int64_t ldy, void* workspace,
                           size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
 {
+    if (drop_p < 0.0f || drop_p >= 1.0f) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_fused: dropout p=%f outside [0,1)", (double)drop_p);
+    if (drop_p > 0.0f && act == 2) return fail(PP_ERR_UNSUPPORTED, "bn_train_fwd_fused: dropout after ReLU6 is not fusable");
     if (!x || !gamma || !beta || !mean || !invstd || !y) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_fused: null");
     if (int rc = need_c4(C, "bn_train_fwd_fused")) return rc;
     if (ldx % 4 || ldy % 4 || (residual && ldr % 4)) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_fused: ld must be multiples of 4");
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
-                reinterpret_cast<xword*>(workspace), sync, g};
+                reinterpret_cast<xword*>(workspace), sync, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev};
     hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel");
 }
 
 int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
                     int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, void* workspace, size_t ws_bytes,
-                    int32_t* sync, size_t sync_ints, pp_stream_t stream)
+                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, void* workspace,
+                    size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
 {
     if (!x || !dy || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: null");
     if (act != 0 && !y_act) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: activation output needed for the mask");
@@ -1454,7 +1485,7 @@ int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_bwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnBwdArgs a{x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr,
-                reinterpret_cast<xword*>(workspace), sync, g};
+                reinterpret_cast<xword*>(workspace), sync, g, grad_scale};
     hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_bwd_kernel");
 }

@@ -359,6 +359,7 @@ def _acc(v: Var, g: torch.Tensor):
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
     rc = _lib.lib().pp_add2d(v.grad.data_ptr(), lda, g.data_ptr(), ldb, out.data_ptr(), C, B * H * W, C, _stream())
     _lib.check(rc, "pp_add2d")
+    out._pp_owned = True
     v.grad = out
 
 
@@ -421,6 +422,8 @@ def add(tape: Tape, a: Var, b: Var) -> Var:
 
 
 def _add_bwd(tape: Tape, dy, a: Var, b: Var):
+    if getattr(dy, "_pp_owned", False):
+        dy._pp_owned = False             # shared by both inputs from here on: nobody may add into it in place
     _acc(a, dy)
     _acc(b, dy)
 
@@ -552,12 +555,17 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
         if db is not None:
             tape.set_param_grad(bias, db)
     if x.needs_grad:
-        dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        # x already has a gradient from another consumer (the residual branch): add into it in the kernel's epilogue
+        acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
+                              and tuple(x.grad.shape) == (B, H, W, Cin)) else None
+        dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
         rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                  dx.data_ptr(), Cin, H, W, Cin, ws, wsn, _stream())
+                                  dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
         _lib.check(rc, "pp_conv2d_bwd_data")
-        _acc(x, dx)
+        if acc_into is None:
+            dx._pp_owned = True              # fresh tensor referenced by x.grad only: later consumers may add in place
+            _acc(x, dx)
 
 
 # ------------------------------------------------------------------------------------------------- depthwise conv
@@ -600,8 +608,12 @@ def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
 # ------------------------------------------------------------------------------------------------- batch norm (+act, +residual)
 def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE,
                    residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
-                   dst: Optional[torch.Tensor] = None) -> Var:
-    """nn.BatchNorm2d -> (+ residual) -> activation.  Training: batch statistics + running-stat update."""
+                   dst: Optional[torch.Tensor] = None, dropout_p: float = 0.0) -> Var:
+    """nn.BatchNorm2d -> (+ residual) -> activation [-> nn.Dropout(dropout_p), already known to be active].
+    Training: batch statistics + running-stat update; the dropout rides in the single-launch kernel's apply pass."""
+    if dropout_p > 0.0 and not (training and _BN_FUSED and act != ACT_RELU6 and dst is None):
+        y = batch_norm_act(tape, x, gamma, beta, running_mean, running_var, training, act, residual, eps, momentum, dst)
+        return dropout(tape, y, dropout_p, True)
     if not training and x._pending is not None and not tape.enabled:
         _launch_deferred(x, (gamma, beta, running_mean, running_var, eps, act, residual, dst))
         return Var(x._t, needs_grad=False)
@@ -620,14 +632,20 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
             _, _, _, _, ldr = _geom(residual.t)
             rptr = residual.t.data_ptr()
         sync, ws = _bn_exchange(dev)
+        dseed, sd = 0, None
+        if dropout_p > 0.0:                           # same seed sequence as dropout()
+            _dropout_counter[0] += 1
+            dseed = (_dropout_counter[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            sd = _dropout_seed_dev[0]
         rc = L.pp_bn_train_fwd_fused(x.t.data_ptr(), ldx, M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                      running_mean.data_ptr() if running_mean is not None else None,
                                      running_var.data_ptr() if running_var is not None else None,
-                                     mean.data_ptr(), invstd.data_ptr(), rptr, ldr, act, y.data_ptr(), ldy,
+                                     mean.data_ptr(), invstd.data_ptr(), rptr, ldr, act, float(dropout_p), dseed,
+                                     sd.data_ptr() if sd is not None else None, y.data_ptr(), ldy,
                                      ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_bn_train_fwd_fused")
         out = Var(y)
-        tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out), out)
+        tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0 / (1.0 - dropout_p)), out)
         return out
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     shift = torch.empty(C, dtype=torch.float32, device=dev)
@@ -656,13 +674,13 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
     _lib.check(rc, "pp_scale_shift_act")
     out = Var(y)
     if training:
-        tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out), out)
+        tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0), out)
     else:
         tape.record(_bn_eval_bwd, (x, scale, act, residual, out), out)
     return out
 
 
-def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, out: Var):
+def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, out: Var, gscale: float = 1.0):
     L = _lib.lib()
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
@@ -677,10 +695,11 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
         sync, ws = _bn_exchange(dev)
         rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(),
                                invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
-                               dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(),
+                               dres.data_ptr() if dres is not None else None, C, float(gscale), ws.data_ptr(), ws.numel(),
                                sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_bn_bwd_fused")
     else:
+        assert gscale == 1.0, "a fused dropout is only created together with the single-launch BatchNorm"
         ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", M, C), dev)
         rc = L.pp_bn_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(), invstd.data_ptr(),
                          gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
@@ -692,6 +711,7 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
         tape.set_param_grad(beta, dbeta)
     _acc(x, dx)
     if dres is not None:
+        dres._pp_owned = True
         _acc(residual, dres)
 
 

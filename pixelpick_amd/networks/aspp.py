@@ -59,8 +59,7 @@ class ASPP(nn.Module):
         x5 = self.global_avg_pool[2].run(tape, self.global_avg_pool[1].run(tape, pooled), E.ACT_RELU)
         x5 = E.broadcast_hw(tape, x5, H, W, dst=buf[..., 1024:1280])
         cat = E.concat_alias(tape, buf, [x1, x2, x3, x4, x5])
-        y = self.bn1.run(tape, self.conv1.run(tape, cat), E.ACT_RELU)
-        return self.dropout.run(tape, y)
+        return self.bn1.run(tape, self.conv1.run(tape, cat), E.ACT_RELU, dropout=self.dropout)
 
 
 def build_aspp(backbone, output_stride, BatchNorm=None):

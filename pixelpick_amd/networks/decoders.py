@@ -109,7 +109,7 @@ class SegmentHead(nn.Module):
 
     def run(self, tape, x):
         s = self.segment_head
-        h = s[3].run(tape, s[1].run(tape, s[0].run(tape, x), E.ACT_RELU))
-        emb = s[7].run(tape, s[5].run(tape, s[4].run(tape, h), E.ACT_RELU))
+        h = s[1].run(tape, s[0].run(tape, x), E.ACT_RELU, dropout=s[3])
+        emb = s[5].run(tape, s[4].run(tape, h), E.ACT_RELU, dropout=s[7])
         pred = self.classifier.run(tape, emb)
         return {"emb": emb, "pred": pred}

@@ -115,7 +115,9 @@ class BatchNorm2d(nn.Module):
             self._nbt_pending = 0
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
-    def run(self, tape, x, act=E.ACT_NONE, residual=None, dst=None):
+    def run(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None):
+        """dropout: the nn.Dropout module that follows BN -> activation in the reference's Sequential (applied here so
+        that it can ride in the BatchNorm kernel when both are in training mode)."""
         training = self.training
         if training:
             B, H, W, _ = x.t.shape
@@ -123,8 +125,9 @@ class BatchNorm2d(nn.Module):
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.t.shape)}")
             self.__dict__["_nbt_pending"] += 1   # folded into the num_batches_tracked buffer when it is read (plain dict
                                                  # write: nn.Module.__setattr__ costs ~2 us x 60 BN layers per step)
+        drop_p = dropout.p if (dropout is not None and dropout.training and dropout.p > 0.0) else 0.0
         return E.batch_norm_act(tape, x, self.weight, self.bias, self.running_mean, self.running_var, training, act,
-                                residual, self.eps, self.momentum, dst=dst)
+                                residual, self.eps, self.momentum, dst=dst, dropout_p=drop_p)
 
     def forward(self, x):
         raise RuntimeError("pixelpick_amd layers execute through run(tape, x)")

@@ -349,11 +349,11 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
                 y, dx = torch.empty_like(x), torch.empty_like(x)
                 dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
                 _lib.check(L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
-                                                   mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
+                                                   mean.data_ptr(), invstd.data_ptr(), None, 0, 2, 0.0, 0, None, y.data_ptr(), C, ws.data_ptr(),
                                                    ws.numel(), sync.data_ptr(), sync.numel(), st), "fwd")
                 _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
                                              invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
-                                             None, 0, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
+                                             None, 0, 1.0, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
                 outs.append((mean, invstd, dg, db, y if it % 20 == 0 else None, dx if it % 20 == 0 else None))
             return outs
         a, b = sequence(), sequence()
@@ -376,11 +376,42 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
         y, dx = torch.empty_like(x), torch.empty_like(x)
         mean, invstd, dg, db = (torch.empty(C, device=DEV) for _ in range(4))
         assert L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
-                                       mean.data_ptr(), invstd.data_ptr(), None, 0, 2, y.data_ptr(), C, ws.data_ptr(),
+                                       mean.data_ptr(), invstd.data_ptr(), None, 0, 2, 0.0, 0, None, y.data_ptr(), C, ws.data_ptr(),
                                        ws.numel(), sync.data_ptr(), 1, st) != 0
         assert L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
                                  invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
-                                 None, 0, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
+                                 None, 0, 1.0, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
+
+
+@pytest.mark.parametrize("shape,p", [((4, 16, 32, 256), 0.5), ((2, 9, 11, 48), 0.1), ((2, 64, 128, 256), 0.5)])
+def test_dropout_fused_into_batchnorm_equals_separate_dropout(shape, p):
+    """BN -> ReLU -> nn.Dropout (aspp.py:59-61, decoders.py:108-114): the dropout rides in the single-launch BatchNorm
+    (same mask stream as pp_dropout), its backward is the 1/(1-p) factor on the masked gradient."""
+    B, H, W, C = shape
+    torch.manual_seed(4)
+    x = torch.randn(B, H, W, C, device=DEV) * 2 + 0.3
+    dy = torch.randn(B, H, W, C, device=DEV)
+    gamma, beta = gparam(torch.rand(C) + 0.5), gparam(torch.randn(C) * 0.2)
+
+    def run(fused):
+        E.set_dropout_seed(77)
+        tape = E.Tape()
+        xv = E.Var(x.clone())
+        if fused:
+            yv = E.batch_norm_act(tape, xv, gamma, beta, None, None, True, E.ACT_RELU, dropout_p=p)
+        else:
+            yv = E.dropout(tape, E.batch_norm_act(tape, xv, gamma, beta, None, None, True, E.ACT_RELU), p, True)
+        n_launch_nodes = len(tape.nodes)
+        tape.backward(yv, dy.clone())
+        return yv.t, xv.grad, tape.param_grads[id(gamma)], tape.param_grads[id(beta)], n_launch_nodes
+
+    yf, dxf, dgf, dbf, nf = run(True)
+    ys, dxs, dgs, dbs, ns = run(False)
+    assert nf == 1 and ns == 2
+    assert torch.equal(yf, ys)
+    frac = (yf == 0).float().mean().item()
+    assert frac > p * 0.5                                   # relu zeros + dropped
+    close(dxf, dxs, tol=1e-5, what="dx"); close(dgf, dgs, tol=1e-5, what="dgamma"); close(dbf, dbs, tol=1e-5, what="dbeta")
 
 
 def test_batchnorm_eval():

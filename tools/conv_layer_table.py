@@ -69,7 +69,7 @@ def main():
         wsd = torch.empty(max(1, L.pp_conv2d_bwd_data_workspace_bytes(Bn, Hh, Ww, Cin, Cout, kh, kw, s, p, d)), dtype=torch.uint8, device="cuda")
         gf = 2.0 * Bn * Ho * Wo * Cin * Cout * kh * kw / 1e9
         tf = timeit(lambda: L.pp_conv2d_fwd(xt.data_ptr(), Cin, Bn, Hh, Ww, Cin, wt.data_ptr(), None, kh, kw, s, p, d, yt.data_ptr(), Cout, Cout, wsf.data_ptr(), wsf.numel(), st))
-        td = timeit(lambda: L.pp_conv2d_bwd_data(dy.data_ptr(), Cout, Bn, Ho, Wo, Cout, wt.data_ptr(), kh, kw, s, p, d, dx.data_ptr(), Cin, Hh, Ww, Cin, wsd.data_ptr(), wsd.numel(), st)) if ng else 0.0
+        td = timeit(lambda: L.pp_conv2d_bwd_data(dy.data_ptr(), Cout, Bn, Ho, Wo, Cout, wt.data_ptr(), kh, kw, s, p, d, dx.data_ptr(), Cin, Hh, Ww, Cin, 0, wsd.data_ptr(), wsd.numel(), st)) if ng else 0.0
         tw = timeit(lambda: L.pp_conv2d_bwd_weight(xt.data_ptr(), Cin, Bn, Hh, Ww, Cin, dy.data_ptr(), Cout, Cout, kh, kw, s, p, d, dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
         tot[0] += tf * cnt; tot[1] += td * cnt; tot[2] += tw * cnt
         f = lambda t: (gf / t * 1e3) if t else 0.0
