@@ -164,11 +164,12 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
  * with pp_dropout's mask stream (same seed / seed_dev -> same mask), act must be 0 or 1. */
 
 /* Single-launch form of pp_bn_bwd (same arguments + sync).  grad_scale = 1/(1-p) when a dropout was fused into the
- * forward (its mask is recovered from y_act == 0), else 1. */
+ * forward (its mask is recovered from y_act == 0), else 1.  y_act == NULL with beta != NULL (no residual, no dropout):
+ * the ReLU/ReLU6 mask is recomputed from x with the forward's own fma (bit-identical), y_act is not read. */
 int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
                     int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, void* workspace,
-                    size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
+                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
+                    void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
 
 /* nn.BatchNorm2d, eval mode: scale/shift from the running statistics. */
 int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,

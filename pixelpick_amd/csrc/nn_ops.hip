@@ -538,6 +538,7 @@ struct BnBwdArgs {
     int64_t M; int C; const float* mean; const float* invstd; const float* gamma; float* dgamma; float* dbeta;
     float* dx; int64_t lddx; float* dres; int64_t lddr; xword* part; int* sync; BnFusedGeom g;
     float gscale;     // 1/(1-p) of a dropout fused after the activation (its mask is y_act == 0), else 1
+    const float* beta_mask;   // non-NULL (and yact NULL): the activation mask is recomputed from x, z = x*scale + shift
 };
 
 __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
@@ -559,11 +560,19 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
     const float* xq = a.x + q * 4;
     const float* gq = a.dy + q * 4;
     const float* aq = a.yact ? a.yact + q * 4 : nullptr;
-    const int act = aq ? a.act : 0;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0, is = s0;
+    // mask source: the saved activation output, or (no residual, no dropout) the forward's own z = fma(x, scale, shift)
+    // recomputed from x, which is read anyway: one tensor less in both passes
+    const bool remask = aq == nullptr && a.beta_mask != nullptr && a.act != 0;
+    const int act = (aq || remask) ? a.act : 0;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0, is = s0, zsc = s0, zsf = s0;
     if (active) {
         mu = *reinterpret_cast<const float4*>(a.mean + q * 4);
         is = *reinterpret_cast<const float4*>(a.invstd + q * 4);
+        if (remask) {
+            const float4 gm = *reinterpret_cast<const float4*>(a.gamma + q * 4), be = *reinterpret_cast<const float4*>(a.beta_mask + q * 4);
+            zsc = make_float4(gm.x * is.x, gm.y * is.y, gm.z * is.z, gm.w * is.w);
+            zsf = make_float4(be.x - mu.x * zsc.x, be.y - mu.y * zsc.y, be.z - mu.z * zsc.z, be.w - mu.w * zsc.w);
+        }
         for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
             float4 v[2], gg[2], ya[2];
             float w[2];
@@ -574,11 +583,14 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
                 const int64_t rc = rr < r1 ? rr : r1 - 1;
                 v[j] = *reinterpret_cast<const float4*>(xq + rc * a.ldx);
                 gg[j] = *reinterpret_cast<const float4*>(gq + rc * a.lddy);
-                if (act != 0) ya[j] = *reinterpret_cast<const float4*>(aq + rc * a.ldya);
+                if (act != 0 && !remask) ya[j] = *reinterpret_cast<const float4*>(aq + rc * a.ldya);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float4 u = gg[j];
+                if (remask)
+                    ya[j] = make_float4(fmaf(v[j].x, zsc.x, zsf.x), fmaf(v[j].y, zsc.y, zsf.y), fmaf(v[j].z, zsc.z, zsf.z),
+                                        fmaf(v[j].w, zsc.w, zsf.w));
                 if (act != 0) {
                     u.x *= act_mask(ya[j].x, act); u.y *= act_mask(ya[j].y, act);
                     u.z *= act_mask(ya[j].z, act); u.w *= act_mask(ya[j].w, act);
@@ -620,7 +632,9 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
         float4 u = *reinterpret_cast<const float4*>(gq + r * a.lddy);
         const float4 v = *reinterpret_cast<const float4*>(xq + r * a.ldx);
         if (act != 0) {
-            const float4 ya = *reinterpret_cast<const float4*>(aq + r * a.ldya);
+            const float4 ya = remask ? make_float4(fmaf(v.x, zsc.x, zsf.x), fmaf(v.y, zsc.y, zsf.y), fmaf(v.z, zsc.z, zsf.z),
+                                                   fmaf(v.w, zsc.w, zsf.w))
+                                     : *reinterpret_cast<const float4*>(aq + r * a.ldya);
             u.x *= act_mask(ya.x, act); u.y *= act_mask(ya.y, act); u.z *= act_mask(ya.z, act); u.w *= act_mask(ya.w, act);
         }
         u.x *= a.gscale; u.y *= a.gscale; u.z *= a.gscale; u.w *= a.gscale;
@@ -1474,18 +1488,20 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
 
 int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
                     int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, void* workspace,
-                    size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
+                    float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
+                    void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
 {
     if (!x || !dy || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: null");
-    if (act != 0 && !y_act) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: activation output needed for the mask");
+    if (act != 0 && !y_act && !beta) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: the mask needs the activation output or beta");
+    if (!y_act && act != 0 && (dres || grad_scale != 1.0f))
+        return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: the mask can only be recomputed from x without residual / dropout");
     if (int rc = need_c4(C, "bn_bwd_fused")) return rc;
     if (ldx % 4 || lddy % 4 || lddx % 4 || (y_act && ldya % 4) || (dres && lddr % 4))
         return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: ld must be multiples of 4");
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_bwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnBwdArgs a{x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr,
-                reinterpret_cast<xword*>(workspace), sync, g, grad_scale};
+                reinterpret_cast<xword*>(workspace), sync, g, grad_scale, y_act ? nullptr : beta};
     hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_bwd_kernel");
 }

@@ -693,10 +693,12 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
     if _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536:
         sync, ws = _bn_exchange(dev)
-        rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(),
-                               invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
-                               dres.data_ptr() if dres is not None else None, C, float(gscale), ws.data_ptr(), ws.numel(),
-                               sync.data_ptr(), sync.numel(), _stream())
+        # ReLU/ReLU6 mask: from the saved output, or - no residual, no fused dropout - recomputed from x (one tensor less)
+        remask = act != ACT_NONE and residual is None and gscale == 1.0
+        rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
+                               mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                               dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),
+                               beta.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_bn_bwd_fused")
     else:
         assert gscale == 1.0, "a fused dropout is only created together with the single-launch BatchNorm"

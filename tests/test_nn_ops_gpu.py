@@ -353,7 +353,7 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
                                                    ws.numel(), sync.data_ptr(), sync.numel(), st), "fwd")
                 _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
                                              invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
-                                             None, 0, 1.0, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
+                                             None, 0, 1.0, None, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
                 outs.append((mean, invstd, dg, db, y if it % 20 == 0 else None, dx if it % 20 == 0 else None))
             return outs
         a, b = sequence(), sequence()
@@ -380,7 +380,43 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
                                        ws.numel(), sync.data_ptr(), 1, st) != 0
         assert L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
                                  invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
-                                 None, 0, 1.0, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
+                                 None, 0, 1.0, None, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
+
+
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("M,C", [(2048, 960), (33540, 96), (700, 24)])
+def test_batchnorm_backward_mask_recomputed_from_x_is_bit_identical(M, C, act):
+    """pp_bn_bwd_fused with y_act == NULL recomputes the ReLU/ReLU6 mask as act'(fma(x, scale, shift)) - the forward's
+    own expression - instead of reading the saved output: every result bit-equal to the y_act path."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    dev = torch.device(DEV)
+    sync, ws = E._bn_exchange(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(M, C, device=DEV, generator=gen) * 2 + 0.7
+    dy = torch.randn(M, C, device=DEV, generator=gen)
+    gamma, beta = torch.rand(C, device=DEV, generator=gen) + 0.5, torch.randn(C, device=DEV, generator=gen) + 1.0
+    mean, invstd, y = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty_like(x)
+    _lib.check(L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                                       mean.data_ptr(), invstd.data_ptr(), None, 0, act, 0.0, 0, None, y.data_ptr(), C,
+                                       ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "fwd")
+    outs = []
+    for ya, be in ((y, None), (None, beta)):
+        dx, dg, db = torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, ya.data_ptr() if ya is not None else None, C, act, M, C,
+                                     mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                     dx.data_ptr(), C, None, 0, 1.0, be.data_ptr() if be is not None else None,
+                                     ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st), "bwd")
+        outs.append((dx, dg, db))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    frac = (y == 0).float().mean().item()
+    assert 0.02 < frac < 0.98            # the mask is not trivial
+    # neither source -> refused
+    assert L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, None, C, act, M, C, mean.data_ptr(), invstd.data_ptr(),
+                             gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C, None, 0, 1.0, None,
+                             ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st) != 0
 
 
 @pytest.mark.parametrize("shape,p", [((4, 16, 32, 256), 0.5), ((2, 9, 11, 48), 0.1), ((2, 64, 128, 256), 0.5)])
