@@ -671,6 +671,20 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
                 return check_launch("acq_kernel");
             }
         }
+        if constexpr (CMAX == 21) {
+            // 21 class planes x 8 pixels do not fit the 170-VGPR budget of 3 waves/SIMD (23 spilled registers, 0.56 of
+            // the HBM roofline on VOC 320x320); at 2 waves/SIMD the kernel has 256 and no scratch traffic
+            if (!alt) {
+                if (g_tune_occ == 3) {
+                    if (pl.ppt == 8) hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 2, 0, 3>), grid, block, 0, st, p);
+                    else             hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 1, 0, 3>), grid, block, 0, st, p);
+                } else {
+                    if (pl.ppt == 8) hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 2, 0, 2>), grid, block, 0, st, p);
+                    else             hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 1, 0, 2>), grid, block, 0, st, p);
+                }
+                return check_launch("acq_kernel");
+            }
+        }
         if constexpr (CMAX <= 32) {
             if (pl.ppt == 8 && !alt) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 2, 0>), grid, block, 0, st, p);
             else                     PP_LAUNCH_ACQ4(4, 1);
