@@ -873,11 +873,13 @@ struct ConvPlan {
     int64_t tiles;
     int n_tiles;
     int splits, ks_per_split;
+    bool bn64;          // cfg 1 with 128x64 tiles
 };
 
 static int g_conv_splitk = 1;
 
 static int g_conv_deepk = 1;
+static int g_conv_n64 = 1;
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
 {
@@ -887,7 +889,11 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
         pl.cfg = 0; pl.n_tiles = 1; pl.tiles = mt128;
     } else if (Cn > 64 && mt128 * cdiv(Cn, 128) >= 384) {
         pl.cfg = 1;
-        pl.n_tiles = (int)cdiv(Cn, g_conv_variant == 2 ? 64 : 128);
+        // ragged output width (backward-data of the 304-channel SegmentHead input): 128-wide tiles compute
+        // cdiv(Cn,128)*128 columns (21 % waste at 304); 64-wide tiles are ~10 % slower per flop but waste 5 %
+        const int rem = Cn % 128;
+        pl.bn64 = g_conv_variant == 2 || (g_conv_n64 && rem != 0 && rem <= 64 && (cdiv(Cn, 128) * 128 - Cn) * 100 > 15 * Cn);
+        pl.n_tiles = (int)cdiv(Cn, pl.bn64 ? 64 : 128);
         pl.tiles = mt128 * pl.n_tiles;
     } else {
         pl.cfg = 2; pl.n_tiles = (int)cdiv(Cn, 64); pl.tiles = mt64 * pl.n_tiles;
@@ -933,7 +939,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, BWD, false>), grid, dim3(kThreads), 0, st, p);
     } else if (pl.cfg == 1) {
-        if (g_conv_variant == 2) {
+        if (pl.bn64) {
             if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
             else     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
         } else {
@@ -959,6 +965,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
 }
 
 static int g_wgrad_narrow = 1;
+static int g_wgrad_m64 = 1;
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
 static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, void* workspace, size_t ws_bytes, hipStream_t st)
@@ -1027,6 +1034,8 @@ void pp_debug_set_conv_variant(int v)
     g_conv_novec = (v & 8) ? 1 : 0;          // bit 3 forces the conditional-load path (A/B)
     g_conv_lds_pad = (v & 16) ? 40 * 1024 : ((v & 32) ? 70 * 1024 : 0);   // bits 4/5: at most 2 / 1 blocks per CU
     g_conv_splitk = (v & 64) ? 0 : 1;        // bit 6 switches split-K off (A/B)
+    g_conv_n64 = (v & 2048) ? 0 : 1;         // bit 11: 64-wide tiles for ragged output widths off (A/B)
+    g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     v &= 3;
@@ -1153,7 +1162,11 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     }
     {
     const bool big = Cin > 64 && Cout > 64;
-    const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+    // 128-row tiles waste (128 - Cin % 128) rows of the last tile: 304 input channels (SegmentHead, decoders.py:107) fill
+    // 2.4 of 3 tiles; 64-row tiles waste 5 % instead of 21 %
+    const int rem = Cin % 128;
+    const bool narrow_m = big && g_wgrad_m64 && rem != 0 && rem <= 64 && (cdiv(Cin, 128) * 128 - Cin) * 100 > 12 * Cin;
+    const int bm = big ? (narrow_m ? 64 : 128) : 64, bn = big ? 128 : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
     int64_t splits = cdiv(1024, tiles);
     const int64_t max_by_m = cdiv(p.M, 256);       // at least 256 pixels per split
@@ -1171,7 +1184,10 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
     const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-    if (big) {
+    if (big && narrow_m) {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+    } else if (big) {
         if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
     } else {
