@@ -1166,7 +1166,9 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     // 2.4 of 3 tiles; 64-row tiles waste 5 % instead of 21 %
     const int rem = Cin % 128;
     const bool narrow_m = big && g_wgrad_m64 && rem != 0 && rem <= 64 && (cdiv(Cin, 128) * 128 - Cin) * 100 > 12 * Cin;
-    const int bm = big ? (narrow_m ? 64 : 128) : 64, bn = big ? 128 : 64;
+    const int remn = Cout % 128;
+    const bool narrow_n = big && g_wgrad_m64 && remn != 0 && remn <= 64 && (cdiv(Cout, 128) * 128 - Cout) * 100 > 12 * Cout;
+    const int bm = big ? (narrow_m ? 64 : 128) : 64, bn = big ? (narrow_n ? 64 : 128) : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
     int64_t splits = cdiv(1024, tiles);
     const int64_t max_by_m = cdiv(p.M, 256);       // at least 256 pixels per split
@@ -1184,9 +1186,15 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
     const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-    if (big && narrow_m) {
+    if (big && narrow_m && narrow_n) {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+    } else if (big && narrow_m) {
         if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+    } else if (big && narrow_n) {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
     } else if (big) {
         if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
         else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
