@@ -296,6 +296,8 @@ void pp_debug_set_acq_tuning(int occ, int ppt);
 /* Dense conv kernel A/B knobs: low 2 bits 0 = 128x128 large tile (default; measured fastest), 2 = 128x64 tiles;
  * bit 2 = linear instead of XCD-aware tile order; bit 3 = conditional (non-vector) loads; bits 4/5 = cap the large
  * tile at 2 / 1 blocks per CU.  Findings: profiles/r01_conv_ablation.txt. */
+void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B) */
+void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
 void pp_debug_set_conv_variant(int v);
 
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The

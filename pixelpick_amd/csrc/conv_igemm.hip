@@ -1028,6 +1028,15 @@ using namespace pp;
 
 extern "C" {
 
+/* tools/conv_layer_table.py: the plan the forward / backward-data launcher picks for an (M x Cn x K = ntaps*Ck) problem:
+ * out = {tile rows, tile cols, tiles, split-K slices} */
+void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out)
+{
+    const ConvPlan pl = plan_conv(M, Cn, Ck, ntaps, Ck % 4 == 0 && Cn % 4 == 0);
+    const int rows[5] = {128, 128, 64, 64, 256}, cols[5] = {32, pl.bn64 ? 64 : 128, 64, 64, 128};
+    out[0] = rows[pl.cfg]; out[1] = cols[pl.cfg]; out[2] = (int)pl.tiles; out[3] = pl.splits;
+}
+
 void pp_debug_set_conv_variant(int v)
 {
     g_conv_xcd_remap = (v & 4) ? 0 : 1;      // bit 2 switches the XCD-aware tile order off (A/B)

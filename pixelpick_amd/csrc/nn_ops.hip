@@ -697,6 +697,78 @@ __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t 
     }
 }
 
+// Stride 1, dilation 1 (13 of MobileNetV2's 17 depthwise layers): one thread produces FOUR neighbouring outputs of a
+// row, so the 3x6 input window and the 9 weights are loaded once for them (27 float4 loads per 4 outputs instead of
+// 72).  FLIP == false: forward (taps read x at (oh - pad + th, ow - pad + tw)); FLIP == true: backward-data of the
+// same layer (dx(ih,iw) = sum dy(ih + pad - th, iw + pad - tw) w[th][tw], i.e. the forward with the weights
+// mirrored and padding 2 - pad).
+template <bool FLIP>
+__global__ __launch_bounds__(kT) void dwconv_s1_x4_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
+                                                         const float* w, int pad, float* y, int64_t ldy, int Ho, int Wo,
+                                                         Epilogue epi)
+{
+    const int C = cq * 4;
+    const int wq = (Wo + 3) / 4;
+    const int64_t total = (int64_t)B * Ho * wq * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int ow0 = (int)(t % wq) * 4; t /= wq;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float4 acc[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const int ih = oh - pad + th;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            const float* row = x + ((int64_t)b * H + ih) * W * ldx + q * 4;
+            float4 v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int iw = ow0 - pad + j;
+                v[j] = (unsigned)iw < (unsigned)W ? *reinterpret_cast<const float4*>(row + (int64_t)iw * ldx)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int wi = FLIP ? (2 - th) * 3 + (2 - tw) : th * 3 + tw;
+                const float4 ww = *reinterpret_cast<const float4*>(w + wi * C + q * 4);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    acc[o].x = fmaf(v[o + tw].x, ww.x, acc[o].x); acc[o].y = fmaf(v[o + tw].y, ww.y, acc[o].y);
+                    acc[o].z = fmaf(v[o + tw].z, ww.z, acc[o].z); acc[o].w = fmaf(v[o + tw].w, ww.w, acc[o].w);
+                }
+            }
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (epi.gamma) {
+            const float4 g = *reinterpret_cast<const float4*>(epi.gamma + q * 4), be = *reinterpret_cast<const float4*>(epi.beta + q * 4);
+            const float4 mu = *reinterpret_cast<const float4*>(epi.mean + q * 4), va = *reinterpret_cast<const float4*>(epi.var + q * 4);
+            sc.x = g.x * (1.0f / sqrtf(va.x + epi.eps)); sf.x = be.x - mu.x * sc.x;
+            sc.y = g.y * (1.0f / sqrtf(va.y + epi.eps)); sf.y = be.y - mu.y * sc.y;
+            sc.z = g.z * (1.0f / sqrtf(va.z + epi.eps)); sf.z = be.z - mu.z * sc.z;
+            sc.w = g.w * (1.0f / sqrtf(va.w + epi.eps)); sf.w = be.w - mu.w * sc.w;
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (ow0 + o >= Wo) break;
+            const int64_t r = ((int64_t)b * Ho + oh) * Wo + ow0 + o;
+            float4 a = acc[o];
+            if (epi.gamma) {
+                a.x = fmaf(a.x, sc.x, sf.x); a.y = fmaf(a.y, sc.y, sf.y); a.z = fmaf(a.z, sc.z, sf.z); a.w = fmaf(a.w, sc.w, sf.w);
+            }
+            if (epi.res) {
+                const float4 rr = *reinterpret_cast<const float4*>(epi.res + r * epi.ldr + q * 4);
+                a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
+            }
+            a.x = epi_act(a.x, epi.act); a.y = epi_act(a.y, epi.act); a.z = epi_act(a.z, epi.act); a.w = epi_act(a.w, epi.act);
+            *reinterpret_cast<float4*>(y + r * ldy + q * 4) = a;
+        }
+    }
+}
+
 // dx(ih,iw) = sum_t dy((ih + pad - th*dil)/stride, ...) * w[t]  where divisible
 __global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq,
                                                             const float* w, int stride, int pad, int dil, float* dx,
@@ -1397,6 +1469,8 @@ __global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_
     }
 }
 
+static int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
+
 static inline unsigned grid_for(int64_t total)
 {
     int64_t b = cdiv(total, kT);
@@ -1416,6 +1490,8 @@ static int need_c4(int C, const char* what)
 using namespace pp;
 
 extern "C" {
+
+void pp_debug_set_dw_variant(int v) { g_dw_x4 = (v & 1) ? 0 : 1; }
 
 // ---- batch norm -----------------------------------------------------------------------------------
 size_t pp_colreduce_workspace_bytes(int64_t M, int C)
@@ -1555,6 +1631,11 @@ static int dwconv_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
     if (int rc = need_c4(C, "dwconv fwd")) return rc;
     const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
     if (Ho < 1 || Wo < 1) return fail(PP_ERR_BAD_ARG, "dwconv fwd: empty output");
+    if (stride == 1 && dil == 1 && g_dw_x4) {
+        hipLaunchKernelGGL((dwconv_s1_x4_kernel<false>), dim3(grid_for((int64_t)B * Ho * ((Wo + 3) / 4) * (C / 4))), dim3(kT), 0,
+                           as_stream(stream), x, ldx, B, H, W, C / 4, w, pad, y, ldy, Ho, Wo, epi);
+        return check_launch("dwconv_s1_x4_kernel");
+    }
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(kT), 0, as_stream(stream), x,
                        ldx, B, H, W, C / 4, w, stride, pad, dil, y, ldy, Ho, Wo, epi);
     return check_launch("dwconv_fwd_kernel");
@@ -1584,6 +1665,11 @@ int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, in
     if (!dy || !w || !dx) return fail(PP_ERR_BAD_ARG, "dwconv bwd_data: null");
     if (int rc = need_c4(C, "dwconv bwd_data")) return rc;
     const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    if (stride == 1 && dil == 1 && g_dw_x4) {
+        hipLaunchKernelGGL((dwconv_s1_x4_kernel<true>), dim3(grid_for((int64_t)B * H * ((W + 3) / 4) * (C / 4))), dim3(kT), 0,
+                           as_stream(stream), dy, lddy, B, Ho, Wo, C / 4, w, 2 - pad, dx, lddx, H, W, Epilogue{});
+        return check_launch("dwconv_s1_x4_kernel");
+    }
     hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(kT), 0, as_stream(stream),
                        dy, lddy, B, Ho, Wo, C / 4, w, stride, pad, dil, dx, lddx, H, W);
     return check_launch("dwconv_bwd_data_kernel");
