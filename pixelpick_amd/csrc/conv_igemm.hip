@@ -899,7 +899,10 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
         pl.cfg = 2; pl.n_tiles = (int)cdiv(Cn, 64); pl.tiles = mt64 * pl.n_tiles;
         // Deep-K variant: at one or two 64x64 blocks per CU the 16-deep K step has 512 MFMA cycles per wave to hide
         // ~2000 cycles of global-load latency behind; a 64-deep step has 2048 (and 4x the bytes in flight).
-        if (g_conv_deepk && vec && Ck >= 64) pl.cfg = 3;
+        // Measured (tools/ab_step.py, bench.py --network FPN): it pays on the ResNet50 shapes (8192 rows, K >= 256:
+        // 28.15 -> 27.92 ms/step) and costs on MobileNetV2's 2048-row layers (7.37 -> 7.43 ms/step: 152 VGPRs, fewer
+        // co-resident blocks for the split-K slices), so it is keyed on both.
+        if (g_conv_deepk && vec && Ck >= 256 && M >= 4096) pl.cfg = 3;
     }
     const int bk = pl.cfg == 3 ? 64 : BK;
     const int nk = ntaps * (int)cdiv(Ck, bk);
