@@ -877,6 +877,7 @@ struct ConvPlan {
 };
 
 static int g_conv_splitk = 1;
+static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_splitk_min_iters = 4;
 
 static int g_conv_deepk = 1;
 static int g_conv_n64 = 1;
@@ -908,9 +909,9 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
     const int nk = ntaps * (int)cdiv(Ck, bk);
     pl.splits = 1;
     pl.ks_per_split = nk;
-    if (g_conv_splitk && pl.tiles < 192 && nk >= (pl.cfg == 3 ? 4 : 12)) {
-        int64_t s = cdiv(512, pl.tiles);
-        const int min_iters = pl.cfg == 3 ? 2 : 4;
+    if (g_conv_splitk && pl.tiles < g_splitk_tiles && nk >= (pl.cfg == 3 ? 4 : g_splitk_min_nk)) {
+        int64_t s = cdiv(g_splitk_target, pl.tiles);
+        const int min_iters = pl.cfg == 3 ? 2 : g_splitk_min_iters;
         if (s > nk / min_iters) s = nk / min_iters;
         if (s > 32) s = 32;
         if (s > 1) {
@@ -1038,6 +1039,15 @@ void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out)
     const ConvPlan pl = plan_conv(M, Cn, Ck, ntaps, Ck % 4 == 0 && Cn % 4 == 0);
     const int rows[5] = {128, 128, 64, 64, 256}, cols[5] = {32, pl.bn64 ? 64 : 128, 64, 64, 128};
     out[0] = rows[pl.cfg]; out[1] = cols[pl.cfg]; out[2] = (int)pl.tiles; out[3] = pl.splits;
+}
+
+/* A/B of the split-K plan: v = tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 (0: defaults) */
+void pp_debug_set_splitk(int v)
+{
+    g_splitk_tiles = (v & 1023) ? (v & 1023) : 192;
+    g_splitk_target = ((v >> 10) & 1023) ? ((v >> 10) & 1023) : 512;
+    g_splitk_min_nk = ((v >> 20) & 63) ? ((v >> 20) & 63) : 12;
+    g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
 
 void pp_debug_set_conv_variant(int v)
