@@ -33,6 +33,28 @@ __device__ __forceinline__ float act_mask(float y, int act)
     return 1.0f;
 }
 
+// flat element index -> (q, w, h, b) for an array [B][H][W][cq]; 32-bit unsigned divisions whenever the index fits
+// (64-bit integer division is emulated in ~100 instructions on this ISA and was most of the depthwise kernels' work)
+__device__ __forceinline__ void decode_bhwq(int64_t e, int cq, int Wd, int Hd, int& q, int& w, int& h, int& b)
+{
+    if (e <= 0xFFFFFFFFll) {
+        const unsigned u = (unsigned)e;
+        const unsigned t = u / (unsigned)cq;
+        q = (int)(u - t * (unsigned)cq);
+        const unsigned t2 = t / (unsigned)Wd;
+        w = (int)(t - t2 * (unsigned)Wd);
+        const unsigned t3 = t2 / (unsigned)Hd;
+        h = (int)(t2 - t3 * (unsigned)Hd);
+        b = (int)t3;
+    } else {
+        q = (int)(e % cq);
+        int64_t t = e / cq;
+        w = (int)(t % Wd); t /= Wd;
+        h = (int)(t % Hd);
+        b = (int)(t / Hd);
+    }
+}
+
 // ================================================================================================
 // Column reductions over an [M, C] matrix (pixel stride ld): partial sums per row-block, then a finalize.
 // Thread mapping: float4 column q = t % cq_blk, row lane ry = t / cq_blk (consecutive threads walk the
@@ -658,11 +680,8 @@ __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t 
     const int C = cq * 4;
     const int64_t total = (int64_t)B * Ho * Wo * cq;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
-        const int q = (int)(e % cq);
-        int64_t t = e / cq;
-        const int ow = (int)(t % Wo); t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+        int q, ow, oh, b;
+        decode_bhwq(e, cq, Wo, Ho, q, ow, oh, b);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int th = 0; th < 3; ++th) {
@@ -711,11 +730,9 @@ __global__ __launch_bounds__(kT) void dwconv_s1_x4_kernel(const float* x, int64_
     const int wq = (Wo + 3) / 4;
     const int64_t total = (int64_t)B * Ho * wq * cq;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
-        const int q = (int)(e % cq);
-        int64_t t = e / cq;
-        const int ow0 = (int)(t % wq) * 4; t /= wq;
-        const int oh = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+        int q, owq, oh, b;
+        decode_bhwq(e, cq, wq, Ho, q, owq, oh, b);
+        const int ow0 = owq * 4;
         float4 acc[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -777,11 +794,8 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, in
     const int C = cq * 4;
     const int64_t total = (int64_t)B * H * W * cq;
     for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
-        const int q = (int)(e % cq);
-        int64_t t = e / cq;
-        const int iw = (int)(t % W); t /= W;
-        const int ih = (int)(t % H);
-        const int b = (int)(t / H);
+        int q, iw, ih, b;
+        decode_bhwq(e, cq, W, H, q, iw, ih, b);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int th = 0; th < 3; ++th) {
@@ -824,10 +838,11 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, i
         const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
         const int64_t r1 = r0 + g.rows_per_block < M ? r0 + g.rows_per_block : M;
         for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
-            const int ow = (int)(r % Wo);
-            const int64_t tt = r / Wo;
-            const int oh = (int)(tt % Ho);
-            const int b = (int)(tt / Ho);
+            const unsigned ru = (unsigned)r;                 // M < 2^31 (checked on the host)
+            const unsigned tt = ru / (unsigned)Wo;
+            const int ow = (int)(ru - tt * (unsigned)Wo);
+            const int b = (int)(tt / (unsigned)Ho);
+            const int oh = (int)(tt - (unsigned)b * (unsigned)Ho);
             const float4 gg = *reinterpret_cast<const float4*>(dy + r * lddy + q * 4);
 #pragma unroll
             for (int th = 0; th < 3; ++th) {
@@ -1682,6 +1697,7 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
     if (int rc = need_c4(C, "dwconv bwd_weight")) return rc;
     const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
+    if (M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "dwconv bwd_weight: more than 2^31 output pixels");
     ColReduceGeom g = col_geom(M, C);
     if (!workspace || ws_bytes < (size_t)g.nblk_rows * 9 * C * 4) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
     hipStream_t st = as_stream(stream);
