@@ -301,6 +301,10 @@ _BN_XCHG_SYNC_INTS = 1 << 14          # 64 KiB of arrival counters (2048 strips:
 _BN_XCHG_PART_BYTES = 1 << 20         # partial-sum exchange area (<= 1024 blocks x 64 floats = 256 KiB needed)
 
 
+class _FineGrainedUnavailable(RuntimeError):
+    pass
+
+
 class _Raw:
     """data_ptr()/numel() view of a raw device allocation."""
     __slots__ = ("ptr", "n")
@@ -337,7 +341,7 @@ def _bn_exchange(device):
         with torch.cuda.device(device):
             rc = hip.hipExtMallocWithFlags(ctypes.byref(ptr), nbytes, 1)          # hipDeviceMallocFinegrained
             if rc != 0 or not ptr.value:
-                raise _lib.PixelPickHipError(f"hipExtMallocWithFlags(finegrained, {nbytes}) -> {rc}")
+                raise _FineGrainedUnavailable(f"hipExtMallocWithFlags(finegrained, {nbytes}) -> {rc}")
             rc = hip.hipMemset(ptr, 0, nbytes)
             if rc != 0:
                 raise _lib.PixelPickHipError(f"hipMemset -> {rc}")
@@ -345,6 +349,20 @@ def _bn_exchange(device):
         ex = (_Raw(ptr.value, _BN_XCHG_SYNC_INTS), _Raw(ptr.value + _BN_XCHG_SYNC_INTS * 4, _BN_XCHG_PART_BYTES))
         _BN_XCHG[key] = ex
     return ex
+
+
+def _bn_exchange_ok(device) -> bool:
+    """False (once, with a warning) when fine-grained memory cannot be allocated: BatchNorm then uses the three-launch
+    kernels, which need no cross-block exchange."""
+    global _BN_FUSED
+    try:
+        _bn_exchange(device)
+        return True
+    except _FineGrainedUnavailable as e:
+        import warnings
+        warnings.warn(f"single-launch BatchNorm disabled: {e}")
+        _BN_FUSED = False
+        return False
 
 
 def _acc(v: Var, g: torch.Tensor):
@@ -611,7 +629,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
                    dst: Optional[torch.Tensor] = None, dropout_p: float = 0.0) -> Var:
     """nn.BatchNorm2d -> (+ residual) -> activation [-> nn.Dropout(dropout_p), already known to be active].
     Training: batch statistics + running-stat update; the dropout rides in the single-launch kernel's apply pass."""
-    if dropout_p > 0.0 and not (training and _BN_FUSED and act != ACT_RELU6 and dst is None):
+    if dropout_p > 0.0 and not (training and _BN_FUSED and act != ACT_RELU6 and dst is None and _bn_exchange_ok(x.t.device)):
         y = batch_norm_act(tape, x, gamma, beta, running_mean, running_var, training, act, residual, eps, momentum, dst)
         return dropout(tape, y, dropout_p, True)
     if not training and x._pending is not None and not tape.enabled:
@@ -621,7 +639,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
     dev = x.t.device
-    if training and _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536:
+    if training and _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536 and _bn_exchange_ok(dev):
         # one launch: statistics + running-stat update + affine + residual + activation
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -691,7 +709,7 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     dbeta = tape.grad_buffer_for(beta)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
     dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
-    if _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536:
+    if _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536 and _bn_exchange_ok(dev):
         sync, ws = _bn_exchange(dev)
         # ReLU/ReLU6 mask: from the saved output, or - no residual, no fused dropout - recomputed from x (one tensor less)
         remask = act != ACT_NONE and residual is None and gscale == 1.0
