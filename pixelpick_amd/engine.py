@@ -98,6 +98,10 @@ def _side_stream(device, i: int = 0) -> "torch.cuda.Stream":
     return st
 
 
+def _MARK():        # sentinel node kind: Tape.mark(name)
+    pass
+
+
 class Tape:
     # Weight-gradient kernels have no consumer until the optimiser step, and most layers of this network are too
     # small to fill 256 CUs on their own: in backward() they run on a second HIP stream, concurrently with the
@@ -114,6 +118,17 @@ class Tape:
         self._side = None
         self._side_rr = 0
         self._keepalive = []
+        self.hooks = {}                # name -> callable run when backward() gets back to Tape.mark(name)
+
+    def mark(self, name: str):
+        """Forward: remember this point.  backward() calls hooks[name] (if set) when every node recorded AFTER this point
+        has been processed, i.e. when all their kernels are enqueued (e.g. "encoder_done": the decoder-side gradients
+        are complete on their streams and can start their all-reduce while the encoder's backward still runs)."""
+        if self.enabled:
+            self.nodes.append((_MARK, name, None))
+
+    def side_streams_in_use(self):
+        return list(self._side.values()) if self._side else []
 
     def record(self, fn, ctx, out: Var):
         if self.enabled:
@@ -163,6 +178,11 @@ class Tape:
             Tape.trace.append(("bwd_begin", _mark()))
         out.grad = dout
         for fn, ctx, o in reversed(self.nodes):
+            if fn is _MARK:
+                hook = self.hooks.get(ctx)
+                if hook is not None:
+                    hook(self)
+                continue
             if o.grad is None:
                 continue
             fn(self, o.grad, *ctx)

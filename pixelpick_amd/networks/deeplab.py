@@ -96,6 +96,7 @@ class DeepLab(nn.Module):
         B, _, H, W = inputs.shape
         x = E.nchw_to_nhwc(inputs)
         high, low = self.backbone.run(tape, x)
+        tape.mark("encoder_done")             # backward: every aspp / low-level / head gradient is enqueued at this point
         a = self.aspp.run(tape, high)
         _, Hl, Wl, _ = low.t.shape
         cat_buf = torch.empty((B, Hl, Wl, 304), dtype=torch.float32, device=inputs.device)

@@ -59,7 +59,9 @@ class FPNSeg(nn.Module):
 
     def _run(self, tape, inputs):
         x = E.nchw_to_nhwc(inputs)
-        outs = self.decoder.run(tape, self.encoder.run(tape, x))
+        feats = self.encoder.run(tape, x)
+        tape.mark("encoder_done")             # backward: every decoder gradient is enqueued at this point
+        outs = self.decoder.run(tape, feats)
         return E.nhwc_to_nchw(tape, outs["pred"]), outs["emb"]
 
     def forward(self, x):

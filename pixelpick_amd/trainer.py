@@ -11,10 +11,16 @@ statistics (the reference has no SyncBN), gradients averaged over ranks.  Nothin
 """
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
 from . import engine as E
+
+
+# PIXELPICK_OVERLAP_ALLREDUCE=0: one all-reduce of the whole flat gradient after backward (the round-1 behaviour)
+OVERLAP_ALLREDUCE = os.environ.get("PIXELPICK_OVERLAP_ALLREDUCE", "1") != "0"
 
 
 class FlatTrainer:
@@ -79,6 +85,9 @@ class FlatTrainer:
         """x [B,3,H,W] f32, y [B,H,W] int64 with ignore_index at unlabelled pixels (model.py:108-110)."""
         tape = E.Tape(enabled=True)
         tape.param_grad_dst = lambda p: self._grad_view.get(id(p))
+        self._early_work = None
+        if self.world > 1 and OVERLAP_ALLREDUCE and self.n_split < self.n and not torch.cuda.is_current_stream_capturing():
+            tape.hooks["encoder_done"] = self._early_all_reduce
         pred, _ = self.model._run(tape, x)
         loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index)
         self.last_logits = pred.t if keep_logits else None
@@ -86,9 +95,33 @@ class FlatTrainer:
         self.last_loss = loss
         return loss
 
+    def _early_all_reduce(self, tape):
+        """Backward hook at the encoder boundary: the gradients of everything BEHIND the encoder (flat_g[n_split:], 16 of
+        the 23 MB for DeepLabv3+-MNv2) are complete once the work already enqueued on the main and the weight-gradient
+        streams has run, while the whole encoder backward (~3 ms) is still ahead.  Their all-reduce is issued now from a
+        helper stream that waits on exactly that work, so it runs under the encoder backward; the main stream only
+        waits for it in all_reduce_grads()."""
+        main = torch.cuda.current_stream()
+        comm = self.__dict__.get("_comm_stream")
+        if comm is None:
+            comm = self.__dict__["_comm_stream"] = torch.cuda.Stream(device=self.flat_g.device)
+        comm.wait_stream(main)
+        for s in tape.side_streams_in_use():
+            comm.wait_stream(s)
+        with torch.cuda.stream(comm):
+            self._early_work = torch.distributed.all_reduce(self.flat_g[self.n_split:], op=torch.distributed.ReduceOp.SUM,
+                                                            group=self.pg, async_op=True)
+        E.refresh_stream()
+
     def all_reduce_grads(self):
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            if self._early_work is not None:
+                torch.distributed.all_reduce(self.flat_g[:self.n_split], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self._early_work.wait()                   # main stream waits for the overlapped part
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                self._early_work = None
+            else:
+                torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def _stage_hyper(self):
         """Host -> pinned -> device copies of the per-step scalars (enqueued on the current stream)."""

@@ -57,6 +57,8 @@ def _worker(rank, world, port, q):
         #     single-process run bit for bit
         tr = _trainer()
         assert tr.world == 2
+        import pixelpick_amd.trainer as T
+        assert T.OVERLAP_ALLREDUCE            # the decoder-side bucket is reduced under the encoder backward
         x, y = _batch(11)
         for _ in range(2):
             tr.train_step(x, y)
@@ -75,7 +77,14 @@ def _worker(rank, world, port, q):
         replicas_equal = all(torch.equal(others[0], o) for o in others[1:])
         differs_from_a = not torch.equal(tr2.flat_p, pa)
         torch.cuda.synchronize()
-        q.put((rank, same_as_single, replicas_equal, differs_from_a, losses))
+        # (C) the single all-reduce after backward (overlap off) gives the same parameters as the two-bucket overlap
+        T.OVERLAP_ALLREDUCE = False
+        tr3 = _trainer()
+        for _ in range(2):
+            tr3.train_step(xs, ys)
+        T.OVERLAP_ALLREDUCE = True
+        overlap_equals_plain = torch.equal(tr3.flat_p, tr2.flat_p)
+        q.put((rank, same_as_single, replicas_equal, differs_from_a and overlap_equals_plain, losses))
     finally:
         dist.destroy_process_group()
 
