@@ -161,12 +161,20 @@ def main():
         import torch.distributed as dist
         assert world == a.gpus, f"WORLD_SIZE={world} but --gpus {a.gpus}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # PIXELPICK_DIST_BACKEND=gloo lets the N>1 code path run on a box with fewer GPUs than ranks (ranks then share
+        # devices; RCCL needs one device per rank) - a plumbing check, not a measurement
+        backend = os.environ.get("PIXELPICK_DIST_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     from pixelpick_amd import _lib
     from pixelpick_amd import acquisition as acq
@@ -351,7 +359,8 @@ def main():
             out = {"metric": "acquisition_throughput", "value": acqr["value"], "unit": "Mpixels/s", "ms_per_step": acqr["ms_per_step"]}
         out.update(head)
         out["config"] = {"workload": wl, "global_batch": world * a.train_batch,
-                         "sharding": f"images over {world} rank(s); train: one RCCL all-reduce of the flat gradient per step; "
+                         "sharding": f"images over {world} rank(s); train: the flat gradient is all-reduced per step in two pieces (everything "
+                                     f"behind the encoder under the encoder backward, the encoder after it); "
                                      f"acquisition: no collective"}
         if train is not None:
             out["train"] = {k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in train.items()}
