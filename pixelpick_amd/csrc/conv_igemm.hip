@@ -970,6 +970,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
 
 static int g_wgrad_narrow = 1;
 static int g_wgrad_m64 = 1;
+static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
 static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, void* workspace, size_t ws_bytes, hipStream_t st)
@@ -1049,6 +1050,8 @@ void pp_debug_set_splitk(int v)
     g_splitk_min_nk = ((v >> 20) & 63) ? ((v >> 20) & 63) : 12;
     g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
+
+void pp_debug_set_wgrad_target(int v) { g_wgrad_target = v > 0 ? v : 1024; }
 
 void pp_debug_set_conv_variant(int v)
 {
@@ -1192,7 +1195,7 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     const bool narrow_n = big && g_wgrad_m64 && remn != 0 && remn <= 64 && (cdiv(Cout, 128) * 128 - Cout) * 100 > 12 * Cout;
     const int bm = big ? (narrow_m ? 64 : 128) : 64, bn = big ? (narrow_n ? 64 : 128) : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
-    int64_t splits = cdiv(1024, tiles);
+    int64_t splits = cdiv(g_wgrad_target, tiles);
     const int64_t max_by_m = cdiv(p.M, 256);       // at least 256 pixels per split
     if (splits > max_by_m) splits = max_by_m;
     if (splits > 64) splits = 64;

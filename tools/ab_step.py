@@ -15,7 +15,9 @@ warnings.simplefilter("ignore")
 fn_name, values = sys.argv[1], [int(v, 0) for v in sys.argv[2:]]
 L = _lib.lib()
 setter = getattr(L, fn_name)
-m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab")).cuda().train()
+NET = os.environ.get("NET", "deeplab")
+m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name=NET, weight_type="random", n_layers=50,
+                        use_softmax=True, use_dilated_resnet=True, width_multiplier=1.0)).cuda().train()
 tr = FlatTrainer(m, ignore_index=19)
 x, y = synth_train_batch(4, 19, 256, 512, 20, torch.device("cuda"), 1)
 for _ in range(5):
@@ -27,8 +29,9 @@ for rep in range(3):
             tr.train_step(x, y)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(40):
+        N = 40 if NET == "deeplab" else 12
+        for _ in range(N):
             tr.train_step(x, y)
         torch.cuda.synchronize()
-        print(f"{fn_name}({v}): {(time.perf_counter() - t0) / 40 * 1e3:.3f} ms/step")
+        print(f"{fn_name}({v}): {(time.perf_counter() - t0) / N * 1e3:.3f} ms/step")
 setter(values[0])
