@@ -167,11 +167,16 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     const int n0 = nt * BN;
 
     // A staging: thread -> (row, k-quad); rows fixed for the whole K loop
-    const int a_kq = tid % KQ;
+    // MK-form staging map: within a wave, 64/KQ consecutive LANES take consecutive ROWS of one k-quad (same address set per
+    // wave instruction as quad-fastest, so the global loads coalesce identically), which makes the 16-byte LDS stores
+    // walk rows at the 80-byte pitch like the fragment reads do instead of packing 4 quads of one row into 4 lanes
+    constexpr int RPW = 64 / KQ;                                  // rows per wave and pass
+    const int a_kq = (tid & 63) / RPW;
+    const int a_rl = (tid >> 6) * RPW + (tid & (RPW - 1));       // row of this thread within a pass (RPP rows)
     int a_b[A_F4], a_ih[A_F4], a_iw[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        const int64_t m = m0 + tid / KQ + i * RPP;
+        const int64_t m = m0 + a_rl + i * RPP;
         if (m < p.M) {
             const unsigned mu = (unsigned)m;                  // M < 2^31 (checked on the host)
             const unsigned t = mu / (unsigned)p.Wo;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
                     ok = e < B_TOTAL && c < p.Cin && n < p.Cout;
                     off = ((int64_t)wt * p.Cin + c) * p.Cout + n;
                 } else {
-                    const int col = e / KQ, kq = e % KQ;
+                    const int col = (e >> 6) * RPW + (e & (RPW - 1)), kq = (e & 63) / RPW;
                     const int cin = n0 + col, k = c0 + kq * 4;
                     ok = e < B_TOTAL && cin < p.Cin && k < p.Cout;
                     off = ((int64_t)wt * p.Cin + cin) * p.Cout + k;
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int e = tid + i * kThreads;
-                const int col = e / KQ, kq = e % KQ;
+                const int col = (e >> 6) * RPW + (e & (RPW - 1)), kq = (e & 63) / RPW;
                 const int cin = n0 + col, k = c0 + kq * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < B_TOTAL && cin < p.Cin && k < p.Cout) {
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i)
-            *reinterpret_cast<float4*>(As + (tid / KQ + i * RPP) * PITCH_A + a_kq * 4) = ra[i];
+            *reinterpret_cast<float4*>(As + (a_rl + i * RPP) * PITCH_A + a_kq * 4) = ra[i];
         if constexpr (!BWD) {
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int e = tid + i * kThreads;
-                if (e < B_TOTAL) *reinterpret_cast<float4*>(Bs + (e / KQ) * PITCH_B + (e % KQ) * 4) = rb[i];
+                if (e < B_TOTAL) *reinterpret_cast<float4*>(Bs + ((e >> 6) * RPW + (e & (RPW - 1))) * PITCH_B + ((e & 63) / RPW) * 4) = rb[i];
             }
         }
     };
