@@ -310,6 +310,9 @@ struct BnFusedGeom {
     int64_t rows_per_chunk;
 };
 
+static int g_bn_target_blocks = 384;     // strips x row chunks aimed at (pp_debug_set_bn_target): measured in-process
+                                         // 128: 7.77, 192: 7.47, 256-384: 7.30-7.36, 512: 7.36, 768: 7.60, 1024: 7.76 ms/step
+
 static BnFusedGeom bn_fused_geom(int64_t M, int C)
 {
     BnFusedGeom g;
@@ -321,7 +324,7 @@ static BnFusedGeom bn_fused_geom(int64_t M, int C)
     }
     g.nrl = kT / g.bq;
     g.nstrips = (int)cdiv(g.cq, g.bq);
-    int64_t R = 512 / g.nstrips;
+    int64_t R = g_bn_target_blocks / g.nstrips;
     if (R > 256) R = 256;
     if (R < 1 || (int64_t)g.nstrips * R > 1024) R = 1;
     int64_t rpc = cdiv(cdiv(M, R), g.nrl) * g.nrl;
@@ -1507,6 +1510,7 @@ using namespace pp;
 extern "C" {
 
 void pp_debug_set_dw_variant(int v) { g_dw_x4 = (v & 1) ? 0 : 1; }
+void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 384; }
 
 // ---- batch norm -----------------------------------------------------------------------------------
 size_t pp_colreduce_workspace_bytes(int64_t M, int C)
