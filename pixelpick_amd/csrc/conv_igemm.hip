@@ -886,6 +886,7 @@ static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_
 
 static int g_conv_deepk = 1;
 static int g_conv_n64 = 1;
+static int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
 {
@@ -893,7 +894,7 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
     const int64_t mt128 = cdiv(M, 128), mt64 = cdiv(M, 64);
     if (Cn <= 32) {
         pl.cfg = 0; pl.n_tiles = 1; pl.tiles = mt128;
-    } else if (Cn > 64 && mt128 * cdiv(Cn, 128) >= 384) {
+    } else if (Cn > 64 && mt128 * cdiv(Cn, 128) >= g_big_tile_min) {
         pl.cfg = 1;
         // ragged output width (backward-data of the 304-channel SegmentHead input): 128-wide tiles compute
         // cdiv(Cn,128)*128 columns (21 % waste at 304); 64-wide tiles are ~10 % slower per flop but waste 5 %
@@ -1057,6 +1058,12 @@ void pp_debug_set_splitk(int v)
 }
 
 void pp_debug_set_wgrad_target(int v) { g_wgrad_target = v > 0 ? v : 1024; }
+/* v = big_tile_min | wgrad_rows_min << 12 (0 fields: defaults 384 / 128) */
+void pp_debug_set_conv_thresholds(int v)
+{
+    g_big_tile_min = (v & 4095) ? (v & 4095) : 384;
+    g_wgrad_rows_min = ((v >> 12) & 4095) ? ((v >> 12) & 4095) : 128;
+}
 
 void pp_debug_set_conv_variant(int v)
 {
@@ -1201,7 +1208,7 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     const int bm = big ? (narrow_m ? 64 : 128) : 64, bn = big ? (narrow_n ? 64 : 128) : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
     int64_t splits = cdiv(g_wgrad_target, tiles);
-    const int64_t max_by_m = cdiv(p.M, 256);       // at least 256 pixels per split
+    const int64_t max_by_m = cdiv(p.M, g_wgrad_rows_min);       // at least this many pixels per split
     if (splits > max_by_m) splits = max_by_m;
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
