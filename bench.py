@@ -128,8 +128,8 @@ def cpu_baseline_acq(C, H, W, k, strategy, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--train-batch", type=int, default=4, help="images per GPU per train step (args.py:89)")
     ap.add_argument("--batch", type=int, default=256, help="acquisition: images per launch per GPU")
     ap.add_argument("--classes", type=int, default=19)
