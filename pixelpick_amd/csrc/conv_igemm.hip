@@ -462,6 +462,7 @@ struct WgradParams {
     int64_t M;
     int64_t m_per_split;
     int pointwise;      // 1x1, stride 1, pad 0: input pixel == output pixel, no index decode
+    float* bias_part;   // optional [splits][Cout]: column sums of dy (the bias gradient), taken by the blocks of tile column 0
     ConvTaps taps;
 };
 
@@ -492,6 +493,10 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
 
     float4 ra[A_F4], rb[B_F4];
     unsigned okmask = 0;
+    const bool want_bias = p.bias_part != nullptr && blockIdx.x == 0;
+    float4 bsum[B_F4];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tiles = [&](int64_t mb) {
         if constexpr (VEC) {   // unconditional float4 loads from clamped addresses; zero-fill happens at the LDS write
@@ -594,6 +599,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
             for (int i = 0; i < B_F4; ++i)
                 if (!((okmask >> (8 + i)) & 1u)) rb[i] = z;
         }
+        if (want_bias) {              // dy tile rows of this K-step (out-of-range rows / columns are zero by now)
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                bsum[i].x += rb[i].x; bsum[i].y += rb[i].y; bsum[i].z += rb[i].z; bsum[i].w += rb[i].w;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * kThreads;
@@ -625,6 +636,30 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
         }
     }
 
+    if (want_bias) {
+        // thread e = tid + i*256 staged row e / (BN/4), column quad e % (BN/4): fold the rows of each column quad (fixed order)
+        constexpr int NQB = BN / 4;
+        float4* red = reinterpret_cast<float4*>(As);            // the A tile is dead; kThreads float4 = 4 KiB fit in it
+        float4 tsum = bsum[0];
+#pragma unroll
+        for (int i = 1; i < B_F4; ++i) { tsum.x += bsum[i].x; tsum.y += bsum[i].y; tsum.z += bsum[i].z; tsum.w += bsum[i].w; }
+        red[tid] = tsum;
+        __syncthreads();
+        if (tid < NQB) {
+            float4 t4 = red[tid];
+            for (int g = 1; g < kThreads / NQB; ++g) {
+                const float4 o = red[g * NQB + tid];
+                t4.x += o.x; t4.y += o.y; t4.z += o.z; t4.w += o.w;
+            }
+            const int n = n0 + tid * 4;
+            float* bp = p.bias_part + (int64_t)split * p.Cout;
+            if (n + 0 < p.Cout) bp[n + 0] = t4.x;
+            if (n + 1 < p.Cout) bp[n + 1] = t4.y;
+            if (n + 2 < p.Cout) bp[n + 2] = t4.z;
+            if (n + 3 < p.Cout) bp[n + 3] = t4.w;
+        }
+        __syncthreads();
+    }
     const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
 #pragma unroll
@@ -740,10 +775,11 @@ __global__ __launch_bounds__(256) void wgrad_narrow_out_kernel(WgradParams p, in
     const int64_t split = (int64_t)blockIdx.x * RL + rl;
     const int64_t m0 = split * rows_per_split;
     const int64_t m1 = m0 + rows_per_split < p.M ? m0 + rows_per_split : p.M;
-    float acc[COUT];
+    float acc[COUT], bacc[COUT];
 #pragma unroll
-    for (int j = 0; j < COUT; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < COUT; ++j) { acc[j] = 0.0f; bacc[j] = 0.0f; }
     const bool live = c < p.Cin;
+    const bool want_bias = p.bias_part != nullptr && c == 0;      // the dy row is a wave-uniform load: lane 0 sums it
     const int dh = p.taps.dh[0], dw = p.taps.dw[0];
     const float* __restrict__ xg = p.x;
     const float* __restrict__ dyg = p.dy;
@@ -762,6 +798,10 @@ __global__ __launch_bounds__(256) void wgrad_narrow_out_kernel(WgradParams p, in
             const float* gr = dyg + (rv ? m + u : m0) * p.lddy;
 #pragma unroll
             for (int j = 0; j < COUT; ++j) g[u][j] = gr[j];
+            if (want_bias && rv) {
+#pragma unroll
+                for (int j = 0; j < COUT; ++j) bacc[j] += g[u][j];
+            }
             it.next(p.Wo, p.Ho);
         }
 #pragma unroll
@@ -773,6 +813,11 @@ __global__ __launch_bounds__(256) void wgrad_narrow_out_kernel(WgradParams p, in
         float* out = p.part + split * (int64_t)p.Cin * COUT + (int64_t)c * COUT;
 #pragma unroll
         for (int j = 0; j < COUT; ++j) out[j] = acc[j];
+    }
+    if (want_bias) {
+        float* bp = p.bias_part + split * (int64_t)COUT;
+#pragma unroll
+        for (int j = 0; j < COUT; ++j) bp[j] = bacc[j];
     }
 }
 
@@ -979,8 +1024,10 @@ static int g_wgrad_m64 = 1;
 static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
-static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, void* workspace, size_t ws_bytes, hipStream_t st)
+static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* dbias, bool* bias_done, void* workspace,
+                               size_t ws_bytes, hipStream_t st)
 {
+    *bias_done = false;
     const int nt = p.taps.n;
     int form = 0;            // 1: lanes over Cout (narrow input), 2: lanes over Cin (narrow output)
     // measured against the MFMA path (tools/conv_layer_table.py, B=4 256x512): wins for 3->32 3x3 (182 -> 136 us), 32->16
@@ -1001,6 +1048,8 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, void* w
     const size_t need = (size_t)splits * nt * cn * 4;
     if (!workspace || ws_bytes < need) return 1;           // caller sized the workspace for the MFMA path: use that
     p.part = reinterpret_cast<float*>(workspace);
+    const bool fuse_bias = form == 2 && dbias != nullptr && ws_bytes >= need + (size_t)splits * p.Cout * 4;
+    p.bias_part = fuse_bias ? p.part + (size_t)splits * nt * cn : nullptr;
     if (nt != kh * kw)
         if (hipMemsetAsync(dw, 0, (size_t)kh * kw * cn * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
     dim3 grid((unsigned)nblk), blk(256);
@@ -1018,6 +1067,11 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, void* w
     hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)cdiv((int64_t)nt * cn, 8)), dim3(256), 0, st, p.part, (int)splits,
                        nt, cn, p.taps, dw);
     if (int rc = check_launch("wgrad_reduce_wide_kernel")) return rc;
+    if (fuse_bias) {
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)cdiv(p.Cout, 8)), dim3(256), 0, st, p.bias_part, (int)splits, p.Cout, dbias);
+        if (int rc = check_launch("bias_grad_final_kernel")) return rc;
+        *bias_done = true;
+    }
     return 0;
 }
 
@@ -1170,9 +1224,10 @@ size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Co
     size_t w = (size_t)64 * kh * kw * Cin * Cout * 4, b = (size_t)256 * Cout * 4;
     const bool narrow = Cin == 3 || ((kh == 1 && kw == 1) && (Cin <= 32 || Cout <= 32) && Cin <= 256 && Cout <= 256);
     if (narrow) {               // wgrad_narrow_*: up to 1024 (+ one block of row lanes) splits
-        const size_t n = (size_t)(1024 + 16) * kh * kw * Cin * Cout * 4;
+        const size_t n = (size_t)(1024 + 16) * kh * kw * Cin * Cout * 4 + (size_t)(1024 + 16) * Cout * 4;
         if (n > w) w = n;
     }
+    w += (size_t)64 * Cout * 4;            // bias-gradient partials ride behind the weight partials
     return align_up(w > b ? w : b, 256);
 }
 
@@ -1191,9 +1246,11 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_weight: more than 2^31 output pixels");
     p.pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
     if (g_wgrad_narrow) {
-        const int rc = launch_wgrad_narrow(p, kh, kw, dw, workspace, ws_bytes, st);
+        bool bias_done = false;
+        const int rc = launch_wgrad_narrow(p, kh, kw, dw, dbias, &bias_done, workspace, ws_bytes, st);
         if (rc != 1) {                       // 0: handled, < 0: error, 1: not a narrow layer
             if (rc < 0) return rc;
+            if (bias_done) return PP_OK;
             goto bias_part;
         }
     }
@@ -1217,6 +1274,9 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     const size_t need = (size_t)splits * p.taps.n * Cin * Cout * 4;
     if (!workspace || ws_bytes < need) return fail(PP_ERR_WORKSPACE, "conv bwd_weight: workspace %zu < %zu", ws_bytes, need);
     p.part = reinterpret_cast<float*>(workspace);
+    // bias gradient = column sums of dy: the blocks of tile column 0 read every dy tile anyway (no second pass over dy)
+    const bool fuse_bias = dbias != nullptr && ws_bytes >= need + (size_t)splits * Cout * 4;
+    p.bias_part = fuse_bias ? p.part + (size_t)splits * p.taps.n * Cin * Cout : nullptr;
     if (p.taps.n != kh * kw)
         if (hipMemsetAsync(dw, 0, (size_t)kh * kw * Cin * Cout * 4, st) != hipSuccess)
             return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
@@ -1244,6 +1304,11 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(p.taps.n * cn, 256)), dim3(256), 0, st, p.part,
                        (int)splits, p.taps.n, cn, p.taps, dw);
     if (int rc = check_launch("wgrad_reduce_kernel")) return rc;
+    if (fuse_bias) {
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)cdiv(Cout, 8)), dim3(256), 0, st, p.bias_part, (int)splits, Cout, dbias);
+        if (int rc = check_launch("bias_grad_final_kernel")) return rc;
+        return PP_OK;
+    }
     }
 bias_part:
     if (dbias) {
