@@ -69,7 +69,9 @@ struct ColReduceGeom {
     int nblk_cols;     // grid.y
 };
 
-static ColReduceGeom col_geom(int64_t M, int C)
+static int g_dw_wgrad_blocks = 1024;    // row blocks aimed at by the depthwise weight gradient (pp_debug_set_dw_variant bits 1..)
+
+static ColReduceGeom col_geom(int64_t M, int C, int target_blocks = 1024)
 {
     ColReduceGeom g;
     g.cq = C / 4;
@@ -78,7 +80,7 @@ static ColReduceGeom col_geom(int64_t M, int C)
     g.nblk_cols = (int)cdiv(g.cq, g.cq_blk);
     // measured (profiles/r01_train_step_*): these reductions are latency-bound, more row blocks win even
     // for the small 1/16-resolution maps; the second-stage combine reads the partials with 4 loads in flight
-    int64_t want_blocks = 1024 / g.nblk_cols;
+    int64_t want_blocks = target_blocks / g.nblk_cols;
     if (want_blocks < 1) want_blocks = 1;
     int64_t rpb = cdiv(cdiv(M, want_blocks), g.rows_per_pass) * g.rows_per_pass;
     if (rpb < g.rows_per_pass * 4) rpb = g.rows_per_pass * 4;
@@ -1509,7 +1511,12 @@ using namespace pp;
 
 extern "C" {
 
-void pp_debug_set_dw_variant(int v) { g_dw_x4 = (v & 1) ? 0 : 1; }
+void pp_debug_set_dw_variant(int v)
+{
+    g_dw_x4 = (v & 1) ? 0 : 1;
+    const int sel = (v >> 1) & 7;                 // 0: default, 1: 512, 2: 256, 3: 128, 4: 2048 row blocks for the weight gradient
+    g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
+}
 void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 384; }
 
 // ---- batch norm -----------------------------------------------------------------------------------
@@ -1518,7 +1525,7 @@ size_t pp_colreduce_workspace_bytes(int64_t M, int C)
     if (M < 1 || C < 4) return 256;
     ColReduceGeom g = col_geom(M, C);
     size_t a = (size_t)g.nblk_rows * 2 * C * 4;
-    size_t b = (size_t)g.nblk_rows * 9 * C * 4;  // depthwise weight-gradient partials share the geometry
+    size_t b = (size_t)col_geom(M, C, 2048).nblk_rows * 9 * C * 4;  // depthwise weight-gradient partials (largest geometry it may pick)
     return align_up(a > b ? a : b, 256);
 }
 
@@ -1702,7 +1709,7 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
     const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
     if (M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "dwconv bwd_weight: more than 2^31 output pixels");
-    ColReduceGeom g = col_geom(M, C);
+    ColReduceGeom g = col_geom(M, C, g_dw_wgrad_blocks);
     if (!workspace || ws_bytes < (size_t)g.nblk_rows * 9 * C * 4) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
