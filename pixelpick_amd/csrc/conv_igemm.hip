@@ -62,6 +62,7 @@ struct ConvParams {
     float* part;      // [splits][M][Cn] partial outputs (no bias)
     Epilogue epi;     // inference only: folded BatchNorm + residual + activation (all NULL / 0 in training)
     int accumulate;   // y += result (backward-data into a gradient that already holds the residual branch's part)
+    int tap_inner;    // K loop order (A/B knob)
     ConvTaps taps;
 };
 
@@ -205,8 +206,18 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         float4 (&ra)[A_F4] = R.a;
         float4 (&rb)[B_F4] = R.b;
         unsigned& okmask = R.ok;
-        const int ti = ks / nchunk;
-        const int c0 = (ks - ti * nchunk) * BKT;
+        // K order: channel chunk OUTER, tap inner - the taps of a 3x3 window re-read the same input rows (shifted by
+        // one pixel), so with the tap innermost those lines are still in L1/L2; tap-outer walked the whole 304-channel
+        // row set once per tap (5 MB per XCD > its 4 MB L2: FETCH_SIZE 8x the algorithmic input)
+        int ti, c0;
+        if (p.tap_inner) {
+            const int ch = ks / p.taps.n;
+            ti = ks - ch * p.taps.n;
+            c0 = ch * BKT;
+        } else {
+            ti = ks / nchunk;
+            c0 = (ks - ti * nchunk) * BKT;
+        }
         const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
         const int wt = p.taps.widx[ti];
         if constexpr (VEC) {
@@ -462,6 +473,7 @@ struct WgradParams {
     int64_t M;
     int64_t m_per_split;
     int pointwise;      // 1x1, stride 1, pad 0: input pixel == output pixel, no index decode
+    int xcd_remap;
     float* bias_part;   // optional [splits][Cout]: column sums of dy (the bias gradient), taken by the blocks of tile column 0
     ConvTaps taps;
 };
@@ -481,10 +493,25 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ctiles = (p.Cin + BM - 1) / BM;
-    const int c0 = (blockIdx.x % ctiles) * BM;
-    const int ti = blockIdx.x / ctiles;            // live tap index
-    const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (one L2 each).  All (tap, c-tile, n-tile) blocks
+    // of one pixel split read the same x / dy rows, so XCD j is given a contiguous range of SPLITS with all their tiles
+    // (measured FETCH_SIZE of the SegmentHead weight gradient: 11x its algorithmic input with the plain order).
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if ((total & 7u) == 0) {
+            const unsigned lin = bx + gx * (by + gy * bz);
+            const unsigned nl = (lin & 7u) * (total >> 3) + (lin >> 3);
+            bx = nl % gx;
+            const unsigned t2 = nl / gx;
+            by = t2 % gy;
+            bz = t2 / gy;
+        }
+    }
+    const int c0 = (int)(bx % (unsigned)ctiles) * BM;
+    const int ti = (int)(bx / (unsigned)ctiles);            // live tap index
+    const int n0 = (int)by * BN;
+    const int split = (int)bz;
     const int64_t m_beg = (int64_t)split * p.m_per_split;
     const int64_t m_end = m_beg + p.m_per_split < p.M ? m_beg + p.m_per_split : p.M;
     const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
@@ -493,7 +520,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
 
     float4 ra[A_F4], rb[B_F4];
     unsigned okmask = 0;
-    const bool want_bias = p.bias_part != nullptr && blockIdx.x == 0;
+    const bool want_bias = p.bias_part != nullptr && bx == 0;
     float4 bsum[B_F4];
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -931,6 +958,7 @@ static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_
 
 static int g_conv_deepk = 1;
 static int g_conv_n64 = 1;
+static int g_conv_tap_inner = 1;
 static int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
@@ -985,6 +1013,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
     }
+    p.tap_inner = g_conv_tap_inner;
     p.n_tiles = pl.n_tiles;
     p.splits = pl.splits;
     p.ks_per_split = pl.ks_per_split;
@@ -1021,6 +1050,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
 
 static int g_wgrad_narrow = 1;
 static int g_wgrad_m64 = 1;
+static int g_wgrad_xcd = 1;
 static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
@@ -1126,6 +1156,8 @@ void pp_debug_set_conv_variant(int v)
     g_conv_lds_pad = (v & 16) ? 40 * 1024 : ((v & 32) ? 70 * 1024 : 0);   // bits 4/5: at most 2 / 1 blocks per CU
     g_conv_splitk = (v & 64) ? 0 : 1;        // bit 6 switches split-K off (A/B)
     g_conv_n64 = (v & 2048) ? 0 : 1;         // bit 11: 64-wide tiles for ragged output widths off (A/B)
+    g_conv_tap_inner = (v & 16384) ? 0 : 1;  // bit 14: tap-outer K order of the forward / backward-data kernel (A/B)
+    g_wgrad_xcd = (v & 8192) ? 0 : 1;        // bit 13: XCD-aware block order of the weight-gradient kernel off (A/B)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
@@ -1245,6 +1277,7 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_weight: more than 2^31 output pixels");
     p.pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    p.xcd_remap = g_wgrad_xcd;
     if (g_wgrad_narrow) {
         bool bias_done = false;
         const int rc = launch_wgrad_narrow(p, kh, kw, dw, dbias, &bias_done, workspace, ws_bytes, st);
