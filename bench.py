@@ -227,7 +227,7 @@ def main():
             model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=a.network,
                                         weight_type="random", n_layers=50, use_softmax=True, use_dilated_resnet=True,
                                         width_multiplier=1.0)).to(dev).train()
-        tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-7, weight_decay=2e-4, ignore_index=C)
+        tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, ignore_index=C)
         E.set_dropout_seed(1234 + rank)
         x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
         if a.graph:

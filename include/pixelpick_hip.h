@@ -273,6 +273,14 @@ int pp_adam_step_flat(float* params, const float* grads, float* exp_avg, float* 
                       float lr_a, float lr_b, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                       float grad_scale, const float* hyper_dev, pp_stream_t stream);
 
+/* torch.optim.SGD(momentum, weight_decay) on flat buffers with the same two-segment learning rate: the optimiser the
+ * reference builds for voc and for optimizer_type "SGD" (utils/utils.py:208-270: lr 1e-3 backbone/encoder, 1e-2 the
+ * rest, momentum 0.9, weight decay 5e-4 / 1e-4).  step == 1 initialises the momentum buffer with the gradient, as
+ * torch does.  hyper_dev (optional): [lr_a, lr_b] read at run time. */
+int pp_sgd_step_flat(float* params, const float* grads, float* momentum_buf, int64_t n, int64_t n_split, float lr_a, float lr_b,
+                     float momentum, float weight_decay, int64_t step, float grad_scale, const float* hyper_dev,
+                     pp_stream_t stream);
+
 /* y = a + b on [M,C] matrices with pixel strides (gradient accumulation for tensors with several
  * consumers: the residual input of mobilenet_v2.py:62, the ASPP input of aspp.py:64-69). */
 int pp_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int C, pp_stream_t stream);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "pp_confusion_matrix_update": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _p, _p]),
     "pp_adam_step_flat": (_int, [_p, _p, _p, _p, _i64, _i64, _f, _f, _f, _f, _f, _f, _i64, _f, _p, _p]),
+    "pp_sgd_step_flat": (_int, [_p, _p, _p, _i64, _i64, _f, _f, _f, _f, _i64, _f, _p, _p]),
     "pp_add2d": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _p]),
     "pp_nhwc_to_nchw": (_int, [_p, _i64, _int, _int, _i64, _p, _p]),
     "pp_nchw_to_nhwc": (_int, [_p, _int, _int, _i64, _p, _i64, _p]),

@@ -1452,6 +1452,26 @@ __global__ __launch_bounds__(kT) void adam_kernel(float* p, const float* g, floa
     }
 }
 
+// SGD with momentum on flat buffers, torch.optim.SGD semantics (L2 weight decay added to the gradient, dampening 0,
+// no Nesterov; the momentum buffer of the FIRST step is the gradient itself), two lr segments
+// (utils/utils.py:208-270: voc and the SGD variant use lr 1e-3 for the backbone/encoder and 1e-2 for the rest).
+__global__ __launch_bounds__(kT) void sgd_kernel(float* p, const float* g, float* buf, int64_t n, int64_t n_split, float lr_a,
+                                                float lr_b, float momentum, float wd, int first, float grad_scale,
+                                                const float* hyper_dev)
+{
+    if (hyper_dev) { lr_a = hyper_dev[0]; lr_b = hyper_dev[1]; }
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) {
+        const float par = p[i];
+        float d = fmaf(wd, par, g[i] * grad_scale);
+        if (momentum != 0.0f) {
+            const float b = first ? d : fmaf(momentum, buf[i], d);
+            buf[i] = b;
+            d = b;
+        }
+        p[i] = par - (i < n_split ? lr_a : lr_b) * d;
+    }
+}
+
 // NCHW -> NHWC (network input, 3 channels) ; generic small-C transpose
 __global__ __launch_bounds__(kT) void nchw_to_nhwc_kernel(const float* x, int B, int C, int64_t HW, float* y, int64_t ldy)
 {
@@ -1882,6 +1902,17 @@ int pp_adam_step_flat(float* params, const float* grads, float* exp_avg, float* 
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
                        n_split, lr_a, lr_b, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, hyper_dev);
     return check_launch("adam_kernel");
+}
+
+int pp_sgd_step_flat(float* params, const float* grads, float* momentum_buf, int64_t n, int64_t n_split, float lr_a, float lr_b,
+                     float momentum, float weight_decay, int64_t step, float grad_scale, const float* hyper_dev,
+                     pp_stream_t stream)
+{
+    if (!params || !grads || (momentum != 0.0f && !momentum_buf)) return fail(PP_ERR_BAD_ARG, "sgd: null");
+    if (n < 1 || step < 1) return fail(PP_ERR_BAD_ARG, "sgd: bad n/step");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(kT), 0, as_stream(stream), params, grads, momentum_buf, n, n_split,
+                       lr_a, lr_b, momentum, weight_decay, step == 1 ? 1 : 0, grad_scale, hyper_dev);
+    return check_launch("sgd_kernel");
 }
 
 int pp_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int C, pp_stream_t stream)

@@ -24,7 +24,7 @@ from . import acquisition as acq
 from .query import QuerySelector
 from .trainer import FlatTrainer
 from .utils.metrics import AverageMeter, RunningScore
-from .utils.utils import get_model
+from .utils.utils import get_model, optimizer_spec
 
 
 def write_log(fp, list_entities=None, header=None):
@@ -96,6 +96,10 @@ class Model:
     def _train_epoch(self, epoch, model, trainer, n_iters_total):
         model.train()
         miou = pixel_acc = float("nan")
+        if self.lr_scheduler_type == "MultiStepLR":
+            # model.py:144-145 calls MultiStepLR([20, 40], 0.1).step(epoch=epoch-1) at the END of every epoch, so the rate
+            # in force DURING epoch E is base * 0.1^#{m <= E-2}: the drops take effect from epochs 22 and 42
+            trainer.lr_factor = 0.1 ** sum(1 for m in (20, 40) if m <= epoch - 2)
         for it, dict_data in enumerate(self.dataloader):
             x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
             if self.n_pixels_by_us != 0:                                   # model.py:108-110
@@ -121,9 +125,9 @@ class Model:
     def _train(self):
         print(f"\n({self.experim_name}) training...\n")
         model = get_model(self.args).to(self.device)
-        op = self.args.optimizer_params
-        trainer = FlatTrainer(model, lr=op['lr'], betas=op.get('betas', (0.9, 0.999)), eps=op.get('eps', 1e-8),
-                              weight_decay=op['weight_decay'], ignore_index=self.ignore_index)
+        kind, slow_lr, lr, wd, momentum = optimizer_spec(self.args)          # utils/utils.py:112-306, quirks included
+        trainer = FlatTrainer(model, lr=lr, slow_lr=slow_lr, weight_decay=wd, optimizer=kind, momentum=momentum,
+                              ignore_index=self.ignore_index)
         n_total = self.n_epochs * len(self.dataloader)
         for e in range(1, 1 + self.n_epochs):
             self._train_epoch(e, model, trainer, n_total)

@@ -24,9 +24,17 @@ OVERLAP_ALLREDUCE = os.environ.get("PIXELPICK_OVERLAP_ALLREDUCE", "1") != "0"
 
 
 class FlatTrainer:
-    def __init__(self, model, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-7, weight_decay: float = 2e-4,
-                 ignore_index: int = 19, slow_module_names=("backbone", "encoder"), process_group=None):
+    def __init__(self, model, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 2e-4,
+                 ignore_index: int = 19, slow_module_names=("backbone", "encoder"), process_group=None,
+                 optimizer: str = "adam", momentum: float = 0.9, slow_lr: float = None):
+        """optimizer "adam": torch.optim.Adam(lr/10 for the backbone|encoder, lr for the rest) - what the reference builds for
+        cs / cv (utils/utils.py:114-141; NOTE it passes only lr and weight_decay to Adam, so betas/eps are torch's defaults
+        (0.9, 0.999), 1e-8 whatever args.optimizer_params says).  "sgd": torch.optim.SGD(momentum) with `slow_lr` for the
+        backbone|encoder (default lr/10) - voc and optimizer_type "SGD" (utils/utils.py:208-270)."""
+        assert optimizer in ("adam", "sgd")
         self.model = model
+        self.optimizer, self.momentum = optimizer, momentum
+        self.slow_lr = lr / 10 if slow_lr is None else slow_lr
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.ignore_index = ignore_index
         self.pg = process_group
@@ -126,7 +134,7 @@ class FlatTrainer:
     def _stage_hyper(self):
         """Host -> pinned -> device copies of the per-step scalars (enqueued on the current stream)."""
         t = self.step_count
-        self._hyper_host[0] = self.lr / 10 * self.lr_factor
+        self._hyper_host[0] = self.slow_lr * self.lr_factor
         self._hyper_host[1] = self.lr * self.lr_factor
         self._hyper_host[2] = 1.0 - self.betas[0] ** t
         self._hyper_host[3] = (1.0 - self.betas[1] ** t) ** 0.5
@@ -136,11 +144,18 @@ class FlatTrainer:
 
     def optimizer_step(self, use_device_hyper: bool = False):
         L = _lib.lib()
+        hyper = self._hyper_dev.data_ptr() if use_device_hyper else None
+        if self.optimizer == "sgd":
+            rc = L.pp_sgd_step_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.n, self.n_split,
+                                    self.slow_lr * self.lr_factor, self.lr * self.lr_factor, self.momentum, self.wd,
+                                    max(self.step_count, 1), 1.0 / self.world, hyper, _lib.current_stream_ptr())
+            E.refresh_stream()
+            _lib.check(rc, "pp_sgd_step_flat")
+            return
         rc = L.pp_adam_step_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                 self.exp_avg_sq.data_ptr(), self.n, self.n_split, self.lr / 10 * self.lr_factor,
+                                 self.exp_avg_sq.data_ptr(), self.n, self.n_split, self.slow_lr * self.lr_factor,
                                  self.lr * self.lr_factor, self.betas[0], self.betas[1], self.eps, self.wd,
-                                 max(self.step_count, 1), 1.0 / self.world,
-                                 self._hyper_dev.data_ptr() if use_device_hyper else None, _lib.current_stream_ptr())
+                                 max(self.step_count, 1), 1.0 / self.world, hyper, _lib.current_stream_ptr())
         E.refresh_stream()
         _lib.check(rc, "pp_adam_step_flat")
 

@@ -14,36 +14,39 @@ def get_model(args):
     raise ValueError(args.network_name)
 
 
-def _param_groups(args, model):
-    """Backbone / encoder at lr/10, everything else at lr (utils/utils.py:117-139)."""
+def optimizer_spec(args):
+    """What utils/utils.py:112-306 builds, as plain numbers: (kind, slow_lr, lr, weight_decay, momentum).
+
+    cs, and cv/custom with optimizer_type "Adam": Adam(backbone|encoder at lr/10, rest at lr, weight_decay) - the
+    reference hands ONLY lr and weight_decay to torch.optim.Adam, so betas and eps are torch's defaults (0.9, 0.999) and
+    1e-8 even though args.optimizer_params carries "betas" and "eps": 1e-7.  voc, and cv/custom with optimizer_type "SGD":
+    SGD(momentum 0.9) with HARD-CODED lr 1e-3 (backbone|encoder) / 1e-2 (rest) and weight decay 5e-4 (1e-4 for voc + FPN);
+    args.optimizer_params is not read at all there."""
     op = args.optimizer_params
+    name, fpn = args.dataset_name, args.network_name == "FPN"
+    if name == "voc":
+        return "sgd", 1e-3, 1e-2, (1e-4 if fpn else 5e-4), 0.9
+    if name != "cs" and getattr(args, "optimizer_type", "Adam") == "SGD":
+        return "sgd", 1e-3, 1e-2, 5e-4, 0.9
+    return "adam", op['lr'] / 10, op['lr'], op['weight_decay'], 0.0
+
+
+def _param_groups(args, model, slow_lr, lr, weight_decay, extra):
     if args.network_name == "FPN":
-        return [{'params': model.encoder.parameters(), 'lr': op['lr'] / 10, 'weight_decay': op['weight_decay']},
-                {'params': model.decoder.parameters(), 'lr': op['lr'], 'weight_decay': op['weight_decay']}]
-    groups = [{'params': model.backbone.parameters(), 'lr': op['lr'] / 10, 'weight_decay': op['weight_decay']}]
-    for part in (model.aspp, model.low_level_conv, model.seg_head):
-        groups.append({'params': part.parameters(), 'lr': op['lr'], 'weight_decay': op['weight_decay']})
-    return groups
+        parts = [(model.encoder, slow_lr), (model.decoder, lr)]
+    else:
+        parts = [(model.backbone, slow_lr), (model.aspp, lr), (model.low_level_conv, lr), (model.seg_head, lr)]
+    return [dict({'params': m.parameters(), 'lr': l, 'weight_decay': weight_decay}, **extra) for m, l in parts]
 
 
 def get_optimizer(args, model):
-    """utils/utils.py:112-306: Adam (cs / cv default / custom) or SGD (voc, cv with optimizer_type SGD)."""
-    op = args.optimizer_params
-    use_sgd = args.dataset_name == "voc" or (args.dataset_name == "cv" and getattr(args, "optimizer_type", "Adam") == "SGD")
-    if use_sgd:
+    """utils/utils.py:112-306 (see optimizer_spec for the quirks that are reproduced)."""
+    kind, slow_lr, lr, wd, momentum = optimizer_spec(args)
+    if kind == "sgd":
         from torch.optim import SGD
-        groups = _param_groups(args, model)
-        for g in groups:
-            g['momentum'] = op.get('momentum', 0.9)
-        return SGD(groups)
+        return SGD(_param_groups(args, model, slow_lr, lr, wd, {'momentum': momentum}))
     from torch.optim import Adam
-    groups = _param_groups(args, model)
-    kw = {}
-    if 'betas' in op:
-        kw['betas'] = op['betas']
-    if 'eps' in op:
-        kw['eps'] = op['eps']
-    return Adam(groups, **kw)
+    return Adam(_param_groups(args, model, slow_lr, lr, wd, {}))
 
 
 def get_lr_scheduler(args, optimizer, iters_per_epoch=-1):

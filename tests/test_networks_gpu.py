@@ -139,7 +139,7 @@ def test_flat_trainer_matches_autograd_path_and_is_deterministic(golden_dir):
     pa = ref_p[:tr.n_split].clone().requires_grad_(True)
     pb = ref_p[tr.n_split:].clone().requires_grad_(True)
     opt = torch.optim.Adam([{"params": [pa], "lr": 5e-5, "weight_decay": 2e-4}, {"params": [pb], "lr": 5e-4, "weight_decay": 2e-4}],
-                           betas=(0.9, 0.999), eps=1e-7)
+                           betas=(0.9, 0.999), eps=1e-8)          # FlatTrainer's default = what the reference's Adam really uses
     pa.grad, pb.grad = ga[:tr.n_split].clone(), ga[tr.n_split:].clone()
     opt.step()
     tr.optimizer_step()
@@ -269,3 +269,30 @@ def test_baseline_size_train_steps_are_bitwise_reproducible():
     for p, l in sigs[1:]:
         assert torch.equal(l, sigs[0][1]), "loss trajectory differs between identical runs"
         assert torch.equal(p, sigs[0][0]), "parameters differ between identical runs"
+
+
+def test_flat_trainer_sgd_is_torch_sgd_with_the_voc_groups():
+    """The voc optimiser (SGD momentum 0.9, lr 1e-3 backbone / 1e-2 rest, wd 5e-4 - utils/utils.py:208-240) through
+    FlatTrainer: three optimiser steps on the gradients of one forward/backward equal torch.optim.SGD on the same
+    gradients and groups (momentum buffer initialised by the first step, as torch does)."""
+    from pixelpick_amd.utils.utils import optimizer_spec
+    a = _args(7); a.dataset_name = "voc"; a.optimizer_params = {"lr": 1e-2, "weight_decay": 1e-4, "momentum": 0.9}
+    kind, slow_lr, lr, wd, mom = optimizer_spec(a)
+    assert (kind, slow_lr, lr, wd, mom) == ("sgd", 1e-3, 1e-2, 5e-4, 0.9)
+    x = fi.formula_input(2, 64, 96, key="sgdx").to(DEV)
+    y = fi.formula_labels(2, 64, 96, 7, 255, 12, key="sgdy").to(DEV)
+    m1 = _build(7).train()
+    tr = FlatTrainer(m1, lr=lr, slow_lr=slow_lr, weight_decay=wd, optimizer=kind, momentum=mom, ignore_index=255)
+    tr.forward_backward(x, y)
+    g = tr.flat_g.clone().cpu()
+    ref_p = tr.flat_p.clone().cpu()
+    pa = ref_p[:tr.n_split].clone().requires_grad_(True)
+    pb = ref_p[tr.n_split:].clone().requires_grad_(True)
+    opt = torch.optim.SGD([{"params": [pa], "lr": 1e-3, "weight_decay": 5e-4, "momentum": 0.9},
+                           {"params": [pb], "lr": 1e-2, "weight_decay": 5e-4, "momentum": 0.9}])
+    for step in range(1, 4):
+        pa.grad, pb.grad = g[:tr.n_split].clone(), g[tr.n_split:].clone()
+        opt.step()
+        tr.step_count = step
+        tr.optimizer_step()
+        assert (tr.flat_p.cpu() - torch.cat([pa.detach(), pb.detach()])).abs().max().item() < 2e-6

@@ -593,3 +593,31 @@ def test_adam_matches_torch():
         assert rc == 0
         ref = torch.cat([pa.detach(), pb.detach()])
         assert (p.cpu() - ref).abs().max().item() < 2e-6
+
+
+def test_sgd_momentum_matches_torch_and_trainer_uses_it():
+    """pp_sgd_step_flat == torch.optim.SGD(momentum 0.9, weight decay) with the reference's voc groups (utils/utils.py:
+    208-240: lr 1e-3 backbone, 1e-2 rest, weight decay 5e-4); FlatTrainer(optimizer="sgd") drives it."""
+    torch.manual_seed(10)
+    n, n_split = 10007, 4001
+    p0 = torch.randn(n)
+    pa = p0[:n_split].clone().requires_grad_(True)
+    pb = p0[n_split:].clone().requires_grad_(True)
+    opt = torch.optim.SGD([{"params": [pa], "lr": 1e-3, "weight_decay": 5e-4, "momentum": 0.9},
+                           {"params": [pb], "lr": 1e-2, "weight_decay": 5e-4, "momentum": 0.9}])
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    p = p0.clone().to(DEV)
+    buf = torch.full((n,), 123.0, device=DEV)             # garbage: step 1 must overwrite, not read it
+    for step in range(1, 5):
+        g = torch.randn(n) * 0.1
+        pa.grad, pb.grad = g[:n_split].clone(), g[n_split:].clone()
+        opt.step()
+        gg = (g * 2).to(DEV)                              # grad_scale 0.5 (the 1/world of a 2-rank all-reduce)
+        rc = L.pp_sgd_step_flat(p.data_ptr(), gg.data_ptr(), buf.data_ptr(), n, n_split, 1e-3, 1e-2, 0.9, 5e-4, step, 0.5, None,
+                                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = torch.cat([pa.detach(), pb.detach()])
+        assert (p.cpu() - ref).abs().max().item() < 2e-6
+    assert L.pp_sgd_step_flat(p.data_ptr(), gg.data_ptr(), None, n, n_split, 1e-3, 1e-2, 0.9, 5e-4, 1, 1.0, None,
+                              torch.cuda.current_stream().cuda_stream) != 0

@@ -25,7 +25,7 @@ with tempfile.TemporaryDirectory() as td:
     m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=dev)
     m._open_logs(td)
     model = get_model(args).to(dev)
-    tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-7, weight_decay=2e-4, ignore_index=C)
+    tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, ignore_index=C)
     with contextlib.redirect_stdout(io.StringIO()):
         m._train_epoch(1, model, tr, 1000)          # warm-up epoch
         torch.cuda.synchronize()
