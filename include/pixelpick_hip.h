@@ -86,6 +86,34 @@ int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int lar
                    int32_t* out_idx, float* out_val,
                    void* workspace, size_t ws_bytes, pp_stream_t stream);
 
+/* Acquisition straight from the LOW-resolution classifier output.  Replaces, in one launch
+ * and without materialising the full-resolution logits,
+ *   deeplab.py:55-56   pred = F.interpolate(pred, size=inputs.shape[2:], mode='bilinear', align_corners=True)
+ *   query.py:190       prob = F.softmax(model(x)["pred"][:, :, :h, :w], dim=1)      ([:h,:w] = the VOC crop, :171-174)
+ *   query.py:229-239, 195-201, 57-61   score, exclusion, top-k   (as pp_acq_score_topk)
+ *   low      f32 [B,h,w,ldx] channels-last classifier output (what SegmentHead's 1x1 conv writes), C valid channels
+ *   H, W     the size the reference interpolates to (the network input size); align_corners as F.interpolate's flag
+ *   Hc, Wc   the crop scored and indexed: pixel (Y,X), Y < Hc <= H, X < Wc <= W, has flat index Y*Wc + X
+ *   exclude  u8 [B,Hc,Wc] or NULL;  out_idx i32 [B,k], out_val f32 [B,k] or NULL, out_map f32 [B,Hc,Wc] or NULL
+ *   k == 0   writes out_map only (out_idx / workspace may be NULL).
+ * The interpolated logits are bit-identical to pp_bilinear_fwd's, so the result equals pp_bilinear_fwd followed by
+ * pp_acq_score_topk bit for bit (tested). */
+size_t pp_acq_lowres_workspace_bytes(int64_t B, int64_t C, int64_t Hc, int64_t Wc, int64_t k);
+
+int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w,
+                             int64_t H, int64_t W, int align_corners, int64_t Hc, int64_t Wc,
+                             const uint8_t* exclude, int strategy, int64_t k,
+                             int32_t* out_idx, float* out_val, float* out_map,
+                             void* workspace, size_t ws_bytes, pp_stream_t stream);
+
+/* The strategy's score (no exclusion) at n listed pixels of the interpolated map: pixel i is image img_idx[i] (i32),
+ * flat index pix_idx[i] = Y*Wc + X (i32) -> out[i].  QueryStats' "entropy at the queried pixels" (query.py:262-266)
+ * without the full softmax map. */
+int pp_acq_lowres_score_at(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w,
+                           int64_t H, int64_t W, int align_corners, int64_t Hc, int64_t Wc, int strategy,
+                           const int32_t* img_idx, const int32_t* pix_idx, int64_t n, float* out,
+                           pp_stream_t stream);
+
 
 /* =============================================================================================
  * Network layers (DeepLabv3+-MobileNetV2 / FPN-ResNet50 forward + backward), NHWC fp32.

@@ -81,6 +81,48 @@ def score_topk(logits: np.ndarray, exclude, strategy: str, k: int, want_map=Fals
     return (idx, val, m) if want_map else (idx, val)
 
 
+def bilinear_resize(x: np.ndarray, size, align_corners: bool = True) -> np.ndarray:
+    """x [B,C,h,w] float32 -> [B,C,H,W]: F.interpolate(x, size, mode='bilinear', align_corners) as deeplab.py:55-56
+    calls it.  The arithmetic lives in torch (ATen upsample_bilinear2d); this restates its published rule in fp32:
+      source index  src = dst * (in-1)/(out-1)                (align_corners; 0 when out == 1)
+                    src = max((dst+0.5) * in/out - 0.5, 0)    (otherwise)
+      i0 = floor(src) clamped to in-1, i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1
+      out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11)
+    pinned by tests/golden/acq_lowres.npz (s1_pred) and, in the CPU suite, against F.interpolate itself."""
+    assert x.dtype == np.float32 and x.ndim == 4
+    h, w = x.shape[2:]
+    H, W = int(size[0]), int(size[1])
+
+    def coords(n_in, n_out):
+        d = np.arange(n_out, dtype=np.float32)
+        if align_corners:
+            scale = np.float32((n_in - 1) / (n_out - 1)) if n_out > 1 else np.float32(0)
+            src = scale * d
+        else:
+            scale = np.float32(n_in / n_out)
+            src = np.maximum(scale * (d + np.float32(0.5)) - np.float32(0.5), np.float32(0)).astype(np.float32)
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, np.float32(1) - l1, l1
+
+    r0, r1, h0, h1 = coords(h, H)
+    c0, c1, w0, w1 = coords(w, W)
+    top = w0[None, None, None, :] * x[:, :, r0][:, :, :, c0] + w1[None, None, None, :] * x[:, :, r0][:, :, :, c1]
+    bot = w0[None, None, None, :] * x[:, :, r1][:, :, :, c0] + w1[None, None, None, :] * x[:, :, r1][:, :, :, c1]
+    return (h0[None, None, :, None] * top + h1[None, None, :, None] * bot).astype(np.float32)
+
+
+def lowres_score_topk(low: np.ndarray, size, exclude, strategy: str, k: int, crop=None, align_corners: bool = True,
+                      want_map=False):
+    """SURVEY.md §8f-1 path on the CPU: low [B,C,h,w] classifier logits -> deeplab.py:55-56 interpolate -> query.py:190
+    [:h,:w] crop -> score_topk above.  Flat indices refer to the crop."""
+    pred = bilinear_resize(low, size, align_corners)
+    if crop is not None:
+        pred = np.ascontiguousarray(pred[:, :, :crop[0], :crop[1]])
+    return score_topk(pred, exclude, strategy, k, want_map=want_map)
+
+
 # ----------------------------------------------------------------------------------------------
 # torch-CPU port of the reference acquisition path (same torch ops the reference calls), used only
 # to time the CPU baseline on the GPU box's host cores (bench.py cpu_baseline.kind == "port").

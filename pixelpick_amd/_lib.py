@@ -25,6 +25,9 @@ SIGNATURES = {
     "pp_uncertainty_from_prob": (_int, [_p] + [_i64] * 8 + [_int, _p, _p]),
     "pp_topk_workspace_bytes": (_sz, [_i64] * 3),
     "pp_topk_select": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p, _sz, _p]),
+    "pp_acq_lowres_workspace_bytes": (_sz, [_i64] * 5),
+    "pp_acq_lowres_score_topk": (_int, [_p] + [_i64] * 7 + [_int, _i64, _i64, _p, _int, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pp_acq_lowres_score_at": (_int, [_p] + [_i64] * 7 + [_int, _i64, _i64, _int, _p, _p, _i64, _p, _p]),
     "pp_conv2d_fwd_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_data_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p]),

@@ -118,3 +118,62 @@ def topk_select(scores: torch.Tensor, k: int, largest: bool) -> Tuple[torch.Tens
                               ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_topk_select")
     return idx, val
+
+
+# ---- acquisition from the low-resolution classifier output -------------------------------
+def _lowres_geom(low: torch.Tensor, size, crop):
+    _require_cuda_f32(low, "low", 4)
+    if low.stride(3) != 1 or low.stride(1) != low.shape[2] * low.stride(2) or low.stride(0) != low.shape[1] * low.stride(1):
+        raise ValueError("low must be a dense channels-last [B,h,w,C] tensor (a channel slice of one is fine)")
+    B, h, w, C = low.shape
+    H, W = int(size[0]), int(size[1])
+    Hc, Wc = (H, W) if crop is None else (int(crop[0]), int(crop[1]))
+    return B, h, w, C, low.stride(2), H, W, Hc, Wc
+
+
+def score_topk_lowres(low: torch.Tensor, size, exclude, strategy: str, k: int, crop=None, align_corners: bool = True,
+                      return_map: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """F.interpolate(low, size, 'bilinear', align_corners)[:, :, :crop_h, :crop_w] -> softmax -> score -> exclusion ->
+    top-k in ONE launch, never writing the full-resolution logits (deeplab.py:55-56 + query.py:190-204,57-61).
+
+    low [B,h,w,C] f32 channels-last on the GPU (the classifier output as the engine keeps it).  Returns
+    (idx int32 [B,k] flat y*crop_w+x, val f32 [B,k], map f32 [B,crop_h,crop_w] | None); k == 0 -> (None, None, map)."""
+    B, h, w, C, ldx, H, W, Hc, Wc = _lowres_geom(low, size, crop)
+    L = _lib.lib()
+    dev = low.device
+    ex = _exclude_u8(exclude, B, Hc, Wc, dev)
+    want_map = return_map or k == 0
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev) if k else None
+    val = torch.empty((B, k), dtype=torch.float32, device=dev) if k else None
+    omap = torch.empty((B, Hc, Wc), dtype=torch.float32, device=dev) if want_map else None
+    ws = _ws(L.pp_acq_lowres_workspace_bytes(B, C, Hc, Wc, k), dev) if k else None
+    with torch.cuda.device(dev):
+        rc = L.pp_acq_lowres_score_topk(low.data_ptr(), ldx, B, C, h, w, H, W, int(bool(align_corners)), Hc, Wc,
+                                        ex.data_ptr() if ex is not None else None, STRATEGY_ID[strategy], k,
+                                        idx.data_ptr() if k else None, val.data_ptr() if k else None,
+                                        omap.data_ptr() if omap is not None else None,
+                                        ws.data_ptr() if k else None, ws.numel() if k else 0, _lib.current_stream_ptr(dev))
+    _lib.check(rc, "pp_acq_lowres_score_topk")
+    return idx, val, omap
+
+
+def score_at_lowres(low: torch.Tensor, size, img_idx, pix_idx, strategy: str = "entropy", crop=None,
+                    align_corners: bool = True) -> torch.Tensor:
+    """The strategy's score (no exclusion) at listed pixels of the interpolated map: pixel i = image img_idx[i], flat
+    index pix_idx[i] = y*crop_w + x.  -> f32 [n] on the GPU.  (QueryStats' entropy at the queried pixels, query.py:262-266.)"""
+    B, h, w, C, ldx, H, W, Hc, Wc = _lowres_geom(low, size, crop)
+    dev = low.device
+    ii = torch.as_tensor(img_idx).to(torch.int32).to(dev).contiguous()
+    pp = torch.as_tensor(pix_idx).to(torch.int32).to(dev).contiguous()
+    if ii.shape != pp.shape or ii.ndim != 1:
+        raise ValueError("img_idx and pix_idx must be 1-d and of equal length")
+    n = ii.numel()
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pp_acq_lowres_score_at(low.data_ptr(), ldx, B, C, h, w, H, W, int(bool(align_corners)), Hc, Wc,
+                                               STRATEGY_ID[strategy], ii.data_ptr(), pp.data_ptr(), n, out.data_ptr(),
+                                               _lib.current_stream_ptr(dev))
+    _lib.check(rc, "pp_acq_lowres_score_at")
+    return out

@@ -10,6 +10,9 @@
 // pixels in registers (softmax needs no second memory pass), planes are read as 16 B/lane coalesced
 // loads, per-wave top-k candidates are extracted with DPP reductions and merged by a tiny second
 // kernel, so the logits are read exactly once and nothing full-size is written unless asked for.
+#include <algorithm>
+#include <cmath>
+
 #include "pp_common.h"
 
 namespace pp {
@@ -368,6 +371,130 @@ __global__ __launch_bounds__(kBlock, 3) void acq_nhwc_kernel(AcqParams p)
     }
 }
 
+// ---- acquisition straight from the LOW-resolution classifier logits -------------------
+// Replaces  deeplab.py:55-56  F.interpolate(pred, size=inputs.shape[2:], mode='bilinear', align_corners=True)
+//        +  query.py:190      softmax(model(x)["pred"][:, :, :h, :w])  + score + exclusion + top-k
+// without ever writing the full-resolution logits (10 MB per 256x512x19 image written and read back; the algorithmic
+// input drops 16x to the 64x128x19 classifier output).  A block owns a 64-column x 4*PPT-row tile of OUTPUT pixels,
+// stages the low-resolution patch the tile interpolates from in LDS ((4*PPT*s+2) x (64*s+2) pixels, 13.7 KB at s = 1/4),
+// and every lane interpolates its pixels' class vectors from LDS with bilerp() - the same bits pp_bilinear_fwd writes -
+// then scores them like acq_kernel.  Wave w of the tile owns PPT consecutive rows, so the row weights are wave-uniform.
+struct LowresParams {
+    const float* low;    // [B,h,w,ldx] channels-last, C valid channels
+    int64_t ldx;
+    const uint8_t* exclude;   // [B,Hc,Wc] or null
+    float* out_map;           // [B,Hc,Wc] or null
+    uint64_t* cand;           // [B, waves_per_image, k] or null
+    int h, w, Hc, Wc;
+    float sh, sw;
+    int align;
+    int C, tiles_x, tiles_y, k, strategy, reduce_mode;
+    int patch_cap;            // floats of dynamic LDS available for the patch
+};
+
+template <int CMAX, bool EXACT, int PPT, bool LDS, int MATH>
+__global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_patch[];
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
+    constexpr int TR = (kBlock / kWave) * PPT, TC = kWave;
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int img = blockIdx.x / tiles;
+    const int t = blockIdx.x - img * tiles;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = EXACT ? CMAX : p.C;
+    const int CP = C | 1;                     // odd pixel pitch: lanes 4 columns apart hit different banks
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const int64_t N = (int64_t)p.Hc * p.Wc;
+    const int X0 = tx * TC, Y0 = ty * TR;
+    const int X1 = min(X0 + TC - 1, p.Wc - 1), Y1 = min(Y0 + TR - 1, p.Hc - 1);
+    const int c_lo = lerp_src(X0, p.w, p.sw, p.align).i0, c_hi = lerp_src(X1, p.w, p.sw, p.align).i1;
+    const int r_lo = lerp_src(Y0, p.h, p.sh, p.align).i0, r_hi = lerp_src(Y1, p.h, p.sh, p.align).i1;
+    const int pw = c_hi - c_lo + 1, ph = r_hi - r_lo + 1;
+    const float* base = p.low + (int64_t)img * p.h * p.w * p.ldx;
+    if constexpr (LDS) {
+        if (ph * pw * CP > p.patch_cap) __builtin_trap();   // host sizing bug: never silently read past the patch
+        const int n = ph * pw * C;
+        for (int e = tid; e < n; e += kBlock) {
+            const int pc = e / C, ch = e - pc * C;
+            const int r = pc / pw, c = pc - r * pw;
+            s_patch[pc * CP + ch] = base[((int64_t)(r_lo + r) * p.w + c_lo + c) * p.ldx + ch];
+        }
+        __syncthreads();
+    }
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * N : nullptr;
+    float* omap = p.out_map ? p.out_map + (int64_t)img * N : nullptr;
+    const int X = X0 + lane;
+    const bool xin = X < p.Wc;
+    const Lerp lw = lerp_src(xin ? X : X1, p.w, p.sw, p.align);
+    const int64_t pitch = LDS ? (int64_t)CP : p.ldx;
+    const int64_t o0 = (int64_t)(LDS ? lw.i0 - c_lo : lw.i0) * pitch, o1 = (int64_t)(LDS ? lw.i1 - c_lo : lw.i1) * pitch;
+    const float* src = LDS ? s_patch : base;
+    const int64_t row_pitch = (LDS ? pw : p.w) * pitch;
+
+    uint32_t kh[PPT], kl[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int Y = Y0 + wv * PPT + j;
+        if (Y < p.Hc && xin) {
+            const Lerp lh = lerp_src(Y, p.h, p.sh, p.align);
+            const float* r0 = src + (int64_t)(LDS ? lh.i0 - r_lo : lh.i0) * row_pitch;
+            const float* r1 = src + (int64_t)(LDS ? lh.i1 - r_lo : lh.i1) * row_pitch;
+            float x[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C)
+                    x[c] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, r0[o0 + c], r0[o1 + c], r1[o0 + c], r1[o1 + c]);
+            float sc;
+            if constexpr (MATH == 0) sc = pixel_score_fast<CMAX, EXACT>(x, p.C, p.strategy);
+            else sc = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, 0);
+            const int64_t pix = (int64_t)Y * p.Wc + X;
+            if (excl && excl[pix]) sc = fill;
+            if (omap) omap[pix] = sc;
+            kh[j] = order_key(sc, largest);
+            kl[j] = 0xFFFFFFFFu - (uint32_t)pix;
+        } else {
+            kh[j] = 0u; kl[j] = 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one pixel's class vector live at a time
+    }
+    if (p.cand) {
+        const int wave_in_image = t * (kBlock / kWave) + wv;
+        const int waves_per_image = tiles * (kBlock / kWave);
+        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
+        if (p.reduce_mode == 2) wave_extract_topk<PPT>(kh, kl, p.k, dst, 0);
+        else wave_extract_topk_prefilter<PPT>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
+    }
+}
+
+// The strategy's score at a list of picked pixels (QueryStats: entropy at the queried pixels, query.py:262-266),
+// interpolated from the low-resolution logits with the same arithmetic.  One thread per pixel.
+template <int CMAX, bool EXACT>
+__global__ __launch_bounds__(kBlock) void acq_lowres_at_kernel(const float* low, int64_t ldx, int h, int w, float sh,
+                                                             float sw, int align, int Wc, int C, int strategy,
+                                                             const int32_t* img_idx, const int32_t* pix_idx,
+                                                             int64_t n, float* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int pix = pix_idx[i], Y = pix / Wc, X = pix - Y * Wc;
+    const Lerp lh = lerp_src(Y, h, sh, align), lw = lerp_src(X, w, sw, align);
+    const float* base = low + (int64_t)img_idx[i] * h * w * ldx;
+    const float* p00 = base + ((int64_t)lh.i0 * w + lw.i0) * ldx;
+    const float* p01 = base + ((int64_t)lh.i0 * w + lw.i1) * ldx;
+    const float* p10 = base + ((int64_t)lh.i1 * w + lw.i0) * ldx;
+    const float* p11 = base + ((int64_t)lh.i1 * w + lw.i1) * ldx;
+    float x[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (EXACT || c < C) x[c] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, p00[c], p01[c], p10[c], p11[c]);
+    out[i] = pixel_score_fast<CMAX, EXACT>(x, C, strategy);
+}
+
 // ---- small-k selection straight from a score map (pp_topk_select) ------------------------------------
 template <int G>
 __global__ __launch_bounds__(kBlock) void topk_small_from_scores_kernel(const float* scores, int64_t N,
@@ -724,6 +851,89 @@ static int validate(const float* logits, int64_t B, int64_t C, int64_t H, int64_
     return PP_OK;
 }
 
+// ---- low-resolution path: host side ---------------------------------------------------------------------
+struct LowresPlan {
+    int ppt, tiles_x, tiles_y, waves_per_image;
+    bool lds;
+    size_t lds_bytes;
+    int patch_cap;
+};
+
+constexpr size_t kLowresLdsMax = 48 * 1024;
+
+static void lowres_scales(int64_t h, int64_t w, int64_t H, int64_t W, int align, float& sh, float& sw)
+{
+    if (align) {
+        sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+        sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    } else {
+        sh = (float)h / (float)H;
+        sw = (float)w / (float)W;
+    }
+}
+
+static LowresPlan make_lowres_plan(int64_t B, int64_t C, int64_t h, int64_t w, int64_t Hc, int64_t Wc, float sh, float sw,
+                                   bool force_ppt4)
+{
+    LowresPlan pl;
+    const int64_t tiles8 = cdiv(Wc, kWave) * cdiv(Hc, (kBlock / kWave) * 8);
+    pl.ppt = (!force_ppt4 && B * tiles8 * (kBlock / kWave) >= 2048) ? 8 : 4;
+    pl.tiles_x = (int)cdiv(Wc, kWave);
+    pl.tiles_y = (int)cdiv(Hc, (kBlock / kWave) * pl.ppt);
+    pl.waves_per_image = pl.tiles_x * pl.tiles_y * (kBlock / kWave);
+    // a tile of T output pixels spans at most ceil(scale*(T-1)) + 3 source pixels (i0 of the first .. i1 of the last)
+    const int64_t pw = std::min<int64_t>(w, (int64_t)std::ceil((double)sw * (kWave - 1)) + 3);
+    const int64_t ph = std::min<int64_t>(h, (int64_t)std::ceil((double)sh * ((kBlock / kWave) * pl.ppt - 1)) + 3);
+    const int64_t fl = ph * pw * (C | 1);
+    pl.lds = (size_t)fl * 4 <= kLowresLdsMax;
+    pl.patch_cap = pl.lds ? (int)fl : 0;
+    pl.lds_bytes = pl.lds ? (size_t)fl * 4 : 0;
+    return pl;
+}
+
+template <int CMAX, bool EXACT>
+static int launch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t B, hipStream_t st)
+{
+    EventScope ev(st);
+    dim3 grid((unsigned)(B * pl.tiles_x * pl.tiles_y)), block(kBlock);
+    if (g_exact_formula) {        // reference operation order: 4-row variant only
+        if (pl.lds) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, true, 1>), grid, block, pl.lds_bytes, st, p);
+        else        hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, false, 1>), grid, block, 0, st, p);
+    } else if (pl.ppt == 8) {
+        if (pl.lds) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 8, true, 0>), grid, block, pl.lds_bytes, st, p);
+        else        hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 8, false, 0>), grid, block, 0, st, p);
+    } else {
+        if (pl.lds) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, true, 0>), grid, block, pl.lds_bytes, st, p);
+        else        hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, false, 0>), grid, block, 0, st, p);
+    }
+    return check_launch("acq_lowres_kernel");
+}
+
+static int dispatch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t B, hipStream_t st)
+{
+    switch (p.C) {
+        case 11: return launch_lowres<11, true>(p, pl, B, st);
+        case 19: return launch_lowres<19, true>(p, pl, B, st);
+        case 21: return launch_lowres<21, true>(p, pl, B, st);
+        default: break;
+    }
+    if (p.C <= 32) return launch_lowres<32, false>(p, pl, B, st);
+    return launch_lowres<64, false>(p, pl, B, st);
+}
+
+static int validate_lowres(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w, int64_t H, int64_t W,
+                           int64_t Hc, int64_t Wc, int strategy)
+{
+    if (int rc = validate(low, B, C, Hc, Wc, strategy)) return rc;
+    if (h < 1 || w < 1 || H < 1 || W < 1) return fail(PP_ERR_BAD_ARG, "bad low-res/full-res shape %lldx%lld -> %lldx%lld",
+                                                    (long long)h, (long long)w, (long long)H, (long long)W);
+    if (Hc > H || Wc > W) return fail(PP_ERR_BAD_ARG, "crop %lldx%lld exceeds the interpolated size %lldx%lld", (long long)Hc,
+                                      (long long)Wc, (long long)H, (long long)W);
+    if (ldx < C) return fail(PP_ERR_BAD_ARG, "ldx=%lld < C=%lld", (long long)ldx, (long long)C);
+    if (B * h * w * ldx > 0x7FFFFFFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "low-res tensor too large");
+    return PP_OK;
+}
+
 }  // namespace pp
 
 using namespace pp;
@@ -824,6 +1034,88 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
                 g_reduce_mode, 0};
     if (int rc = dispatch_acq(p, pl, B, st)) return rc;
     return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st);
+}
+
+size_t pp_acq_lowres_workspace_bytes(int64_t B, int64_t C, int64_t Hc, int64_t Wc, int64_t k)
+{
+    (void)C;
+    if (B < 1 || Hc < 1 || Wc < 1 || k < 1) return 0;
+    if (k <= kSmallKMax) {   // sized for the 4-row tile (most waves)
+        const int64_t waves = cdiv(Wc, kWave) * cdiv(Hc, (kBlock / kWave) * 4) * (kBlock / kWave);
+        return merge_ws_bytes(B, waves * k, k);
+    }
+    return align_up((size_t)B * Hc * Wc * 4, 256) + pp_topk_workspace_bytes(B, Hc * Wc, k);
+}
+
+int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w, int64_t H,
+                             int64_t W, int align_corners, int64_t Hc, int64_t Wc, const uint8_t* exclude, int strategy,
+                             int64_t k, int32_t* out_idx, float* out_val, float* out_map, void* workspace,
+                             size_t ws_bytes, pp_stream_t stream)
+{
+    if (int rc = validate_lowres(low, ldx, B, C, h, w, H, W, Hc, Wc, strategy)) return rc;
+    const int64_t N = Hc * Wc;
+    hipStream_t st = as_stream(stream);
+    float sh, sw;
+    lowres_scales(h, w, H, W, align_corners, sh, sw);
+    LowresParams p{low, ldx, exclude, out_map, nullptr, (int)h, (int)w, (int)Hc, (int)Wc, sh, sw, align_corners ? 1 : 0,
+                   (int)C, 0, 0, 0, strategy, g_reduce_mode, 0};
+    if (k == 0) {     // score map only
+        if (!out_map) return fail(PP_ERR_BAD_ARG, "k == 0 (map only) needs out_map");
+        LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0);
+        p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.patch_cap = pl.patch_cap;
+        return dispatch_lowres(p, pl, B, st);
+    }
+    if (k < 1 || k > N) return fail(PP_ERR_BAD_K, "k=%lld outside [1, H*W=%lld]", (long long)k, (long long)N);
+    if (!out_idx) return fail(PP_ERR_BAD_ARG, "out_idx is null");
+    const size_t need = pp_acq_lowres_workspace_bytes(B, C, Hc, Wc, k);
+    if (!workspace || ws_bytes < need)
+        return fail(PP_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(PP_ERR_BAD_ARG, "workspace must be 256-B aligned");
+    const int largest = strategy != PP_ACQ_MARGIN;
+    LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0);
+    p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.patch_cap = pl.patch_cap;
+    if (k <= kSmallKMax) {
+        const int64_t n_cand = (int64_t)pl.waves_per_image * k;
+        uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
+        uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
+                                                      align_up((size_t)B * n_cand * 8, 256));
+        p.cand = cand;
+        p.k = (int)k;
+        if (int rc = dispatch_lowres(p, pl, B, st)) return rc;
+        return run_merge(cand, n_cand, other, B, (int)k, largest, out_idx, out_val, st);
+    }
+    float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
+    uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
+    p.out_map = map;
+    if (int rc = dispatch_lowres(p, pl, B, st)) return rc;
+    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st);
+}
+
+int pp_acq_lowres_score_at(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w, int64_t H,
+                           int64_t W, int align_corners, int64_t Hc, int64_t Wc, int strategy, const int32_t* img_idx,
+                           const int32_t* pix_idx, int64_t n, float* out, pp_stream_t stream)
+{
+    if (int rc = validate_lowres(low, ldx, B, C, h, w, H, W, Hc, Wc, strategy)) return rc;
+    if (n == 0) return PP_OK;
+    if (n < 0 || !img_idx || !pix_idx || !out) return fail(PP_ERR_BAD_ARG, "score_at: null pointer or n < 0");
+    float sh, sw;
+    lowres_scales(h, w, H, W, align_corners, sh, sw);
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)cdiv(n, kBlock)), block(kBlock);
+    const int al = align_corners ? 1 : 0;
+#define PP_AT(CM, EX)                                                                                                   \
+    hipLaunchKernelGGL((acq_lowres_at_kernel<CM, EX>), grid, block, 0, st, low, ldx, (int)h, (int)w, sh, sw, al, (int)Wc, \
+                       (int)C, strategy, img_idx, pix_idx, n, out)
+    switch (C) {
+        case 11: PP_AT(11, true); break;
+        case 19: PP_AT(19, true); break;
+        case 21: PP_AT(21, true); break;
+        default:
+            if (C <= 32) PP_AT(32, false);
+            else PP_AT(64, false);
+    }
+#undef PP_AT
+    return check_launch("acq_lowres_at_kernel");
 }
 
 int pp_topk_select(const float* scores, int64_t B, int64_t N, int64_t k, int largest, int32_t* out_idx,

@@ -937,18 +937,7 @@ __global__ __launch_bounds__(kT) void crop_kernel(const float* xp, int64_t ldxp,
 //   align_corners:  src = scale*dst,               scale = (in-1)/(out-1)   (0 if out == 1)
 //   otherwise:      src = max(scale*(dst+0.5)-0.5, 0),  scale = in/out (or 1/scale_factor)
 // ================================================================================================
-struct Lerp { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Lerp lerp_src(int dst, int in, float scale, int align)
-{
-    float src = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.0f);
-    Lerp L;
-    L.i0 = (int)src;
-    if (L.i0 > in - 1) L.i0 = in - 1;
-    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
-    L.l1 = src - (float)L.i0;
-    L.l0 = 1.0f - L.l1;
-    return L;
-}
+// (Lerp / lerp_src / bilerp live in pp_common.h: the fused low-resolution acquisition kernel shares them bit for bit)
 
 // NHWC -> NHWC (channel slices allowed) or NHWC -> NCHW (out_nchw: y is [B,C,Ho,Wo] contiguous)
 template <bool OUT_NCHW>
@@ -972,10 +961,10 @@ __global__ __launch_bounds__(kT) void bilinear_fwd_kernel(const float* x, int64_
             const float4 v10 = *reinterpret_cast<const float4*>(base + ((int64_t)lh.i1 * W + lw.i0) * ldx);
             const float4 v11 = *reinterpret_cast<const float4*>(base + ((int64_t)lh.i1 * W + lw.i1) * ldx);
             float4 o;
-            o.x = lh.l0 * (lw.l0 * v00.x + lw.l1 * v01.x) + lh.l1 * (lw.l0 * v10.x + lw.l1 * v11.x);
-            o.y = lh.l0 * (lw.l0 * v00.y + lw.l1 * v01.y) + lh.l1 * (lw.l0 * v10.y + lw.l1 * v11.y);
-            o.z = lh.l0 * (lw.l0 * v00.z + lw.l1 * v01.z) + lh.l1 * (lw.l0 * v10.z + lw.l1 * v11.z);
-            o.w = lh.l0 * (lw.l0 * v00.w + lw.l1 * v01.w) + lh.l1 * (lw.l0 * v10.w + lw.l1 * v11.w);
+            o.x = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, v00.x, v01.x, v10.x, v11.x);
+            o.y = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, v00.y, v01.y, v10.y, v11.y);
+            o.z = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, v00.z, v01.z, v10.z, v11.z);
+            o.w = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, v00.w, v01.w, v10.w, v11.w);
             *reinterpret_cast<float4*>(y + (((int64_t)b * Ho + oh) * Wo + ow) * ldy + q * 4) = o;
         }
     } else {
@@ -992,7 +981,7 @@ __global__ __launch_bounds__(kT) void bilinear_fwd_kernel(const float* x, int64_
             const float* base = x + (int64_t)b * H * W * ldx + c;
             const float v00 = base[((int64_t)lh.i0 * W + lw.i0) * ldx], v01 = base[((int64_t)lh.i0 * W + lw.i1) * ldx];
             const float v10 = base[((int64_t)lh.i1 * W + lw.i0) * ldx], v11 = base[((int64_t)lh.i1 * W + lw.i1) * ldx];
-            y[e] = lh.l0 * (lw.l0 * v00 + lw.l1 * v01) + lh.l1 * (lw.l0 * v10 + lw.l1 * v11);
+            y[e] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, v00, v01, v10, v11);
         }
     }
 }

@@ -63,6 +63,31 @@ struct Epilogue {
     int act;                   // 0 none, 1 ReLU, 2 ReLU6
 };
 
+// ---- bilinear source coordinates (torch upsample_bilinear2d index arithmetic, fp32) ---------------------
+//   align_corners:  src = scale*dst,                      scale = (in-1)/(out-1)   (0 if out == 1)
+//   otherwise:      src = max(scale*(dst+0.5)-0.5, 0),    scale = in/out (or 1/scale_factor)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_src(int dst, int in, float scale, int align)
+{
+    float src = align ? __fmul_rn(scale, (float)dst) : fmaxf(__fsub_rn(__fmul_rn(scale, (float)dst + 0.5f), 0.5f), 0.0f);
+    Lerp L;
+    L.i0 = (int)src;
+    if (L.i0 > in - 1) L.i0 = in - 1;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.0f - L.l1;
+    return L;
+}
+
+// h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11) with the contraction spelled out, so that every kernel that
+// interpolates (pp_bilinear_fwd and the fused low-resolution acquisition) produces the same bits.
+__device__ __forceinline__ float bilerp(float h0, float h1, float w0, float w1, float v00, float v01, float v10, float v11)
+{
+    const float top = __fmaf_rn(w1, v01, __fmul_rn(w0, v00));
+    const float bot = __fmaf_rn(w1, v11, __fmul_rn(w0, v10));
+    return __fmaf_rn(h1, bot, __fmul_rn(h0, top));
+}
+
 #ifdef __HIPCC__
 __device__ __forceinline__ float epi_act(float z, int act)
 {

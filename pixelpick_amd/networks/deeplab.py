@@ -92,7 +92,7 @@ class DeepLab(nn.Module):
         self.return_attention = return_attention
 
     # ---- the graph (deeplab.py:43-59) ---------------------------------------------------------------------
-    def _run(self, tape, inputs):
+    def _run(self, tape, inputs, upsample=True):
         B, _, H, W = inputs.shape
         x = E.nchw_to_nhwc(inputs)
         high, low = self.backbone.run(tape, x)
@@ -105,8 +105,19 @@ class DeepLab(nn.Module):
         low_ = llc[1].run(tape, llc[0].run(tape, low), E.ACT_RELU, dst=cat_buf[..., 256:304])
         cat = E.concat_alias(tape, cat_buf, [up, low_])
         outs = self.seg_head.run(tape, cat)
+        if not upsample:
+            return outs["pred"], outs["emb"]
         pred = E.bilinear(tape, outs["pred"], (H, W), True, 0.0, out_nchw=True)
         return pred, outs["emb"]
+
+    def forward_lowres(self, inputs):
+        """Inference forward that stops in front of deeplab.py:55-56: -> (classifier logits [B,H/4,W/4,C] channels-last,
+        (H, W)).  `acquisition.score_topk_lowres` interpolates them on the fly, so an acquisition
+        round never writes the full-resolution logits.  Same module state semantics as forward() under no_grad."""
+        if not inputs.is_cuda:
+            raise RuntimeError("pixelpick_amd.DeepLab runs on the GPU only (no CPU fallback)")
+        pred_v, _ = self._run(E.Tape(enabled=False), inputs.to(torch.float32), upsample=False)
+        return pred_v.t, tuple(inputs.shape[2:])
 
     def forward(self, inputs):
         if not inputs.is_cuda:

@@ -10,6 +10,8 @@ reference (`model.py:44,83`, `train.py:9,82`, `datasets/*.py` codecs) runs uncha
     first — the reference inherits an implementation-defined order from torch.topk;
   * the MC-dropout branch (query.py:177-187, NameError `up_map` in the reference) is implemented as
     the evident intent: mean over `mc_n_steps` stochastic passes;
+  * for models that expose `forward_lowres` (DeepLab) the x4 bilinear upsample of deeplab.py:55-56 is folded into the
+    scoring kernel as well (pp_acq_lowres_score_topk, SURVEY.md §8f rank 1): identical queries, no full-size logits;
   * there is no CPU fallback: tensors must live on the GPU and the extension must be built.
 """
 import os
@@ -25,6 +27,8 @@ import torch.nn.functional as F
 from . import acquisition as acq
 
 _LARGEST_STRATEGIES = ("entropy", "least_confidence")
+# PIXELPICK_FUSED_LOWRES=0: always materialise the full-resolution logits (model(x)["pred"]) before scoring
+FUSED_LOWRES = os.environ.get("PIXELPICK_FUSED_LOWRES", "1") != "0"
 
 
 class QuerySelector:
@@ -166,9 +170,14 @@ class QuerySelector:
                 return
             xs = torch.cat([it[0] for it in pending], dim=0)
             logits_b = None
-            if not self.use_mc_dropout:
-                logits_b = model(xs)["pred"]
             sizes = {it[4] for it in pending}
+            # DeepLab exposes its classifier output in front of the x4 upsample; the scoring
+            # kernel interpolates on the fly and the full-resolution logits are never written
+            fused = (FUSED_LOWRES and not self.use_mc_dropout and len(sizes) == 1 and hasattr(model, "forward_lowres"))
+            if fused:
+                low, full_size = model.forward_lowres(xs)
+            elif not self.use_mc_dropout:
+                logits_b = model(xs)["pred"]
             if not self.use_mc_dropout and len(sizes) == 1:
                 # one scoring launch, one index read-back and one entropy read-back for the whole batch
                 (h, w), = sizes
@@ -179,8 +188,11 @@ class QuerySelector:
                     k = self.n_pixels_by_us
                 else:
                     k = self._k_topk(h, w)
-                lg = logits_b[:, :, :h, :w]
-                idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, k)
+                if fused:
+                    idx, _, _ = acq.score_topk_lowres(low, full_size, torch.from_numpy(excl), self.query_strategy, k, crop=(h, w))
+                else:
+                    lg = logits_b[:, :, :h, :w]
+                    idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, k)
                 idx_h = idx.cpu().numpy().astype(np.int64)
                 chosen = [np.sort(self._choose(idx_h[j])) for j in range(len(pending))]
                 want_stats = (not human_labels) and all(it[1] is not None for it in pending)
@@ -188,9 +200,12 @@ class QuerySelector:
                 if want_stats:
                     flat = np.concatenate(chosen)
                     img = np.repeat(np.arange(len(pending)), [len(c) for c in chosen])
-                    dev = lg.device
-                    picked = lg[torch.from_numpy(img).to(dev), :, torch.from_numpy(flat // w).to(dev), torch.from_numpy(flat % w).to(dev)]
-                    ent_all = acq.score_map(picked.t().reshape(1, picked.shape[1], 1, -1).contiguous(), None, "entropy").reshape(-1).cpu().numpy()
+                    if fused:
+                        ent_all = acq.score_at_lowres(low, full_size, img, flat, "entropy", crop=(h, w)).cpu().numpy()
+                    else:
+                        dev = lg.device
+                        picked = lg[torch.from_numpy(img).to(dev), :, torch.from_numpy(flat // w).to(dev), torch.from_numpy(flat % w).to(dev)]
+                        ent_all = acq.score_map(picked.t().reshape(1, picked.shape[1], 1, -1).contiguous(), None, "entropy").reshape(-1).cpu().numpy()
                 off = 0
                 for j, (x1, yj, exclude, p_img, _) in enumerate(pending):
                     sel = chosen[j]

@@ -425,3 +425,46 @@ def test_query_selector_mc_dropout_mean_of_maps():
         want = uc.flatten().topk(k).indices.cpu().numpy()
         got = dq[n]["y_coords"].astype(np.int64) * w + dq[n]["x_coords"]
         assert set(got.tolist()) == set(want.tolist())
+
+
+# ---------------------------------------------------------------- SURVEY.md §8f rank 1 through the real network
+@pytest.mark.parametrize("dataset,st,top_n", [("cs", "entropy", 0.0), ("voc", "margin_sampling", 0.0), ("cs", "least_confidence", 0.05)])
+def test_query_selector_fused_lowres_gives_identical_queries_and_stats(monkeypatch, dataset, st, top_n):
+    """DeepLab exposes forward_lowres: the selector then scores straight from the 1/4-resolution classifier output
+    (pp_acq_lowres_score_topk).  Coordinates and QueryStats must equal the full-resolution-logits path exactly —
+    including the VOC reflect-pad / crop branch (query.py:171-174,190) and the top-n-percent mode (query.py:36,62-64)."""
+    from pixelpick_amd.networks.deeplab import DeepLab
+    C = 21 if dataset == "voc" else 19
+    h, w = (77, 90) if dataset == "voc" else (64, 96)
+    torch.manual_seed(3)
+    net_args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, use_aspp=True, use_softmax=False, use_img_inp=False)
+    model = DeepLab(net_args).to(DEV)
+    n = 5
+    xs, ys = torch.randn(n, 3, h, w), torch.randint(0, C + 1, (n, h, w))
+    ys[ys == C] = 255 if dataset == "voc" else C
+    rng = np.random.RandomState(0)
+    prev = [rng.rand(h, w) < 0.01 for _ in range(n)]
+    names = [f"/img{i}.png" for i in range(n)]
+    outs, stats = [], []
+    for fused in (True, False):
+        monkeypatch.setattr(ppq, "FUSED_LOWRES", fused)
+        called = []
+        orig = model.forward_lowres
+        monkeypatch.setattr(model, "forward_lowres", lambda x, _o=orig: (called.append(1), _o(x))[1], raising=False)
+        with tempfile.TemporaryDirectory() as td:
+            a = _args(query_strategy=st, dir_root=td, dataset_name=dataset, n_classes=C, ignore_index=255 if dataset == "voc" else C,
+                      top_n_percent=top_n, query_batch_size=2)
+            np.random.seed(4)
+            qs = ppq.QuerySelector(a, _DL(_DS(xs, ys, prev, names)), device=torch.device(DEV))
+            outs.append(qs(nth_query=1, model=model))
+            stats.append(qs.query_stats)
+        assert bool(called) == fused
+        monkeypatch.undo()
+    for nme in names:
+        np.testing.assert_array_equal(outs[0][nme]["x_coords"], outs[1][nme]["x_coords"])
+        np.testing.assert_array_equal(outs[0][nme]["y_coords"], outs[1][nme]["y_coords"])
+        assert outs[0][nme]["height"] == h and outs[0][nme]["width"] == w
+    assert len(stats[0].list_entropy) >= n and stats[0].list_entropy == stats[1].list_entropy
+    assert stats[0].list_n_unique_labels == stats[1].list_n_unique_labels
+    assert stats[0].list_spatial_coverage == stats[1].list_spatial_coverage
+    assert stats[0].dict_label_cnt == stats[1].dict_label_cnt

@@ -122,3 +122,33 @@ def test_oracle_reproduces_voc_pad_and_human_label_branches(golden_dir):
         ys, xs = np.where(q.reshape(24, 40))
         np.testing.assert_array_equal(xs, gb[f"hl_x_{i}"])
         np.testing.assert_array_equal(ys, gb[f"hl_y_{i}"])
+
+
+# ---- low-resolution logits -> interpolate -> crop -> score -> top-k ---------------------------
+@pytest.fixture(scope="module")
+def glow(golden_dir):
+    return np.load(os.path.join(golden_dir, "acq_lowres.npz"))
+
+
+def test_bilinear_restatement_matches_torch_and_golden(glow):
+    import torch
+    import torch.nn.functional as F
+    np.testing.assert_allclose(orc.bilinear_resize(glow["s1_low"], tuple(glow["s1_size"])), glow["s1_pred"], rtol=1e-5, atol=2e-6)
+    x = np.random.RandomState(0).randn(2, 5, 7, 9).astype(np.float32)
+    for ac in (True, False):
+        for size in [(28, 36), (13, 20), (7, 9), (3, 4), (1, 1), (40, 5)]:
+            ref = F.interpolate(torch.from_numpy(x), size=size, mode="bilinear", align_corners=ac).numpy()
+            np.testing.assert_allclose(orc.bilinear_resize(x, size, ac), ref, rtol=1e-5, atol=2e-6, err_msg=f"{ac} {size}")
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+@pytest.mark.parametrize("st", STRATS)
+def test_lowres_path_matches_reference(glow, si, st):
+    low, excl = glow[f"s{si}_low"], glow[f"s{si}_exclude"]
+    size, crop = tuple(glow[f"s{si}_size"]), tuple(glow[f"s{si}_crop"])
+    idx, val, m = orc.lowres_score_topk(low, size, excl, st, 20, crop=crop, want_map=True)
+    _, _, raw = orc.lowres_score_topk(low, size, None, st, 1, crop=crop, want_map=True)
+    np.testing.assert_allclose(raw, glow[f"s{si}_map_{st}"], rtol=2e-5, atol=4e-6)
+    for b in range(low.shape[0]):
+        assert sorted(idx[b].tolist()) == glow[f"s{si}_sel_{st}"][b].tolist()
+        assert idx[b].tolist() == glow[f"s{si}_order_{st}"][b].tolist()

@@ -11,6 +11,7 @@ Reference call sites exercised:
   query.py:144-221   QuerySelector.__call__ with a fake dataloader + 1x1-conv model   (G4)
   query.py:71-142    encode_query / decode_queries                                    (G5)
   query.py:320-351   merge_previous_query_files                                       (G5)
+  deeplab.py:55-56 + query.py:190   low-res logits -> interpolate -> crop -> score  (--lowres, §8f-1)
 """
 import os
 import sys
@@ -428,7 +429,60 @@ def gen_branches():
     print("branches written")
 
 
+def gen_lowres():
+    """SURVEY.md §8f-1 fixture: low-resolution classifier logits -> deeplab.py:55-56 F.interpolate(bilinear,
+    align_corners=True) -> [:h,:w] crop (query.py:190) -> reference sampler + _select_queries."""
+    cases = [((2, 19, 8, 16), (32, 64), None), ((1, 11, 12, 15), (45, 60), None), ((2, 21, 5, 7), (40, 56), (37, 53))]
+    out = {}
+    for si, ((b, c, hl, wl), size, crop) in enumerate(cases):
+        seed = 700 + si
+        hc, wc = size if crop is None else crop
+        while True:
+            torch.manual_seed(seed)
+            low = torch.randn(b, c, hl, wl) * 3
+            rng = np.random.RandomState(seed)
+            excl = np.zeros((b, hc, wc), dtype=np.uint8)
+            for i in range(b):
+                excl[i].reshape(-1)[rng.choice(hc * wc, 40, replace=False)] = 1
+                excl[i][rng.rand(hc, wc) < 0.05] = 1
+            pred = F.interpolate(low, size=size, mode="bilinear", align_corners=True)[:, :, :hc, :wc]
+            prob = F.softmax(pred, dim=1)
+            ok, rec = True, {}
+            for st in STRATS:
+                uc = refq.UncertaintySampler(st)(prob)
+                rec[f"map_{st}"] = uc.numpy().copy()
+                largest = st in ["entropy", "least_confidence"]
+                sets, orders = [], []
+                for i in range(b):
+                    qs = refq.QuerySelector(mk_args(st, c, k=20), dataloader=None, device=torch.device("cpu"))
+                    m = uc[i].clone()
+                    m[torch.from_numpy(excl[i].astype(bool))] = FILL[st]
+                    srt = torch.sort(m.flatten(), descending=largest).values.numpy()
+                    if not gap_ok(srt, 20) or not all_gaps_ok(srt[:21]):
+                        ok = False
+                    sets.append(np.flatnonzero(qs._select_queries(m.clone()).reshape(-1)).astype(np.int64))
+                    orders.append(m.flatten().topk(20, largest=largest).indices.numpy().astype(np.int64))
+                rec[f"sel_{st}"] = np.stack(sets)
+                rec[f"order_{st}"] = np.stack(orders)
+            if ok:
+                break
+            seed += 1000
+        out[f"s{si}_low"] = low.numpy()
+        out[f"s{si}_size"] = np.array(size, dtype=np.int64)
+        out[f"s{si}_crop"] = np.array([hc, wc], dtype=np.int64)
+        out[f"s{si}_exclude"] = excl
+        if si == 1:          # the interpolated logits themselves, one case (pins the bilinear restatement)
+            out[f"s{si}_pred"] = pred.numpy()
+        for kk, v in rec.items():
+            out[f"s{si}_{kk}"] = v
+    np.savez_compressed(os.path.join(OUT, "acq_lowres.npz"), **out)
+    print("lowres written", os.path.getsize(os.path.join(OUT, "acq_lowres.npz")))
+
+
 if __name__ == "__main__":
+    if "--lowres" in sys.argv:
+        gen_lowres()
+        sys.exit(0)
     if "--branches" in sys.argv:
         gen_branches()
         sys.exit(0)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""SURVEY.md §8f rank 1 measurement: acquisition from the 1/4-resolution classifier output in one launch
+(pp_acq_lowres_score_topk) vs the two-launch path it replaces (pp_bilinear_fwd -> pp_acq_score_topk).
+    python tools/lowres_bench.py [B ...]
+"""
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pixelpick_amd import acquisition as acq  # noqa: E402
+from pixelpick_amd import engine as E  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    Bs = [int(v) for v in sys.argv[1:]] or [1, 8, 64, 256]
+    cfgs = [("cs", 19, (64, 128), (256, 512), "entropy"), ("cv", 11, (90, 120), (360, 480), "margin_sampling"),
+            ("voc", 21, (80, 80), (320, 320), "margin_sampling"), ("cs-full", 19, (256, 512), (1024, 2048), "least_confidence")]
+    print(f"{'cfg':8s} {'B':>4s} {'fused ms':>9s} {'2-launch ms':>11s} {'speed-up':>8s} {'Gpix/s fused':>12s} {'low-res GB/s':>12s}")
+    for name, C, lo, size, st in cfgs:
+        for B in Bs:
+            if name == "cs-full" and B > 16:
+                continue
+            torch.manual_seed(0)
+            low = torch.randn(B, *lo, C, device=DEV) * 3
+            excl = (torch.rand(B, *size, device=DEV) < 0.05).to(torch.uint8)
+            k = 20
+
+            def fused():
+                acq.score_topk_lowres(low, size, excl, st, k)
+
+            def two():
+                pred = E.bilinear(E.Tape(False), E.Var(low), size, True, 0.0, out_nchw=True).t
+                acq.score_topk(pred, excl, st, k)
+
+            tf, t2 = timeit(fused), timeit(two)
+            npix = B * size[0] * size[1]
+            print(f"{name:8s} {B:4d} {tf:9.4f} {t2:11.4f} {t2 / tf:8.2f} {npix / tf / 1e6:12.1f} {low.numel() * 4 / tf / 1e6:12.1f}")
+
+
+if __name__ == "__main__":
+    main()
