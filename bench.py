@@ -344,6 +344,23 @@ def main():
                             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
                             "kernel_ms_min": round(min(kms), 4)}
 
+        # the same selection straight from the classifier output at 1/4 resolution (what DeepLab's
+        # head writes before deeplab.py:55-56), interpolated on the fly - the production path of QuerySelector for DeepLab
+        if a.layout == "nchw" and H % 4 == 0 and W % 4 == 0:
+            low = torch.randn((B, H // 4, W // 4, C), device=dev, generator=gen) * 3
+            ws2 = torch.empty(max(L.pp_acq_lowres_workspace_bytes(B, C, H, W, k), 256), dtype=torch.uint8, device=dev)
+
+            def lowres_step():
+                rc = L.pp_acq_lowres_score_topk(low.data_ptr(), C, B, C, H // 4, W // 4, H, W, 1, H, W, excl.data_ptr(), sid, k,
+                                                idx.data_ptr(), val.data_ptr(), None, ws2.data_ptr(), ws2.numel(), stream)
+                _lib.check(rc, "pp_acq_lowres_score_topk")
+            el2 = timed(lowres_step, a.steps, a.warmup)
+            acqr["from_lowres_logits"] = {"value": round(world * B * H * W * a.steps / el2 / 1e6, 1), "unit": "Mpixels/s",
+                                          "ms_per_step": round(el2 / a.steps * 1e3, 4), "kernel": "acq_lowres_kernel",
+                                          "input": f"[{B},{H // 4},{W // 4},{C}] channels-last logits, bilinear x4 align_corners folded in",
+                                          "bound": "valu (interpolation + softmax arithmetic; 16x less input than the full-size logits)"}
+            del low, ws2
+
     if rank == 0:
         head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
