@@ -21,6 +21,9 @@ from . import engine as E
 
 # PIXELPICK_OVERLAP_ALLREDUCE=0: one all-reduce of the whole flat gradient after backward (the round-1 behaviour)
 OVERLAP_ALLREDUCE = os.environ.get("PIXELPICK_OVERLAP_ALLREDUCE", "1") != "0"
+# PIXELPICK_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank process group (lets a single-GPU box
+# exercise the RCCL call path - communicator setup, the overlapped bucket on the helper stream - end to end)
+FORCE_COLLECTIVES = os.environ.get("PIXELPICK_FORCE_COLLECTIVES", "0") == "1"
 
 
 class FlatTrainer:
@@ -39,8 +42,10 @@ class FlatTrainer:
         self.ignore_index = ignore_index
         self.pg = process_group
         self.world = 1
+        self.collectives = False
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        self.collectives = self.world > 1 or (FORCE_COLLECTIVES and torch.distributed.is_available() and torch.distributed.is_initialized())
         slow, fast = [], []
         seen = set()
         for name, p in model.named_parameters():
@@ -94,7 +99,7 @@ class FlatTrainer:
         tape = E.Tape(enabled=True)
         tape.param_grad_dst = lambda p: self._grad_view.get(id(p))
         self._early_work = None
-        if self.world > 1 and OVERLAP_ALLREDUCE and self.n_split < self.n and not torch.cuda.is_current_stream_capturing():
+        if self.collectives and OVERLAP_ALLREDUCE and self.n_split < self.n and not torch.cuda.is_current_stream_capturing():
             tape.hooks["encoder_done"] = self._early_all_reduce
         pred, _ = self.model._run(tape, x)
         loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index)
@@ -122,7 +127,7 @@ class FlatTrainer:
         E.refresh_stream()
 
     def all_reduce_grads(self):
-        if self.world > 1:
+        if self.collectives:
             if self._early_work is not None:
                 torch.distributed.all_reduce(self.flat_g[:self.n_split], op=torch.distributed.ReduceOp.SUM, group=self.pg)
                 self._early_work.wait()                   # main stream waits for the overlapped part

@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
             tr.train_step(x, y)
         pa = tr.flat_p.clone()
         ref = _trainer()
-        ref.world = 1                                   # no all-reduce, grad_scale 1
+        ref.world, ref.collectives = 1, False           # no all-reduce, grad_scale 1
         for _ in range(2):
             ref.train_step(x, y)
         same_as_single = torch.equal(pa, ref.flat_p)
@@ -105,3 +105,46 @@ def test_two_rank_train_step_on_one_gpu():
         assert same_as_single, f"rank {rank}: identical shards must reproduce the single-process step"
         assert replicas_equal, f"rank {rank}: replicas diverged"
         assert differs and all(l == l and l < 50 for l in losses)
+
+
+def _rccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        import pixelpick_amd.trainer as T
+        x, y = _batch(11)
+        ref = _trainer()
+        assert not ref.collectives
+        for _ in range(3):
+            ref.train_step(x, y)
+        out = {}
+        for overlap in (True, False):
+            T.FORCE_COLLECTIVES, T.OVERLAP_ALLREDUCE = True, overlap
+            tr = _trainer()
+            assert tr.collectives and tr.world == 1
+            for _ in range(3):
+                tr.train_step(x, y)
+            torch.cuda.synchronize()
+            out[overlap] = torch.equal(tr.flat_p, ref.flat_p)
+            out[f"early{overlap}"] = hasattr(tr, "_comm_stream") == overlap
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_call_path_with_one_rank():
+    """backend "nccl" (= RCCL) on the one GPU this box has: communicator setup, the overlapped decoder-side bucket issued
+    from the helper stream and the encoder bucket after the join all run for real (PIXELPICK_FORCE_COLLECTIVES); a sum
+    over one rank is the identity, so the parameters must equal the collective-free run bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert out[True] and out[False], out
+    assert out["earlyTrue"] and out["earlyFalse"], out
