@@ -286,6 +286,18 @@ int pp_sparse_ce_fwd_bwd(const float* logits, int B, int C, int64_t HW, int64_t 
                          int ignore_index, float* loss, float* count, const float* grad_out, float* dlogits, void* workspace,
                          size_t ws_bytes, pp_stream_t stream);
 
+/* The same loss and its gradient taken straight from the LOW-resolution classifier output, for a model whose last op is
+ * deeplab.py:55-56  F.interpolate(low, size=(H,W), mode='bilinear', align_corners):
+ *   *loss = F.cross_entropy(F.interpolate(low), target, ignore_index)  (model.py:116),  *count = labelled pixels,
+ *   dlow (NULL to skip) f32 [B,h,w,lddx] = grad_out * d loss / d low  (what autograd hands to the classifier conv).
+ * low f32 [B,h,w,ldx] channels-last, C valid channels; target i64 [B,H,W].  The labels are scanned once, the class vector
+ * is interpolated only at labelled pixels (80 of 524 288 in the BASELINE step) and the backward gathers per low-res
+ * pixel in a fixed order (no atomics: bitwise reproducible).  Neither the [B,C,H,W] logits nor their gradient exist. */
+size_t pp_sparse_ce_lowres_workspace_bytes(void);
+int pp_sparse_ce_lowres_fwd_bwd(const float* low, int64_t ldx, int B, int C, int h, int w, int H, int W, int align_corners,
+                                const int64_t* target, int ignore_index, float* loss, float* count, const float* grad_out,
+                                float* dlow, int64_t lddx, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
 /* Step metrics on the device (model.py:124-125,194-196 + utils/metrics.py:168-177): hist[t*C + argmax_c logits] += 1
  * for every pixel whose target t is in [0, C) (ignore_index >= C is skipped like RunningScore._fast_hist).  hist is
  * an int64 [C,C] accumulator the caller zeroes / reads (C*C*8 bytes D2H instead of two full maps). */

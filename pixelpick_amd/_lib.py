@@ -63,6 +63,8 @@ SIGNATURES = {
     "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p, _p]),
     "pp_sparse_ce_workspace_bytes": (_sz, []),
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
+    "pp_sparse_ce_lowres_workspace_bytes": (_sz, []),
+    "pp_sparse_ce_lowres_fwd_bwd": (_int, [_p, _i64] + [_int] * 7 + [_p, _int, _p, _p, _p, _p, _i64, _p, _sz, _p]),
     "pp_confusion_matrix_update": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _p, _p]),
     "pp_adam_step_flat": (_int, [_p, _p, _p, _p, _i64, _i64, _f, _f, _f, _f, _f, _f, _i64, _f, _p, _p]),
     "pp_sgd_step_flat": (_int, [_p, _p, _p, _i64, _i64, _f, _f, _f, _f, _i64, _f, _p, _p]),

@@ -1378,16 +1378,6 @@ __global__ __launch_bounds__(kT) void ce_partial_kernel(const float* logits, con
     if (threadIdx.x == 0) { part[blockIdx.x * 2] = sh[0][0]; part[blockIdx.x * 2 + 1] = sh[1][0]; }
 }
 
-__global__ void ce_finalize_kernel(const float* part, int nblk, float* loss, float* count)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0, n = 0.0;
-        for (int b = 0; b < nblk; ++b) { s += (double)part[b * 2]; n += (double)part[b * 2 + 1]; }
-        *count = (float)n;
-        *loss = (float)(s / n);  // 0/0 = NaN when no pixel is labelled, like F.cross_entropy
-    }
-}
-
 // dlogits (NCHW contiguous) = grad_scale * (softmax - onehot) / N at labelled pixels, 0 elsewhere
 __global__ __launch_bounds__(kT) void ce_bwd_kernel(const float* logits, const int64_t* target, int B, int C, int64_t HW,
                                                    int64_t sB, int64_t sC, int ignore_index, const float* count,
@@ -1414,6 +1404,146 @@ __global__ __launch_bounds__(kT) void ce_bwd_kernel(const float* logits, const i
             dst[c * HW] = gs * (pr - (c == tg ? 1.0f : 0.0f));
         }
     }
+}
+
+// ================================================================================================
+// The same loss taken straight from the LOW-resolution classifier output (model.py:113-121 for DeepLab):
+//   logits = F.interpolate(low, size=(H,W), 'bilinear', align_corners)   deeplab.py:55-56
+//   loss   = F.cross_entropy(logits, target, ignore_index)               model.py:116
+//   dlow   = d loss / d low                                              (autograd through both)
+// PixelPick labels 10-100 pixels per image (80 of 524 288 at B=4), so neither the full-size logits
+// (40 MB), nor their gradient (40 MB of zeros) need to exist: the forward scans the labels and interpolates the class
+// vector only where a label is, the backward GATHERS per low-resolution pixel from the labelled pixels in its
+// footprint (fixed order, no atomics: bitwise reproducible).
+// ================================================================================================
+template <int CMAX, bool EXACT>
+__device__ __forceinline__ void lowres_class_vector(const float* base, int64_t ldx, int w, const Lerp& lh, const Lerp& lw, int C,
+                                                    float (&x)[CMAX])
+{
+    const float* p00 = base + ((int64_t)lh.i0 * w + lw.i0) * ldx;
+    const float* p01 = base + ((int64_t)lh.i0 * w + lw.i1) * ldx;
+    const float* p10 = base + ((int64_t)lh.i1 * w + lw.i0) * ldx;
+    const float* p11 = base + ((int64_t)lh.i1 * w + lw.i1) * ldx;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (EXACT || c < C) x[c] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, p00[c], p01[c], p10[c], p11[c]);
+}
+
+template <int CMAX, bool EXACT>
+__global__ __launch_bounds__(kT) void ce_lowres_partial_kernel(const float* low, int64_t ldx, int B, int C, int h, int w, int H,
+                                                              int W, float sh, float sw, int align, const int64_t* target,
+                                                              int ignore_index, float* part /*[nblk][2]*/)
+{
+    __shared__ float shm[2][kT];
+    float ls = 0.0f, cnt = 0.0f;
+    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t tg = target[e];
+        if (tg == ignore_index) continue;
+        const int64_t b = e / HW, pix = e - b * HW;
+        const int Y = (int)(pix / W), X = (int)(pix - (int64_t)Y * W);
+        float x[CMAX];
+        lowres_class_vector<CMAX, EXACT>(low + b * h * w * ldx, ldx, w, lerp_src(Y, h, sh, align), lerp_src(X, w, sw, align), C, x);
+        float m = x[0], xt = 0.0f;
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c)
+            if (EXACT || c < C) m = fmaxf(m, x[c]);
+        float S = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (EXACT || c < C) {
+                S += expf(x[c] - m);
+                xt = (c == tg) ? x[c] : xt;
+            }
+        ls += (m + logf(S)) - xt;
+        cnt += 1.0f;
+    }
+    shm[0][threadIdx.x] = ls;
+    shm[1][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = kT / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            shm[0][threadIdx.x] += shm[0][threadIdx.x + s];
+            shm[1][threadIdx.x] += shm[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = shm[0][0]; part[blockIdx.x * 2 + 1] = shm[1][0]; }
+}
+
+// one 64-lane wave, fixed order: lane l adds part[l], part[l+64], ... in double, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void ce_finalize_wave_kernel(const float* part, int nblk, float* loss, float* count)
+{
+    double s = 0.0, n = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) { s += (double)part[b * 2]; n += (double)part[b * 2 + 1]; }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        n += __shfl_down(n, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        *count = (float)n;
+        *loss = (float)(s / n);   // 0/0 = NaN when no pixel is labelled, like F.cross_entropy
+    }
+}
+
+// One thread per low-resolution pixel: walk the output pixels that interpolate from it, and for the (rare) labelled
+// ones add  weight * (softmax - onehot).  dlow [B,h,w,lddx] is fully written (zeros included).
+template <int CMAX, bool EXACT>
+__global__ __launch_bounds__(kT) void ce_lowres_bwd_kernel(const float* low, int64_t ldx, int B, int C, int h, int w, int H,
+                                                          int W, float sh, float sw, int align, const int64_t* target,
+                                                          int ignore_index, const float* count, const float* grad_out,
+                                                          float* dlow, int64_t lddx)
+{
+    const int64_t total = (int64_t)B * h * w;
+    const int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (e >= total) return;
+    const int c0 = (int)(e % w);
+    const int64_t t = e / w;
+    const int r0 = (int)(t % h);
+    const int b = (int)(t / h);
+    const float gs = (grad_out ? *grad_out : 1.0f) / *count;
+    float acc[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) acc[c] = 0.0f;
+    int ylo, yhi, xlo, xhi;
+    out_window(r0, h, H, sh, align, ylo, yhi);
+    out_window(c0, w, W, sw, align, xlo, xhi);
+    const float* base = low + (int64_t)b * h * w * ldx;
+    const int64_t* tb = target + (int64_t)b * H * W;
+    for (int Y = ylo; Y <= yhi; ++Y) {
+        const Lerp lh = lerp_src(Y, h, sh, align);
+        const float wh = (lh.i0 == r0 ? lh.l0 : 0.0f) + (lh.i1 == r0 ? lh.l1 : 0.0f);
+        if (lh.i0 != r0 && lh.i1 != r0) continue;
+        const int64_t* trow = tb + (int64_t)Y * W;
+        for (int X = xlo; X <= xhi; ++X) {
+            const int64_t tg = trow[X];
+            if (tg == ignore_index) continue;
+            const Lerp lw = lerp_src(X, w, sw, align);
+            if (lw.i0 != c0 && lw.i1 != c0) continue;
+            const float ww = (lw.i0 == c0 ? lw.l0 : 0.0f) + (lw.i1 == c0 ? lw.l1 : 0.0f);
+            float x[CMAX];
+            lowres_class_vector<CMAX, EXACT>(base, ldx, w, lh, lw, C, x);
+            float m = x[0];
+#pragma unroll
+            for (int c = 1; c < CMAX; ++c)
+                if (EXACT || c < C) m = fmaxf(m, x[c]);
+            float S = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C) {
+                    x[c] = expf(x[c] - m);
+                    S += x[c];
+                }
+            const float inv = 1.0f / S, wgt = wh * ww;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C) acc[c] = fmaf(wgt, gs * (x[c] * inv - (c == tg ? 1.0f : 0.0f)), acc[c]);
+        }
+    }
+    float* dst = dlow + e * lddx;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (EXACT || c < C) dst[c] = acc[c];
 }
 
 // ================================================================================================
@@ -1869,13 +1999,59 @@ int pp_sparse_ce_fwd_bwd(const float* logits, int B, int C, int64_t HW, int64_t 
     if (nblk < 1) nblk = 1;
     hipLaunchKernelGGL(ce_partial_kernel, dim3(nblk), dim3(kT), 0, st, logits, target, B, C, HW, sB, sC, ignore_index, part);
     if (int rc = check_launch("ce_partial_kernel")) return rc;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblk, loss, count);
-    if (int rc = check_launch("ce_finalize_kernel")) return rc;
+    hipLaunchKernelGGL(ce_finalize_wave_kernel, dim3(1), dim3(64), 0, st, part, nblk, loss, count);
+    if (int rc = check_launch("ce_finalize_wave_kernel")) return rc;
     if (dlogits) {
         hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid_for((int64_t)B * HW)), dim3(kT), 0, st, logits, target, B, C, HW, sB, sC,
                            ignore_index, count, grad_out, dlogits);
         if (int rc = check_launch("ce_bwd_kernel")) return rc;
     }
+    return PP_OK;
+}
+
+size_t pp_sparse_ce_lowres_workspace_bytes(void) { return pp_sparse_ce_workspace_bytes(); }
+
+int pp_sparse_ce_lowres_fwd_bwd(const float* low, int64_t ldx, int B, int C, int h, int w, int H, int W, int align_corners,
+                                const int64_t* target, int ignore_index, float* loss, float* count, const float* grad_out,
+                                float* dlow, int64_t lddx, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!low || !target || !loss || !count) return fail(PP_ERR_BAD_ARG, "sparse_ce_lowres: null");
+    if (B < 1 || C < 1 || h < 1 || w < 1 || H < 1 || W < 1 || ldx < C || (dlow && lddx < C))
+        return fail(PP_ERR_BAD_ARG, "sparse_ce_lowres: bad shape B=%d C=%d %dx%d -> %dx%d ldx=%lld lddx=%lld", B, C, h, w, H, W,
+                    (long long)ldx, (long long)lddx);
+    if (C > 64) return fail(PP_ERR_UNSUPPORTED, "sparse_ce_lowres: C=%d > 64", C);
+    if (!workspace || ws_bytes < pp_sparse_ce_lowres_workspace_bytes()) return fail(PP_ERR_WORKSPACE, "sparse_ce_lowres: workspace");
+    hipStream_t st = as_stream(stream);
+    float sh, sw;
+    bil_scales(h, w, H, W, align_corners, 0.0f, 0.0f, sh, sw);
+    const int al = align_corners ? 1 : 0;
+    float* part = reinterpret_cast<float*>(workspace);
+    int nblk = (int)cdiv((int64_t)B * H * W, kT * 8);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    const unsigned gb = (unsigned)cdiv((int64_t)B * h * w, kT);
+#define PP_CE_LOW(CM, EX)                                                                                                      \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((ce_lowres_partial_kernel<CM, EX>), dim3(nblk), dim3(kT), 0, st, low, ldx, B, C, h, w, H, W, sh, sw, al, \
+                           target, ignore_index, part);                                                                        \
+        if (int rc = check_launch("ce_lowres_partial_kernel")) return rc;                                                      \
+        hipLaunchKernelGGL(ce_finalize_wave_kernel, dim3(1), dim3(64), 0, st, part, nblk, loss, count);                        \
+        if (int rc = check_launch("ce_finalize_wave_kernel")) return rc;                                                       \
+        if (dlow) {                                                                                                            \
+            hipLaunchKernelGGL((ce_lowres_bwd_kernel<CM, EX>), dim3(gb), dim3(kT), 0, st, low, ldx, B, C, h, w, H, W, sh, sw, al, \
+                               target, ignore_index, count, grad_out, dlow, lddx);                                             \
+            if (int rc = check_launch("ce_lowres_bwd_kernel")) return rc;                                                      \
+        }                                                                                                                      \
+    } while (0)
+    switch (C) {
+        case 11: PP_CE_LOW(11, true); break;
+        case 19: PP_CE_LOW(19, true); break;
+        case 21: PP_CE_LOW(21, true); break;
+        default:
+            if (C <= 32) PP_CE_LOW(32, false);
+            else PP_CE_LOW(64, false);
+    }
+#undef PP_CE_LOW
     return PP_OK;
 }
 

@@ -961,3 +961,27 @@ def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index:
                                 dl.data_ptr() if dl is not None else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "pp_sparse_ce_fwd_bwd")
     return loss, dl
+
+
+def cross_entropy_lowres(low: torch.Tensor, size, target: torch.Tensor, ignore_index: int, align_corners: bool = True,
+                         want_grad: bool = True):
+    """F.cross_entropy(F.interpolate(low, size, 'bilinear', align_corners), target, ignore_index) and its gradient w.r.t.
+    `low`, without the full-size logits (deeplab.py:55-56 + model.py:116).  low [B,h,w,C] channels-last (the classifier
+    output), target [B,H,W] int64 -> (loss [1], dlow [B,h,w,C] | None)."""
+    assert low.is_cuda and low.dtype == torch.float32 and low.dim() == 4 and low.stride(3) == 1
+    B, h, w, C = low.shape
+    assert low.stride(1) == w * low.stride(2) and low.stride(0) == h * low.stride(1)
+    H, W = int(size[0]), int(size[1])
+    target = target.to(low.device, torch.int64).contiguous()
+    assert tuple(target.shape) == (B, H, W)
+    dev = low.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.float32, device=dev)
+    dlow = torch.empty((B, h, w, C), dtype=torch.float32, device=dev) if want_grad else None
+    ws = _ws(_wsbytes("pp_sparse_ce_lowres_workspace_bytes"), dev)
+    rc = _lib.lib().pp_sparse_ce_lowres_fwd_bwd(low.data_ptr(), low.stride(2), B, C, h, w, H, W, int(bool(align_corners)),
+                                                target.data_ptr(), int(ignore_index), loss.data_ptr(), count.data_ptr(), None,
+                                                dlow.data_ptr() if dlow is not None else None, C, ws.data_ptr(), ws.numel(),
+                                                _stream())
+    _lib.check(rc, "pp_sparse_ce_lowres_fwd_bwd")
+    return loss, dlow

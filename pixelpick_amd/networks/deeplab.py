@@ -63,6 +63,8 @@ class _NetFunction(torch.autograd.Function):
 
 
 class DeepLab(nn.Module):
+    LOWRES_LOGITS = True      # _run(..., upsample=False) stops in front of the final x4 bilinear (deeplab.py:55-56)
+
     def __init__(self, args, backbone='mobilenet', output_stride=16):
         super().__init__()
         self.backbone = MobileNetV2(output_stride, BatchNorm2d, mc_dropout=args.use_mc_dropout)

@@ -23,6 +23,9 @@ from . import engine as E
 OVERLAP_ALLREDUCE = os.environ.get("PIXELPICK_OVERLAP_ALLREDUCE", "1") != "0"
 # PIXELPICK_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank process group (lets a single-GPU box
 # exercise the RCCL call path - communicator setup, the overlapped bucket on the helper stream - end to end)
+# PIXELPICK_SPARSE_LOWRES_CE=0: materialise the full-size logits and run the dense loss kernels even for models whose
+# last op is the x4 bilinear upsample (DeepLab)
+SPARSE_LOWRES_CE = os.environ.get("PIXELPICK_SPARSE_LOWRES_CE", "1") != "0"
 FORCE_COLLECTIVES = os.environ.get("PIXELPICK_FORCE_COLLECTIVES", "0") == "1"
 
 
@@ -101,10 +104,19 @@ class FlatTrainer:
         self._early_work = None
         if self.collectives and OVERLAP_ALLREDUCE and self.n_split < self.n and not torch.cuda.is_current_stream_capturing():
             tape.hooks["encoder_done"] = self._early_all_reduce
-        pred, _ = self.model._run(tape, x)
-        loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index)
-        self.last_logits = pred.t if keep_logits else None
-        tape.backward(pred, dlogits)
+        if SPARSE_LOWRES_CE and getattr(self.model, "LOWRES_LOGITS", False):
+            # deeplab.py:55-56 + model.py:116 without the [B,C,H,W] logits: the loss kernels interpolate the classifier output
+            # at the labelled pixels only (80 of 524 288 here) and hand its gradient straight to the classifier conv
+            low, _ = self.model._run(tape, x, upsample=False)
+            size = tuple(x.shape[2:])
+            loss, dlow = E.cross_entropy_lowres(low.t, size, y, self.ignore_index)
+            self.last_logits = E.bilinear(E.Tape(False), low, size, True, 0.0, out_nchw=True).t if keep_logits else None
+            tape.backward(low, dlow)
+        else:
+            pred, _ = self.model._run(tape, x)
+            loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index)
+            self.last_logits = pred.t if keep_logits else None
+            tape.backward(pred, dlogits)
         self.last_loss = loss
         return loss
 

@@ -570,6 +570,58 @@ def test_cross_entropy(B, C, H, W, n_lab, ign):
     assert (dl.cpu()[(y == ign)[:, None].expand(-1, C, -1, -1)] == 0).all()
 
 
+LOWRES_CE_CASES = [
+    # B, C, (h,w), (H,W), labelled px/img, ignore_index, align_corners
+    (4, 19, (64, 128), (256, 512), 20, 19, True),      # the BASELINE train step
+    (2, 21, (20, 20), (80, 80), 10, 255, True),        # VOC ignore 255
+    (2, 11, (23, 30), (90, 120), 100, 11, True),       # CamVid, ragged ratio
+    (1, 19, (9, 13), (33, 47), 33 * 47, 19, True),     # EVERY pixel labelled (borders, corners, clamped taps)
+    (2, 26, (8, 8), (32, 32), 64, 26, True),           # generic C <= 32
+    (1, 40, (8, 12), (16, 24), 50, 40, True),          # generic C <= 64
+    (2, 19, (16, 32), (64, 128), 40, 19, False),       # align_corners=False arithmetic
+    (1, 19, (16, 16), (16, 16), 30, 19, True),         # identity size
+]
+
+
+@pytest.mark.parametrize("B,C,lo,size,n_lab,ign,align", LOWRES_CE_CASES)
+def test_cross_entropy_from_lowres_logits(B, C, lo, size, n_lab, ign, align):
+    """deeplab.py:55-56 + model.py:116 in the sparse kernels vs torch autograd through F.interpolate + F.cross_entropy,
+    and vs the dense product path (pp_bilinear_fwd -> pp_sparse_ce_fwd_bwd -> pp_bilinear_bwd)."""
+    torch.manual_seed(8)
+    H, W = size
+    low = (torch.randn(B, C, *lo) * 3).requires_grad_(True)
+    y = torch.full((B, H, W), ign, dtype=torch.int64)
+    for b in range(B):
+        idx = torch.randperm(H * W)[:n_lab]
+        y[b].view(-1)[idx] = torch.randint(0, C, (len(idx),))
+    lr = F.cross_entropy(F.interpolate(low, size=size, mode="bilinear", align_corners=align), y, ignore_index=ign)
+    lr.backward()
+    wide = torch.full((B, *lo, C + 3), 5.0, device=DEV)                   # channel slice of a wider buffer (ldx > C)
+    wide[..., :C] = low.detach().permute(0, 2, 3, 1).to(DEV)
+    low_d = wide[..., :C]
+    loss, dlow = E.cross_entropy_lowres(low_d, size, y.to(DEV), ign, align_corners=align)
+    assert abs(loss.item() - lr.item()) < 1e-5 * max(1.0, abs(lr.item()))
+    close(dlow.permute(0, 3, 1, 2).cpu(), low.grad, tol=2e-5, what="dlow")
+    # dense product path
+    tape = E.Tape(True)
+    lv = E.Var(low_d.contiguous())
+    pred = E.bilinear(tape, lv, size, align, 0.0, out_nchw=True)
+    loss2, dl = E.cross_entropy_nchw(pred.t, y.to(DEV), ign)
+    tape.backward(pred, dl)
+    assert abs(loss.item() - loss2.item()) < 2e-6 * max(1.0, abs(loss2.item()))
+    close(dlow, lv.grad, tol=1e-5, what="dlow vs dense path")
+    # fixed-order gather: bitwise reproducible
+    loss3, dlow3 = E.cross_entropy_lowres(low_d, size, y.to(DEV), ign, align_corners=align)
+    assert torch.equal(loss3, loss) and torch.equal(dlow3, dlow)
+
+
+def test_cross_entropy_from_lowres_logits_without_labels_is_nan():
+    low = torch.randn(1, 8, 8, 19, device=DEV)
+    y = torch.full((1, 32, 32), 19, dtype=torch.int64, device=DEV)
+    loss, _ = E.cross_entropy_lowres(low, (32, 32), y, 19)
+    assert torch.isnan(loss).all()                     # 0/0 like F.cross_entropy (SURVEY 8 L2)
+
+
 def test_adam_matches_torch():
     torch.manual_seed(9)
     n, n_split = 10007, 4001
