@@ -371,6 +371,97 @@ __global__ __launch_bounds__(kBlock, 3) void acq_nhwc_kernel(AcqParams p)
     }
 }
 
+// ---- dense NHWC, asynchronous variant ------------------------------------------------------------------
+// Same pixel -> wave mapping and the same results as acq_nhwc_kernel, but every WAVE streams its own 64-pixel slices
+// into a private, double-buffered LDS slot with LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no
+// staging registers, no ds_write pass) and keeps the NEXT slice in flight while it scores the current one: the only
+// synchronisation is the issuing wave's counted `s_waitcnt vmcnt(N)` (MI355X_MICROARCH.md item 7) - no barrier at all.
+// The DMA pieces are written in inline asm so that hipcc's own s_waitcnt bookkeeping (which would drain vmcnt(0) in
+// front of the first LDS read) does not see them.
+__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds1(const uint8_t* gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int CMAX, int G>
+__global__ __launch_bounds__(kBlock, (CMAX > 19 ? 2 : 3)) void acq_nhwc_dma_kernel(AcqParams p)
+{
+    constexpr int NW = kBlock / kWave;
+    constexpr int NCH = (CMAX * 256 + 1023) / 1024;      // 1-KiB DMA pieces per 64-pixel slice (5 at C = 19)
+    constexpr int SLOT = NCH * 256;                      // floats per slot (the last piece may overhang the slice)
+    __shared__ __attribute__((aligned(1024))) float s_x[NW][2][SLOT];
+    __shared__ __attribute__((aligned(256))) uint32_t s_e[NW][2][kWave];   // sub-dword LDS-DMA lands one DWORD per lane
+    __shared__ uint64_t s_surv[NW][kSurvCap];
+    __shared__ uint32_t s_cnt[NW];
+    const int img = blockIdx.x / p.blocks_per_image;
+    const int blk = blockIdx.x - img * p.blocks_per_image;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const float* base = p.logits + (int64_t)img * p.sB;
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+    float* omap = p.out_map ? p.out_map + (int64_t)img * p.N : nullptr;
+    const uint32_t lds_x = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&s_x[wave][0][0]);
+    const uint32_t lds_e = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&s_e[wave][0][0]);
+
+    auto issue = [&](int g, int buf) {
+        const int64_t pix0 = ((int64_t)blk * G + g) * kBlock + wave * kWave;          // first pixel of this wave's slice
+        const int64_t left = p.N - pix0;
+        const int nflt = (int)(left <= 0 ? 0 : (left < kWave ? left : kWave)) * CMAX;  // valid floats of the slice
+        const float* src0 = base + (left > 0 ? pix0 : 0) * CMAX;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's previous contents have been read
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int f = (j * kWave + lane) * 4;
+            glds16(src0 + (f < nflt ? f : 0), lds_x + (uint32_t)(buf * SLOT * 4 + j * 1024));   // every lane active: fixed op count
+        }
+        if (excl) glds1(excl + (lane < left ? pix0 + lane : 0), lds_e + (uint32_t)(buf * kWave * 4));
+    };
+
+    uint32_t kh[G], kl[G];
+    issue(0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) {
+            issue(g + 1, (g + 1) & 1);
+            if (excl) wait_vmcnt<NCH + 1>(); else wait_vmcnt<NCH>();     // slice g has landed, slice g+1 stays in flight
+        } else {
+            wait_vmcnt<0>();
+        }
+        const int64_t pix = ((int64_t)blk * G + g) * kBlock + tid;
+        if (pix < p.N) {
+            const float* sx = &s_x[wave][g & 1][lane * CMAX];
+            float x[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) x[c] = sx[c];
+            float sc = pixel_score_fast<CMAX, true>(x, p.C, p.strategy);
+            if (excl && (s_e[wave][g & 1][lane] & 0xFFu)) sc = fill;
+            if (omap) omap[pix] = sc;
+            kh[g] = order_key(sc, largest);
+            kl[g] = 0xFFFFFFFFu - (uint32_t)pix;
+        } else {
+            kh[g] = 0u; kl[g] = 0u;
+        }
+    }
+    if (p.cand) {
+        const int wave_in_image = blk * NW + wave;
+        const int waves_per_image = p.blocks_per_image * NW;
+        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
+        if (p.reduce_mode == 2) wave_extract_topk<G>(kh, kl, p.k, dst, 0);
+        else wave_extract_topk_prefilter<G>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
+    }
+}
+
 // ---- acquisition straight from the LOW-resolution classifier logits -------------------
 // Replaces  deeplab.py:55-56  F.interpolate(pred, size=inputs.shape[2:], mode='bilinear', align_corners=True)
 //        +  query.py:190      softmax(model(x)["pred"][:, :, :h, :w])  + score + exclusion + top-k
@@ -769,6 +860,14 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
     // the non-default scorers (reference-order, from-prob) are only built for the 4-pixel tile
     const bool alt = p.from_prob || g_exact_formula;
     if (pl.nhwc) {
+        if constexpr (EXACT && CMAX <= 21) {
+            // asynchronous LDS-DMA variant for the three dataset class counts (tuning value 8 keeps the synchronous kernel)
+            if (!alt && g_tune_occ != 8) {
+                if (pl.ppt == 8) hipLaunchKernelGGL((acq_nhwc_dma_kernel<CMAX, 8>), grid, block, 0, st, p);
+                else             hipLaunchKernelGGL((acq_nhwc_dma_kernel<CMAX, 4>), grid, block, 0, st, p);
+                return check_launch("acq_nhwc_dma_kernel");
+            }
+        }
         if constexpr (CMAX <= 32) {
             if (p.from_prob)          hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 2>), grid, block, 0, st, p);
             else if (g_exact_formula) hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 1>), grid, block, 0, st, p);
@@ -946,7 +1045,7 @@ void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
 
 void pp_debug_set_acq_tuning(int occ, int ppt)
 {
-    g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 9) ? occ : 0;
+    g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9) ? occ : 0;
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
 }
 

@@ -377,7 +377,16 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         store_tiles(R0);
         __syncthreads();
         if (ks + 1 < ks_end) load_tiles(ks + 1, R0);
-        mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B, BKT>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
+        if constexpr (BKT > BK && TM * TN >= 4) {
+            // large wave tile with a deep K step: fragments of 16 K values at a time (all of them up front would cost
+            // 32 more VGPRs per 16 K values and a wave per SIMD of occupancy)
+#pragma unroll
+            for (int s = 0; s < BKT / BK; ++s)
+                mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B, BK>(As + s * BK, BWD ? Bs + s * BK : Bs + s * BK * PITCH_B,
+                                                                 wm * TM * 32, wn * TN * 32, acc);
+        } else {
+            mma_step<TM, TN, true, BWD, PITCH_A, PITCH_B, BKT>(As, Bs, wm * TM * 32, wn * TN * 32, acc);
+        }
         __syncthreads();
     }
 
@@ -957,6 +966,8 @@ static int g_conv_splitk = 1;
 static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_splitk_min_iters = 4;
 
 static int g_conv_deepk = 1;
+static int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
+static int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static int g_conv_n64 = 1;
 static int g_conv_tap_inner = 1;
 static int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
@@ -975,6 +986,7 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
         pl.bn64 = g_conv_variant == 2 || (g_conv_n64 && rem != 0 && rem <= 64 && (cdiv(Cn, 128) * 128 - Cn) * 100 > 15 * Cn);
         pl.n_tiles = (int)cdiv(Cn, pl.bn64 ? 64 : 128);
         pl.tiles = mt128 * pl.n_tiles;
+        if (g_conv_big_bk32 && !pl.bn64 && vec && Ck >= 64) pl.cfg = 4;
     } else {
         pl.cfg = 2; pl.n_tiles = (int)cdiv(Cn, 64); pl.tiles = mt64 * pl.n_tiles;
         // Deep-K variant: at one or two 64x64 blocks per CU the 16-deep K step has 512 MFMA cycles per wave to hide
@@ -984,7 +996,7 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
         // co-resident blocks for the split-K slices), so it is keyed on both.
         if (g_conv_deepk && vec && Ck >= 256 && M >= 4096) pl.cfg = 3;
     }
-    const int bk = pl.cfg == 3 ? 64 : BK;
+    const int bk = pl.cfg == 3 ? 64 : (pl.cfg == 4 ? 32 : BK);
     const int nk = ntaps * (int)cdiv(Ck, bk);
     pl.splits = 1;
     pl.ks_per_split = nk;
@@ -1030,6 +1042,8 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
             if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
             else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
         }
+    } else if (pl.cfg == 4) {
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true, 32>), grid, dim3(kThreads), 0, st, p);
     } else if (pl.cfg == 3) {
         hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true, 64>), grid, dim3(kThreads), 0, st, p);
     } else {
@@ -1037,7 +1051,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         else     hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
     }
     if (int rc = check_launch("conv_igemm_kernel")) return rc;
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && !(g_conv_ablate_reduce & (BWD ? 2 : 1))) {
         const bool plain = p.epi.gamma == nullptr && p.epi.res == nullptr && p.epi.act == 0 && p.Cn % 4 == 0 && p.ldy % 4 == 0;
         int64_t nb = cdiv(plain ? p.M * (p.Cn / 4) : p.M * p.Cn, 256);
         if (nb > 8192) nb = 8192;
@@ -1128,7 +1142,7 @@ extern "C" {
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out)
 {
     const ConvPlan pl = plan_conv(M, Cn, Ck, ntaps, Ck % 4 == 0 && Cn % 4 == 0);
-    const int rows[5] = {128, 128, 64, 64, 256}, cols[5] = {32, pl.bn64 ? 64 : 128, 64, 64, 128};
+    const int rows[5] = {128, 128, 64, 64, 128}, cols[5] = {32, pl.bn64 ? 64 : 128, 64, 64, 128};
     out[0] = rows[pl.cfg]; out[1] = cols[pl.cfg]; out[2] = (int)pl.tiles; out[3] = pl.splits;
 }
 
@@ -1160,6 +1174,8 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_xcd = (v & 8192) ? 0 : 1;        // bit 13: XCD-aware block order of the weight-gradient kernel off (A/B)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
+    g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
+    g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
