@@ -120,6 +120,47 @@ __device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][tm][j], b[q][tn][j], acc[tm][tn], 0, 0, 0);
 }
 
+// ---- epilogue shared by the register-staged and the LDS-DMA kernels --------------------------------------
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn)
+{
+    const int tid = threadIdx.x;
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + l31;
+        if (n >= p.Cn) continue;
+        const bool final_pass = p.splits <= 1;
+        const float bv = (p.bias && final_pass) ? p.bias[n] : 0.0f;
+        const bool affine = final_pass && p.epi.gamma != nullptr;
+        float sc = 1.0f, sf = 0.0f;
+        if (affine) {
+            const float is = 1.0f / sqrtf(p.epi.var[n] + p.epi.eps);
+            sc = p.epi.gamma[n] * is;
+            sf = p.epi.beta[n] - p.epi.mean[n] * sc;
+        }
+        const float* res = final_pass ? p.epi.res : nullptr;
+        const int act = final_pass ? p.epi.act : 0;
+        float* out = p.splits > 1 ? p.part + (int64_t)blockIdx.y * p.M * p.Cn : p.y;
+        const int64_t ldo = p.splits > 1 ? (int64_t)p.Cn : p.ldy;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m < p.M) {
+                    float o = acc[tm][tn][r] + bv;
+                    if (affine) o = fmaf(o, sc, sf);
+                    if (res) o += res[m * p.epi.ldr + n];
+                    if (final_pass && p.accumulate) o += out[m * ldo + n];
+                    out[m * ldo + n] = epi_act(o, act);
+                }
+            }
+        }
+    }
+}
+
 // ---- forward / backward-data kernel ---------------------------------------------------------------------
 // BWD == false: B operand W[t][c][n]  -> KN form (n contiguous in memory)
 // BWD == true : B operand W[t][n'][k'] with k' = conv Cout contiguous -> NK form
@@ -390,40 +431,256 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wn * TN + tn) * 32 + l31;
-        if (n >= p.Cn) continue;
-        const bool final_pass = p.splits <= 1;
-        const float bv = (p.bias && final_pass) ? p.bias[n] : 0.0f;
-        const bool affine = final_pass && p.epi.gamma != nullptr;
-        float sc = 1.0f, sf = 0.0f;
-        if (affine) {
-            const float is = 1.0f / sqrtf(p.epi.var[n] + p.epi.eps);
-            sc = p.epi.gamma[n] * is;
-            sf = p.epi.beta[n] - p.epi.mean[n] * sc;
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
+}
+
+// ---- LDS-DMA variant of the 128x128 kernel (VEC operands only) ----------------------------------------------
+// Same tiles, same MFMA order and the same results as conv_igemm_kernel<128,128,2,2,BWD,true>, but the operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction) into a THREE-stage ring: no staging
+// registers, no ds_write pass, the loads of steps k+1 and k+2 in flight behind the MFMAs of step k, ONE barrier per
+// K step (the register-staged kernel has two and a prefetch distance of one).  Conventions:
+//   * LDS-DMA writes lane-linearly (wave-uniform base + lane*16), so the tiles are unpadded; bank conflicts are avoided
+//     by a swizzle applied on the SOURCE side (which element a lane fetches) and again in the fragment reads:
+//       MK / NK form [128 rows][4 quads]:  quad q of row r sits at slot r*4 + (q ^ ((r >> 2) & 3))
+//       KN form      [16 k][128 n]      :  row k is rotated by 32*((k >> 2) & 1) floats
+//   * out-of-range elements (padding taps, ragged channel tails, rows past M) are fetched from a 16-byte zero word;
+//   * ordering: each wave waits for ITS pieces with a counted s_waitcnt vmcnt, then one s_barrier publishes the stage
+//     (MI355X_MICROARCH.md item 7); the asm statements keep the DMA out of hipcc's own waitcnt bookkeeping.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void conv_glds16(const float* gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+struct DmaFrags { float a[2][2][4], b[2][2][4]; };
+
+template <bool BWD>
+__global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams p)
+{
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2, NSTAGE = 3;
+    constexpr int STAGE_FLOATS = BM * BK + BK * BN;               // 4096 floats = 16 KiB
+    __shared__ __attribute__((aligned(1024))) float smem[NSTAGE * STAGE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    {
+        const int ntn = p.n_tiles, nblk = gridDim.x;
+        const int bid = blockIdx.x;
+        const int per_xcd = nblk / 8;
+        if (p.xcd_remap && per_xcd * 8 == nblk) {
+            const int lin = (bid & 7) * per_xcd + (bid >> 3);
+            mt = lin / ntn;
+            nt = lin - mt * ntn;
+        } else {
+            mt = bid / ntn;
+            nt = bid - mt * ntn;
         }
-        const float* res = final_pass ? p.epi.res : nullptr;
-        const int act = final_pass ? p.epi.act : 0;
-        float* out = p.splits > 1 ? p.part + (int64_t)blockIdx.y * p.M * p.Cn : p.y;
-        const int64_t ldo = p.splits > 1 ? (int64_t)p.Cn : p.ldy;
+    }
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const float* zero = g_zero16;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+
+    // ---- per-thread addressing, fixed for the whole K loop (host guarantees 32-bit element offsets, <= 32 taps, unit
+    //      backward stride): A piece i of this wave = 16 rows x 4 quads, lane -> row = piece*16 + lane/4, slot lane&3
+    int a_e0[2], a_c[2];
+    unsigned a_vm[2];            // bit t: tap t reads inside the image for this row
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m < p.M) {
-                    float o = acc[tm][tn][r] + bv;
-                    if (affine) o = fmaf(o, sc, sf);
-                    if (res) o += res[m * p.epi.ldr + n];
-                    if (final_pass && p.accumulate) o += out[m * ldo + n];
-                    out[m * ldo + n] = epi_act(o, act);
-                }
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        a_c[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 4;            // logical channel offset fetched into this slot
+        const int64_t m = m0 + row;
+        a_e0[i] = 0;
+        a_vm[i] = 0u;
+        if (m < p.M) {
+            const unsigned mu = (unsigned)m;
+            const unsigned t = mu / (unsigned)p.Wo;
+            const int ow = (int)(mu - t * (unsigned)p.Wo);
+            const unsigned bb = t / (unsigned)p.Ho;
+            const int oh = (int)(t - bb * (unsigned)p.Ho);
+            const int ih0 = oh * p.stride, iw0 = ow * p.stride;
+            a_e0[i] = (((int)bb * p.H + ih0) * p.W + iw0) * (int)p.ldx + a_c[i];
+            for (int t2 = 0; t2 < p.taps.n; ++t2) {
+                const int ih = ih0 + p.taps.dh[t2], iw = iw0 + p.taps.dw[t2];
+                a_vm[i] |= ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (1u << t2) : 0u;
             }
         }
     }
+    int b_e[2], b_k[2];          // B piece i: element offset inside one (tap, chunk) slab, and the coordinate checked per step
+    bool b_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int P = (wave * 2 + i) * 64 + lane;
+        if constexpr (!BWD) {
+            const int k = P >> 5, nq = ((P & 31) - 8 * ((k >> 2) & 1)) & 31;
+            b_k[i] = k;                                           // checked against Cin with c0
+            b_ok[i] = n0 + nq * 4 < p.Cout;
+            b_e[i] = k * p.Cout + n0 + nq * 4;
+        } else {
+            const int row = P >> 2, kq = (P & 3) ^ ((row >> 2) & 3);
+            b_k[i] = kq * 4;                                      // checked against Cout with c0
+            b_ok[i] = n0 + row < p.Cin;
+            b_e[i] = (n0 + row) * p.Cout + kq * 4;
+        }
+    }
+
+    const int nchunk = (p.Ck + BK - 1) / BK;
+    const int nk = p.taps.n * nchunk;
+    const int ks_beg = p.splits > 1 ? (int)blockIdx.y * p.ks_per_split : 0;
+    const int ks_end = p.splits > 1 ? (ks_beg + p.ks_per_split < nk ? ks_beg + p.ks_per_split : nk) : nk;
+    const int n = ks_end - ks_beg;
+
+    // per-tap uniform offsets in LDS (a dynamic index into the kernel-argument tap table would be a scalar load per step,
+    // and scalar loads force lgkmcnt(0) waits that also drain the fragment reads)
+    __shared__ int s_tap[32][2];
+    if (tid < p.taps.n) {
+        s_tap[tid][0] = (p.taps.dh[tid] * p.W + p.taps.dw[tid]) * (int)p.ldx;
+        s_tap[tid][1] = p.taps.widx[tid] * p.Cin * p.Cout;
+    }
+    __syncthreads();
+    // (tap, chunk) of the next step to issue, advanced incrementally (steps are issued strictly in order)
+    int is_ti, is_ch;
+    if (p.tap_inner) { is_ch = ks_beg / p.taps.n; is_ti = ks_beg - is_ch * p.taps.n; }
+    else             { is_ti = ks_beg / nchunk;   is_ch = ks_beg - is_ti * nchunk; }
+    int te_a = s_tap[is_ti][0], te_b = s_tap[is_ti][1];
+
+    // ---- the DMA of one K step, in four slices (one 1-KiB piece each) so that they can sit between MFMA groups
+    int st_ti = 0, st_c0 = 0, st_aoff = 0, st_boff = 0;
+    uint32_t st_la = 0;
+    auto issue_begin = [&](int stage) {
+        st_ti = is_ti;
+        st_c0 = is_ch * BK;
+        st_aoff = __builtin_amdgcn_readfirstlane(te_a) + st_c0;
+        st_boff = __builtin_amdgcn_readfirstlane(te_b) + (BWD ? st_c0 : st_c0 * p.Cout);
+        st_la = lds0 + (uint32_t)(stage * STAGE_FLOATS * 4 + wave * 2048);
+    };
+    auto issue_a = [&](int i) {
+        const bool ok = ((a_vm[i] >> st_ti) & 1u) && (st_c0 + a_c[i] < p.Ck);
+        const float* src = p.x + (a_e0[i] + st_aoff);
+        conv_glds16(ok ? src : zero, st_la + (uint32_t)(i * 1024));
+    };
+    auto issue_b = [&](int i) {
+        const bool ok = b_ok[i] && (st_c0 + b_k[i] < (BWD ? p.Cout : p.Cin));
+        const float* src = p.w + (b_e[i] + st_boff);
+        conv_glds16(ok ? src : zero, st_la + (uint32_t)(BM * BK * 4 + i * 1024));
+    };
+    auto issue_end = [&]() {      // advance to the following step and fetch its tap entry now (used one K step later)
+        if (p.tap_inner) { if (++is_ti == p.taps.n) { is_ti = 0; ++is_ch; } }
+        else             { if (++is_ch == nchunk) { is_ch = 0; ++is_ti; } }
+        const int tn = is_ti < p.taps.n ? is_ti : 0;
+        te_a = s_tap[tn][0];
+        te_b = s_tap[tn][1];
+    };
+    auto issue = [&](int stage) {
+        issue_begin(stage);
+        issue_a(0); issue_a(1); issue_b(0); issue_b(1);
+        issue_end();
+    };
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+    auto read_a = [&](int stage, DmaFrags& F, int q, int tm) {
+        const float4* As4 = reinterpret_cast<const float4*>(smem + stage * STAGE_FLOATS);
+        const int r = (wm * TM + tm) * 32 + l31;
+        const float4 v = As4[r * 4 + ((2 * q + h) ^ swz)];
+        F.a[q][tm][0] = v.x; F.a[q][tm][1] = v.y; F.a[q][tm][2] = v.z; F.a[q][tm][3] = v.w;
+    };
+    auto read_b = [&](int stage, DmaFrags& F, int q, int tn) {
+        const float* Bs = smem + stage * STAGE_FLOATS + BM * BK;
+        const int c = (wn * TN + tn) * 32 + l31;
+        if constexpr (BWD) {
+            const float4 v = reinterpret_cast<const float4*>(Bs)[c * 4 + ((2 * q + h) ^ swz)];
+            F.b[q][tn][0] = v.x; F.b[q][tn][1] = v.y; F.b[q][tn][2] = v.z; F.b[q][tn][3] = v.w;
+        } else {
+            const int cc = (c + 32 * h) & 127;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) F.b[q][tn][j] = Bs[(8 * q + 4 * h + j) * BN + cc];
+        }
+    };
+    auto read_frags = [&](int stage, DmaFrags& F) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            read_a(stage, F, q, 0); read_a(stage, F, q, 1);
+            read_b(stage, F, q, 0); read_b(stage, F, q, 1);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto mma4 = [&](const DmaFrags& F, int q, int j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[q][tm][j], F.b[q][tn][j], acc[tm][tn], 0, 0, 0);
+    };
+
+    // One K step.  The fragments of step k are already in `cur` (read one step ago), so its MFMAs start right behind the
+    // barrier; the 32 MFMAs go out in eight groups of four and every group is followed by a SLICE of the step's other
+    // work - two fragment reads of step k+1, or one DMA piece of step k+3 - which issues in the shadow of the group's
+    // last MFMA (64 matrix-pipe cycles) instead of forming a separate phase in which the matrix pipe idles.
+    auto kstep = [&](int k, DmaFrags& cur, DmaFrags& nxt) {
+        const bool rd = k + 1 < n, dm = k + 3 < n;
+        const int sn = (k + 1) % NSTAGE;
+        if (rd) {
+            if (k + 2 < n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // my pieces of step k+1 landed; k+2 flies on
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                        // everyone's pieces; stage k%3 is free
+            asm volatile("" ::: "memory");
+        }
+        mma4(cur, 0, 0); __builtin_amdgcn_sched_barrier(0);
+        if (rd) { read_a(sn, nxt, 0, 0); read_a(sn, nxt, 0, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 0, 1); __builtin_amdgcn_sched_barrier(0);
+        if (rd) { read_b(sn, nxt, 0, 0); read_b(sn, nxt, 0, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 0, 2); __builtin_amdgcn_sched_barrier(0);
+        if (rd) { read_a(sn, nxt, 1, 0); read_a(sn, nxt, 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 0, 3); __builtin_amdgcn_sched_barrier(0);
+        if (rd) { read_b(sn, nxt, 1, 0); read_b(sn, nxt, 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 0); __builtin_amdgcn_sched_barrier(0);
+        if (dm) { issue_begin(k % NSTAGE); issue_a(0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 1); __builtin_amdgcn_sched_barrier(0);
+        if (dm) issue_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 2); __builtin_amdgcn_sched_barrier(0);
+        if (dm) issue_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 3); __builtin_amdgcn_sched_barrier(0);
+        if (dm) { issue_b(1); issue_end(); }
+    };
+
+    DmaFrags F0, F1;
+    if (n > 0) issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    if (n > 0) {
+        if (n > 2)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(0, F0);
+    }
+    for (int k = 0; k < n; k += 2) {
+        kstep(k, F0, F1);
+        if (k + 1 < n) kstep(k + 1, F1, F0);
+    }
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
 // split-K second stage: y[m][n] = epilogue(bias[n] + sum_z part[z][m][n]), z in fixed order (deterministic)
@@ -967,6 +1224,9 @@ static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_
 
 static int g_conv_deepk = 1;
 static int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
+static int g_conv_dma = 2;         // 128x128 tiles, LDS-DMA three-stage kernel: 0 off, 1 forward + backward-data, 2 forward only (default:
+                                   // under the concurrent weight-gradient stream of the backward pass its 48 KiB of LDS per block cost more
+                                   // than the denser MFMA schedule gains - FPN 28.11 -> 28.29 ms/step with 1, 28.03 with 2)
 static int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static int g_conv_n64 = 1;
 static int g_conv_tap_inner = 1;
@@ -1039,7 +1299,11 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
             if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
             else     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
         } else {
-            if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
+            const bool dma_ok = vec && g_conv_dma && (!BWD || g_conv_dma == 1) && p.taps.n <= 32 && (!BWD || p.bwd_stride <= 1) &&
+                                (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) &&
+                                (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
+            if (dma_ok) hipLaunchKernelGGL((conv_igemm_dma_kernel<BWD>), grid, dim3(kThreads), 0, st, p);
+            else if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
             else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
         }
     } else if (pl.cfg == 4) {
@@ -1175,6 +1439,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
+    g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 1 : 2);   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     v &= 3;
