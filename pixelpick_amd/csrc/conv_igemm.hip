@@ -455,12 +455,15 @@ __device__ __forceinline__ void conv_glds16(const float* gsrc, uint32_t lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-struct DmaFrags { float a[2][2][4], b[2][2][4]; };
+template <int TM, int TN> struct DmaFrags { float a[2][TM][4], b[2][TN][4]; };
 
-template <bool BWD>
-__global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams p)
+template <int BM, int BN, bool BWD>
+__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv_igemm_dma_kernel(ConvParams p)
 {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2, NSTAGE = 3;
+    constexpr int TM = BM / 64, TN = BN / 64, WN = 2, NSTAGE = 3;
+    constexpr int PA = BM / 64, PB = BN / 64;                     // 1-KiB DMA pieces per wave and K step
+    constexpr int NQB = BN / 4;                                   // quads per k row of the KN-form B tile
+    using Frags = DmaFrags<TM, TN>;
     constexpr int STAGE_FLOATS = BM * BK + BK * BN;               // 4096 floats = 16 KiB
     __shared__ __attribute__((aligned(1024))) float smem[NSTAGE * STAGE_FLOATS];
 
@@ -488,11 +491,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams 
 
     // ---- per-thread addressing, fixed for the whole K loop (host guarantees 32-bit element offsets, <= 32 taps, unit
     //      backward stride): A piece i of this wave = 16 rows x 4 quads, lane -> row = piece*16 + lane/4, slot lane&3
-    int a_e0[2], a_c[2];
-    unsigned a_vm[2];            // bit t: tap t reads inside the image for this row
+    int a_e0[PA], a_c[PA];
+    unsigned a_vm[PA];            // bit t: tap t reads inside the image for this row
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * 16 + (lane >> 2);
         a_c[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 4;            // logical channel offset fetched into this slot
         const int64_t m = m0 + row;
         a_e0[i] = 0;
@@ -511,13 +514,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams 
             }
         }
     }
-    int b_e[2], b_k[2];          // B piece i: element offset inside one (tap, chunk) slab, and the coordinate checked per step
-    bool b_ok[2];
+    int b_e[PB], b_k[PB];          // B piece i: element offset inside one (tap, chunk) slab, and the coordinate checked per step
+    bool b_ok[PB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int P = (wave * 2 + i) * 64 + lane;
+    for (int i = 0; i < PB; ++i) {
+        const int P = (wave * PB + i) * 64 + lane;
         if constexpr (!BWD) {
-            const int k = P >> 5, nq = ((P & 31) - 8 * ((k >> 2) & 1)) & 31;
+            const int k = P / NQB, nq = ((P % NQB) - 8 * ((k >> 2) & 1)) & (NQB - 1);
             b_k[i] = k;                                           // checked against Cin with c0
             b_ok[i] = n0 + nq * 4 < p.Cout;
             b_e[i] = k * p.Cout + n0 + nq * 4;
@@ -557,17 +560,17 @@ __global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams 
         st_c0 = is_ch * BK;
         st_aoff = __builtin_amdgcn_readfirstlane(te_a) + st_c0;
         st_boff = __builtin_amdgcn_readfirstlane(te_b) + (BWD ? st_c0 : st_c0 * p.Cout);
-        st_la = lds0 + (uint32_t)(stage * STAGE_FLOATS * 4 + wave * 2048);
+        st_la = lds0 + (uint32_t)(stage * STAGE_FLOATS * 4);
     };
     auto issue_a = [&](int i) {
         const bool ok = ((a_vm[i] >> st_ti) & 1u) && (st_c0 + a_c[i] < p.Ck);
         const float* src = p.x + (a_e0[i] + st_aoff);
-        conv_glds16(ok ? src : zero, st_la + (uint32_t)(i * 1024));
+        conv_glds16(ok ? src : zero, st_la + (uint32_t)((wave * PA + i) * 1024));
     };
     auto issue_b = [&](int i) {
         const bool ok = b_ok[i] && (st_c0 + b_k[i] < (BWD ? p.Cout : p.Cin));
         const float* src = p.w + (b_e[i] + st_boff);
-        conv_glds16(ok ? src : zero, st_la + (uint32_t)(BM * BK * 4 + i * 1024));
+        conv_glds16(ok ? src : zero, st_la + (uint32_t)(BM * BK * 4 + (wave * PB + i) * 1024));
     };
     auto issue_end = [&]() {      // advance to the following step and fetch its tap entry now (used one K step later)
         if (p.tap_inner) { if (++is_ti == p.taps.n) { is_ti = 0; ++is_ch; } }
@@ -578,35 +581,40 @@ __global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams 
     };
     auto issue = [&](int stage) {
         issue_begin(stage);
-        issue_a(0); issue_a(1); issue_b(0); issue_b(1);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) issue_a(i);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) issue_b(i);
         issue_end();
     };
 
     const int l31 = lane & 31, h = lane >> 5;
     const int swz = (l31 >> 2) & 3;
-    auto read_a = [&](int stage, DmaFrags& F, int q, int tm) {
+    auto read_a = [&](int stage, Frags& F, int q, int tm) {
         const float4* As4 = reinterpret_cast<const float4*>(smem + stage * STAGE_FLOATS);
         const int r = (wm * TM + tm) * 32 + l31;
         const float4 v = As4[r * 4 + ((2 * q + h) ^ swz)];
         F.a[q][tm][0] = v.x; F.a[q][tm][1] = v.y; F.a[q][tm][2] = v.z; F.a[q][tm][3] = v.w;
     };
-    auto read_b = [&](int stage, DmaFrags& F, int q, int tn) {
+    auto read_b = [&](int stage, Frags& F, int q, int tn) {
         const float* Bs = smem + stage * STAGE_FLOATS + BM * BK;
         const int c = (wn * TN + tn) * 32 + l31;
         if constexpr (BWD) {
             const float4 v = reinterpret_cast<const float4*>(Bs)[c * 4 + ((2 * q + h) ^ swz)];
             F.b[q][tn][0] = v.x; F.b[q][tn][1] = v.y; F.b[q][tn][2] = v.z; F.b[q][tn][3] = v.w;
         } else {
-            const int cc = (c + 32 * h) & 127;
+            const int cc = (c + 32 * h) & (BN - 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) F.b[q][tn][j] = Bs[(8 * q + 4 * h + j) * BN + cc];
         }
     };
-    auto read_frags = [&](int stage, DmaFrags& F) {
+    auto read_frags = [&](int stage, Frags& F) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            read_a(stage, F, q, 0); read_a(stage, F, q, 1);
-            read_b(stage, F, q, 0); read_b(stage, F, q, 1);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) read_a(stage, F, q, t);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) read_b(stage, F, q, t);
         }
     };
 
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    auto mma4 = [&](const DmaFrags& F, int q, int j) {
+    auto mma4 = [&](const Frags& F, int q, int j) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -630,47 +638,62 @@ __global__ __launch_bounds__(kThreads, 3) void conv_igemm_dma_kernel(ConvParams 
     // barrier; the 32 MFMAs go out in eight groups of four and every group is followed by a SLICE of the step's other
     // work - two fragment reads of step k+1, or one DMA piece of step k+3 - which issues in the shadow of the group's
     // last MFMA (64 matrix-pipe cycles) instead of forming a separate phase in which the matrix pipe idles.
-    auto kstep = [&](int k, DmaFrags& cur, DmaFrags& nxt) {
+    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
         const bool rd = k + 1 < n, dm = k + 3 < n;
         const int sn = (k + 1) % NSTAGE;
         if (rd) {
-            if (k + 2 < n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // my pieces of step k+1 landed; k+2 flies on
+            if (k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");   // my pieces of step k+1 landed; k+2 flies on
             else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                        // everyone's pieces; stage k%3 is free
             asm volatile("" ::: "memory");
         }
         mma4(cur, 0, 0); __builtin_amdgcn_sched_barrier(0);
-        if (rd) { read_a(sn, nxt, 0, 0); read_a(sn, nxt, 0, 1); }
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) read_a(sn, nxt, 0, t);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 0, 1); __builtin_amdgcn_sched_barrier(0);
-        if (rd) { read_b(sn, nxt, 0, 0); read_b(sn, nxt, 0, 1); }
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) read_b(sn, nxt, 0, t);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 0, 2); __builtin_amdgcn_sched_barrier(0);
-        if (rd) { read_a(sn, nxt, 1, 0); read_a(sn, nxt, 1, 1); }
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) read_a(sn, nxt, 1, t);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 0, 3); __builtin_amdgcn_sched_barrier(0);
-        if (rd) { read_b(sn, nxt, 1, 0); read_b(sn, nxt, 1, 1); }
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) read_b(sn, nxt, 1, t);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 0); __builtin_amdgcn_sched_barrier(0);
         if (dm) { issue_begin(k % NSTAGE); issue_a(0); }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 1); __builtin_amdgcn_sched_barrier(0);
-        if (dm) issue_a(1);
+        if constexpr (PA > 1) { if (dm) issue_a(1); }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 2); __builtin_amdgcn_sched_barrier(0);
         if (dm) issue_b(0);
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 3); __builtin_amdgcn_sched_barrier(0);
-        if (dm) { issue_b(1); issue_end(); }
+        if (dm) {
+            if constexpr (PB > 1) issue_b(1);
+            issue_end();
+        }
     };
 
-    DmaFrags F0, F1;
+    Frags F0, F1;
     if (n > 0) issue(0);
     if (n > 1) issue(1);
     if (n > 2) issue(2);
     if (n > 0) {
-        if (n > 2)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (n > 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PA + PB)) : "memory");
+        else if (n > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");
         else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1227,6 +1250,8 @@ static int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1
 static int g_conv_dma = 2;         // 128x128 tiles, LDS-DMA three-stage kernel: 0 off, 1 forward + backward-data, 2 forward only (default:
                                    // under the concurrent weight-gradient stream of the backward pass its 48 KiB of LDS per block cost more
                                    // than the denser MFMA schedule gains - FPN 28.11 -> 28.29 ms/step with 1, 28.03 with 2)
+static int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-DMA kernel: 0 off, 1 forward + backward-data (default: DeepLab 7.29 ->
+                                   // 7.21 ms/step, FPN 28.06 -> 27.06), 2 forward only (7.25 / 27.42).  Replaces the 64-deep K step.
 static int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static int g_conv_n64 = 1;
 static int g_conv_tap_inner = 1;
@@ -1254,7 +1279,7 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
         // Measured (tools/ab_step.py, bench.py --network FPN): it pays on the ResNet50 shapes (8192 rows, K >= 256:
         // 28.15 -> 27.92 ms/step) and costs on MobileNetV2's 2048-row layers (7.37 -> 7.43 ms/step: 152 VGPRs, fewer
         // co-resident blocks for the split-K slices), so it is keyed on both.
-        if (g_conv_deepk && vec && Ck >= 256 && M >= 4096) pl.cfg = 3;
+        if (g_conv_deepk && !g_conv_dma64 && vec && Ck >= 256 && M >= 4096) pl.cfg = 3;
     }
     const int bk = pl.cfg == 3 ? 64 : (pl.cfg == 4 ? 32 : BK);
     const int nk = ntaps * (int)cdiv(Ck, bk);
@@ -1302,7 +1327,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
             const bool dma_ok = vec && g_conv_dma && (!BWD || g_conv_dma == 1) && p.taps.n <= 32 && (!BWD || p.bwd_stride <= 1) &&
                                 (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) &&
                                 (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
-            if (dma_ok) hipLaunchKernelGGL((conv_igemm_dma_kernel<BWD>), grid, dim3(kThreads), 0, st, p);
+            if (dma_ok) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, BWD>), grid, dim3(kThreads), 0, st, p);
             else if (vec) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, true>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
             else     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BWD, false>), grid, dim3(kThreads), g_conv_lds_pad, st, p);
         }
@@ -1311,8 +1336,12 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     } else if (pl.cfg == 3) {
         hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true, 64>), grid, dim3(kThreads), 0, st, p);
     } else {
-        if (vec) hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
-        else     hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
+        const bool dma_ok = vec && g_conv_dma64 && (!BWD || g_conv_dma64 == 1) && p.taps.n <= 32 && (!BWD || p.bwd_stride <= 1) &&
+                            (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) &&
+                            (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
+        if (dma_ok)   hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, BWD>), grid, dim3(kThreads), 0, st, p);
+        else if (vec) hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, true>), grid, dim3(kThreads), 0, st, p);
+        else          hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
     }
     if (int rc = check_launch("conv_igemm_kernel")) return rc;
     if (pl.splits > 1 && !(g_conv_ablate_reduce & (BWD ? 2 : 1))) {
@@ -1440,6 +1469,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
     g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 1 : 2);   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
+    g_conv_dma64 = (v & 262144) ? 0 : ((v & 524288) ? 2 : 1);   // bit 18: LDS-DMA kernel of the 64x64 tiles off; bit 19: forward only
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     v &= 3;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the LDS-DMA 128x128 convolution kernel (pp_debug_set_conv_variant: bit 8 = off, bit 15 = backward-data too) against the register-staged one:
+"""A/B of the LDS-DMA 128x128 convolution kernel (pp_debug_set_conv_variant: bits 8 / 18 = 128x128 / 64x64 variant off, bit 15 = 128x128 backward-data too) against the register-staged one:
 outputs must be bit-identical (same tiles, same MFMA order); prints per-shape timings."""
 import os, sys
 import torch
@@ -34,6 +34,8 @@ def timeit(fn, n=20):
 
 
 shapes = [  # B, H, W, Cin, Cout, k, stride, pad, dil
+    (4, 16, 32, 160, 960, 1, 1, 0, 1), (4, 16, 32, 960, 160, 1, 1, 0, 1), (4, 16, 32, 1280, 256, 1, 1, 0, 1), (4, 32, 64, 256, 1024, 1, 1, 0, 1),
+    (4, 32, 64, 64, 64, 3, 1, 1, 1), (4, 32, 64, 144, 32, 1, 1, 0, 1),
     (4, 64, 128, 304, 256, 3, 1, 1, 1), (4, 64, 128, 256, 256, 3, 1, 1, 1), (4, 32, 64, 1024, 256, 1, 1, 0, 1),
     (4, 32, 64, 512, 512, 3, 1, 2, 2), (4, 128, 256, 128, 128, 3, 1, 1, 1), (3, 37, 53, 132, 260, 3, 1, 1, 1),
     (4, 64, 128, 256, 512, 1, 2, 0, 1), (2, 45, 61, 136, 192, 3, 2, 1, 1), (4, 16, 32, 320, 256, 3, 1, 12, 12),
@@ -45,15 +47,16 @@ for (B, H, W, Ci, Co, k, st, pad, dil) in shapes:
     w = torch.randn(k, k, Ci, Co, device=DEV) * 0.05
     Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
     dy = torch.randn(B, Ho, Wo, Co, device=DEV)
-    L.pp_debug_set_conv_variant(256)
+    L.pp_debug_set_conv_variant(256 | 262144)
     y0, dx0 = run(x, w, None, st, pad, dil, dy)
     L.pp_debug_set_conv_variant(32768)
     y1, dx1 = run(x, w, None, st, pad, dil, dy)
     same = torch.equal(y0, y1) and torch.equal(dx0, dx1)
-    ok &= same
+    close = torch.allclose(y0, y1, rtol=1e-4, atol=1e-4) and torch.allclose(dx0, dx1, rtol=1e-4, atol=1e-4)   # the 64-deep-K baseline sums in another order
+    ok &= close
     fl = 2.0 * B * Ho * Wo * Ci * Co * k * k
     t = {}
-    for v in (256, 0):
+    for v in (256 | 262144, 0):
         L.pp_debug_set_conv_variant(v)
         ws, wsn = E._conv_ws(False, x.device, B, H, W, Ci, Co, k, k, st, pad, dil)
         y = torch.empty(B, Ho, Wo, Co, device=DEV)
@@ -63,6 +66,6 @@ for (B, H, W, Ci, Co, k, st, pad, dil) in shapes:
                             _lib.current_stream_ptr())
         t[v] = timeit(f)
     print(f"{B}x{H}x{W} {Ci}->{Co} k{k} s{st} d{dil}: bit-identical={same}  max|dy|={float((y0 - y1).abs().max()):.2e} "
-          f"max|ddx|={float((dx0 - dx1).abs().max()):.2e}  fwd {t[256]:.1f} -> {t[0]:.1f} us  ({fl / t[256] / 1e6:.1f} -> {fl / t[0] / 1e6:.1f} TF)")
+          f"max|ddx|={float((dx0 - dx1).abs().max()):.2e}  fwd {t[256 | 262144]:.1f} -> {t[0]:.1f} us  ({fl / t[256 | 262144] / 1e6:.1f} -> {fl / t[0] / 1e6:.1f} TF)")
 L.pp_debug_set_conv_variant(0)
-print("ALL IDENTICAL" if ok else "MISMATCH")
+print("ALL EQUAL (bit-identical unless the baseline used the 64-deep K step)" if ok else "MISMATCH")
