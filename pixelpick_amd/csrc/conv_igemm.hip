@@ -1358,6 +1358,8 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
 static int g_wgrad_narrow = 1;
 static int g_wgrad_m64 = 1;
 static int g_wgrad_xcd = 1;
+static const int g_wgrad_lds_pad_default = 0;
+static int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
 static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
@@ -1448,7 +1450,11 @@ void pp_debug_set_splitk(int v)
     g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
 
-void pp_debug_set_wgrad_target(int v) { g_wgrad_target = v > 0 ? v : 1024; }
+void pp_debug_set_wgrad_target(int v)
+{
+    g_wgrad_target = (v & 0xFFFF) > 0 ? (v & 0xFFFF) : 1024;
+    g_wgrad_lds_pad = v > 0 ? ((v >> 16) & 0xFF) * 1024 : g_wgrad_lds_pad_default;   // bits 16-23: KiB of LDS padding (A/B)
+}
 /* v = big_tile_min | wgrad_rows_min << 12 (0 fields: defaults 384 / 128) */
 void pp_debug_set_conv_thresholds(int v)
 {
@@ -1628,20 +1634,20 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     if (big && narrow_m && narrow_n) {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
-        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
     } else if (big && narrow_m) {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
-        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
     } else if (big && narrow_n) {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
-        else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
     } else if (big) {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
-        else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
     } else {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), 0, st, p);
-        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), 0, st, p);
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
+        else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
     }
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
     const int64_t cn = (int64_t)Cin * Cout;
