@@ -346,7 +346,8 @@ void pp_debug_set_acq_tuning(int occ, int ppt);
  * tile at 2 / 1 blocks per CU; bit 6 split-K off; bit 7 64-deep K step of the 64x64 tiles off; bit 8 LDS-DMA kernel of the
  * 128x128 tiles off (bit 15: use it for backward-data too); bits 9-14 weight-gradient / ragged-tile / K-order variants;
  * bit 12 32-deep K step for the 128x128 tiles; bits 16/17 TIMING-ONLY ablation (skips the split-K reduce: wrong results);
- * bit 18 LDS-DMA kernel of the 64x64 tiles off (bit 19: forward only).
+ * bit 18 LDS-DMA kernel of the 64x64 tiles off (bit 19: forward only); bit 20 LDS-DMA weight-gradient kernel of the
+ * 128-wide tiles off; bit 21 LDS-DMA weight-gradient kernel for the 64x64 tiles on.
  * Findings: profiles/r01_conv_ablation.txt. */
 void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B) */
 void pp_debug_set_splitk(int v);       /* tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 */

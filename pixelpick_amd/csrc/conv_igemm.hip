@@ -992,6 +992,238 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
     }
 }
 
+// (b, oh, ow) of an output pixel, advanced without divisions
+struct RowIter {
+    int ow, oh, bb;
+    __device__ __forceinline__ void init(int64_t m, int Wo, int Ho)
+    {
+        const unsigned mu = (unsigned)m;
+        const unsigned q = mu / (unsigned)Wo;
+        ow = (int)(mu - q * (unsigned)Wo);
+        bb = (int)(q / (unsigned)Ho);
+        oh = (int)(q - (unsigned)bb * (unsigned)Ho);
+    }
+    __device__ __forceinline__ void next(int Wo, int Ho)
+    {
+        if (++ow == Wo) { ow = 0; if (++oh == Ho) { oh = 0; ++bb; } }
+    }
+    __device__ __forceinline__ void advance(int n, int Wo, int Ho)
+    {
+        ow += n;
+        while (ow >= Wo) { ow -= Wo; if (++oh == Ho) { oh = 0; ++bb; } }
+    }
+};
+
+// ---- LDS-DMA variant of the weight-gradient kernel (vector operands, no fused bias gradient) --------------------
+// Same tiles / MFMA order / results as conv_wgrad_kernel<BM,BN,2,2,true>.  Both operand tiles are "k rows of contiguous
+// channels" (x[pixel][c0 .. c0+BM), dy[pixel][n0 .. n0+BN)), i.e. exactly what the lane-linear LDS-DMA writes: a 1-KiB
+// piece is 2 (128 wide) or 4 (64 wide) pixel rows.  Row k is rotated by 32*((k >> 2) & 1) floats on the source side so
+// that the two half-waves of a fragment read (k and k+4) use different banks.  Pipeline and slicing as conv_igemm_dma_kernel:
+// three stages, fragments of step k+1 read and the DMA of step k+3 issued between the MFMA groups of step k.
+template <int BM, int BN>
+__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv_wgrad_dma_kernel(WgradParams p)
+{
+    constexpr int TM = BM / 64, TN = BN / 64, WN = 2, NSTAGE = 3;
+    constexpr int PA = BM / 64, PB = BN / 64;
+    constexpr int QA = BM / 4, QB = BN / 4;                       // quads per k row
+    constexpr int STAGE_FLOATS = BK * BM + BK * BN;
+    using Frags = DmaFrags<TM, TN>;
+    __shared__ __attribute__((aligned(1024))) float smem[NSTAGE * STAGE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ctiles = (p.Cin + BM - 1) / BM;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if ((total & 7u) == 0) {
+            const unsigned lin = bx + gx * (by + gy * bz);
+            const unsigned nl = (lin & 7u) * (total >> 3) + (lin >> 3);
+            bx = nl % gx;
+            const unsigned t2 = nl / gx;
+            by = t2 % gy;
+            bz = t2 / gy;
+        }
+    }
+    const int c0 = (int)(bx % (unsigned)ctiles) * BM;
+    const int ti = (int)(bx / (unsigned)ctiles);
+    const int n0 = (int)by * BN;
+    const int split = (int)bz;
+    const int64_t m_beg = (int64_t)split * p.m_per_split;
+    const int64_t m_end = m_beg + p.m_per_split < p.M ? m_beg + p.m_per_split : p.M;
+    const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
+    const float* zero = g_zero16;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const int n = m_beg < m_end ? (int)((m_end - m_beg + BK - 1) / BK) : 0;   // K steps of this split
+
+    // per-lane row state: piece i of this wave covers k rows; this lane sits in row ka[i] / kb[i] of the 16-pixel step
+    int ka[PA], ca[PA], kb[PB], nb[PB];
+    bool ca_ok[PA], nb_ok[PB];
+    RowIter ita[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int P = (wave * PA + i) * 64 + lane;
+        ka[i] = P / QA;
+        const int cq = ((P % QA) - 8 * ((ka[i] >> 2) & 1)) & (QA - 1);
+        ca[i] = c0 + cq * 4;
+        ca_ok[i] = ca[i] < p.Cin;
+        if (!p.pointwise) ita[i].init(m_beg + ka[i] < p.M ? m_beg + ka[i] : 0, p.Wo, p.Ho);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int P = (wave * PB + i) * 64 + lane;
+        kb[i] = P / QB;
+        const int nq = ((P % QB) - 8 * ((kb[i] >> 2) & 1)) & (QB - 1);
+        nb[i] = n0 + nq * 4;
+        nb_ok[i] = nb[i] < p.Cout;
+    }
+    int64_t is_mb = m_beg;              // first pixel of the next step to issue
+    uint32_t st_la = 0;
+    auto issue_a = [&](int i) {
+        const int64_t m = is_mb + ka[i];
+        bool ok = m < m_end && ca_ok[i];
+        int64_t pix = m;
+        if (!p.pointwise) {
+            const int ih = ita[i].oh * p.stride + dh, iw = ita[i].ow * p.stride + dw;
+            ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            pix = ((int64_t)ita[i].bb * p.H + ih) * p.W + iw;
+            ita[i].advance(BK, p.Wo, p.Ho);
+        }
+        conv_glds16(ok ? p.x + (pix * p.ldx + ca[i]) : zero, st_la + (uint32_t)((wave * PA + i) * 1024));
+    };
+    auto issue_b = [&](int i) {
+        const int64_t m = is_mb + kb[i];
+        const bool ok = m < m_end && nb_ok[i];
+        conv_glds16(ok ? p.dy + (m * p.lddy + nb[i]) : zero, st_la + (uint32_t)(BK * BM * 4 + (wave * PB + i) * 1024));
+    };
+    auto issue_begin = [&](int stage) { st_la = lds0 + (uint32_t)(stage * STAGE_FLOATS * 4); };
+    auto issue_end = [&]() { is_mb += BK; };
+    auto issue = [&](int stage) {
+        issue_begin(stage);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) issue_a(i);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) issue_b(i);
+        issue_end();
+    };
+
+    const int l31 = lane & 31, h = lane >> 5;
+    auto read_a = [&](int stage, Frags& F, int q, int tm) {
+        const float* As = smem + stage * STAGE_FLOATS;
+        const int r = ((wm * TM + tm) * 32 + l31 + 32 * h) & (BM - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) F.a[q][tm][j] = As[(8 * q + 4 * h + j) * BM + r];
+    };
+    auto read_b = [&](int stage, Frags& F, int q, int tn) {
+        const float* Bs = smem + stage * STAGE_FLOATS + BK * BM;
+        const int c = ((wn * TN + tn) * 32 + l31 + 32 * h) & (BN - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) F.b[q][tn][j] = Bs[(8 * q + 4 * h + j) * BN + c];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto mma4 = [&](const Frags& F, int q, int j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[q][tm][j], F.b[q][tn][j], acc[tm][tn], 0, 0, 0);
+    };
+    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
+        const bool rd = k + 1 < n, dm = k + 3 < n;
+        const int sn = (k + 1) % NSTAGE;
+        if (rd) {
+            if (k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        mma4(cur, 0, 0); __builtin_amdgcn_sched_barrier(0);
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) read_a(sn, nxt, 0, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 0, 1); __builtin_amdgcn_sched_barrier(0);
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) read_b(sn, nxt, 0, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 0, 2); __builtin_amdgcn_sched_barrier(0);
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) read_a(sn, nxt, 1, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 0, 3); __builtin_amdgcn_sched_barrier(0);
+        if (rd) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) read_b(sn, nxt, 1, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 0); __builtin_amdgcn_sched_barrier(0);
+        if (dm) { issue_begin(k % NSTAGE); issue_a(0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 1); __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PA > 1) { if (dm) issue_a(1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 2); __builtin_amdgcn_sched_barrier(0);
+        if (dm) issue_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(cur, 1, 3); __builtin_amdgcn_sched_barrier(0);
+        if (dm) {
+            if constexpr (PB > 1) issue_b(1);
+            issue_end();
+        }
+    };
+
+    Frags F0, F1;
+    if (n > 0) issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    if (n > 0) {
+        if (n > 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PA + PB)) : "memory");
+        else if (n > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");
+        else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) read_a(0, F0, q, t);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) read_b(0, F0, q, t);
+        }
+    }
+    for (int k = 0; k < n; k += 2) {
+        kstep(k, F0, F1);
+        if (k + 1 < n) kstep(k + 1, F1, F0);
+    }
+
+    const int hh = h;
+    float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nn = n0 + (wn * TN + tn) * 32 + l31;
+        if (nn >= p.Cout) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (c < p.Cin) out[(int64_t)c * p.Cout + nn] = acc[tm][tn][r];
+            }
+    }
+}
+
 // dW[widx[ti]][c][n] = sum_split part[split][ti][c][n]  (fixed order: deterministic); dead taps stay 0.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int splits, int ntaps, int64_t cn,
                                                           ConvTaps taps, float* dw)
@@ -1013,21 +1245,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
 //   lanes-over-Cout form: thread = output channel n, registers = the NTAPS*CIN input taps (x values are wave-uniform
 //   loads), rows split over row lanes and blocks; partials [split][tap][c][n] feed the common fixed-order reduce.
 // (row, column, image) of output pixel m, advanced incrementally: no integer division in the row loops
-struct RowIter {
-    int ow, oh, bb;
-    __device__ __forceinline__ void init(int64_t m, int Wo, int Ho)
-    {
-        const unsigned mu = (unsigned)m;
-        const unsigned q = mu / (unsigned)Wo;
-        ow = (int)(mu - q * (unsigned)Wo);
-        bb = (int)(q / (unsigned)Ho);
-        oh = (int)(q - (unsigned)bb * (unsigned)Ho);
-    }
-    __device__ __forceinline__ void next(int Wo, int Ho)
-    {
-        if (++ow == Wo) { ow = 0; if (++oh == Ho) { oh = 0; ++bb; } }
-    }
-};
 
 template <int CIN, int NTAPS, int U>
 __global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int NL, int RL, int64_t rows_per_split)
@@ -1358,6 +1575,8 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
 static int g_wgrad_narrow = 1;
 static int g_wgrad_m64 = 1;
 static int g_wgrad_xcd = 1;
+static int g_wgrad_dma = 1;          // LDS-DMA weight-gradient kernels: bit 0 = the 128-wide tiles (default on: DeepLab 7.17 -> 7.12 ms/step,
+                                     // FPN 26.86 -> 26.77), bit 1 = the 64x64 tiles (off: 7.17 -> 7.20)
 static const int g_wgrad_lds_pad_default = 0;
 static int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
 static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
@@ -1475,6 +1694,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
     g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 1 : 2);   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
+    g_wgrad_dma = ((v >> 20) & 1 ? 0 : 1) | ((v >> 21) & 1 ? 2 : 0);   // bit 20: LDS-DMA weight-gradient kernel of the 128-wide tiles off; bit 21: 64x64 tiles on
     g_conv_dma64 = (v & 262144) ? 0 : ((v & 524288) ? 2 : 1);   // bit 18: LDS-DMA kernel of the 64x64 tiles off; bit 19: forward only
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
@@ -1633,6 +1853,15 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
     const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    // LDS-DMA kernels: vector operands, no fused bias gradient, 32-bit safe row pitch; bits of g_wgrad_dma: 1 = 128-wide tiles, 2 = 64x64
+    const bool dma = vec && p.bias_part == nullptr && (int64_t)p.M * std::max(ldx, lddy) < (1ll << 40);
+    if (dma && (g_wgrad_dma & 1) && big && !(narrow_m && narrow_n)) {
+        if (narrow_m)      hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), grid, dim3(kThreads), 0, st, p);
+        else if (narrow_n) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), grid, dim3(kThreads), 0, st, p);
+        else               hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 128>), grid, dim3(kThreads), 0, st, p);
+    } else if (dma && (g_wgrad_dma & 2) && (!big || (narrow_m && narrow_n))) {
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 64>), grid, dim3(kThreads), 0, st, p);
+    } else
     if (big && narrow_m && narrow_n) {
         if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
         else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);

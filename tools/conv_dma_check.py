@@ -17,7 +17,8 @@ def run(x, w, b, stride, pad, dil, dy):
     w.requires_grad_(True)
     y = E.conv2d(tape, xv, w, b, stride, pad, dil)
     tape.backward(y, dy)
-    return y.t.clone(), xv.grad.clone()
+    torch.cuda.synchronize()
+    return y.t.clone(), xv.grad.clone(), tape.param_grads[id(w)].clone()
 
 
 def timeit(fn, n=20):
@@ -47,11 +48,13 @@ for (B, H, W, Ci, Co, k, st, pad, dil) in shapes:
     w = torch.randn(k, k, Ci, Co, device=DEV) * 0.05
     Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
     dy = torch.randn(B, Ho, Wo, Co, device=DEV)
-    L.pp_debug_set_conv_variant(256 | 262144)
-    y0, dx0 = run(x, w, None, st, pad, dil, dy)
-    L.pp_debug_set_conv_variant(32768)
-    y1, dx1 = run(x, w, None, st, pad, dil, dy)
+    L.pp_debug_set_conv_variant(256 | 262144 | (1 << 20))
+    y0, dx0, dw0 = run(x, w, None, st, pad, dil, dy)
+    L.pp_debug_set_conv_variant(32768 | (2 << 20))
+    y1, dx1, dw1 = run(x, w, None, st, pad, dil, dy)
     same = torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    same_w = torch.equal(dw0, dw1)
+    ok &= same_w
     close = torch.allclose(y0, y1, rtol=1e-4, atol=1e-4) and torch.allclose(dx0, dx1, rtol=1e-4, atol=1e-4)   # the 64-deep-K baseline sums in another order
     ok &= close
     fl = 2.0 * B * Ho * Wo * Ci * Co * k * k
@@ -65,7 +68,18 @@ for (B, H, W, Ci, Co, k, st, pad, dil) in shapes:
             L.pp_conv2d_fwd(x.data_ptr(), Ci, B, H, W, Ci, w.data_ptr(), None, k, k, st, pad, dil, y.data_ptr(), Co, Co, ws, wsn,
                             _lib.current_stream_ptr())
         t[v] = timeit(f)
-    print(f"{B}x{H}x{W} {Ci}->{Co} k{k} s{st} d{dil}: bit-identical={same}  max|dy|={float((y0 - y1).abs().max()):.2e} "
+    tw = {}
+    for v in (1 << 20, 2 << 20):
+        L.pp_debug_set_conv_variant(v)
+        dwb = torch.empty_like(w)
+        nb = L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Ci, Co, k, k, st, pad, dil)
+        wsb = torch.empty(max(nb, 256), dtype=torch.uint8, device=DEV)
+
+        def g():
+            L.pp_conv2d_bwd_weight(x.data_ptr(), Ci, B, H, W, Ci, dy.data_ptr(), Co, Co, k, k, st, pad, dil, dwb.data_ptr(), None,
+                                   wsb.data_ptr(), wsb.numel(), _lib.current_stream_ptr())
+        tw[v] = timeit(g)
+    print(f"{B}x{H}x{W} {Ci}->{Co} k{k} s{st} d{dil}: bit-identical={same} wgrad-identical={same_w} wgrad {tw[1 << 20]:.1f} -> {tw[2 << 20]:.1f} us ({fl / tw[1 << 20] / 1e6:.1f} -> {fl / tw[2 << 20] / 1e6:.1f} TF)  max|dy|={float((y0 - y1).abs().max()):.2e} "
           f"max|ddx|={float((dx0 - dx1).abs().max()):.2e}  fwd {t[256 | 262144]:.1f} -> {t[0]:.1f} us  ({fl / t[256 | 262144] / 1e6:.1f} -> {fl / t[0] / 1e6:.1f} TF)")
 L.pp_debug_set_conv_variant(0)
 print("ALL EQUAL (bit-identical unless the baseline used the 64-deep K step)" if ok else "MISMATCH")
