@@ -673,3 +673,51 @@ def test_sgd_momentum_matches_torch_and_trainer_uses_it():
         assert (p.cpu() - ref).abs().max().item() < 2e-6
     assert L.pp_sgd_step_flat(p.data_ptr(), gg.data_ptr(), None, n, n_split, 1e-3, 1e-2, 0.9, 5e-4, 1, 1.0, None,
                               torch.cuda.current_stream().cuda_stream) != 0
+
+
+# ---- LDS-DMA convolution kernels (csrc/conv_igemm.hip: conv_igemm_dma_kernel, conv_wgrad_dma_kernel) vs the register-staged ones
+DMA_CONV_SHAPES = [  # B, H, W, Cin, Cout, k, stride, pad, dil
+    (4, 64, 128, 304, 256, 3, 1, 1, 1),     # SegmentHead conv 1 (decoders.py:107): 128x128 tiles, ragged Cin
+    (2, 64, 128, 256, 256, 3, 1, 1, 1),     # SegmentHead conv 2
+    (4, 16, 32, 160, 960, 1, 1, 0, 1),      # MobileNetV2 expand: 64x64 tiles, ragged Cout tile in backward-data, split-K
+    (4, 16, 32, 1280, 256, 1, 1, 0, 1),     # ASPP fuse (aspp.py:73): split-K
+    (4, 16, 32, 320, 256, 3, 1, 12, 12),    # ASPP atrous branch: dead taps
+    (3, 37, 53, 132, 260, 3, 1, 1, 1),      # ragged rows, ragged channel chunks (132 = 8*16 + 4)
+    (2, 45, 61, 136, 192, 3, 2, 1, 1),      # stride 2: backward-data stays on the register-staged kernel
+    (2, 32, 64, 64, 64, 3, 1, 1, 1),        # one 64x64 tile column
+    (1, 9, 11, 72, 68, 1, 1, 0, 1),         # tiny: fewer K steps than pipeline stages
+]
+
+
+@pytest.mark.parametrize("shape", DMA_CONV_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_lds_dma_conv_kernels_match_register_staged_kernels(shape):
+    """Same tiles and MFMA order, so forward, backward-data and weight gradient must agree bit for bit (to 1e-4 relative
+    where the register-staged plan uses the 64-deep K step, whose summation order differs)."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    B, H, W, Ci, Co, k, st, pad, dil = shape
+    torch.manual_seed(1)
+    x = torch.randn(B, H, W, Ci, device=DEV)
+    w = (torch.randn(k, k, Ci, Co, device=DEV) * 0.05).requires_grad_(True)
+    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
+    dy = torch.randn(B, Ho, Wo, Co, device=DEV)
+
+    def run(variant):
+        L.pp_debug_set_conv_variant(variant)
+        tape = E.Tape(True)
+        xv = E.Var(x)
+        y = E.conv2d(tape, xv, w, None, st, pad, dil)
+        tape.backward(y, dy)
+        torch.cuda.synchronize()
+        return y.t.clone(), xv.grad.clone(), tape.param_grads[id(w)].clone()
+    try:
+        ref = run(256 | 262144 | (1 << 20))                 # every LDS-DMA kernel off
+        for variant in (0, 32768 | (2 << 20)):              # the default mix; DMA everywhere it exists
+            got = run(variant)
+            for name, a, b in zip(("y", "dx", "dw"), got, ref):
+                if torch.equal(a, b):
+                    continue
+                close(a, b, tol=1e-4, what=f"{name} (variant {variant})")
+                assert max(Ci, Co) >= 256 and B * H * W >= 4096, f"{name}: only the 64-deep-K baseline may differ in rounding"
+    finally:
+        L.pp_debug_set_conv_variant(0)
