@@ -254,7 +254,7 @@ def main():
         evc.destroy()
         flops = 2.0 * TB * Hq * Wq * 256 * 9 * 304
         cavg = sum(cms) / len(cms)
-        line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<128,128> SegmentHead 3x3 304->256 fwd",
+        line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_igemm_dma_kernel<128,128> SegmentHead 3x3 304->256 fwd",
                                  "achieved": round(flops / (cavg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": round(flops / (cavg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
                                  "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
