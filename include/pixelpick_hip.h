@@ -261,8 +261,11 @@ int pp_crop2d_add(const float* xp, int64_t ldxp, int B, int Hp, int Wp, int C, i
  * "pred", deeplab.py:55-56).  Backward is a deterministic gather; dy_nchw likewise. */
 int pp_bilinear_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, float* y, int64_t ldy, int Ho, int Wo,
                     int align_corners, float scale_h, float scale_w, int out_nchw, pp_stream_t stream);
+/* workspace (optional, may be NULL): B*Ho*W*C floats let up-sampling factors >= 3 run as two separable gathers. */
+size_t pp_bilinear_bwd_workspace_bytes(int B, int Ho, int W, int C);
 int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C, float* dx, int64_t lddx, int H, int W,
-                    int align_corners, float scale_h, float scale_w, int dy_nchw, pp_stream_t stream);
+                    int align_corners, float scale_h, float scale_w, int dy_nchw, void* workspace, size_t ws_bytes,
+                    pp_stream_t stream);
 
 /* out[b][c] = mul * sum_p x[b][p][c]  (nn.AdaptiveAvgPool2d(1), aspp.py:54, with mul = 1/P; also the
  * adjoint of the broadcast below) and y[b][p][c] = mul * v[b][c] (the 1x1 -> HxW bilinear broadcast of
@@ -349,7 +352,7 @@ void pp_debug_set_acq_tuning(int occ, int ppt);
  * bit 18 LDS-DMA kernel of the 64x64 tiles off (bit 19: forward only); bit 20 LDS-DMA weight-gradient kernel of the
  * 128-wide tiles off; bit 21 LDS-DMA weight-gradient kernel for the 64x64 tiles on.
  * Findings: profiles/r01_conv_ablation.txt. */
-void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B) */
+void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B); bit 8: separable bilinear backward off */
 void pp_debug_set_splitk(int v);       /* tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 */
 void pp_debug_set_wgrad_target(int blocks);   /* split-M target of the weight-gradient kernels (default 1024) */
 void pp_debug_set_bn_target(int blocks);   /* strips x row chunks of the single-launch BatchNorm (default 384, <= 1024) */

@@ -57,7 +57,8 @@ SIGNATURES = {
     "pp_pad2d": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p]),
     "pp_crop2d_add": (_int, [_p, _i64, _int, _int, _int, _int, _int, _int, _p, _i64, _p, _i64, _int, _int, _p]),
     "pp_bilinear_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p]),
-    "pp_bilinear_bwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p]),
+    "pp_bilinear_bwd_workspace_bytes": (_sz, [_int] * 4),
+    "pp_bilinear_bwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _f, _f, _int, _p, _sz, _p]),
     "pp_image_colsum": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
     "pp_image_broadcast": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
     "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p, _p]),

@@ -1628,6 +1628,7 @@ __global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_
     }
 }
 
+static int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
 static int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
 
 static inline unsigned grid_for(int64_t total)
@@ -1653,6 +1654,7 @@ extern "C" {
 void pp_debug_set_dw_variant(int v)
 {
     g_dw_x4 = (v & 1) ? 0 : 1;
+    g_bil_sep = (v & 256) ? 0 : 1;
     const int sel = (v >> 1) & 7;                 // 0: default, 1: 512, 2: 256, 3: 128, 4: 2048 row blocks for the weight gradient
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
@@ -1882,6 +1884,60 @@ int pp_crop2d_add(const float* xp, int64_t ldxp, int B, int Hp, int Wp, int C, i
 }
 
 // ---- bilinear ---------------------------------------------------------------------------------------------
+// Separable backward for large up-sampling factors (the ASPP x4 upsample of deeplab.py:49: 64x128 -> 16x32, 256 channels):
+//   dx = Rh^T (dy Rw)   as two gathers - along W into tmp[B,Ho,W,C], then along H - instead of one thread walking a
+// (2/s+2)^2 window (10x10 float4 loads per thread, 131 K threads: 145 us for 33.5 MB of dy).  Fixed order, no atomics.
+__global__ __launch_bounds__(kT) void bilinear_bwd_sepw_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq,
+                                                              float* tmp, int W, float sw, int align)
+{
+    const int64_t total = (int64_t)B * Ho * W * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int iw = (int)(t % W);
+        const int64_t row = t / W;                     // b*Ho + oh
+        int lo, hi;
+        out_window(iw, W, Wo, sw, align, lo, hi);
+        const float* src = dy + row * Wo * lddy + q * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ow = lo; ow <= hi; ++ow) {
+            const Lerp l = lerp_src(ow, W, sw, align);
+            const float wgt = (l.i0 == iw ? l.l0 : 0.0f) + (l.i1 == iw ? l.l1 : 0.0f);
+            if (wgt != 0.0f) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)ow * lddy);
+                acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(tmp + e * 4) = acc;
+    }
+}
+
+__global__ __launch_bounds__(kT) void bilinear_bwd_seph_kernel(const float* tmp, int B, int Ho, int W, int cq, float* dx,
+                                                              int64_t lddx, int H, float sh, int align)
+{
+    const int64_t total = (int64_t)B * H * W * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        int lo, hi;
+        out_window(ih, H, Ho, sh, align, lo, hi);
+        const float* src = tmp + (((int64_t)b * Ho) * W + iw) * cq * 4 + q * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = lo; oh <= hi; ++oh) {
+            const Lerp l = lerp_src(oh, H, sh, align);
+            const float wgt = (l.i0 == ih ? l.l0 : 0.0f) + (l.i1 == ih ? l.l1 : 0.0f);
+            if (wgt != 0.0f) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)oh * W * cq * 4);
+                acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4) = acc;
+    }
+}
+
 static void bil_scales(int H, int W, int Ho, int Wo, int align, float scale_h, float scale_w, float& sh, float& sw)
 {
     if (align) {
@@ -1911,14 +1967,34 @@ int pp_bilinear_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, flo
     return check_launch("bilinear_fwd_kernel");
 }
 
+size_t pp_bilinear_bwd_workspace_bytes(int B, int Ho, int W, int C)
+{
+    if (B < 1 || Ho < 1 || W < 1 || C < 1) return 0;
+    return align_up((size_t)B * Ho * W * C * 4, 256);
+}
+
 int pp_bilinear_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int C, float* dx, int64_t lddx, int H, int W,
-                    int align_corners, float scale_h, float scale_w, int dy_nchw, pp_stream_t stream)
+                    int align_corners, float scale_h, float scale_w, int dy_nchw, void* workspace, size_t ws_bytes,
+                    pp_stream_t stream)
 {
     if (!dy || !dx) return fail(PP_ERR_BAD_ARG, "bilinear bwd: null");
     float sh, sw;
     bil_scales(H, W, Ho, Wo, align_corners, scale_h, scale_w, sh, sw);
     hipStream_t st = as_stream(stream);
     const bool win_ok = sh > 0.0f && sw > 0.0f && (int)(2.0f / sw) + 6 <= kMaxWin;   // candidate columns fit the weight table
+    const bool up2_special = !align_corners && Ho == 2 * H && Wo == 2 * W && H >= 2 && W >= 2 &&
+                             (scale_h == 0.0f || scale_h == 2.0f) && (scale_w == 0.0f || scale_w == 2.0f);
+    if (!dy_nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && sh > 0.0f && sw > 0.0f && Ho >= 3 * H && Wo >= 3 * W &&
+        !up2_special && workspace && ws_bytes >= pp_bilinear_bwd_workspace_bytes(B, Ho, W, C) && g_bil_sep) {
+        float* tmp = reinterpret_cast<float*>(workspace);
+        const int cq = C / 4;
+        hipLaunchKernelGGL(bilinear_bwd_sepw_kernel, dim3(grid_for((int64_t)B * Ho * W * cq)), dim3(kT), 0, st, dy, lddy, B, Ho, Wo, cq,
+                           tmp, W, sw, align_corners);
+        if (int rc = check_launch("bilinear_bwd_sepw_kernel")) return rc;
+        hipLaunchKernelGGL(bilinear_bwd_seph_kernel, dim3(grid_for((int64_t)B * H * W * cq)), dim3(kT), 0, st, tmp, B, Ho, W, cq, dx,
+                           lddx, H, sh, align_corners);
+        return check_launch("bilinear_bwd_seph_kernel");
+    }
     if (dy_nchw && win_ok) {
         hipLaunchKernelGGL(bilinear_bwd_planes_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(kT), 0, st, dy, B, Ho, Wo, C,
                            dx, lddx, H, W, sh, sw, align_corners);

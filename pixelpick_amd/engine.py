@@ -821,8 +821,12 @@ def _bilinear_bwd(tape: Tape, dy, x: Var, size, align_corners, scale_factor, out
     else:
         _, _, _, _, lddy = _geom(dy)
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    ws_ptr, ws_n = None, 0
+    if not out_nchw and Ho >= 3 * H and Wo >= 3 * W:          # separable two-gather form for large up-sampling factors
+        ws = _ws(_wsbytes("pp_bilinear_bwd_workspace_bytes", B, Ho, W, C), dy.device)
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     rc = _lib.lib().pp_bilinear_bwd(dy.data_ptr(), lddy, B, Ho, Wo, C, dx.data_ptr(), C, H, W, int(align_corners),
-                                    float(scale_factor), float(scale_factor), int(out_nchw), _stream())
+                                    float(scale_factor), float(scale_factor), int(out_nchw), ws_ptr, ws_n, _stream())
     _lib.check(rc, "pp_bilinear_bwd")
     _acc(x, dx)
 

@@ -482,7 +482,8 @@ def test_pad_and_crop_accumulate():
 BIL_CASES = [((2, 16, 32, 256), (64, 128), True, 0.0), ((2, 23, 30, 16), (90, 120), True, 0.0),
              ((2, 8, 12, 128), (16, 24), False, 2.0), ((1, 9, 7, 256), (18, 14), False, 0.0),
              ((2, 5, 6, 8), (11, 17), False, 0.0), ((2, 1, 1, 16), (4, 6), True, 0.0),
-             ((2, 2, 2, 8), (4, 4), False, 2.0), ((1, 3, 2, 4), (6, 4), False, 0.0), ((1, 1, 5, 8), (2, 10), False, 0.0)]
+             ((2, 2, 2, 8), (4, 4), False, 2.0), ((1, 3, 2, 4), (6, 4), False, 0.0), ((1, 1, 5, 8), (2, 10), False, 0.0),
+             ((2, 6, 5, 12), (24, 20), False, 0.0), ((1, 7, 9, 8), (25, 31), True, 0.0), ((2, 4, 4, 4), (12, 16), False, 0.0)]   # separable backward
 
 
 @pytest.mark.parametrize("case", BIL_CASES, ids=[str(c) for c in BIL_CASES])
