@@ -191,6 +191,16 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
 /* drop_p > 0: the nn.Dropout(p) that follows BN -> ReLU (aspp.py:60-61, decoders.py:108-114) is applied in the same pass
  * with pp_dropout's mask stream (same seed / seed_dev -> same mask), act must be 0 or 1. */
 
+/* Depthwise 3x3 convolution + training-mode BatchNorm (+ residual) + activation in ONE launch (mobilenet_v2.py:38-40, 52-54):
+ * the single-launch BatchNorm computes the convolution in its statistics pass, writes it to x_out [B,Ho,Wo,C] (BatchNorm's
+ * input, needed by the backward pass) and applies the normalisation from there.  Bit-identical to pp_dwconv3x3_fwd followed
+ * by pp_bn_train_fwd_fused.  workspace / sync as pp_bn_train_fwd_fused (fine-grained memory). */
+int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H, int W, int C, const float* w, int stride, int pad,
+                                    int dil, float* x_out, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                                    const float* residual, int64_t ldr, int act, float* y, int64_t ldy, void* workspace,
+                                    size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
+
 /* Single-launch form of pp_bn_bwd (same arguments + sync).  grad_scale = 1/(1-p) when a dropout was fused into the
  * forward (its mask is recovered from y_act == 0), else 1.  y_act == NULL with beta != NULL (no residual, no dropout):
  * the ReLU/ReLU6 mask is recomputed from x with the forward's own fma (bit-identical), y_act is not read. */

@@ -45,6 +45,8 @@ SIGNATURES = {
     "pp_bn_fused_workspace_bytes": (_sz, [_i64, _int]),
     "pp_bn_fused_sync_ints": (_sz, [_int]),
     "pp_bn_train_fwd_fused": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _int, _f, _u64, _p, _p, _i64, _p, _sz, _p, _sz, _p]),
+    "pp_dwconv3x3_bn_train_fwd_fused": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p, _p, _f, _f, _p, _p, _p, _p,
+                                               _p, _i64, _int, _p, _i64, _p, _sz, _p, _sz, _p]),
     "pp_bn_bwd_fused": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _p, _sz, _p, _sz, _p]),
     "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),

@@ -457,8 +457,38 @@ struct BnFwdArgs {
     const float* res; int64_t ldr; int act; float* y; int64_t ldy;
     xword* part; int* sync; BnFusedGeom g;
     float drop_p, drop_inv_keep; uint64_t drop_seed; const uint64_t* drop_seed_dev;   // nn.Dropout after the activation (p = 0: none)
+    // DW variant: x is not an input but the OUTPUT of a depthwise 3x3 convolution computed here (mobilenet_v2.py:38,52 -> :39,53)
+    const float* dw_in; int64_t dw_ld; const float* dw_w; float* x_out;
+    int dw_H, dw_W, dw_Ho, dw_Wo, dw_stride, dw_pad, dw_dil;
 };
 
+// one output quad of the depthwise 3x3 convolution, same tap order / fma chain as dwconv_fwd_kernel (bit-identical)
+__device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int q)
+{
+    const unsigned ru = (unsigned)row;
+    const unsigned t = ru / (unsigned)a.dw_Wo;
+    const int ow = (int)(ru - t * (unsigned)a.dw_Wo);
+    const unsigned b = t / (unsigned)a.dw_Ho;
+    const int oh = (int)(t - b * (unsigned)a.dw_Ho);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int th = 0; th < 3; ++th) {
+        const int ih = oh * a.dw_stride - a.dw_pad + th * a.dw_dil;
+        if ((unsigned)ih >= (unsigned)a.dw_H) continue;
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) {
+            const int iw = ow * a.dw_stride - a.dw_pad + tw * a.dw_dil;
+            if ((unsigned)iw >= (unsigned)a.dw_W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(a.dw_in + (((int64_t)b * a.dw_H + ih) * a.dw_W + iw) * a.dw_ld + q * 4);
+            const float4 ww = *reinterpret_cast<const float4*>(a.dw_w + (th * 3 + tw) * a.C + q * 4);
+            acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
+            acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+        }
+    }
+    return acc;
+}
+
+template <bool DW>
 __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 {
     __shared__ unsigned sh_tag;
@@ -485,7 +515,12 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
             for (int j = 0; j < 4; ++j) {
                 const int64_t rr = r + (int64_t)j * g.nrl;
                 w[j] = rr < r1 ? 1.0f : 0.0f;
-                v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);
+                if constexpr (DW) {
+                    v[j] = dw_point(a, rr < r1 ? rr : r1 - 1, q);
+                    if (rr < r1) *reinterpret_cast<float4*>(a.x_out + rr * a.ldx + q * 4) = v[j];   // BN's input, kept for backward
+                } else {
+                    v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1724,9 +1759,33 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
-                reinterpret_cast<xword*>(workspace), sync, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev};
-    hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+                reinterpret_cast<xword*>(workspace), sync, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev,
+                nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<false>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel");
+}
+
+int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H, int W, int C, const float* w, int stride, int pad,
+                                    int dil, float* x_out, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                                    const float* residual, int64_t ldr, int act, float* y, int64_t ldy, void* workspace,
+                                    size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
+{
+    if (!in || !w || !x_out || !gamma || !beta || !mean || !invstd || !y) return fail(PP_ERR_BAD_ARG, "dwconv_bn_train_fwd_fused: null");
+    if (int rc = need_c4(C, "dwconv_bn_train_fwd_fused")) return rc;
+    if (ld_in % 4 || ldx % 4 || ldy % 4 || (residual && ldr % 4)) return fail(PP_ERR_BAD_ARG, "dwconv_bn_train_fwd_fused: ld must be multiples of 4");
+    if (stride < 1 || dil < 1) return fail(PP_ERR_BAD_ARG, "dwconv_bn_train_fwd_fused: stride / dilation");
+    const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    if (Ho < 1 || Wo < 1) return fail(PP_ERR_BAD_ARG, "dwconv_bn_train_fwd_fused: empty output");
+    const int64_t M = (int64_t)B * Ho * Wo;
+    if (M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "dwconv_bn_train_fwd_fused: more than 2^31 output pixels");
+    BnFusedGeom g = bn_fused_geom(M, C);
+    if (int rc = bn_fused_check("dwconv_bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
+    BnFwdArgs a{x_out, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
+                reinterpret_cast<xword*>(workspace), sync, g, 0.0f, 1.0f, 0ull, nullptr,
+                in, ld_in, w, x_out, H, W, Ho, Wo, stride, pad, dil};
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<true>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    return check_launch("bn_fused_fwd_kernel<dw>");
 }
 
 int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,

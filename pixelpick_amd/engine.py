@@ -46,8 +46,22 @@ class Var:
         self._t = value
 
 
+def shape_of(v: "Var"):
+    """(B, H, W, C) of a Var WITHOUT launching a deferred convolution."""
+    if v._pending is None:
+        return tuple(v._t.shape)
+    kind, x, w, _, stride, pad, dil = v._pending
+    B, H, W, C = shape_of(x)
+    kh, kw = (w.shape[0], w.shape[1]) if kind == "conv" else (3, 3)
+    return (B, out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil), w.shape[3] if kind == "conv" else C)
+
+
 # PIXELPICK_FUSE_EVAL=0 keeps the three-launch inference form (conv, bn_eval_affine, scale_shift_act) for A/B.
 _FUSE_EVAL = os.environ.get("PIXELPICK_FUSE_EVAL", "1") != "0"
+# PIXELPICK_FUSE_DW_BN=1: compute a depthwise convolution inside the single-launch training BatchNorm behind it
+# (pp_dwconv3x3_bn_train_fwd_fused; bit-identical).  Off by default: measured 7.16-7.18 vs 7.05 ms/step - the BatchNorm grid
+# (384 blocks) is too small for the nine-tap gather, the 17 saved launches do not pay for it.
+_FUSE_DW_BN = os.environ.get("PIXELPICK_FUSE_DW_BN", "0") == "1"
 
 
 def _launch_deferred(v: "Var", bn):
@@ -613,6 +627,13 @@ def dwconv3x3(tape: Tape, x: Var, w: torch.Tensor, stride=1, pad=0, dil=1) -> Va
         out = Var(None, needs_grad=False)
         out._pending = ("dw", x, w, None, stride, pad, dil)
         return out
+    if _FUSE_DW_BN and tape.enabled:
+        # training: defer as well - a training-mode BatchNorm right behind it computes the convolution inside its own
+        # single launch (pp_dwconv3x3_bn_train_fwd_fused); any other consumer's `.t` launches the plain convolution
+        out = Var(None)
+        out._pending = ("dw", x, w, None, stride, pad, dil)
+        tape.record(_dwconv_bwd, (x, w, stride, pad, dil), out)
+        return out
     B, H, W, C, ldx = _geom(x.t)
     Ho, Wo = out_size(H, 3, stride, pad, dil), out_size(W, 3, stride, pad, dil)
     y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.t.device)
@@ -643,6 +664,39 @@ def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
         _acc(x, dx)
 
 
+def _dw_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst):
+    """x is a DEFERRED depthwise convolution: run it inside the single-launch training BatchNorm.  Returns the output Var,
+    or None when the shape is outside the fused kernel's range (the caller then takes the ordinary path)."""
+    _, xin, w, _, stride, pad, dil = x._pending
+    B, H, W, C, ld_in = _geom(xin.t)
+    Ho, Wo = out_size(H, 3, stride, pad, dil), out_size(W, 3, stride, pad, dil)
+    M = B * Ho * Wo
+    if M > _BN_FUSED_MAXM or M >= (1 << 31) or C > 65536 or C % 4 or ld_in % 4:
+        return None
+    dev = xin.t.device
+    xbuf = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    y = dst if dst is not None else torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+    _, _, _, _, ldy = _geom(y)
+    rptr, ldr = (None, 0)
+    if residual is not None:
+        _, _, _, _, ldr = _geom(residual.t)
+        rptr = residual.t.data_ptr()
+    sync, ws = _bn_exchange(dev)
+    rc = _lib.lib().pp_dwconv3x3_bn_train_fwd_fused(
+        xin.t.data_ptr(), ld_in, B, H, W, C, w.data_ptr(), stride, pad, dil, xbuf.data_ptr(), C, gamma.data_ptr(), beta.data_ptr(),
+        eps, momentum, running_mean.data_ptr() if running_mean is not None else None,
+        running_var.data_ptr() if running_var is not None else None, mean.data_ptr(), invstd.data_ptr(), rptr, ldr, act,
+        y.data_ptr(), ldy, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
+    _lib.check(rc, "pp_dwconv3x3_bn_train_fwd_fused")
+    x._pending = None
+    x._t = xbuf                                   # the convolution output exists now (BatchNorm backward reads it)
+    out = Var(y)
+    tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0), out)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- batch norm (+act, +residual)
 def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE,
                    residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
@@ -656,6 +710,11 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         _launch_deferred(x, (gamma, beta, running_mean, running_var, eps, act, residual, dst))
         return Var(x._t, needs_grad=False)
     L = _lib.lib()
+    if (training and x._pending is not None and x._pending[0] == "dw" and tape.enabled and dropout_p == 0.0 and _BN_FUSED
+            and _bn_exchange_ok(x._pending[1].t.device)):
+        fused = _dw_bn_train_fused(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst)
+        if fused is not None:
+            return fused
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
     dev = x.t.device

@@ -120,7 +120,7 @@ class BatchNorm2d(nn.Module):
         that it can ride in the BatchNorm kernel when both are in training mode)."""
         training = self.training
         if training:
-            B, H, W, _ = x.t.shape
+            B, H, W, _ = E.shape_of(x)          # (does not launch a deferred depthwise convolution)
             if B * H * W <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.t.shape)}")
             self.__dict__["_nbt_pending"] += 1   # folded into the num_batches_tracked buffer when it is read (plain dict

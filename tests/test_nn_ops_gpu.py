@@ -722,3 +722,42 @@ def test_lds_dma_conv_kernels_match_register_staged_kernels(shape):
                 assert max(Ci, Co) >= 256 and B * H * W >= 4096, f"{name}: only the 64-deep-K baseline may differ in rounding"
     finally:
         L.pp_debug_set_conv_variant(0)
+
+
+@pytest.mark.parametrize("shape,stride,pad,dil,act,res", [
+    ((4, 16, 32, 960), 1, 1, 1, E.ACT_RELU6, False),      # 1/16-resolution MobileNetV2 block (mobilenet_v2.py:38-40)
+    ((2, 33, 47, 96), 2, 1, 1, E.ACT_RELU6, False),       # stride 2, ragged size
+    ((2, 18, 34, 192), 1, 0, 1, E.ACT_RELU6, False),      # pre-padded input, padding 0 (fixed_padding, mobilenet_v2.py:15-21)
+    ((2, 20, 36, 64), 1, 2, 2, E.ACT_RELU6, False),       # dilation 2 (features.17)
+    ((1, 9, 11, 8), 1, 1, 1, E.ACT_NONE, True),           # tiny, with a residual
+    ((4, 128, 256, 32), 1, 1, 1, E.ACT_RELU6, False),     # the largest map of the network
+])
+def test_dwconv_fused_into_training_batchnorm_is_bit_identical(monkeypatch, bn_fused, shape, stride, pad, dil, act, res):
+    """pp_dwconv3x3_bn_train_fwd_fused (the depthwise convolution computed inside the single-launch BatchNorm) against the
+    two launches it replaces: outputs, saved statistics, running statistics and every gradient must agree bit for bit."""
+    B, H, W, C = shape
+    torch.manual_seed(4)
+    x = torch.randn(B, H, W, C, device=DEV)
+    w = (torch.randn(3, 3, C, device=DEV) * 0.3).requires_grad_(True)
+    gamma = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device=DEV) * 0.1).requires_grad_(True)
+    Ho, Wo = (H + 2 * pad - 2 * dil - 1) // stride + 1, (W + 2 * pad - 2 * dil - 1) // stride + 1
+    r = torch.randn(B, Ho, Wo, C, device=DEV) if res else None
+    dy = torch.randn(B, Ho, Wo, C, device=DEV)
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(E, "_FUSE_DW_BN", fuse)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        tape = E.Tape(True)
+        xv = E.Var(x.clone())
+        rvar = E.Var(r.clone()) if res else None
+        d = E.dwconv3x3(tape, xv, w, stride, pad, dil)
+        assert (d._pending is not None) == fuse
+        y = E.batch_norm_act(tape, d, gamma, beta, rm, rv, True, act, rvar)
+        assert d._pending is None
+        tape.backward(y, dy.clone())
+        torch.cuda.synchronize()
+        outs.append((y.t.clone(), d.t.clone(), rm, rv, xv.grad.clone(), tape.param_grads[id(w)].clone(),
+                     tape.param_grads[id(gamma)].clone(), tape.param_grads[id(beta)].clone()) + ((rvar.grad.clone(),) if res else ()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
