@@ -916,6 +916,78 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, i
     }
 }
 
+// Stride-1, dilation-1 variant: one work item = FOUR consecutive output pixels of one image row (Wo % 4 == 0) x one
+// channel quad.  The four 3x3 windows overlap in a 3 x 6 input patch, so an item costs 18 + 4 float4 loads instead of 40,
+// all in flight at once; fewer, fatter row blocks then keep the partial traffic ([blocks][9][C]) below the input size
+// (the one-pixel kernel needed 512 row blocks on a 2048-pixel map to hide its latency: 17.7 MB of partials for 7.8 MB of x).
+__global__ __launch_bounds__(kT) void dwconv_bwd_weight_x4_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
+                                                                 const float* dy, int64_t lddy, int Ho, int Wo, int pad,
+                                                                 ColReduceGeom g, float* part)
+{
+    __shared__ float4 sh[kT];
+    const int C = cq * 4;
+    const int t = threadIdx.x;
+    const int ql = t % g.cq_blk, ry = t / g.cq_blk;
+    const int q = blockIdx.y * g.cq_blk + ql;
+    const bool active = ry < g.rows_per_pass && q < cq;
+    const int wq = Wo / 4;
+    const int64_t M4 = (int64_t)B * Ho * wq;            // work items
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
+        const int64_t r1 = r0 + g.rows_per_block < M4 ? r0 + g.rows_per_block : M4;
+        for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
+            const unsigned ru = (unsigned)r;
+            const unsigned tt = ru / (unsigned)wq;
+            const int ow0 = (int)(ru - tt * (unsigned)wq) * 4;
+            const int b = (int)(tt / (unsigned)Ho);
+            const int oh = (int)(tt - (unsigned)b * (unsigned)Ho);
+            const float* gp = dy + (((int64_t)b * Ho + oh) * Wo + ow0) * lddy + q * 4;
+            float4 gg[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) gg[o] = *reinterpret_cast<const float4*>(gp + (int64_t)o * lddy);
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                const int ih = oh - pad + th;
+                if ((unsigned)ih >= (unsigned)H) continue;
+                const float* row = x + ((int64_t)b * H + ih) * W * ldx + q * 4;
+                float4 v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int iw = ow0 - pad + j;
+                    v[j] = (unsigned)iw < (unsigned)W ? *reinterpret_cast<const float4*>(row + (int64_t)iw * ldx)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                    float4& a = acc[th * 3 + tw];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        a.x = fmaf(v[o + tw].x, gg[o].x, a.x); a.y = fmaf(v[o + tw].y, gg[o].y, a.y);
+                        a.z = fmaf(v[o + tw].z, gg[o].z, a.z); a.w = fmaf(v[o + tw].w, gg[o].w, a.w);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        sh[t] = acc[k];
+        __syncthreads();
+        if (ry == 0 && q < cq) {
+            float4 s = acc[k];
+            for (int j = 1; j < g.rows_per_pass; ++j) {
+                const float4 a = sh[j * g.cq_blk + ql];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * 9 + k) * C + q * 4) = s;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(kT) void sum_partials_kernel(const float* part, int nblk, int64_t n, float* out, float mul)
 {
     __shared__ double shd[kT];
@@ -1664,6 +1736,7 @@ __global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_
 }
 
 static int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
+static int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
 static int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
 
 static inline unsigned grid_for(int64_t total)
@@ -1690,6 +1763,8 @@ void pp_debug_set_dw_variant(int v)
 {
     g_dw_x4 = (v & 1) ? 0 : 1;
     g_bil_sep = (v & 256) ? 0 : 1;
+    g_dw_wgrad_x4 = (v & 512) ? 0 : 1;                      // bit 9: four-pixel depthwise weight-gradient kernel off
+    { const int s4 = (v >> 10) & 7; g_dw_wgrad_x4_blocks = s4 == 1 ? 128 : s4 == 2 ? 512 : s4 == 3 ? 1024 : s4 == 4 ? 64 : 256; }
     const int sel = (v >> 1) & 7;                 // 0: default, 1: 512, 2: 256, 3: 128, 4: 2048 row blocks for the weight gradient
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
@@ -1913,6 +1988,18 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
     if (!workspace || ws_bytes < (size_t)g.nblk_rows * 9 * C * 4) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
+    if (stride == 1 && dil == 1 && Wo % 4 == 0 && g_dw_wgrad_x4) {
+        // items of four pixels; the same workspace bound holds (never more row blocks than the one-pixel geometry)
+        ColReduceGeom g4 = col_geom(M / 4, C, g_dw_wgrad_x4_blocks);
+        if (g4.nblk_rows <= g.nblk_rows) {
+            hipLaunchKernelGGL(dwconv_bwd_weight_x4_kernel, dim3(g4.nblk_rows, g4.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4,
+                               dy, lddy, Ho, Wo, pad, g4, part);
+            if (int rc = check_launch("dwconv_bwd_weight_x4_kernel")) return rc;
+            hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv((int64_t)9 * C, 8)), dim3(kT), 0, st, part, g4.nblk_rows,
+                               (int64_t)9 * C, dw, 1.0f);
+            return check_launch("sum_partials_kernel");
+        }
+    }
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4, dy,
                        lddy, Ho, Wo, stride, pad, dil, g, part);
     if (int rc = check_launch("dwconv_bwd_weight_kernel")) return rc;
