@@ -29,6 +29,9 @@ from . import acquisition as acq
 _LARGEST_STRATEGIES = ("entropy", "least_confidence")
 # PIXELPICK_FUSED_LOWRES=0: always materialise the full-resolution logits (model(x)["pred"]) before scoring
 FUSED_LOWRES = os.environ.get("PIXELPICK_FUSED_LOWRES", "1") != "0"
+# PIXELPICK_QUERY_PIPELINE=0: finish every batch of an acquisition round (index / entropy read-back, masks, statistics)
+# before the next one is loaded, instead of doing that host work while the GPU already runs the next batch
+QUERY_PIPELINE = os.environ.get("PIXELPICK_QUERY_PIPELINE", "1") != "0"
 
 
 class QuerySelector:
@@ -163,11 +166,77 @@ class QuerySelector:
         y = None
 
         pending = []      # (x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w))
+        inflight = []     # at most one launched-but-unfinished batch of the pipelined path
+        want_any_stats = not human_labels
+        # Deterministic default configuration (k = n_pixels_by_us, no random sub-sampling, low-resolution scoring): the GPU
+        # work of a batch is only ENQUEUED by flush(); its results come back through pinned buffers and are turned into
+        # masks / statistics after the next batch has been loaded and enqueued, so host and GPU overlap.  Configurations
+        # that draw random numbers keep the strict per-batch order (their RNG sequence is part of the contract).
+        pipelined = (QUERY_PIPELINE and FUSED_LOWRES and not self.use_mc_dropout and hasattr(model, "forward_lowres")
+                     and not self.reverse_order and not (self.top_n_percent > 0.) and torch.device(self.device).type == "cuda")
+        copy_stream = self.__dict__.get("_copy_stream")
+        if pipelined and copy_stream is None:
+            copy_stream = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
+
+        def finish(hd):
+            """Host half of a pipelined batch: wait for ITS read-back (not for whatever the GPU runs now)."""
+            nonlocal n_pixels
+            items, h, w, idx_host, ent_host, ev = hd
+            ev.synchronize()
+            idx_h = idx_host.numpy().astype(np.int64)
+            ent_h = ent_host.numpy() if ent_host is not None else None
+            for j, (_, yj, _, p_img, _) in enumerate(items):
+                order = np.argsort(idx_h[j], kind="stable")
+                sel = idx_h[j][order]
+                query = np.zeros(h * w, dtype=np.bool_)
+                query[sel] = True
+                query = query.reshape(h, w)
+                list_queries.append(query)
+                n_pixels += len(sel)
+                if ent_h is not None:
+                    self.query_stats.update_from_picked(query, yj, ent_h[j][order].tolist(), coords=(sel // w, sel % w))
+                dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
+
+        def launch_pipelined():
+            (h, w), = {it[4] for it in pending}
+            main = torch.cuda.current_stream(self.device)
+            excl = np.ascontiguousarray(np.stack([it[2] for it in pending]))
+            with torch.cuda.stream(copy_stream):               # a pageable upload on the main stream would block the host
+                excl_dev = torch.from_numpy(excl).view(torch.uint8).to(self.device)    # behind everything enqueued there
+            main.wait_stream(copy_stream)                      # images and exclusion masks of this batch have arrived
+            excl_dev.record_stream(main)
+            xs = torch.cat([it[0] for it in pending], dim=0)
+            for it in pending:
+                it[0].record_stream(main)
+            low, full_size = model.forward_lowres(xs)
+            k = self._k_topk(h, w)
+            idx, _, _ = acq.score_topk_lowres(low, full_size, excl_dev, self.query_strategy, k, crop=(h, w))
+            n = len(pending)
+            idx_host = torch.empty((n, k), dtype=torch.int32, pin_memory=True)
+            idx_host.copy_(idx, non_blocking=True)
+            ent_host = None
+            if want_any_stats and all(it[1] is not None for it in pending):
+                img = torch.arange(n, device=idx.device, dtype=torch.int32).repeat_interleave(k)
+                ent = acq.score_at_lowres(low, full_size, img, idx.reshape(-1), "entropy", crop=(h, w))
+                ent_host = torch.empty((n, k), dtype=torch.float32, pin_memory=True)
+                ent_host.copy_(ent.reshape(n, k), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            handle = (list(pending), h, w, idx_host, ent_host, ev)
+            pending.clear()
+            if inflight:
+                finish(inflight.pop())                         # the PREVIOUS batch, while the GPU works on this one
+            inflight.append(handle)
 
         def flush():
             nonlocal n_pixels
             if not pending:
                 return
+            if pipelined and len({it[4] for it in pending}) == 1:
+                launch_pipelined()
+                return
+            if inflight:
+                finish(inflight.pop())
             xs = torch.cat([it[0] for it in pending], dim=0)
             logits_b = None
             sizes = {it[4] for it in pending}
@@ -252,7 +321,11 @@ class QuerySelector:
 
         with torch.no_grad():
             for batch_ind, dict_data in enumerate(self.dataloader):
-                x = dict_data['x'].to(self.device)
+                if pipelined and not dict_data['x'].is_cuda:
+                    with torch.cuda.stream(copy_stream):       # the upload must not queue behind the previous batch's kernels
+                        x = dict_data['x'].to(self.device, non_blocking=False)
+                else:
+                    x = dict_data['x'].to(self.device)
                 y = dict_data.get('y', None)
                 mask = np.asarray(prev_queries[batch_ind])  # h x w
 
@@ -276,6 +349,8 @@ class QuerySelector:
                 if self.debug:
                     break
             flush()
+            if inflight:
+                finish(inflight.pop())
 
         assert len(list_queries) > 0, f"no queries are chosen!"
         if not human_labels and y is not None:
