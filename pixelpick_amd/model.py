@@ -92,6 +92,28 @@ class Model:
         write_log(self.log_train, header=["epoch", "mIoU", "pixel_acc", "loss"])
         write_log(self.log_val, header=["epoch", "mIoU", "pixel_acc"])
 
+    # ------------------------------------------------------------------ host -> device uploads off the compute stream
+    def _upload(self):
+        """Context in which `.to(device)` runs on a dedicated copy stream (a no-op context on a CPU-only device string)."""
+        import contextlib
+        if torch.device(self.device).type != "cuda":
+            return contextlib.nullcontext()
+        st = self.__dict__.get("_copy_stream")
+        if st is None:
+            st = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(st)
+
+    def _uploaded(self, *tensors):
+        """The compute stream waits for the copy stream; the uploaded tensors are marked as used by the compute stream."""
+        st = self.__dict__.get("_copy_stream")
+        if st is None:
+            return
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(st)
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(main)
+
     # ------------------------------------------------------------------ model.py:88-159
     def _train_epoch(self, epoch, model, trainer, n_iters_total):
         model.train()
@@ -101,9 +123,17 @@ class Model:
             # in force DURING epoch E is base * 0.1^#{m <= E-2}: the drops take effect from epochs 22 and 42
             trainer.lr_factor = 0.1 ** sum(1 for m in (20, 40) if m <= epoch - 2)
         for it, dict_data in enumerate(self.dataloader):
-            x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+            # model.py:106-108 uploads on the compute stream: a pageable copy there queues behind the previous step's kernels
+            # and blocks the host until they finish, so the host could never enqueue ahead of the GPU.  Upload on a copy
+            # stream instead and let the compute stream wait for it.
+            mask = None
+            with self._upload():
+                x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+                if self.n_pixels_by_us != 0:
+                    mask = dict_data['queries'].to(self.device)
+            self._uploaded(x, y, mask)
             if self.n_pixels_by_us != 0:                                   # model.py:108-110
-                mask = dict_data['queries'].to(self.device).view(y.shape)
+                mask = mask.view(y.shape)
                 # same values as `y.flatten()[~mask.flatten()] = ignore_index`, without the nonzero() + host sync
                 # that boolean-index assignment performs on every step
                 y = torch.where(mask != 0, y, torch.full_like(y, self.ignore_index))
@@ -164,7 +194,9 @@ class Model:
             pend_y.clear()
 
         for dict_data in self.dataloader_val:
-            x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+            with self._upload():
+                x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+            self._uploaded(x, y)
             if pend_x and (pend_x[0].shape[1:] != x.shape[1:] or pend_y[0].shape[1:] != y.shape[1:]
                            or sum(t.shape[0] for t in pend_x) + x.shape[0] > vbs):
                 flush()
