@@ -61,6 +61,7 @@ class QuerySelector:
         # query loader has batch_size 1, model.py:36-37; in eval mode the per-image results do not depend on the batch)
         # Default 8: identical picks (tested), 385 -> ~1500 images/s for an acquisition round on MI355X (tools/query_bench.py)
         self.query_batch_size = int(getattr(args, "query_batch_size", 8))
+        self.mc_chunk = int(getattr(args, "mc_chunk", 32))     # stochastic passes per forward in the MC-dropout branch
 
     # ------------------------------------------------------------------ selection (query.py:33-69)
     @property
@@ -292,13 +293,18 @@ class QuerySelector:
                 return
             for j, (x1, yj, exclude, p_img, (h, w)) in enumerate(pending):
                 if self.use_mc_dropout:
-                    # mean uncertainty / mean probability over mc_n_steps stochastic passes
+                    # mean uncertainty / mean probability over mc_n_steps stochastic passes: the passes differ only in their
+                    # dropout masks (eval-mode BatchNorm is per sample), so they run as ONE forward over mc_n_steps copies of
+                    # the image instead of mc_n_steps launch-bound forwards at batch 1 (`mc_chunk` copies at a time)
                     uc_map = torch.zeros((h, w), device=self.device)
                     prob = torch.zeros((1, self.n_classes, h, w), device=self.device)
-                    for _ in range(self.mc_n_steps):
-                        logits = self._forward_logits(model, x1, h, w)
-                        uc_map += acq.score_map(logits, None, self.query_strategy)[0]
-                        prob += F.softmax(logits, dim=1)
+                    left = self.mc_n_steps
+                    while left > 0:
+                        t = min(left, self.mc_chunk)
+                        logits = self._forward_logits(model, x1.expand(t, -1, -1, -1).contiguous(), h, w)
+                        uc_map += acq.score_map(logits, None, self.query_strategy).sum(dim=0)
+                        prob += F.softmax(logits, dim=1).sum(dim=0, keepdim=True)
+                        left -= t
                     uc_map /= self.mc_n_steps
                     prob /= self.mc_n_steps
                     uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0

@@ -396,9 +396,11 @@ class _DropModel(torch.nn.Module):
         return {"pred": torch.nn.functional.conv2d(self.drop(x), self.w, self.b)}
 
 
-def test_query_selector_mc_dropout_mean_of_maps():
+@pytest.mark.parametrize("chunk", [32, 3])
+def test_query_selector_mc_dropout_mean_of_maps(chunk):
     """MC-dropout branch (query.py:176-188 as intended — upstream's version crashes): the selector must
-    pick top-k of the MEAN uncertainty map over mc_n_steps stochastic passes.  Re-derive it with the same torch RNG."""
+    pick top-k of the MEAN uncertainty map over mc_n_steps stochastic passes.  The passes of one image run as ONE forward
+    over copies of it (`mc_chunk` at a time); re-derive that with the same torch RNG."""
     torch.manual_seed(5)
     C, h, w, steps, k = 7, 24, 40, 4, 9
     W, b = (torch.randn(C, 3, 1, 1) * 2).to(DEV), (torch.randn(C) * .5).to(DEV)
@@ -409,7 +411,7 @@ def test_query_selector_mc_dropout_mean_of_maps():
     model = _DropModel(W, b)
     with tempfile.TemporaryDirectory() as td:
         a = _args(query_strategy="entropy", dir_root=td, n_classes=C, ignore_index=C, n_pixels_by_us=k,
-                  use_mc_dropout=True, mc_n_steps=steps)
+                  use_mc_dropout=True, mc_n_steps=steps, mc_chunk=chunk)
         torch.manual_seed(11); torch.cuda.manual_seed(11)
         dq = ppq.QuerySelector(a, _DL(_DS(xs, ys, prev, names)), device=torch.device(DEV))(nth_query=1, model=model)
     torch.manual_seed(11); torch.cuda.manual_seed(11)
@@ -417,9 +419,12 @@ def test_query_selector_mc_dropout_mean_of_maps():
     for i, n in enumerate(names):
         uc = torch.zeros(h, w, device=DEV)
         with torch.no_grad():
-            for _ in range(steps):
-                lg = model(xs[i:i + 1].to(DEV))["pred"]
-                uc += acq.score_map(lg, None, "entropy")[0]
+            left = steps
+            while left > 0:
+                t = min(left, chunk)
+                lg = model(xs[i:i + 1].to(DEV).expand(t, -1, -1, -1).contiguous())["pred"]
+                uc += acq.score_map(lg, None, "entropy").sum(dim=0)
+                left -= t
         uc /= steps
         uc[torch.from_numpy(prev[i]).to(DEV)] = 0.0
         want = uc.flatten().topk(k).indices.cpu().numpy()
