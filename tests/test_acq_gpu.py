@@ -473,3 +473,32 @@ def test_query_selector_fused_lowres_gives_identical_queries_and_stats(monkeypat
     assert stats[0].list_n_unique_labels == stats[1].list_n_unique_labels
     assert stats[0].list_spatial_coverage == stats[1].list_spatial_coverage
     assert stats[0].dict_label_cnt == stats[1].dict_label_cnt
+
+
+def test_query_selector_pipelined_round_equals_the_strict_order(monkeypatch):
+    """The default configuration only ENQUEUES a batch in flush() and finishes it (read-back, masks, statistics, codec) after
+    the next batch has been launched; coordinates, statistics and the dataset side effect must equal the strict per-batch order."""
+    from pixelpick_amd.networks.deeplab import DeepLab
+    C, h, w, n = 19, 64, 96, 7
+    torch.manual_seed(9)
+    model = DeepLab(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, use_aspp=True, use_softmax=False, use_img_inp=False)).to(DEV)
+    xs, ys = torch.randn(n, 3, h, w), torch.randint(0, C + 1, (n, h, w))
+    rng = np.random.RandomState(1)
+    prev = [rng.rand(h, w) < 0.02 for _ in range(n)]
+    names = [f"/img{i}.png" for i in range(n)]
+    outs = []
+    for pipe in (True, False):
+        monkeypatch.setattr(ppq, "QUERY_PIPELINE", pipe)
+        ds = _DS(xs, ys, prev, names)
+        with tempfile.TemporaryDirectory() as td:
+            qs = ppq.QuerySelector(_args(query_strategy="entropy", dir_root=td, query_batch_size=3), _DL(ds), device=torch.device(DEV))
+            dq = qs(nth_query=1, model=model)
+        st = qs.query_stats
+        outs.append((dq, st.list_entropy, st.list_n_unique_labels, st.list_spatial_coverage, st.dict_label_cnt, ds.labelled))
+    a, b = outs
+    assert list(a[0].keys()) == list(b[0].keys()) == names
+    for nme in names:
+        np.testing.assert_array_equal(a[0][nme]["x_coords"], b[0][nme]["x_coords"])
+        np.testing.assert_array_equal(a[0][nme]["y_coords"], b[0][nme]["y_coords"])
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+    assert a[5][1] == b[5][1] == 1 and list(a[5][0].keys()) == names
