@@ -83,6 +83,7 @@ CASES = [
     (2, 40, (12, 20), (48, 80), None, True, 20),            # generic C <= 64 bucket
     (2, 26, (12, 20), (48, 80), (48, 77), True, 48),        # generic C <= 32 bucket, largest fused k
     (1, 19, (200, 300), (25, 40), None, True, 20),          # 8x down-sampling: patch exceeds LDS -> global-read variant
+    (2, 19, (256, 512), (1024, 2048), None, True, 20),      # Cityscapes full resolution (BASELINE configs[4])
 ]
 
 
