@@ -169,12 +169,13 @@ class QuerySelector:
         pending = []      # (x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w))
         inflight = []     # at most one launched-but-unfinished batch of the pipelined path
         want_any_stats = not human_labels
-        # Deterministic default configuration (k = n_pixels_by_us, no random sub-sampling, low-resolution scoring): the GPU
-        # work of a batch is only ENQUEUED by flush(); its results come back through pinned buffers and are turned into
-        # masks / statistics after the next batch has been loaded and enqueued, so host and GPU overlap.  Configurations
-        # that draw random numbers keep the strict per-batch order (their RNG sequence is part of the contract).
+        # Low-resolution scoring, no reverse-order sampling: the GPU work of a batch is only ENQUEUED by flush(); its results
+        # come back through pinned buffers and are turned into masks / statistics after the next batch has been loaded and
+        # enqueued, so host and GPU overlap.  The random sub-sampling of the top-n-percent mode (query.py:63-64) happens in
+        # that host half, image by image in loader order, so its numpy RNG sequence is the reference's; the reverse-order
+        # mode draws BEFORE scoring and keeps the strict per-batch order.
         pipelined = (QUERY_PIPELINE and FUSED_LOWRES and not self.use_mc_dropout and hasattr(model, "forward_lowres")
-                     and not self.reverse_order and not (self.top_n_percent > 0.) and torch.device(self.device).type == "cuda")
+                     and not self.reverse_order and torch.device(self.device).type == "cuda")
         copy_stream = self.__dict__.get("_copy_stream")
         if pipelined and copy_stream is None:
             copy_stream = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
@@ -187,15 +188,23 @@ class QuerySelector:
             idx_h = idx_host.numpy().astype(np.int64)
             ent_h = ent_host.numpy() if ent_host is not None else None
             for j, (_, yj, _, p_img, _) in enumerate(items):
-                order = np.argsort(idx_h[j], kind="stable")
-                sel = idx_h[j][order]
+                if self.top_n_percent > 0.:
+                    # query.py:63-64 `np.random.choice(ind, n_pixels_by_us, False)`: numpy draws permutation(len)[:n] and
+                    # indexes the array with it, so drawing the POSITIONS consumes the same random numbers and picks the same
+                    # pixels (tests/test_host_logic.py) - and tells which of the read-back entropies belong to them
+                    pos = np.random.choice(idx_h.shape[1], self.n_pixels_by_us, False)
+                    cand, cand_ent = idx_h[j][pos], (ent_h[j][pos] if ent_h is not None else None)
+                else:
+                    cand, cand_ent = idx_h[j], (ent_h[j] if ent_h is not None else None)
+                order = np.argsort(cand, kind="stable")
+                sel = cand[order]
                 query = np.zeros(h * w, dtype=np.bool_)
                 query[sel] = True
                 query = query.reshape(h, w)
                 list_queries.append(query)
                 n_pixels += len(sel)
                 if ent_h is not None:
-                    self.query_stats.update_from_picked(query, yj, ent_h[j][order].tolist(), coords=(sel // w, sel % w))
+                    self.query_stats.update_from_picked(query, yj, cand_ent[order].tolist(), coords=(sel // w, sel % w))
                 dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
 
         def launch_pipelined():

@@ -151,3 +151,18 @@ def test_exclusion_mask_is_reinterpreted_not_converted():
         assert got.dtype == torch.uint8 and tuple(got.shape) == (2, 5, 7)
         np.testing.assert_array_equal(got.numpy(), want.astype(np.uint8))
     assert acq._exclude_u8(None, 2, 5, 7, torch.device("cpu")) is None
+
+
+def test_numpy_choice_over_an_array_equals_choice_over_its_positions():
+    """The pipelined QuerySelector draws POSITIONS of the value-sorted candidate list instead of the candidates themselves
+    (query.py:63-64 `np.random.choice(ind, n, False)`): same picks, same RNG consumption."""
+    import numpy as np
+    for s in range(6):
+        a = np.random.RandomState(100 + s).permutation(200000)[:6553]
+        np.random.seed(s)
+        r1 = np.random.choice(a, 10, False)
+        nxt1 = np.random.rand()
+        np.random.seed(s)
+        pos = np.random.choice(len(a), 10, False)
+        nxt2 = np.random.rand()
+        assert (a[pos] == r1).all() and nxt1 == nxt2
