@@ -19,6 +19,8 @@
 // registers (next K-step's global loads are in flight while the current one is multiplied).  A fragment
 // reads are ds_read_b128 using a permuted K order (lane-half h consumes k = 8q+4h+j), B fragment reads
 // are conflict-free ds_read_b32.
+#include <type_traits>
+
 #include "pp_common.h"
 
 namespace pp {
@@ -572,9 +574,16 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         const float* src = p.w + (b_e[i] + st_boff);
         conv_glds16(ok ? src : zero, st_la + (uint32_t)(BM * BK * 4 + (wave * PB + i) * 1024));
     };
+    const bool tap_in = p.tap_inner != 0;
+    const int inner_lim = tap_in ? p.taps.n : nchunk;
     auto issue_end = [&]() {      // advance to the following step and fetch its tap entry now (used one K step later)
-        if (p.tap_inner) { if (++is_ti == p.taps.n) { is_ti = 0; ++is_ch; } }
-        else             { if (++is_ch == nchunk) { is_ch = 0; ++is_ti; } }
+        // branch-free (scalar selects): the inner counter wraps into the outer one
+        int inner = (tap_in ? is_ti : is_ch) + 1, outer = tap_in ? is_ch : is_ti;
+        const bool wrap = inner == inner_lim;
+        inner = wrap ? 0 : inner;
+        outer += wrap ? 1 : 0;
+        is_ti = tap_in ? inner : outer;
+        is_ch = tap_in ? outer : inner;
         const int tn = is_ti < p.taps.n ? is_ti : 0;
         te_a = s_tap[tn][0];
         te_b = s_tap[tn][1];
@@ -638,11 +647,14 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     // barrier; the 32 MFMAs go out in eight groups of four and every group is followed by a SLICE of the step's other
     // work - two fragment reads of step k+1, or one DMA piece of step k+3 - which issues in the shadow of the group's
     // last MFMA (64 matrix-pipe cycles) instead of forming a separate phase in which the matrix pipe idles.
-    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
-        const bool rd = k + 1 < n, dm = k + 3 < n;
+    // STEADY (compile time): the step is at least three steps from the end of the K loop, so every `if` below is known
+    // to be taken - the steady-state loop body has no branches (a few runtime-uniform branches cost this kernel ~10 %)
+    auto kstep = [&](auto steady_tag, int k, Frags& cur, Frags& nxt) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const bool rd = STEADY || k + 1 < n, dm = STEADY || k + 3 < n;
         const int sn = (k + 1) % NSTAGE;
         if (rd) {
-            if (k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");   // my pieces of step k+1 landed; k+2 flies on
+            if (STEADY || k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");   // my pieces of step k+1 landed; k+2 flies on
             else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                        // everyone's pieces; stage k%3 is free
             asm volatile("" ::: "memory");
@@ -699,9 +711,14 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         asm volatile("" ::: "memory");
         read_frags(0, F0);
     }
-    for (int k = 0; k < n; k += 2) {
-        kstep(k, F0, F1);
-        if (k + 1 < n) kstep(k + 1, F1, F0);
+    int k = 0;
+    for (; k + 4 < n; k += 2) {                                   // steady state: both steps have k + 3 < n
+        kstep(std::true_type{}, k, F0, F1);
+        kstep(std::true_type{}, k + 1, F1, F0);
+    }
+    for (; k < n; k += 2) {                                       // the last (up to four) steps
+        kstep(std::false_type{}, k, F0, F1);
+        if (k + 1 < n) kstep(std::false_type{}, k + 1, F1, F0);
     }
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
@@ -1136,11 +1153,14 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[q][tm][j], F.b[q][tn][j], acc[tm][tn], 0, 0, 0);
     };
-    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
-        const bool rd = k + 1 < n, dm = k + 3 < n;
+    // STEADY (compile time): the step is at least three steps from the end of the K loop, so every `if` below is known
+    // to be taken - the steady-state loop body has no branches (a few runtime-uniform branches cost this kernel ~10 %)
+    auto kstep = [&](auto steady_tag, int k, Frags& cur, Frags& nxt) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const bool rd = STEADY || k + 1 < n, dm = STEADY || k + 3 < n;
         const int sn = (k + 1) % NSTAGE;
         if (rd) {
-            if (k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");
+            if (STEADY || k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");
             else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1203,9 +1223,14 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
             for (int t = 0; t < TN; ++t) read_b(0, F0, q, t);
         }
     }
-    for (int k = 0; k < n; k += 2) {
-        kstep(k, F0, F1);
-        if (k + 1 < n) kstep(k + 1, F1, F0);
+    int k = 0;
+    for (; k + 4 < n; k += 2) {                                   // steady state: both steps have k + 3 < n
+        kstep(std::true_type{}, k, F0, F1);
+        kstep(std::true_type{}, k + 1, F1, F0);
+    }
+    for (; k < n; k += 2) {                                       // the last (up to four) steps
+        kstep(std::false_type{}, k, F0, F1);
+        if (k + 1 < n) kstep(std::false_type{}, k + 1, F1, F0);
     }
 
     const int hh = h;
