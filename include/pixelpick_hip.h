@@ -357,7 +357,7 @@ void pp_debug_set_acq_tuning(int occ, int ppt);
 /* Dense conv kernel A/B knobs: low 2 bits 0 = 128x128 large tile (default; measured fastest), 2 = 128x64 tiles;
  * bit 2 = linear instead of XCD-aware tile order; bit 3 = conditional (non-vector) loads; bits 4/5 = cap the large
  * tile at 2 / 1 blocks per CU; bit 6 split-K off; bit 7 64-deep K step of the 64x64 tiles off; bit 8 LDS-DMA kernel of the
- * 128-row tiles off (bit 15: use it for every backward-data layer; bit 22: forward only); bits 9-14 weight-gradient / ragged-tile / K-order variants;
+ * 128-row tiles off (bit 15: backward-data only for the 128x64-tiled layers; bit 22: forward only); bits 9-14 weight-gradient / ragged-tile / K-order variants;
  * bit 12 32-deep K step for the 128x128 tiles; bits 16/17 TIMING-ONLY ablation (skips the split-K reduce: wrong results);
  * bit 18 LDS-DMA kernel of the 64x64 tiles off (bit 19: forward only); bit 20 LDS-DMA weight-gradient kernel of the
  * 128-wide tiles off; bit 21 LDS-DMA weight-gradient kernel for the 64x64 tiles on.

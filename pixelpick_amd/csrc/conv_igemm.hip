@@ -1489,11 +1489,10 @@ static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_
 
 static int g_conv_deepk = 1;
 static int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
-static int g_conv_dma = 3;         // 128-row tiles, LDS-DMA three-stage kernel: 0 off, 1 forward + backward-data, 2 forward only, 3 (default)
-                                   // forward + the backward-data of the 128x64-tiled layers (DeepLab 7.11 -> 7.09 ms/step, FPN unchanged;
-                                   // with 1 DeepLab gains another 0.03 ms but FPN loses 0.27:
-                                   // under the concurrent weight-gradient stream of the backward pass its 48 KiB of LDS per block cost more
-                                   // than the denser MFMA schedule gains - FPN 28.11 -> 28.29 ms/step with 1, 28.03 with 2)
+static int g_conv_dma = 1;         // 128-row tiles, LDS-DMA three-stage kernel: 0 off, 1 (default) forward + backward-data, 2 forward only,
+                                   // 3 forward + the backward-data of the 128x64-tiled layers only.  History: before the steady-state loop
+                                   // lost its branches, backward-data through this kernel cost FPN 0.27 ms/step (48 KiB of LDS per block
+                                   // beside the weight-gradient stream); after it: DeepLab 6.92 -> 6.89 ms/step, FPN 25.96 -> 26.02.
 static int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-DMA kernel: 0 off, 1 forward + backward-data (default: DeepLab 7.29 ->
                                    // 7.21 ms/step, FPN 28.06 -> 27.06), 2 forward only (7.25 / 27.42).  Replaces the 64-deep K step.
 static int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
@@ -1741,7 +1740,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
-    g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 1 : ((v & 4194304) ? 2 : 3));   // bit 15: every backward-data layer too; bit 22: forward only   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
+    g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 3 : ((v & 4194304) ? 2 : 1));   // bit 15: backward-data only for the 128x64 tiles; bit 22: forward only   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
     g_wgrad_dma = ((v >> 20) & 1 ? 0 : 1) | ((v >> 21) & 1 ? 2 : 0);   // bit 20: LDS-DMA weight-gradient kernel of the 128-wide tiles off; bit 21: 64x64 tiles on
     g_conv_dma64 = (v & 262144) ? 0 : ((v & 524288) ? 2 : 1);   // bit 18: LDS-DMA kernel of the 64x64 tiles off; bit 19: forward only
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
