@@ -457,6 +457,17 @@ __device__ __forceinline__ void conv_glds16(const float* gsrc, uint32_t lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// two consecutive 1-KiB pieces (LDS destinations lds_dst and lds_dst + 1024) behind ONE M0 set-up: the instruction offset of
+// the second load moves both its LDS destination and its global address by 1024, so its pointer is passed 1024 bytes low
+__device__ __forceinline__ void conv_glds16x2(const float* g0, const float* g1, uint32_t lds_dst)
+{
+    unsigned keep;
+    const char* g1m = reinterpret_cast<const char*>(g1) - 1024;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1m), "s"(lds_dst) : "memory");
+}
+
 template <int TM, int TN> struct DmaFrags { float a[2][TM][4], b[2][TN][4]; };
 
 template <int BM, int BN, bool BWD>
@@ -566,16 +577,32 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     };
     auto issue_a = [&](int i) {
         const bool ok = ((a_vm[i] >> st_ti) & 1u) && (st_c0 + a_c[i] < p.Ck);
-        const float* src = p.x + (a_e0[i] + st_aoff);
+        const float* src = p.x + (size_t)(unsigned)(a_e0[i] + st_aoff);       // >= 0 whenever ok (zero-extend: no sign fix-up)
         conv_glds16(ok ? src : zero, st_la + (uint32_t)((wave * PA + i) * 1024));
     };
     auto issue_b = [&](int i) {
         const bool ok = b_ok[i] && (st_c0 + b_k[i] < (BWD ? p.Cout : p.Cin));
-        const float* src = p.w + (b_e[i] + st_boff);
+        const float* src = p.w + (size_t)(unsigned)(b_e[i] + st_boff);
         conv_glds16(ok ? src : zero, st_la + (uint32_t)(BM * BK * 4 + (wave * PB + i) * 1024));
     };
     const bool tap_in = p.tap_inner != 0;
     const int inner_lim = tap_in ? p.taps.n : nchunk;
+    auto a_src = [&](int i) -> const float* {
+        const bool ok = ((a_vm[i] >> st_ti) & 1u) && (st_c0 + a_c[i] < p.Ck);
+        return ok ? p.x + (size_t)(unsigned)(a_e0[i] + st_aoff) : zero;
+    };
+    auto b_src = [&](int i) -> const float* {
+        const bool ok = b_ok[i] && (st_c0 + b_k[i] < (BWD ? p.Cout : p.Cin));
+        return ok ? p.w + (size_t)(unsigned)(b_e[i] + st_boff) : zero;
+    };
+    auto issue_a_all = [&]() {
+        if constexpr (PA == 2) conv_glds16x2(a_src(0), a_src(1), st_la + (uint32_t)(wave * PA * 1024));
+        else issue_a(0);
+    };
+    auto issue_b_all = [&]() {
+        if constexpr (PB == 2) conv_glds16x2(b_src(0), b_src(1), st_la + (uint32_t)(BM * BK * 4 + wave * PB * 1024));
+        else issue_b(0);
+    };
     auto issue_end = [&]() {      // advance to the following step and fetch its tap entry now (used one K step later)
         // branch-free (scalar selects): the inner counter wraps into the outer one
         int inner = (tap_in ? is_ti : is_ch) + 1, outer = tap_in ? is_ch : is_ti;
@@ -649,10 +676,11 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     // last MFMA (64 matrix-pipe cycles) instead of forming a separate phase in which the matrix pipe idles.
     // STEADY (compile time): the step is at least three steps from the end of the K loop, so every `if` below is known
     // to be taken - the steady-state loop body has no branches (a few runtime-uniform branches cost this kernel ~10 %)
-    auto kstep = [&](auto steady_tag, int k, Frags& cur, Frags& nxt) {
+    auto kstep = [&](auto steady_tag, auto stage_tag, int k, Frags& cur, Frags& nxt) {
         constexpr bool STEADY = decltype(steady_tag)::value;
+        constexpr int SK = decltype(stage_tag)::value;            // k % NSTAGE when known at compile time, else -1
         const bool rd = STEADY || k + 1 < n, dm = STEADY || k + 3 < n;
-        const int sn = (k + 1) % NSTAGE;
+        const int sn = SK >= 0 ? (SK + 1) % NSTAGE : (k + 1) % NSTAGE;
         if (rd) {
             if (STEADY || k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");   // my pieces of step k+1 landed; k+2 flies on
             else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -684,19 +712,14 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 0); __builtin_amdgcn_sched_barrier(0);
-        if (dm) { issue_begin(k % NSTAGE); issue_a(0); }
+        if (dm) { issue_begin(SK >= 0 ? SK : k % NSTAGE); issue_a_all(); }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 1); __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PA > 1) { if (dm) issue_a(1); }
-        __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 2); __builtin_amdgcn_sched_barrier(0);
-        if (dm) issue_b(0);
+        if (dm) issue_b_all();
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 3); __builtin_amdgcn_sched_barrier(0);
-        if (dm) {
-            if constexpr (PB > 1) issue_b(1);
-            issue_end();
-        }
+        if (dm) issue_end();
     };
 
     Frags F0, F1;
@@ -711,14 +734,24 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         asm volatile("" ::: "memory");
         read_frags(0, F0);
     }
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    using SR = std::integral_constant<int, -1>;
     int k = 0;
+    for (; k + 8 < n; k += 6) {                                   // steady state, six steps: ring slots are compile-time constants
+        kstep(std::true_type{}, S0{}, k, F0, F1);
+        kstep(std::true_type{}, S1{}, k + 1, F1, F0);
+        kstep(std::true_type{}, S2{}, k + 2, F0, F1);
+        kstep(std::true_type{}, S0{}, k + 3, F1, F0);
+        kstep(std::true_type{}, S1{}, k + 4, F0, F1);
+        kstep(std::true_type{}, S2{}, k + 5, F1, F0);
+    }
     for (; k + 4 < n; k += 2) {                                   // steady state: both steps have k + 3 < n
-        kstep(std::true_type{}, k, F0, F1);
-        kstep(std::true_type{}, k + 1, F1, F0);
+        kstep(std::true_type{}, SR{}, k, F0, F1);
+        kstep(std::true_type{}, SR{}, k + 1, F1, F0);
     }
     for (; k < n; k += 2) {                                       // the last (up to four) steps
-        kstep(std::false_type{}, k, F0, F1);
-        if (k + 1 < n) kstep(std::false_type{}, k + 1, F1, F0);
+        kstep(std::false_type{}, SR{}, k, F0, F1);
+        if (k + 1 < n) kstep(std::false_type{}, SR{}, k + 1, F1, F0);
     }
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
@@ -1097,7 +1130,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     }
     int64_t is_mb = m_beg;              // first pixel of the next step to issue
     uint32_t st_la = 0;
-    auto issue_a = [&](int i) {
+    auto a_src = [&](int i) -> const float* {
         const int64_t m = is_mb + ka[i];
         bool ok = m < m_end && ca_ok[i];
         int64_t pix = m;
@@ -1107,12 +1140,22 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
             pix = ((int64_t)ita[i].bb * p.H + ih) * p.W + iw;
             ita[i].advance(BK, p.Wo, p.Ho);
         }
-        conv_glds16(ok ? p.x + (pix * p.ldx + ca[i]) : zero, st_la + (uint32_t)((wave * PA + i) * 1024));
+        return ok ? p.x + (pix * p.ldx + ca[i]) : zero;
     };
-    auto issue_b = [&](int i) {
+    auto b_src = [&](int i) -> const float* {
         const int64_t m = is_mb + kb[i];
         const bool ok = m < m_end && nb_ok[i];
-        conv_glds16(ok ? p.dy + (m * p.lddy + nb[i]) : zero, st_la + (uint32_t)(BK * BM * 4 + (wave * PB + i) * 1024));
+        return ok ? p.dy + (m * p.lddy + nb[i]) : zero;
+    };
+    auto issue_a = [&](int i) { conv_glds16(a_src(i), st_la + (uint32_t)((wave * PA + i) * 1024)); };
+    auto issue_b = [&](int i) { conv_glds16(b_src(i), st_la + (uint32_t)(BK * BM * 4 + (wave * PB + i) * 1024)); };
+    auto issue_a_all = [&]() {
+        if constexpr (PA == 2) { const float* s0 = a_src(0); const float* s1 = a_src(1); conv_glds16x2(s0, s1, st_la + (uint32_t)(wave * PA * 1024)); }
+        else issue_a(0);
+    };
+    auto issue_b_all = [&]() {
+        if constexpr (PB == 2) { const float* s0 = b_src(0); const float* s1 = b_src(1); conv_glds16x2(s0, s1, st_la + (uint32_t)(BK * BM * 4 + wave * PB * 1024)); }
+        else issue_b(0);
     };
     auto issue_begin = [&](int stage) { st_la = lds0 + (uint32_t)(stage * STAGE_FLOATS * 4); };
     auto issue_end = [&]() { is_mb += BK; };
@@ -1155,10 +1198,11 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     };
     // STEADY (compile time): the step is at least three steps from the end of the K loop, so every `if` below is known
     // to be taken - the steady-state loop body has no branches (a few runtime-uniform branches cost this kernel ~10 %)
-    auto kstep = [&](auto steady_tag, int k, Frags& cur, Frags& nxt) {
+    auto kstep = [&](auto steady_tag, auto stage_tag, int k, Frags& cur, Frags& nxt) {
         constexpr bool STEADY = decltype(steady_tag)::value;
+        constexpr int SK = decltype(stage_tag)::value;            // k % NSTAGE when known at compile time, else -1
         const bool rd = STEADY || k + 1 < n, dm = STEADY || k + 3 < n;
-        const int sn = (k + 1) % NSTAGE;
+        const int sn = SK >= 0 ? (SK + 1) % NSTAGE : (k + 1) % NSTAGE;
         if (rd) {
             if (STEADY || k + 2 < n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PB) : "memory");
             else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1190,19 +1234,14 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 0); __builtin_amdgcn_sched_barrier(0);
-        if (dm) { issue_begin(k % NSTAGE); issue_a(0); }
+        if (dm) { issue_begin(SK >= 0 ? SK : k % NSTAGE); issue_a_all(); }
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 1); __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PA > 1) { if (dm) issue_a(1); }
-        __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 2); __builtin_amdgcn_sched_barrier(0);
-        if (dm) issue_b(0);
+        if (dm) issue_b_all();
         __builtin_amdgcn_sched_barrier(0);
         mma4(cur, 1, 3); __builtin_amdgcn_sched_barrier(0);
-        if (dm) {
-            if constexpr (PB > 1) issue_b(1);
-            issue_end();
-        }
+        if (dm) issue_end();
     };
 
     Frags F0, F1;
@@ -1223,14 +1262,24 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
             for (int t = 0; t < TN; ++t) read_b(0, F0, q, t);
         }
     }
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    using SR = std::integral_constant<int, -1>;
     int k = 0;
+    for (; k + 8 < n; k += 6) {                                   // steady state, six steps: ring slots are compile-time constants
+        kstep(std::true_type{}, S0{}, k, F0, F1);
+        kstep(std::true_type{}, S1{}, k + 1, F1, F0);
+        kstep(std::true_type{}, S2{}, k + 2, F0, F1);
+        kstep(std::true_type{}, S0{}, k + 3, F1, F0);
+        kstep(std::true_type{}, S1{}, k + 4, F0, F1);
+        kstep(std::true_type{}, S2{}, k + 5, F1, F0);
+    }
     for (; k + 4 < n; k += 2) {                                   // steady state: both steps have k + 3 < n
-        kstep(std::true_type{}, k, F0, F1);
-        kstep(std::true_type{}, k + 1, F1, F0);
+        kstep(std::true_type{}, SR{}, k, F0, F1);
+        kstep(std::true_type{}, SR{}, k + 1, F1, F0);
     }
     for (; k < n; k += 2) {                                       // the last (up to four) steps
-        kstep(std::false_type{}, k, F0, F1);
-        if (k + 1 < n) kstep(std::false_type{}, k + 1, F1, F0);
+        kstep(std::false_type{}, SR{}, k, F0, F1);
+        if (k + 1 < n) kstep(std::false_type{}, SR{}, k + 1, F1, F0);
     }
 
     const int hh = h;
