@@ -500,6 +500,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
     const float* zero = g_zero16;
+    asm volatile("" : "+v"(zero));          // keep the pointer in registers (hipcc re-derives it from the PC in every K step otherwise)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
 
     // ---- per-thread addressing, fixed for the whole K loop (host guarantees 32-bit element offsets, <= 32 taps, unit
@@ -1104,6 +1105,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     const int64_t m_end = m_beg + p.m_per_split < p.M ? m_beg + p.m_per_split : p.M;
     const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
     const float* zero = g_zero16;
+    asm volatile("" : "+v"(zero));          // keep the pointer in registers (hipcc re-derives it from the PC in every K step otherwise)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
     const int n = m_beg < m_end ? (int)((m_end - m_beg + BK - 1) / BK) : 0;   // K steps of this split
 
