@@ -11,8 +11,18 @@ import torch
 from . import _lib
 
 STRATEGY_ID = {"entropy": 0, "least_confidence": 1, "margin_sampling": 2, "margin": 2}
-LARGEST = {"entropy": True, "least_confidence": True, "margin_sampling": False, "margin": False}
-FILL = {"entropy": 0.0, "least_confidence": 0.0, "margin_sampling": 1.0, "margin": 1.0}
+# "random" (query.py:242-244) has no score kernel: its map is host RNG output (torch.rand on the CPU, as the reference);
+# only its exclusion fill / top-k direction are listed here and the selection itself runs through topk_select().
+LARGEST = {"entropy": True, "least_confidence": True, "margin_sampling": False, "margin": False, "random": False}
+FILL = {"entropy": 0.0, "least_confidence": 0.0, "margin_sampling": 1.0, "margin": 1.0, "random": 1.0}
+
+
+def strategy_id(strategy: str) -> int:
+    try:
+        return STRATEGY_ID[strategy]
+    except KeyError:
+        raise ValueError(f"no score kernel for query strategy {strategy!r} (kernels: {sorted(STRATEGY_ID)}; 'random' maps "
+                         f"come from the host RNG and go through topk_select)") from None
 
 
 def _require_cuda_f32(t: torch.Tensor, name: str, ndim: int):
@@ -64,7 +74,7 @@ def score_topk(logits: torch.Tensor, exclude, strategy: str, k: int, return_map:
     sB, sC, sH, sW = logits.stride()
     with torch.cuda.device(dev):
         rc = L.pp_acq_score_topk(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW,
-                                 ex.data_ptr() if ex is not None else None, STRATEGY_ID[strategy], k,
+                                 ex.data_ptr() if ex is not None else None, strategy_id(strategy), k,
                                  idx.data_ptr(), val.data_ptr(), omap.data_ptr() if omap is not None else None,
                                  ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_acq_score_topk")
@@ -82,7 +92,7 @@ def score_map(logits: torch.Tensor, exclude, strategy: str) -> torch.Tensor:
     sB, sC, sH, sW = logits.stride()
     with torch.cuda.device(dev):
         rc = L.pp_acq_score_map(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW,
-                                ex.data_ptr() if ex is not None else None, STRATEGY_ID[strategy],
+                                ex.data_ptr() if ex is not None else None, strategy_id(strategy),
                                 omap.data_ptr(), _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_acq_score_map")
     return omap
@@ -97,7 +107,7 @@ def uncertainty_from_prob(prob: torch.Tensor, strategy: str) -> torch.Tensor:
     omap = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     sB, sC, sH, sW = prob.stride()
     with torch.cuda.device(dev):
-        rc = L.pp_uncertainty_from_prob(prob.data_ptr(), B, C, H, W, sB, sC, sH, sW, STRATEGY_ID[strategy],
+        rc = L.pp_uncertainty_from_prob(prob.data_ptr(), B, C, H, W, sB, sC, sH, sW, strategy_id(strategy),
                                         omap.data_ptr(), _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_uncertainty_from_prob")
     return omap
@@ -149,7 +159,7 @@ def score_topk_lowres(low: torch.Tensor, size, exclude, strategy: str, k: int, c
     ws = _ws(L.pp_acq_lowres_workspace_bytes(B, C, Hc, Wc, k), dev) if k else None
     with torch.cuda.device(dev):
         rc = L.pp_acq_lowres_score_topk(low.data_ptr(), ldx, B, C, h, w, H, W, int(bool(align_corners)), Hc, Wc,
-                                        ex.data_ptr() if ex is not None else None, STRATEGY_ID[strategy], k,
+                                        ex.data_ptr() if ex is not None else None, strategy_id(strategy), k,
                                         idx.data_ptr() if k else None, val.data_ptr() if k else None,
                                         omap.data_ptr() if omap is not None else None,
                                         ws.data_ptr() if k else None, ws.numel() if k else 0, _lib.current_stream_ptr(dev))
@@ -173,7 +183,7 @@ def score_at_lowres(low: torch.Tensor, size, img_idx, pix_idx, strategy: str = "
         return out
     with torch.cuda.device(dev):
         rc = _lib.lib().pp_acq_lowres_score_at(low.data_ptr(), ldx, B, C, h, w, H, W, int(bool(align_corners)), Hc, Wc,
-                                               STRATEGY_ID[strategy], ii.data_ptr(), pp.data_ptr(), n, out.data_ptr(),
+                                               strategy_id(strategy), ii.data_ptr(), pp.data_ptr(), n, out.data_ptr(),
                                                _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_acq_lowres_score_at")
     return out

@@ -120,6 +120,23 @@ class QuerySelector:
                                    self.query_strategy, k)
         return self._finish_selection(idx[0].cpu().numpy().astype(np.int64), h, w)
 
+    def _random_topk(self, rmaps: np.ndarray, exclude: np.ndarray) -> np.ndarray:
+        """`random` strategy (args.py:27; query.py:242-244,195-201,57-61): rmaps [n,h,w] are the host `torch.rand` maps the
+        reference's UncertaintySampler._random draws (a CPU tensor there as well), exclude bool [n,h,w].  Excluded pixels
+        are filled with 1.0 and the k SMALLEST values win; the selection runs on the GPU (pp_topk_select, ties towards the
+        lower flat index).  -> value-sorted flat indices int64 [n,k]."""
+        n, h, w = rmaps.shape
+        if self.reverse_order:
+            exclude = exclude.copy()
+            for j in range(n):                                  # numpy RNG draws in image order (query.py:40)
+                exclude[j] |= ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
+            k = self.n_pixels_by_us
+        else:
+            k = self._k_topk(h, w)
+        rmaps = np.where(exclude, np.float32(1.0), rmaps.astype(np.float32, copy=False))
+        idx, _ = acq.topk_select(torch.from_numpy(np.ascontiguousarray(rmaps.reshape(n, h * w))).to(self.device), k, False)
+        return idx.cpu().numpy().astype(np.int64)
+
     # ------------------------------------------------------------------ codecs (query.py:71-142)
     @staticmethod
     def encode_query(p_img: str, size: Tuple[int, int], query: np.ndarray) -> Dict[str, dict]:
@@ -166,7 +183,8 @@ class QuerySelector:
         dict_queries: dict = dict()
         y = None
 
-        pending = []      # (x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w))
+        is_random = self.query_strategy == "random"
+        pending = []      # (x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w), rand map | None)
         inflight = []     # at most one launched-but-unfinished batch of the pipelined path
         want_any_stats = not human_labels
         # Low-resolution scoring, no reverse-order sampling: the GPU work of a batch is only ENQUEUED by flush(); its results
@@ -175,7 +193,7 @@ class QuerySelector:
         # that host half, image by image in loader order, so its numpy RNG sequence is the reference's; the reverse-order
         # mode draws BEFORE scoring and keeps the strict per-batch order.
         pipelined = (QUERY_PIPELINE and FUSED_LOWRES and not self.use_mc_dropout and hasattr(model, "forward_lowres")
-                     and not self.reverse_order and torch.device(self.device).type == "cuda")
+                     and not self.reverse_order and not is_random and torch.device(self.device).type == "cuda")
         copy_stream = self.__dict__.get("_copy_stream")
         if pipelined and copy_stream is None:
             copy_stream = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
@@ -187,7 +205,7 @@ class QuerySelector:
             ev.synchronize()
             idx_h = idx_host.numpy().astype(np.int64)
             ent_h = ent_host.numpy() if ent_host is not None else None
-            for j, (_, yj, _, p_img, _) in enumerate(items):
+            for j, (_, yj, _, p_img, _, _) in enumerate(items):
                 if self.top_n_percent > 0.:
                     # query.py:63-64 `np.random.choice(ind, n_pixels_by_us, False)`: numpy draws permutation(len)[:n] and
                     # indexes the array with it, so drawing the POSITIONS consumes the same random numbers and picks the same
@@ -247,6 +265,11 @@ class QuerySelector:
                 return
             if inflight:
                 finish(inflight.pop())
+            if pipelined:                                      # images were uploaded (and voc-padded) on copy_stream
+                main = torch.cuda.current_stream(self.device)
+                main.wait_stream(copy_stream)
+                for it in pending:
+                    it[0].record_stream(main)
             xs = torch.cat([it[0] for it in pending], dim=0)
             logits_b = None
             sizes = {it[4] for it in pending}
@@ -261,18 +284,23 @@ class QuerySelector:
                 # one scoring launch, one index read-back and one entropy read-back for the whole batch
                 (h, w), = sizes
                 excl = np.stack([it[2] for it in pending])
-                if self.reverse_order:
-                    for j in range(len(pending)):           # RNG draws in image order, as the per-image loop
-                        excl[j] |= ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
-                    k = self.n_pixels_by_us
-                else:
-                    k = self._k_topk(h, w)
-                if fused:
-                    idx, _, _ = acq.score_topk_lowres(low, full_size, torch.from_numpy(excl), self.query_strategy, k, crop=(h, w))
-                else:
+                if not fused:
                     lg = logits_b[:, :, :h, :w]
-                    idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, k)
-                idx_h = idx.cpu().numpy().astype(np.int64)
+                if is_random:
+                    # the forward above only feeds the statistics (the reference runs it too, query.py:190)
+                    idx_h = self._random_topk(np.stack([it[5] for it in pending]), excl)
+                else:
+                    if self.reverse_order:
+                        for j in range(len(pending)):           # RNG draws in image order, as the per-image loop
+                            excl[j] |= ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
+                        k = self.n_pixels_by_us
+                    else:
+                        k = self._k_topk(h, w)
+                    if fused:
+                        idx, _, _ = acq.score_topk_lowres(low, full_size, torch.from_numpy(excl), self.query_strategy, k, crop=(h, w))
+                    else:
+                        idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, k)
+                    idx_h = idx.cpu().numpy().astype(np.int64)
                 chosen = [np.sort(self._choose(idx_h[j])) for j in range(len(pending))]
                 want_stats = (not human_labels) and all(it[1] is not None for it in pending)
                 ent_all = None
@@ -286,7 +314,7 @@ class QuerySelector:
                         picked = lg[torch.from_numpy(img).to(dev), :, torch.from_numpy(flat // w).to(dev), torch.from_numpy(flat % w).to(dev)]
                         ent_all = acq.score_map(picked.t().reshape(1, picked.shape[1], 1, -1).contiguous(), None, "entropy").reshape(-1).cpu().numpy()
                 off = 0
-                for j, (x1, yj, exclude, p_img, _) in enumerate(pending):
+                for j, (x1, yj, exclude, p_img, _, _) in enumerate(pending):
                     sel = chosen[j]
                     query = np.zeros(h * w, dtype=np.bool_)
                     query[sel] = True
@@ -300,7 +328,7 @@ class QuerySelector:
                     dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
                 pending.clear()
                 return
-            for j, (x1, yj, exclude, p_img, (h, w)) in enumerate(pending):
+            for j, (x1, yj, exclude, p_img, (h, w), rmap) in enumerate(pending):
                 if self.use_mc_dropout:
                     # mean uncertainty / mean probability over mc_n_steps stochastic passes: the passes differ only in their
                     # dropout masks (eval-mode BatchNorm is per sample), so they run as ONE forward over mc_n_steps copies of
@@ -311,19 +339,26 @@ class QuerySelector:
                     while left > 0:
                         t = min(left, self.mc_chunk)
                         logits = self._forward_logits(model, x1.expand(t, -1, -1, -1).contiguous(), h, w)
-                        uc_map += acq.score_map(logits, None, self.query_strategy).sum(dim=0)
+                        if not is_random:
+                            uc_map += acq.score_map(logits, None, self.query_strategy).sum(dim=0)
                         prob += F.softmax(logits, dim=1).sum(dim=0, keepdim=True)
                         left -= t
-                    uc_map /= self.mc_n_steps
                     prob /= self.mc_n_steps
-                    uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0
-                    query = self._select_queries(uc_map)
+                    if is_random:                       # rmap is already the mean of the mc_n_steps host draws
+                        query = self._finish_selection(self._random_topk(rmap[None], exclude[None])[0], h, w)
+                    else:
+                        uc_map /= self.mc_n_steps
+                        uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0
+                        query = self._select_queries(uc_map)
                     logits_for_stats = None
                 else:
                     logits = logits_b[j:j + 1, :, :h, :w]
                     prob = None
                     logits_for_stats = logits
-                    query = self._select_from_logits(logits, exclude)
+                    if is_random:
+                        query = self._finish_selection(self._random_topk(rmap[None], exclude[None])[0], h, w)
+                    else:
+                        query = self._select_from_logits(logits, exclude)
                 list_queries.append(query)
                 n_pixels += query.sum()
                 if not human_labels and yj is not None:
@@ -353,16 +388,31 @@ class QuerySelector:
                 if self.dataset_name == "voc":  # query.py:171-174
                     pad_h = ceil(h / self.stride_total) * self.stride_total - h
                     pad_w = ceil(w / self.stride_total) * self.stride_total - w
-                    x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
+                    if pipelined and x.is_cuda:
+                        # x was uploaded on copy_stream: pad it THERE, so that the tensor kept in `pending` is the one the
+                        # batch reads and the un-padded upload is released on the stream that owns it (padding on the
+                        # main stream would free it for the next upload while the pad kernel is still queued)
+                        with torch.cuda.stream(copy_stream):
+                            x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
+                    else:
+                        x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
+
+                rmap = None
+                if is_random:
+                    # UncertaintySampler._random (query.py:242-244): one CPU torch.rand((1,h,w)) per image in loader order -
+                    # per stochastic pass in the MC-dropout branch (query.py:183-185 sums them; their mean is used)
+                    n_draws = self.mc_n_steps if self.use_mc_dropout else 1
+                    rmap = torch.rand((1, h, w))[0].numpy()
+                    for _ in range(n_draws - 1):
+                        rmap = rmap + torch.rand((1, h, w))[0].numpy()
+                    if n_draws > 1:
+                        rmap = rmap / np.float32(n_draws)
 
                 if pending and (pending[0][0].shape != x.shape or len(pending) >= self.query_batch_size):
                     flush()
-                pending.append((x, y, exclude, dict_data["p_img"][0], (h, w)))
+                pending.append((x, y, exclude, dict_data["p_img"][0], (h, w), rmap))
                 if len(pending) >= self.query_batch_size:
                     flush()
-
-                if self.debug:
-                    break
             flush()
             if inflight:
                 finish(inflight.pop())

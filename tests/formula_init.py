@@ -24,25 +24,27 @@ def fill(shape, key: str, lo: float, hi: float) -> torch.Tensor:
     return torch.from_numpy((lo + (hi - lo) * u).astype(np.float32)).reshape(tuple(shape))
 
 
-def formula_state_dict(template: dict) -> dict:
-    """template: a state_dict (reference layout: conv OIHW) -> same keys/shapes with formula values."""
+def formula_state_dict(template: dict, salt: str = "") -> dict:
+    """template: a state_dict (reference layout: conv OIHW) -> same keys/shapes with formula values.  `salt` selects
+    another member of the family (the well-conditioned fixtures search over it, tools/gen_golden_net_tight.py)."""
     out = {}
-    for k, v in template.items():
+    for k0, v in template.items():
+        k = k0 + salt
         shape = tuple(v.shape)
-        if k.endswith("num_batches_tracked"):
-            out[k] = torch.zeros((), dtype=torch.long)
-        elif k.endswith("running_mean"):
-            out[k] = fill(shape, k, -0.2, 0.2)
-        elif k.endswith("running_var"):
-            out[k] = fill(shape, k, 0.6, 1.6)
+        if k0.endswith("num_batches_tracked"):
+            out[k0] = torch.zeros((), dtype=torch.long)
+        elif k0.endswith("running_mean"):
+            out[k0] = fill(shape, k, -0.2, 0.2)
+        elif k0.endswith("running_var"):
+            out[k0] = fill(shape, k, 0.6, 1.6)
         elif v.dim() == 4:                               # conv weight OIHW: variance-preserving uniform
             fan_in = shape[1] * shape[2] * shape[3]
             a = float(np.sqrt(6.0 / fan_in))             # He-uniform
-            out[k] = fill(shape, k, -a, a)
-        elif k.endswith("weight"):                       # BN / GN gamma
-            out[k] = fill(shape, k, 0.7, 1.3)
+            out[k0] = fill(shape, k, -a, a)
+        elif k0.endswith("weight"):                      # BN / GN gamma
+            out[k0] = fill(shape, k, 0.7, 1.3)
         else:                                            # biases, BN beta
-            out[k] = fill(shape, k, -0.2, 0.2)
+            out[k0] = fill(shape, k, -0.2, 0.2)
     return out
 
 

@@ -1,0 +1,198 @@
+"""Layer-by-layer ("teacher-forced") parity harness: the HIP network against the plain-PyTorch oracle at FULL chain depth.
+
+Why it exists.  A free-running comparison of a 60-layer train-mode-BatchNorm network in fp32 cannot be tight: every
+BatchNorm removes the per-channel mean of an all-positive (post-ReLU) signal, so rounding noise grows relative to the
+signal by ~sqrt(E[x^2]/Var[x]) ~ 1.2 per layer - measured on the GPU box: 5e-7 after the stem, 1e-4 .. 1e-3 of a layer's
+standard deviation at the segmentation head, for the HIP kernels AND for torch fp32 against torch fp64 alike
+(tools/act_deviation.py).  A few ReLU units within that distance of their threshold then take the other branch, and
+one flipped unit moves a sparse-label gradient tensor by 1e-3 .. 1e-2.  None of that says anything about a kernel.
+
+What this harness does instead: run the oracle once (forward + backward, hooks keep every convolution output, every
+normalisation+activation output and the gradient that arrives at each of them), then run the HIP network and, after
+EVERY convolution / BatchNorm(+residual+activation) / GroupNorm+ReLU, (1) compare the HIP result with the oracle's
+tensor and (2) overwrite it with the oracle's, so that the next layer starts from the oracle's activations; in the
+backward sweep the gradient arriving at every such layer is (1) compared with the oracle's and (2) replaced by it.
+Each layer's forward, backward-data and backward-weight kernels are therefore checked on the oracle's inputs, in the
+place and with the data they see in the real network, and rounding noise cannot compound: the errors are those of ONE
+layer (~1e-6) and the bar can be tight (1e-4, no noise term) for every activation, every arriving gradient and every
+one of the 182 / 213 parameter gradients.  The glue between forced sites (bilinear, concat, residual adds, global
+pooling, max pooling, the loss) is NOT forced, so it is covered by the comparison at the next site.
+
+`force=False` turns the overwriting off (free-running): same bookkeeping, used to count flipped ReLU units and to
+report how far the compounded noise goes.
+
+Test infrastructure only (imports oracle/)."""
+import numpy as np
+import torch
+
+from pixelpick_amd import engine as E
+from pixelpick_amd.networks import decoders as D
+from pixelpick_amd.networks import layers as L
+
+_ACTS = (torch.nn.ReLU, torch.nn.ReLU6)
+_HOOKED = (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.GroupNorm) + _ACTS
+
+
+class OracleTrace:
+    """Forward outputs and arriving gradients of every conv / norm / activation module of a plain-PyTorch model."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.model = model
+        self.fwd, self.grad = {}, {}
+        self._hooks = []
+        for name, mod in model.named_modules():
+            if isinstance(mod, _HOOKED):
+                self._hooks.append(mod.register_forward_hook(self._make(name)))
+
+    def _make(self, name):
+        def hook(mod, inp, out):
+            assert name not in self.fwd, f"{name} executed twice"
+            self.fwd[name] = out.detach()
+            if out.requires_grad:
+                out.register_hook(lambda g, n=name: self.grad.__setitem__(n, g.detach()))
+        return hook
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+
+    def site(self, norm_name: str) -> str:
+        """Name of the module whose output is what the HIP BatchNorm/GroupNorm node `norm_name` produces: the activation
+        behind it (for a Bottleneck's bn3 the ReLU behind the residual add), or the normalisation itself."""
+        parent_name, _, child = norm_name.rpartition(".")
+        parent = self.model.get_submodule(parent_name) if parent_name else self.model
+        if child.startswith("bn") and child[2:] and isinstance(getattr(parent, "relu" + child[2:], None), _ACTS):
+            return f"{parent_name}.relu{child[2:]}"
+        kids = list(parent.named_children())
+        i = [n for n, _ in kids].index(child)
+        if i + 1 < len(kids) and isinstance(kids[i + 1][1], _ACTS):
+            return f"{parent_name}.{kids[i + 1][0]}"
+        return norm_name
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    nb = b.norm().item()
+    return (a - b).norm().item() / nb if nb > 0 else (a.norm().item())
+
+
+def _nhwc(t: torch.Tensor, device) -> torch.Tensor:
+    return t.permute(0, 2, 3, 1).contiguous().to(device)
+
+
+def _to_oihw(g: torch.Tensor) -> torch.Tensor:
+    if g.dim() == 4:
+        return g.permute(3, 2, 0, 1)
+    if g.dim() == 3:
+        return g.permute(2, 0, 1).unsqueeze(1)
+    return g
+
+
+class LayerwiseParity:
+    """Context manager: patches the layer entry points of pixelpick_amd while a HIP forward/backward runs."""
+
+    def __init__(self, hip_model: torch.nn.Module, trace: OracleTrace, force: bool = True):
+        self.m, self.tr, self.force = hip_model, trace, force
+        self.mod_name = {id(mod): n for n, mod in hip_model.named_modules()}
+        self.param_owner = {}
+        for n, p in hip_model.named_parameters():
+            self.param_owner[id(p)] = n.rpartition(".")[0]
+        self.rec = []                  # (kind, name, error, numel)
+        self.flips = {}                # norm name -> (flipped units, units)
+        self.dev = next(hip_model.parameters()).device
+
+    # ------------------------------------------------------------------ forward sites
+    def _fwd_site(self, kind, name, site, out, act=None):
+        ref = _nhwc(self.tr.fwd[site], self.dev)
+        got = out.t
+        assert tuple(got.shape) == tuple(ref.shape), f"{name}: {tuple(got.shape)} vs oracle {tuple(ref.shape)}"
+        self.rec.append((kind, name, rel_l2(got, ref), got.numel()))
+        if act is not None and act != E.ACT_NONE:
+            hi = 6.0 if act == E.ACT_RELU6 else float("inf")
+            on_g, on_r = (got > 0) & (got < hi), (ref > 0) & (ref < hi)
+            self.flips[name] = (int((on_g != on_r).sum().item()), got.numel())
+        if self.force:
+            got.copy_(ref)
+
+    def __enter__(self):
+        me = self
+        self._saved = (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd)
+        conv_run, bn_run, gn_run, conv_bwd, dw_bwd, bn_bwd, gn_bwd = self._saved
+
+        def conv_run_p(self, tape, x, dst=None, extra_pad=0):
+            out = conv_run(self, tape, x, dst, extra_pad)
+            n = me.mod_name[id(self)]
+            me._fwd_site("conv", n, n, out)
+            return out
+
+        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None):
+            out = bn_run(self, tape, x, act, residual, dst, dropout)
+            n = me.mod_name[id(self)]
+            site = me.tr.site(n)
+            assert (site != n) == (act != E.ACT_NONE), f"{n}: activation site mismatch ({site}, act {act})"
+            me._fwd_site("norm", n, site, out, act)
+            return out
+
+        def gn_run_p(self, tape, x, relu=True):
+            out = gn_run(self, tape, x, relu)
+            n = me.mod_name[id(self)]
+            me._fwd_site("norm", n, me.tr.site(n), out, E.ACT_RELU if relu else E.ACT_NONE)
+            return out
+
+        def arriving(name, site, dy):
+            ref = _nhwc(me.tr.grad[site], me.dev)
+            me.rec.append(("dy", name, rel_l2(dy, ref), ref.numel()))
+            return ref if me.force else dy
+
+        def conv_bwd_p(tape, dy, x, w, *rest):
+            n = me.param_owner[id(w)]
+            return conv_bwd(tape, arriving(n, n, dy), x, w, *rest)
+
+        def dw_bwd_p(tape, dy, x, w, *rest):
+            n = me.param_owner[id(w)]
+            return dw_bwd(tape, arriving(n, n, dy), x, w, *rest)
+
+        def bn_bwd_p(tape, dy, x, gamma, *rest):
+            n = me.param_owner[id(gamma)]
+            return bn_bwd(tape, arriving(n, me.tr.site(n), dy), x, gamma, *rest)
+
+        def gn_bwd_p(tape, dy, x, gamma, *rest):
+            n = me.param_owner[id(gamma)]
+            return gn_bwd(tape, arriving(n, me.tr.site(n), dy), x, gamma, *rest)
+
+        L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run = conv_run_p, bn_run_p, gn_run_p
+        E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd = conv_bwd_p, dw_bwd_p, bn_bwd_p, gn_bwd_p
+        return self
+
+    def __exit__(self, *exc):
+        (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd) = self._saved
+        return False
+
+    # ------------------------------------------------------------------ after the sweep
+    def compare_param_grads(self, grads_by_name: dict):
+        """grads_by_name: parameter name -> HIP gradient (kernel layout).  Against oracle_param.grad, rel-L2 per tensor."""
+        torch.cuda.synchronize()
+        oracle = dict(self.tr.model.named_parameters())
+        for n, g in grads_by_name.items():
+            ref = oracle[n].grad
+            got = _to_oihw(g).cpu()
+            assert tuple(got.shape) == tuple(ref.shape), n
+            self.rec.append(("param_grad", n, rel_l2(got, ref), ref.numel()))
+
+    def worst(self, kind):
+        rows = [r for r in self.rec if r[0] == kind]
+        return max(rows, key=lambda r: r[2]) if rows else None
+
+    def summary(self) -> str:
+        out = []
+        for kind in ("conv", "norm", "dy", "param_grad"):
+            rows = [r for r in self.rec if r[0] == kind]
+            if not rows:
+                continue
+            errs = np.array([r[2] for r in rows])
+            w = max(rows, key=lambda r: r[2])
+            out.append(f"{kind:10s} n={len(rows):3d} median {np.median(errs):.2e} max {errs.max():.2e} ({w[1]})")
+        nfl = sum(f for f, _ in self.flips.values())
+        nun = sum(u for _, u in self.flips.values())
+        out.append(f"activation units {nun}, branch differs on {nfl}")
+        return "\n".join(out)

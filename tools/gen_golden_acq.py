@@ -429,6 +429,75 @@ def gen_branches():
     print("branches written")
 
 
+def gen_random():
+    """args.py:27 `random` strategy through QuerySelector.__call__ (query.py:190-204,242-247): the score map is a CPU
+    torch.rand((1,h,w)) per image, excluded pixels are filled with 1.0 and the k smallest win.  Three modes: k = 20,
+    top-5 % + numpy sub-sample, reverse order.  torch / numpy seeds are part of the fixture."""
+    out = {}
+    C, h, w, n_img = 19, 40, 56, 3
+    for mode, kw in (("k20", dict(k=20)), ("top5", dict(k=10, top_n_percent=0.05)),
+                     ("rev", dict(k=10, top_n_percent=0.05, reverse_order=True))):
+        seed = 300
+        while True:
+            torch.manual_seed(seed)
+            rng = np.random.RandomState(seed)
+            W = torch.randn(C, 3, 1, 1) * 2.0
+            Bv = torch.randn(C) * 0.5
+            xs = [torch.randn(3, h, w) * 1.5 for _ in range(n_img)]
+            ys = [torch.from_numpy(rng.randint(0, C + 1, size=(h, w)).astype(np.int64)) for _ in range(n_img)]
+            prev = []
+            for _ in range(n_img):
+                q = np.zeros((h, w), dtype=bool)
+                q.reshape(-1)[rng.choice(h * w, 30, replace=False)] = True
+                prev.append(q)
+            # gap guard on the maps the selector is going to draw (no other consumer of the torch CPU RNG in between)
+            torch.manual_seed(seed + 1000)
+            np.random.seed(seed + 2000)
+            ok = True
+            for i in range(n_img):
+                uc = torch.rand((1, h, w))[0]
+                uc[torch.from_numpy(prev[i])] = 1.0
+                uc[ys[i] == C] = 1.0
+                uc = uc.flatten()
+                if mode == "rev":
+                    k5 = int(h * w * 0.05)
+                    cand = np.random.choice(range(h * w), k5, False)
+                    sm = np.zeros(h * w, dtype=bool)
+                    sm[cand] = True
+                    uc[torch.from_numpy(~sm)] = 1.0
+                    n_chk = kw["k"] + 1
+                else:
+                    n_chk = (int(h * w * 0.05) if mode == "top5" else kw["k"]) + 1
+                srt = torch.sort(uc).values.numpy()
+                if not all_gaps_ok(srt[:n_chk]) or srt[n_chk - 1] >= 1.0:
+                    ok = False
+            if ok:
+                break
+            seed += 1
+        names = [f"/data/rnd_{i:03d}.png" for i in range(n_img)]
+        ds = FakeDataset(xs, ys, prev, names)
+        with tempfile.TemporaryDirectory() as td:
+            args = mk_args("random", C, dir_root=td, **kw)
+            qs = refq.QuerySelector(args, FakeLoader(ds), device=torch.device("cpu"))
+            torch.manual_seed(seed + 1000)
+            np.random.seed(seed + 2000)
+            dq = qs(nth_query=1, model=OneConv(W, Bv))
+            stats = pkl.load(open(f"{td}/checkpoints/golden/1_query/query_stats.pkl", "rb"))
+        out[f"{mode}_seed"] = np.int64(seed)
+        out[f"{mode}_W"], out[f"{mode}_b"] = W.numpy(), Bv.numpy()
+        out[f"{mode}_xs"], out[f"{mode}_ys"], out[f"{mode}_prev"] = torch.stack(xs).numpy(), torch.stack(ys).numpy(), np.stack(prev)
+        for i, nme in enumerate(names):
+            out[f"{mode}_x_{i}"] = np.asarray(dq[nme]["x_coords"], dtype=np.int64)
+            out[f"{mode}_y_{i}"] = np.asarray(dq[nme]["y_coords"], dtype=np.int64)
+            assert len(dq[nme]["x_coords"]) == kw["k"]
+        out[f"{mode}_stats_label_cnt"] = np.array([stats["label_distribution"][l] for l in range(C)], dtype=np.int64)
+        out[f"{mode}_stats_avg_entropy"] = np.float64(stats["avg_entropy"])
+        out[f"{mode}_stats_avg_cov"] = np.float64(stats["avg_spatial_coverage"])
+        print("random", mode, "seed", seed)
+    np.savez_compressed(os.path.join(OUT, "acq_random.npz"), **out)
+    print("random written")
+
+
 def gen_lowres():
     """SURVEY.md §8f-1 fixture: low-resolution classifier logits -> deeplab.py:55-56 F.interpolate(bilinear,
     align_corners=True) -> [:h,:w] crop (query.py:190) -> reference sampler + _select_queries."""
@@ -482,6 +551,9 @@ def gen_lowres():
 if __name__ == "__main__":
     if "--lowres" in sys.argv:
         gen_lowres()
+        sys.exit(0)
+    if "--random" in sys.argv:
+        gen_random()
         sys.exit(0)
     if "--branches" in sys.argv:
         gen_branches()
