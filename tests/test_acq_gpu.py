@@ -274,6 +274,42 @@ def test_query_selector_end_to_end_matches_reference(golden_dir, st):
     assert ds.labelled is not None and ds.labelled[1] == 1
 
 
+@pytest.mark.parametrize("bs", [1, 3])
+@pytest.mark.parametrize("mode,kw", [("k20", dict(n_pixels_by_us=20)), ("top5", dict(n_pixels_by_us=10, top_n_percent=0.05)),
+                                     ("rev", dict(n_pixels_by_us=10, top_n_percent=0.05, reverse_order=True))])
+def test_query_selector_random_strategy_matches_reference(golden_dir, mode, kw, bs):
+    """args.py:27 `random` through QuerySelector.__call__ (query.py:190-204,242-247): host torch.rand map per image, fill
+    1.0, k smallest; fixture from the imported reference with the torch / numpy seeds it was drawn under."""
+    gr = np.load(os.path.join(golden_dir, "acq_random.npz"))
+    seed = int(gr[f"{mode}_seed"])
+    names = [f"/data/rnd_{i:03d}.png" for i in range(3)]
+    ds = _DS(torch.from_numpy(gr[f"{mode}_xs"]), torch.from_numpy(gr[f"{mode}_ys"]), list(gr[f"{mode}_prev"]), names)
+    model = _OneConv(torch.from_numpy(gr[f"{mode}_W"]).to(DEV), torch.from_numpy(gr[f"{mode}_b"]).to(DEV))
+    with tempfile.TemporaryDirectory() as td:
+        qs = ppq.QuerySelector(_args(query_strategy="random", dir_root=td, query_batch_size=bs, **kw), _DL(ds),
+                               device=torch.device(DEV))
+        torch.manual_seed(seed + 1000)
+        np.random.seed(seed + 2000)
+        dq = qs(nth_query=1, model=model)
+        import pickle
+        stats = pickle.load(open(f"{td}/checkpoints/golden/1_query/query_stats.pkl", "rb"))
+    for i, n in enumerate(names):
+        np.testing.assert_array_equal(dq[n]["x_coords"], gr[f"{mode}_x_{i}"])
+        np.testing.assert_array_equal(dq[n]["y_coords"], gr[f"{mode}_y_{i}"])
+        picked = np.zeros((40, 56), bool)
+        picked[dq[n]["y_coords"], dq[n]["x_coords"]] = True
+        assert not (picked & (gr[f"{mode}_prev"][i] | (gr[f"{mode}_ys"][i] == 19))).any()
+    np.testing.assert_array_equal(np.array([stats["label_distribution"][l] for l in range(19)]), gr[f"{mode}_stats_label_cnt"])
+    assert abs(stats["avg_entropy"] - float(gr[f"{mode}_stats_avg_entropy"])) < 1e-5
+    assert abs(stats["avg_spatial_coverage"] - float(gr[f"{mode}_stats_avg_cov"])) < 1e-9
+    assert ds.labelled is not None
+
+
+def test_random_strategy_has_no_score_kernel():
+    with pytest.raises(ValueError):
+        acq.score_topk(torch.zeros(1, 19, 8, 8, device=DEV), None, "random", 4)
+
+
 # ---------------------------------------------------------------- full-size, size-independent properties
 @pytest.mark.parametrize("st,shape", [("entropy", (8, 19, 256, 512)), ("margin_sampling", (4, 21, 320, 320)),
                                        ("least_confidence", (1, 19, 1024, 2048))])
