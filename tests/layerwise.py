@@ -19,7 +19,10 @@ one of the 182 / 213 parameter gradients.  The glue between forced sites (biline
 pooling, max pooling, the loss) is NOT forced, so it is covered by the comparison at the next site.
 
 `force=False` turns the overwriting off (free-running): same bookkeeping, used to count flipped ReLU units and to
-report how far the compounded noise goes.
+report how far the compounded noise goes.  `force="branch"` is the free-running network with ONE intervention: the
+handful of ReLU/ReLU6 units (tens out of millions) whose branch differs from the oracle's are put on the oracle's side.
+The function both sides evaluate is then the same smooth one, values and gradients still flow through all layers with
+the HIP kernels' own rounding, and the remaining deviation is compounded rounding noise only (no discontinuity).
 
 Test infrastructure only (imports oracle/)."""
 import numpy as np
@@ -41,7 +44,9 @@ class OracleTrace:
         self.fwd, self.grad = {}, {}
         self._hooks = []
         for name, mod in model.named_modules():
-            if isinstance(mod, _HOOKED):
+            # _InvertedResidual: its output (x + conv(x_pad) when it has a residual connection) is what the HIP project
+            # BatchNorm node with the fused residual add produces
+            if isinstance(mod, _HOOKED) or type(mod).__name__ == "_InvertedResidual":
                 self._hooks.append(mod.register_forward_hook(self._make(name)))
 
     def _make(self, name):
@@ -56,10 +61,13 @@ class OracleTrace:
         for h in self._hooks:
             h.remove()
 
-    def site(self, norm_name: str) -> str:
+    def site(self, norm_name: str, residual: bool = False) -> str:
         """Name of the module whose output is what the HIP BatchNorm/GroupNorm node `norm_name` produces: the activation
-        behind it (for a Bottleneck's bn3 the ReLU behind the residual add), or the normalisation itself."""
+        behind it (for a Bottleneck's bn3 the ReLU behind the residual add), the enclosing InvertedResidual block when the
+        node adds the block's input (mobilenet_v2.py:62-63), or the normalisation itself."""
         parent_name, _, child = norm_name.rpartition(".")
+        if residual and parent_name.endswith(".conv") and type(self.model.get_submodule(parent_name[:-5])).__name__ == "_InvertedResidual":
+            return parent_name[:-5]
         parent = self.model.get_submodule(parent_name) if parent_name else self.model
         if child.startswith("bn") and child[2:] and isinstance(getattr(parent, "relu" + child[2:], None), _ACTS):
             return f"{parent_name}.relu{child[2:]}"
@@ -99,10 +107,11 @@ class LayerwiseParity:
             self.param_owner[id(p)] = n.rpartition(".")[0]
         self.rec = []                  # (kind, name, error, numel)
         self.flips = {}                # norm name -> (flipped units, units)
+        self.res_nodes = {}            # norm name -> node adds a residual
         self.dev = next(hip_model.parameters()).device
 
     # ------------------------------------------------------------------ forward sites
-    def _fwd_site(self, kind, name, site, out, act=None):
+    def _fwd_site(self, kind, name, site, out, act=None, bn_ctx=None):
         ref = _nhwc(self.tr.fwd[site], self.dev)
         got = out.t
         assert tuple(got.shape) == tuple(ref.shape), f"{name}: {tuple(got.shape)} vs oracle {tuple(ref.shape)}"
@@ -110,8 +119,25 @@ class LayerwiseParity:
         if act is not None and act != E.ACT_NONE:
             hi = 6.0 if act == E.ACT_RELU6 else float("inf")
             on_g, on_r = (got > 0) & (got < hi), (ref > 0) & (ref < hi)
-            self.flips[name] = (int((on_g != on_r).sum().item()), got.numel())
-        if self.force:
+            flipped = on_g != on_r
+            nfl = int(flipped.sum().item())
+            self.flips[name] = (nfl, got.numel())
+            if self.force and nfl:
+                # ONLY the units whose ReLU/ReLU6 branch differs from the oracle's are put on the oracle's side: their
+                # output, and - BatchNorm without residual recomputes its backward mask from its input - the input
+                # value, moved just far enough (1e-5) that the recomputed pre-activation lands where the oracle's did.
+                # In "branch" mode everything else keeps the HIP values, so rounding still compounds through all layers;
+                # in forced mode this only matters for the unit or two (of ~1e8) that sit within 1e-7 of a threshold.
+                got[flipped] = ref[flipped]
+                if bn_ctx is not None:
+                    x_in, gamma, beta, mean, invstd = bn_ctx
+                    c = flipped.nonzero()[:, 3]
+                    r = ref[flipped]
+                    eps = 1e-5
+                    target = torch.where(r <= 0, torch.full_like(r, -eps),
+                                         torch.where(r >= hi, torch.full_like(r, hi + eps), r.clamp(eps, hi - eps)))
+                    x_in.t[flipped] = mean[c] + (target - beta.detach()[c]) / (gamma.detach()[c] * invstd[c])
+        if self.force is True:
             got.copy_(ref)
 
     def __enter__(self):
@@ -128,9 +154,16 @@ class LayerwiseParity:
         def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None):
             out = bn_run(self, tape, x, act, residual, dst, dropout)
             n = me.mod_name[id(self)]
-            site = me.tr.site(n)
-            assert (site != n) == (act != E.ACT_NONE), f"{n}: activation site mismatch ({site}, act {act})"
-            me._fwd_site("norm", n, site, out, act)
+            site = me.tr.site(n, residual is not None)
+            me.res_nodes[n] = residual is not None
+            assert (site != n) == (act != E.ACT_NONE or (residual is not None and ".conv." in n)), \
+                f"{n}: activation site mismatch ({site}, act {act})"
+            ctx = None
+            if tape.enabled and residual is None and act != E.ACT_NONE:
+                fn, c, _ = tape.nodes[-1]
+                assert c[1] is self.weight, "the BatchNorm node is expected to be the last one on the tape"
+                ctx = (c[0], c[1], c[2], c[3], c[4])            # x, gamma, beta, mean, invstd
+            me._fwd_site("norm", n, site, out, act, ctx)
             return out
 
         def gn_run_p(self, tape, x, relu=True):
@@ -142,7 +175,7 @@ class LayerwiseParity:
         def arriving(name, site, dy):
             ref = _nhwc(me.tr.grad[site], me.dev)
             me.rec.append(("dy", name, rel_l2(dy, ref), ref.numel()))
-            return ref if me.force else dy
+            return ref if me.force is True else dy
 
         def conv_bwd_p(tape, dy, x, w, *rest):
             n = me.param_owner[id(w)]
@@ -154,7 +187,7 @@ class LayerwiseParity:
 
         def bn_bwd_p(tape, dy, x, gamma, *rest):
             n = me.param_owner[id(gamma)]
-            return bn_bwd(tape, arriving(n, me.tr.site(n), dy), x, gamma, *rest)
+            return bn_bwd(tape, arriving(n, me.tr.site(n, me.res_nodes[n]), dy), x, gamma, *rest)
 
         def gn_bwd_p(tape, dy, x, gamma, *rest):
             n = me.param_owner[id(gamma)]
@@ -169,15 +202,29 @@ class LayerwiseParity:
         return False
 
     # ------------------------------------------------------------------ after the sweep
-    def compare_param_grads(self, grads_by_name: dict):
-        """grads_by_name: parameter name -> HIP gradient (kernel layout).  Against oracle_param.grad, rel-L2 per tensor."""
+    def compare_param_grads(self, grads_by_name: dict, oracle_grads: dict = None):
+        """grads_by_name: parameter name -> HIP gradient (kernel layout).  Against oracle_param.grad, rel-L2 per tensor.
+
+        Normalisation parameters: d(beta) = sum over pixels of the arriving gradient, d(gamma) = sum of gradient x xhat.
+        Where the loss is analytically invariant to that parameter the true value is ~0 and what either side holds is the
+        cancellation residue of the sum (e.g. the beta of the LAST backbone BatchNorm: every consumer is conv -> train-mode
+        BatchNorm, which removes a per-channel constant again - at 64x96 its gradient is 1e-6 of the terms it sums).  A
+        ratio of two residues says nothing, so for these 1-d tensors the denominator is at least 1e-3 of the L2 norm of
+        the per-channel ABSOLUTE sums of the terms: the bar stays "2e-4 of the tensor" for every gradient that is a
+        gradient and becomes "2e-7 of the summed magnitudes" (a few fp32 ulps of the accumulation) for a residue."""
         torch.cuda.synchronize()
-        oracle = dict(self.tr.model.named_parameters())
+        oracle = oracle_grads or {n: p.grad for n, p in self.tr.model.named_parameters()}
         for n, g in grads_by_name.items():
-            ref = oracle[n].grad
+            ref = oracle[n]
             got = _to_oihw(g).cpu()
             assert tuple(got.shape) == tuple(ref.shape), n
-            self.rec.append(("param_grad", n, rel_l2(got, ref), ref.numel()))
+            owner = n.rpartition(".")[0]
+            floor = 0.0
+            if ref.dim() == 1 and owner in self.res_nodes:
+                dy = self.tr.grad[self.tr.site(owner, self.res_nodes[owner])]
+                floor = 1e-3 * dy.abs().sum(dim=(0, 2, 3)).double().norm().item()
+            num = (got.double() - ref.double()).norm().item()
+            self.rec.append(("param_grad", n, num / max(ref.double().norm().item(), floor, 1e-300), ref.numel()))
 
     def worst(self, kind):
         rows = [r for r in self.rec if r[0] == kind]

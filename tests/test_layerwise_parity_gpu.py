@@ -2,11 +2,17 @@
 the method): every convolution output, every BatchNorm/GroupNorm(+residual+activation) output, the gradient arriving at
 each of them and every parameter gradient of DeepLabv3+-MobileNetV2 (182) and FPN-ResNet50 (213) against the
 plain-PyTorch oracle ON THE ORACLE'S OWN INPUTS for that layer (reference: model.py:113-121 forward, cross_entropy,
-backward).  The oracle is pinned to the imported reference by tests/test_oracle_net_golden.py and
-tests/test_oracle_tight_golden.py (CPU suite).
+backward).  The oracle is pinned to the imported reference module by module - outputs, arriving gradients, parameter
+gradients, bit for bit - by tests/test_oracle_trace_golden.py (CPU suite).
 
-Bars (rel-L2 per tensor, NO noise allowance): forward sites 1e-4, arriving gradients and parameter gradients 2e-4
-(observed: ~1e-6; see the printed summaries)."""
+Three modes (tests/layerwise.py):
+  forced         every layer starts from the oracle's activation / arriving gradient: errors are those of ONE layer.
+                 Bars (rel-L2 per tensor, NO noise allowance): forward sites 1e-4, arriving and parameter gradients 2e-4;
+                 measured <= 2e-6 and <= 6e-6.
+  branch-forced  the network runs FREE (nothing overwritten, rounding compounds through all layers, forward and backward)
+                 except that the few ReLU/ReLU6 units whose branch differs from the oracle's run (tens out of 1e7..1e8)
+                 are put on the oracle's side: every one of the 182 / 213 parameter gradients within 5e-4, no noise term.
+  free-running   reported: how many units flip and what that does to a sparse-label gradient (1e-2, every tensor alike)."""
 import warnings
 from argparse import Namespace
 
@@ -25,6 +31,10 @@ from pixelpick_amd.utils.utils import get_model
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL_FWD, TOL_GRAD = 1e-4, 2e-4
+# branch-aligned free-running network: measured worst parameter gradient 5.4e-5 (DeepLab 128x192), 4.7e-5 (DeepLab 256x512),
+# 1.0e-4 (FPN 64x96) against the fp32 oracle; 3.2e-5 / 6.5e-5 / 6.0e-5 against the oracle evaluated in fp64
+# (profiles/r02_layerwise_parity.txt).  The bar is half the north_star's 1e-3 and carries no noise term.
+TOL_BRANCH = 5e-4
 
 
 def _models(network, C, salt=""):
@@ -107,7 +117,10 @@ def test_free_running_noise_is_reported_and_bounded(network, n_params, B, H, W):
     """Same bookkeeping WITHOUT forcing: how far fp32 rounding compounds through the train-mode network and how many
     ReLU/ReLU6 units end up on the other branch than in the oracle's run.  Bounds here are those of the phenomenon (the
     oracle's own fp32-vs-fp64 deviation has the same size, tools/act_deviation.py), not kernel bars: flipped units
-    <= 2e-5 of all units, median parameter-gradient rel-L2 <= 5e-3."""
+    <= 2e-5 of all units.  The gradients are dominated by a handful of flipped units at the segmentation head: with 20
+    labelled pixels per image the gradient entering the last ReLU lives on 80 pixels x 256 channels = 20 K units, so ONE
+    flipped unit there is 1/sqrt(20 K) = 0.7 % of every downstream gradient tensor (1.3e-2 .. 1.5e-2 measured, every
+    tensor alike - see the branch-forced test below for the same run without that discontinuity)."""
     lp, loss, o_loss, m, o = _run(network, 19, 19, B, H, W, 20, force=False, key="free")
     print("\n[free-running] " + lp.summary().replace("\n", "\n[free-running] "))
     assert abs(loss - o_loss) <= 1e-3 * max(1.0, abs(o_loss))
@@ -115,4 +128,18 @@ def test_free_running_noise_is_reported_and_bounded(network, n_params, B, H, W):
     nun = sum(u for _, u in lp.flips.values())
     assert nfl <= max(4, 2e-5 * nun), (nfl, nun)
     errs = np.array([e for k, _, e, _ in lp.rec if k == "param_grad"])
-    assert len(errs) == n_params and np.median(errs) <= 5e-3
+    assert len(errs) == n_params and np.median(errs) <= 5e-2
+
+
+@pytest.mark.parametrize("network,n_params,B,H,W", [("deeplab", 182, 4, 128, 192), ("deeplab", 182, 4, 256, 512), ("FPN", 213, 2, 64, 96)])
+def test_branch_forced_free_running_gradients_are_tight(network, n_params, B, H, W):
+    """The whole network FREE-RUNNING (no tensor is overwritten, rounding compounds through all 60 layers forward and
+    backward) with one intervention: the few ReLU/ReLU6 units whose branch differs from the oracle's run are put on the
+    oracle's side, so both sides differentiate the same piecewise-linear function.  What is left is compounded fp32
+    rounding: every parameter gradient within TOL_BRANCH rel-L2 of the oracle's, no noise term."""
+    lp, loss, o_loss, m, o = _run(network, 19, 19, B, H, W, 20, force="branch", key="free")
+    print("\n[branch-forced] " + lp.summary().replace("\n", "\n[branch-forced] "))
+    errs = sorted(((e, n) for k, n, e, _ in lp.rec if k == "param_grad"), reverse=True)
+    print("[branch-forced] worst parameter gradients:", [(n, f"{e:.2e}") for e, n in errs[:5]])
+    assert len(errs) == n_params
+    assert errs[0][0] <= TOL_BRANCH, errs[:8]
