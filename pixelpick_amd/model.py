@@ -61,6 +61,15 @@ class Model:
         self.dataloader, self.dataloader_query, self.dataloader_val = dataloader, dataloader_query, dataloader_val
         self.lr_scheduler_type = args.lr_scheduler_type
         self.query_selector = QuerySelector(args, self.dataloader_query, device=self.device)
+        # Data parallel (the reference is single-process): with torch.distributed initialised every rank runs this
+        # same driver on its own GPU.  Train batches and validation images are taken round-robin (batch i -> rank i mod W;
+        # the loaders must yield the SAME order on every rank - seed them identically - so that the shards are disjoint),
+        # gradients are averaged by FlatTrainer's all-reduce, confusion matrices are summed over ranks, BatchNorm running
+        # statistics are broadcast from rank 0 at the end of every epoch, the acquisition round is sharded by QuerySelector
+        # and only rank 0 writes files.
+        self.rank, self.world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
         self.running_loss, self.running_score = AverageMeter(), RunningScore(args.n_classes)
         self.history = []
 
@@ -89,6 +98,8 @@ class Model:
 
     def _open_logs(self, d):
         self.log_train, self.log_val = f"{d}/log_train.txt", f"{d}/log_val.txt"
+        if self.rank != 0:
+            return
         write_log(self.log_train, header=["epoch", "mIoU", "pixel_acc", "loss"])
         write_log(self.log_val, header=["epoch", "mIoU", "pixel_acc"])
 
@@ -122,7 +133,16 @@ class Model:
             # model.py:144-145 calls MultiStepLR([20, 40], 0.1).step(epoch=epoch-1) at the END of every epoch, so the rate
             # in force DURING epoch E is base * 0.1^#{m <= E-2}: the drops take effect from epochs 22 and 42
             trainer.lr_factor = 0.1 ** sum(1 for m in (20, 40) if m <= epoch - 2)
+        n_batches = len(self.dataloader)
+        n_local = n_batches // self.world if n_batches >= self.world else 0      # equal step counts on every rank
+        local_it = -1
         for it, dict_data in enumerate(self.dataloader):
+            if self.world > 1:
+                if it >= n_local * self.world:
+                    break                                                   # ragged tail: dropped, like drop_last
+                if it % self.world != self.rank:
+                    continue
+            local_it += 1
             # model.py:106-108 uploads on the compute stream: a pageable copy there queues behind the previous step's kernels
             # and blocks the host until they finish, so the host could never enqueue ahead of the GPU.  Upload on a copy
             # stream instead and let the compute stream wait for it.
@@ -138,16 +158,19 @@ class Model:
                 # that boolean-index assignment performs on every step
                 y = torch.where(mask != 0, y, torch.full_like(y, self.ignore_index))
             if self.lr_scheduler_type == "Poly":                           # per-iteration poly decay (lr_scheduler.py:15-17)
-                trainer.set_poly_lr((epoch - 1) * len(self.dataloader) + it, n_iters_total)
+                trainer.set_poly_lr((epoch - 1) * self._steps_per_epoch() + local_it, n_iters_total)
             tape_pred = trainer.train_step(x, y, keep_logits=True)
             self.running_score.update_from_logits(y, trainer.last_logits)  # device-side confusion matrix (L6)
             self.running_loss.update(trainer.last_loss)
             if self.debug:
                 break
+        trainer.sync_buffers()
+        self._all_reduce_scores()
         scores = self.running_score.get_scores()[0]
         miou, pixel_acc = scores['Mean IoU'], scores['Pixel Acc']
         avg_loss = float(self.running_loss.avg) if torch.is_tensor(self.running_loss.avg) else self.running_loss.avg
-        write_log(self.log_train, list_entities=[epoch, miou, pixel_acc, avg_loss])
+        if self.rank == 0:
+            write_log(self.log_train, list_entities=[epoch, miou, pixel_acc, avg_loss])
         self.history.append(("train", self.nth_query, epoch, miou, pixel_acc, avg_loss))
         self._reset_meters()
         return model
@@ -158,7 +181,7 @@ class Model:
         kind, slow_lr, lr, wd, momentum = optimizer_spec(self.args)          # utils/utils.py:112-306, quirks included
         trainer = FlatTrainer(model, lr=lr, slow_lr=slow_lr, weight_decay=wd, optimizer=kind, momentum=momentum,
                               ignore_index=self.ignore_index)
-        n_total = self.n_epochs * len(self.dataloader)
+        n_total = self.n_epochs * self._steps_per_epoch()
         for e in range(1, 1 + self.n_epochs):
             self._train_epoch(e, model, trainer, n_total)
             self._val(e, model)
@@ -166,6 +189,22 @@ class Model:
                 break
         self.best_miou = -1.0
         return model
+
+    def _steps_per_epoch(self) -> int:
+        n = len(self.dataloader)
+        return n if self.world == 1 else (n // self.world if n >= self.world else 0)
+
+    def _all_reduce_scores(self):
+        """Sum the confusion matrices of the ranks' shards (exact integer counts) so that every rank reports the scores
+        of the whole epoch."""
+        if self.world <= 1:
+            return
+        self.running_score._sync()
+        t = torch.from_numpy(self.running_score.confusion_matrix).to(torch.float64)
+        if torch.distributed.get_backend() == "nccl":
+            t = t.to(self.device)
+        torch.distributed.all_reduce(t)
+        self.running_score.confusion_matrix = t.cpu().numpy()
 
     # ------------------------------------------------------------------ model.py:175-238
     @torch.no_grad()
@@ -193,7 +232,9 @@ class Model:
             pend_x.clear()
             pend_y.clear()
 
-        for dict_data in self.dataloader_val:
+        for iv, dict_data in enumerate(self.dataloader_val):
+            if self.world > 1 and iv % self.world != self.rank:
+                continue
             with self._upload():
                 x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
             self._uploaded(x, y)
@@ -205,13 +246,16 @@ class Model:
             if self.debug:
                 break
         flush()
+        self._all_reduce_scores()
         scores = self.running_score.get_scores()[0]
         miou, pixel_acc = scores['Mean IoU'], scores['Pixel Acc']
         if miou > self.best_miou:
             sub = f"{self.nth_query}_query" if self.n_pixels_by_us != 0 else "fully_sup"
-            torch.save({"model": model.state_dict()}, f"{self.dir_checkpoints}/{sub}/best_miou_model.pt")
+            if self.rank == 0:
+                torch.save({"model": model.state_dict()}, f"{self.dir_checkpoints}/{sub}/best_miou_model.pt")
             self.best_miou = miou
-        write_log(self.log_val, list_entities=[epoch, miou, pixel_acc])
+        if self.rank == 0:
+            write_log(self.log_val, list_entities=[epoch, miou, pixel_acc])
         self.history.append(("val", self.nth_query, epoch, miou, pixel_acc))
         self._reset_meters()
 

@@ -120,19 +120,13 @@ class QuerySelector:
                                    self.query_strategy, k)
         return self._finish_selection(idx[0].cpu().numpy().astype(np.int64), h, w)
 
-    def _random_topk(self, rmaps: np.ndarray, exclude: np.ndarray) -> np.ndarray:
+    def _random_topk(self, rmaps: np.ndarray, exclude: np.ndarray, k: int) -> np.ndarray:
         """`random` strategy (args.py:27; query.py:242-244,195-201,57-61): rmaps [n,h,w] are the host `torch.rand` maps the
-        reference's UncertaintySampler._random draws (a CPU tensor there as well), exclude bool [n,h,w].  Excluded pixels
-        are filled with 1.0 and the k SMALLEST values win; the selection runs on the GPU (pp_topk_select, ties towards the
-        lower flat index).  -> value-sorted flat indices int64 [n,k]."""
+        reference's UncertaintySampler._random draws (a CPU tensor there as well), exclude bool [n,h,w] (already or-ed with
+        the complement of the reverse-order candidate set when that mode is on).  Excluded pixels are filled with 1.0 and
+        the k SMALLEST values win; the selection runs on the GPU (pp_topk_select, ties towards the lower flat index).
+        -> value-sorted flat indices int64 [n,k]."""
         n, h, w = rmaps.shape
-        if self.reverse_order:
-            exclude = exclude.copy()
-            for j in range(n):                                  # numpy RNG draws in image order (query.py:40)
-                exclude[j] |= ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
-            k = self.n_pixels_by_us
-        else:
-            k = self._k_topk(h, w)
         rmaps = np.where(exclude, np.float32(1.0), rmaps.astype(np.float32, copy=False))
         idx, _ = acq.topk_select(torch.from_numpy(np.ascontiguousarray(rmaps.reshape(n, h * w))).to(self.device), k, False)
         return idx.cpu().numpy().astype(np.int64)
@@ -170,72 +164,109 @@ class QuerySelector:
     def _forward_logits(self, model, x, h, w) -> torch.Tensor:
         return model(x)["pred"][:, :, :h, :w]
 
+    def _dist(self):
+        """(rank, world, group) of the acquisition round.  `self.process_group` (None = the default group) is used when
+        torch.distributed is initialised; otherwise the round is single-rank."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            g = getattr(self, "process_group", None)
+            return dist.get_rank(g), dist.get_world_size(g), g
+        return 0, 1, None
+
+    def _draw(self, h: int, w: int) -> dict:
+        """Every host random number ONE image consumes, drawn when the loop reaches the image - the reference's order
+        (query.py:190 sampler -> :40 / :64 numpy choice).  Drawing per image, not per flushed batch, keeps the torch / numpy
+        global streams in the reference's sequence whatever the batching, and lets a rank of a sharded round advance the
+        streams past images it does not own."""
+        d = {}
+        if self.query_strategy == "random":
+            # UncertaintySampler._random (query.py:242-244): one CPU torch.rand((1,h,w)) per image - per stochastic pass in
+            # the MC-dropout branch (query.py:183-185 sums them; their mean is used)
+            n_draws = self.mc_n_steps if self.use_mc_dropout else 1
+            rmap = torch.rand((1, h, w))[0].numpy()
+            for _ in range(n_draws - 1):
+                rmap = rmap + torch.rand((1, h, w))[0].numpy()
+            d["rmap"] = rmap / np.float32(n_draws) if n_draws > 1 else rmap
+        if self.reverse_order:
+            d["cand"] = self._reverse_order_sampling_mask(h, w).reshape(h, w)                 # query.py:40
+        elif self.top_n_percent > 0.:
+            # query.py:63-64 `np.random.choice(ind, n_pixels_by_us, False)`: numpy draws permutation(len)[:n] and indexes the
+            # array with it, so drawing the POSITIONS consumes the same random numbers and picks the same pixels
+            # (tests/test_host_logic.py) - and tells which of the read-back entropies belong to them
+            d["pos"] = np.random.choice(self._k_topk(h, w), self.n_pixels_by_us, False)
+        return d
+
+    def _k_launch(self, h: int, w: int) -> int:
+        return self.n_pixels_by_us if self.reverse_order else self._k_topk(h, w)
+
     def __call__(self, nth_query, model, human_labels: bool = False):
+        """One acquisition round (query.py:144-221).  With torch.distributed initialised the images are sharded
+        `i -> rank i mod world`: every rank forwards / scores only its own images, ONE all_gather of the
+        per-image picks (and statistics contributions) follows, and every rank ends with the same `dict_queries`, the same
+        QueryStats and the same `dataset.label_queries` side effect as a single-rank round; rank 0 writes query_stats.pkl."""
         dataset = self.dataloader.dataset
         prev_queries = dataset.list_labelled_queries if human_labels else dataset.queries
+        rank, world, group = self._dist()
 
         model.eval()
         if self.use_mc_dropout:
             model.turn_on_dropout()
 
         print(f"Choosing pixels by {self.query_strategy}")
-        list_queries, n_pixels = list(), 0
-        dict_queries: dict = dict()
-        y = None
-
         is_random = self.query_strategy == "random"
-        pending = []      # (x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w), rand map | None)
+        records = []      # (image index, p_img, h, w, sorted flat indices int64, statistics contribution | None)
+        y = None
+        n_seen = 0
+
+        pending = []      # _Item: x [1,3,H,W] on device, y numpy | None, exclude bool [h,w], p_img, (h, w), draws, index
         inflight = []     # at most one launched-but-unfinished batch of the pipelined path
         want_any_stats = not human_labels
         # Low-resolution scoring, no reverse-order sampling: the GPU work of a batch is only ENQUEUED by flush(); its results
         # come back through pinned buffers and are turned into masks / statistics after the next batch has been loaded and
-        # enqueued, so host and GPU overlap.  The random sub-sampling of the top-n-percent mode (query.py:63-64) happens in
-        # that host half, image by image in loader order, so its numpy RNG sequence is the reference's; the reverse-order
-        # mode draws BEFORE scoring and keeps the strict per-batch order.
+        # enqueued, so host and GPU overlap.
         pipelined = (QUERY_PIPELINE and FUSED_LOWRES and not self.use_mc_dropout and hasattr(model, "forward_lowres")
                      and not self.reverse_order and not is_random and torch.device(self.device).type == "cuda")
         copy_stream = self.__dict__.get("_copy_stream")
         if pipelined and copy_stream is None:
             copy_stream = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
 
+        def emit(it, cand, cand_ent):
+            """cand: the chosen flat indices of image `it` (any order), cand_ent: their entropies in the same order | None."""
+            h, w = it.size
+            order = np.argsort(cand, kind="stable")
+            sel = np.asarray(cand, dtype=np.int64)[order]
+            contrib = None
+            if cand_ent is not None:
+                contrib = QueryStats.contribution(it.y, np.asarray(cand_ent)[order].tolist(), (sel // w, sel % w))
+            records.append((it.index, it.p_img, h, w, sel, contrib))
+
+        def choose(it, idx_sorted, ent_sorted=None):
+            """query.py:63-64 on the value-sorted top-k of one image -> (flat indices, their entropies | None)."""
+            pos = it.draws.get("pos")
+            if pos is not None:
+                return idx_sorted[pos], (ent_sorted[pos] if ent_sorted is not None else None)
+            return idx_sorted, ent_sorted
+
         def finish(hd):
             """Host half of a pipelined batch: wait for ITS read-back (not for whatever the GPU runs now)."""
-            nonlocal n_pixels
-            items, h, w, idx_host, ent_host, ev = hd
+            items, idx_host, ent_host, ev = hd
             ev.synchronize()
             idx_h = idx_host.numpy().astype(np.int64)
             ent_h = ent_host.numpy() if ent_host is not None else None
-            for j, (_, yj, _, p_img, _, _) in enumerate(items):
-                if self.top_n_percent > 0.:
-                    # query.py:63-64 `np.random.choice(ind, n_pixels_by_us, False)`: numpy draws permutation(len)[:n] and
-                    # indexes the array with it, so drawing the POSITIONS consumes the same random numbers and picks the same
-                    # pixels (tests/test_host_logic.py) - and tells which of the read-back entropies belong to them
-                    pos = np.random.choice(idx_h.shape[1], self.n_pixels_by_us, False)
-                    cand, cand_ent = idx_h[j][pos], (ent_h[j][pos] if ent_h is not None else None)
-                else:
-                    cand, cand_ent = idx_h[j], (ent_h[j] if ent_h is not None else None)
-                order = np.argsort(cand, kind="stable")
-                sel = cand[order]
-                query = np.zeros(h * w, dtype=np.bool_)
-                query[sel] = True
-                query = query.reshape(h, w)
-                list_queries.append(query)
-                n_pixels += len(sel)
-                if ent_h is not None:
-                    self.query_stats.update_from_picked(query, yj, cand_ent[order].tolist(), coords=(sel // w, sel % w))
-                dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
+            for j, it in enumerate(items):
+                emit(it, *choose(it, idx_h[j], ent_h[j] if ent_h is not None else None))
 
         def launch_pipelined():
-            (h, w), = {it[4] for it in pending}
+            (h, w), = {it.size for it in pending}
             main = torch.cuda.current_stream(self.device)
-            excl = np.ascontiguousarray(np.stack([it[2] for it in pending]))
+            excl = np.ascontiguousarray(np.stack([it.exclude for it in pending]))
             with torch.cuda.stream(copy_stream):               # a pageable upload on the main stream would block the host
                 excl_dev = torch.from_numpy(excl).view(torch.uint8).to(self.device)    # behind everything enqueued there
             main.wait_stream(copy_stream)                      # images and exclusion masks of this batch have arrived
             excl_dev.record_stream(main)
-            xs = torch.cat([it[0] for it in pending], dim=0)
+            xs = torch.cat([it.x for it in pending], dim=0)
             for it in pending:
-                it[0].record_stream(main)
+                it.x.record_stream(main)
             low, full_size = model.forward_lowres(xs)
             k = self._k_topk(h, w)
             idx, _, _ = acq.score_topk_lowres(low, full_size, excl_dev, self.query_strategy, k, crop=(h, w))
@@ -243,24 +274,23 @@ class QuerySelector:
             idx_host = torch.empty((n, k), dtype=torch.int32, pin_memory=True)
             idx_host.copy_(idx, non_blocking=True)
             ent_host = None
-            if want_any_stats and all(it[1] is not None for it in pending):
+            if want_any_stats and all(it.y is not None for it in pending):
                 img = torch.arange(n, device=idx.device, dtype=torch.int32).repeat_interleave(k)
                 ent = acq.score_at_lowres(low, full_size, img, idx.reshape(-1), "entropy", crop=(h, w))
                 ent_host = torch.empty((n, k), dtype=torch.float32, pin_memory=True)
                 ent_host.copy_(ent.reshape(n, k), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(main)
-            handle = (list(pending), h, w, idx_host, ent_host, ev)
+            handle = (list(pending), idx_host, ent_host, ev)
             pending.clear()
             if inflight:
                 finish(inflight.pop())                         # the PREVIOUS batch, while the GPU works on this one
             inflight.append(handle)
 
         def flush():
-            nonlocal n_pixels
             if not pending:
                 return
-            if pipelined and len({it[4] for it in pending}) == 1:
+            if pipelined and len({it.size for it in pending}) == 1:
                 launch_pipelined()
                 return
             if inflight:
@@ -269,10 +299,10 @@ class QuerySelector:
                 main = torch.cuda.current_stream(self.device)
                 main.wait_stream(copy_stream)
                 for it in pending:
-                    it[0].record_stream(main)
-            xs = torch.cat([it[0] for it in pending], dim=0)
+                    it.x.record_stream(main)
+            xs = torch.cat([it.x for it in pending], dim=0)
             logits_b = None
-            sizes = {it[4] for it in pending}
+            sizes = {it.size for it in pending}
             # DeepLab exposes its classifier output in front of the x4 upsample; the scoring
             # kernel interpolates on the fly and the full-resolution logits are never written
             fused = (FUSED_LOWRES and not self.use_mc_dropout and len(sizes) == 1 and hasattr(model, "forward_lowres"))
@@ -283,26 +313,23 @@ class QuerySelector:
             if not self.use_mc_dropout and len(sizes) == 1:
                 # one scoring launch, one index read-back and one entropy read-back for the whole batch
                 (h, w), = sizes
-                excl = np.stack([it[2] for it in pending])
+                excl = np.stack([it.exclude for it in pending])
                 if not fused:
                     lg = logits_b[:, :, :h, :w]
+                if self.reverse_order:
+                    excl = excl | ~np.stack([it.draws["cand"] for it in pending])
                 if is_random:
                     # the forward above only feeds the statistics (the reference runs it too, query.py:190)
-                    idx_h = self._random_topk(np.stack([it[5] for it in pending]), excl)
-                else:
-                    if self.reverse_order:
-                        for j in range(len(pending)):           # RNG draws in image order, as the per-image loop
-                            excl[j] |= ~self._reverse_order_sampling_mask(h, w).reshape(h, w)
-                        k = self.n_pixels_by_us
-                    else:
-                        k = self._k_topk(h, w)
-                    if fused:
-                        idx, _, _ = acq.score_topk_lowres(low, full_size, torch.from_numpy(excl), self.query_strategy, k, crop=(h, w))
-                    else:
-                        idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, k)
+                    idx_h = self._random_topk(np.stack([it.draws["rmap"] for it in pending]), excl, self._k_launch(h, w))
+                elif fused:
+                    idx, _, _ = acq.score_topk_lowres(low, full_size, torch.from_numpy(excl), self.query_strategy,
+                                                      self._k_launch(h, w), crop=(h, w))
                     idx_h = idx.cpu().numpy().astype(np.int64)
-                chosen = [np.sort(self._choose(idx_h[j])) for j in range(len(pending))]
-                want_stats = (not human_labels) and all(it[1] is not None for it in pending)
+                else:
+                    idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, self._k_launch(h, w))
+                    idx_h = idx.cpu().numpy().astype(np.int64)
+                chosen = [choose(it, idx_h[j])[0] for j, it in enumerate(pending)]
+                want_stats = (not human_labels) and all(it.y is not None for it in pending)
                 ent_all = None
                 if want_stats:
                     flat = np.concatenate(chosen)
@@ -314,21 +341,15 @@ class QuerySelector:
                         picked = lg[torch.from_numpy(img).to(dev), :, torch.from_numpy(flat // w).to(dev), torch.from_numpy(flat % w).to(dev)]
                         ent_all = acq.score_map(picked.t().reshape(1, picked.shape[1], 1, -1).contiguous(), None, "entropy").reshape(-1).cpu().numpy()
                 off = 0
-                for j, (x1, yj, exclude, p_img, _, _) in enumerate(pending):
-                    sel = chosen[j]
-                    query = np.zeros(h * w, dtype=np.bool_)
-                    query[sel] = True
-                    query = query.reshape(h, w)
-                    list_queries.append(query)
-                    n_pixels += len(sel)
-                    if want_stats:
-                        self.query_stats.update_from_picked(query, yj, ent_all[off:off + len(sel)].tolist(), coords=(sel // w, sel % w))
-                        off += len(sel)
-                    # encode_query(p_img, size, query) without re-scanning the mask: the sorted flat indices ARE np.nonzero order
-                    dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
+                for j, it in enumerate(pending):
+                    n_j = len(chosen[j])
+                    emit(it, chosen[j], ent_all[off:off + n_j] if want_stats else None)
+                    off += n_j
                 pending.clear()
                 return
-            for j, (x1, yj, exclude, p_img, (h, w), rmap) in enumerate(pending):
+            for j, it in enumerate(pending):
+                h, w = it.size
+                excl_j = it.exclude | ~it.draws["cand"] if self.reverse_order else it.exclude
                 if self.use_mc_dropout:
                     # mean uncertainty / mean probability over mc_n_steps stochastic passes: the passes differ only in their
                     # dropout masks (eval-mode BatchNorm is per sample), so they run as ONE forward over mc_n_steps copies of
@@ -338,52 +359,67 @@ class QuerySelector:
                     left = self.mc_n_steps
                     while left > 0:
                         t = min(left, self.mc_chunk)
-                        logits = self._forward_logits(model, x1.expand(t, -1, -1, -1).contiguous(), h, w)
+                        logits = self._forward_logits(model, it.x.expand(t, -1, -1, -1).contiguous(), h, w)
                         if not is_random:
                             uc_map += acq.score_map(logits, None, self.query_strategy).sum(dim=0)
                         prob += F.softmax(logits, dim=1).sum(dim=0, keepdim=True)
                         left -= t
                     prob /= self.mc_n_steps
-                    if is_random:                       # rmap is already the mean of the mc_n_steps host draws
-                        query = self._finish_selection(self._random_topk(rmap[None], exclude[None])[0], h, w)
+                    if is_random:                       # the drawn map is already the mean of the mc_n_steps host draws
+                        idx_sorted = self._random_topk(it.draws["rmap"][None], excl_j[None], self._k_launch(h, w))[0]
                     else:
                         uc_map /= self.mc_n_steps
-                        uc_map[torch.from_numpy(exclude).to(self.device)] = 0.0 if self._largest else 1.0
-                        query = self._select_queries(uc_map)
-                    logits_for_stats = None
+                        uc_map[torch.from_numpy(excl_j).to(self.device)] = 0.0 if self._largest else 1.0
+                        idx_t, _ = acq.topk_select(uc_map.reshape(1, h * w), self._k_launch(h, w), self._largest)
+                        idx_sorted = idx_t[0].cpu().numpy().astype(np.int64)
+                    cand = choose(it, idx_sorted)[0]
+                    ent = None
+                    if not human_labels and it.y is not None:
+                        qmask = np.zeros(h * w, dtype=np.bool_)
+                        qmask[cand] = True
+                        ent_rowmajor = QueryStats._get_entropy(qmask.reshape(h, w), prob)     # row-major = ascending flat index
+                        ent = np.empty(len(cand), dtype=np.float64)
+                        ent[np.argsort(cand, kind="stable")] = ent_rowmajor
+                    emit(it, cand, ent)
                 else:
                     logits = logits_b[j:j + 1, :, :h, :w]
-                    prob = None
-                    logits_for_stats = logits
                     if is_random:
-                        query = self._finish_selection(self._random_topk(rmap[None], exclude[None])[0], h, w)
+                        idx_sorted = self._random_topk(it.draws["rmap"][None], excl_j[None], self._k_launch(h, w))[0]
                     else:
-                        query = self._select_from_logits(logits, exclude)
-                list_queries.append(query)
-                n_pixels += query.sum()
-                if not human_labels and yj is not None:
-                    if logits_for_stats is not None:
-                        self.query_stats.update_from_logits(query, yj, logits_for_stats)
-                    else:
-                        self.query_stats.update(query, yj, prob)
-                dict_queries.update(self.encode_query(p_img, size=(h, w), query=query))
+                        idx_t, _, _ = acq.score_topk(logits, torch.from_numpy(np.ascontiguousarray(excl_j))[None],
+                                                     self.query_strategy, self._k_launch(h, w))
+                        idx_sorted = idx_t[0].cpu().numpy().astype(np.int64)
+                    cand = choose(it, idx_sorted)[0]
+                    ent = None
+                    if not human_labels and it.y is not None:
+                        qmask = np.zeros(h * w, dtype=np.bool_)
+                        qmask[cand] = True
+                        ent_rowmajor = QueryStats._get_entropy_from_logits(qmask.reshape(h, w), logits)
+                        ent = np.empty(len(cand), dtype=np.float64)
+                        ent[np.argsort(cand, kind="stable")] = ent_rowmajor
+                    emit(it, cand, ent)
             pending.clear()
 
         with torch.no_grad():
             for batch_ind, dict_data in enumerate(self.dataloader):
+                n_seen += 1
+                h, w = dict_data['x'].shape[2:]
+                draws = self._draw(h, w)                       # every rank advances the host RNG streams for every image
+                y = dict_data.get('y', None)
+                if world > 1 and batch_ind % world != rank:
+                    continue                                   # another rank's image (i -> rank i mod W)
                 if pipelined and not dict_data['x'].is_cuda:
                     with torch.cuda.stream(copy_stream):       # the upload must not queue behind the previous batch's kernels
                         x = dict_data['x'].to(self.device, non_blocking=False)
                 else:
                     x = dict_data['x'].to(self.device)
-                y = dict_data.get('y', None)
                 mask = np.asarray(prev_queries[batch_ind])  # h x w
 
-                h, w = x.shape[2:]
                 exclude = (mask != self.ignore_index) if human_labels else mask.astype(np.bool_)
+                y_np = None
                 if y is not None:
-                    y = y.squeeze(dim=0).numpy()  # h x w
-                    exclude = exclude | (y == self.ignore_index)
+                    y_np = y.squeeze(dim=0).numpy()  # h x w
+                    exclude = exclude | (y_np == self.ignore_index)
 
                 if self.dataset_name == "voc":  # query.py:171-174
                     pad_h = ceil(h / self.stride_total) * self.stride_total - h
@@ -397,33 +433,44 @@ class QuerySelector:
                     else:
                         x = F.pad(x, pad=(0, pad_w, 0, pad_h), mode='reflect')
 
-                rmap = None
-                if is_random:
-                    # UncertaintySampler._random (query.py:242-244): one CPU torch.rand((1,h,w)) per image in loader order -
-                    # per stochastic pass in the MC-dropout branch (query.py:183-185 sums them; their mean is used)
-                    n_draws = self.mc_n_steps if self.use_mc_dropout else 1
-                    rmap = torch.rand((1, h, w))[0].numpy()
-                    for _ in range(n_draws - 1):
-                        rmap = rmap + torch.rand((1, h, w))[0].numpy()
-                    if n_draws > 1:
-                        rmap = rmap / np.float32(n_draws)
-
-                if pending and (pending[0][0].shape != x.shape or len(pending) >= self.query_batch_size):
+                if pending and (pending[0].x.shape != x.shape or len(pending) >= self.query_batch_size):
                     flush()
-                pending.append((x, y, exclude, dict_data["p_img"][0], (h, w), rmap))
+                pending.append(_Item(x, y_np, exclude, dict_data["p_img"][0], (h, w), draws, batch_ind))
                 if len(pending) >= self.query_batch_size:
                     flush()
             flush()
             if inflight:
                 finish(inflight.pop())
 
-        assert len(list_queries) > 0, f"no queries are chosen!"
+        if world > 1:
+            import torch.distributed as dist
+            gathered = [None] * world
+            dist.all_gather_object(gathered, records, group=group)      # ~100 B per image; the only exchange of the round
+            records = [r for part in gathered for r in part]
+        records.sort(key=lambda r: r[0])                               # loader order, as the single-rank loop
+        assert len(records) == n_seen and n_seen > 0, f"no queries are chosen!" if n_seen == 0 else (len(records), n_seen)
+        dict_queries: dict = dict()
+        n_pixels = 0
+        for _, p_img, h, w, sel, contrib in records:
+            # encode_query(p_img, size, query) without re-scanning a mask: the sorted flat indices ARE np.nonzero order
+            dict_queries.update({p_img: {"height": h, "width": w, "x_coords": sel % w, "y_coords": sel // w}})
+            n_pixels += len(sel)
+            if contrib is not None:
+                self.query_stats.apply(contrib)
         if not human_labels and y is not None:
-            self.query_stats.save(nth_query)
+            if rank == 0:
+                self.query_stats.save(nth_query)
             print(f"{n_pixels} labelled pixels  are chosen by {self.query_strategy} strategy")
             # updates labels for the query dataloader only (query.py:219-220)
             dataset.label_queries(dict_queries, nth_query)
         return dict_queries
+
+
+class _Item:
+    __slots__ = ("x", "y", "exclude", "p_img", "size", "draws", "index")
+
+    def __init__(self, x, y, exclude, p_img, size, draws, index):
+        self.x, self.y, self.exclude, self.p_img, self.size, self.draws, self.index = x, y, exclude, p_img, size, draws, index
 
 
 class UncertaintySampler:
@@ -507,6 +554,21 @@ class QueryStats:
         os.makedirs(f"{self.dir_checkpoints}/{nth_query}_query", exist_ok=True)
         with open(f"{self.dir_checkpoints}/{nth_query}_query/query_stats.pkl", "wb") as f:
             pkl.dump(dict_stats, f)
+
+    @staticmethod
+    def contribution(y, pixel_entropy, coords) -> tuple:
+        """What ONE image adds to the statistics (query.py:262-289), as plain python data so that a sharded round can
+        ship it: (labels at the picked pixels in row-major order, their entropies, #unique labels, mean pairwise distance)."""
+        labels = [int(l) for l in y[coords]]
+        return (labels, list(pixel_entropy), len(set(labels)), QueryStats._spatial_coverage(None, coords))
+
+    def apply(self, contrib):
+        labels, pixel_entropy, n_unique, coverage = contrib
+        for l in labels:
+            self.dict_label_cnt[l] += 1
+        self.list_entropy.extend(pixel_entropy)
+        self.list_n_unique_labels.append(n_unique)
+        self.list_spatial_coverage.append(coverage)
 
     def update_from_picked(self, query, y, pixel_entropy, coords=None):
         """Host-only part of update(): everything except the entropy evaluation.  coords = (rows, cols) of the picked

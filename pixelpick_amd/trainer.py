@@ -73,6 +73,12 @@ class FlatTrainer:
             p.data = self.flat_p[off:off + k].view(p.shape)          # parameters alias the flat buffer
             self._grad_view[id(p)] = self.flat_g[off:off + k].view(p.shape)
             off += k
+        if self.world > 1:
+            # replicas must start identical whatever each rank's RNG drew at construction (DistributedDataParallel does the
+            # same at wrap time): rank 0's parameters and BatchNorm statistics win
+            src = torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0
+            torch.distributed.broadcast(self.flat_p, src=src, group=self.pg)
+            self.sync_buffers()
         self.step_count = 0
         self.lr_factor = 1.0
         self.last_loss: Optional[torch.Tensor] = None
@@ -218,6 +224,24 @@ class FlatTrainer:
             self._step_body(self._gx, self._gy, True, True)
         self._graph = g
         return self
+
+    def sync_buffers(self, src: int = 0):
+        """Data-parallel runs keep per-GPU BatchNorm statistics while training (the reference has no SyncBN); before the
+        replicas are used for validation / acquisition their running statistics are made identical by broadcasting rank
+        `src`'s buffers (what DistributedDataParallel(broadcast_buffers=True) does every forward), so that a sharded
+        acquisition round scores every image with the same network."""
+        if self.world <= 1:
+            return
+        bufs = [b for b in self.model.buffers() if b.dtype.is_floating_point]
+        if not bufs:
+            return
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        torch.distributed.broadcast(flat, src=torch.distributed.get_global_rank(self.pg, src) if self.pg is not None else src,
+                                    group=self.pg)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
 
     def set_poly_lr(self, T: int, N: int, power: float = 0.9):
         """utils/lr_scheduler.py:15-17 applied to both segments."""

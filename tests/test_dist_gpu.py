@@ -148,3 +148,136 @@ def test_rccl_call_path_with_one_rank():
     assert p.exitcode == 0
     assert out[True] and out[False], out
     assert out["earlyTrue"] and out["earlyFalse"], out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Sharded acquisition round and the data-parallel driver: images i -> rank i mod W, one gather of the picks.
+def _al_args(td, **kw):
+    base = dict(dataset_name="cs", debug=False, dir_root=td, experim_name="dist", ignore_index=5, mc_n_steps=20,
+                n_classes=5, n_pixels_by_us=10, network_name="deeplab", query_strategy="margin_sampling", reverse_order=False,
+                stride_total=16, top_n_percent=0.0, use_mc_dropout=False, vote_type="hard", mc_dropout_p=0.2,
+                n_init_pixels=10, max_budget=10, n_epochs=1, lr_scheduler_type="Poly", query_batch_size=2,
+                optimizer_params={"lr": 5e-4, "betas": (0.9, 0.999), "weight_decay": 2e-4, "eps": 1e-7})
+    base.update(kw)
+    return Namespace(**base)
+
+
+def _round(td, strategy, top, rev, model):
+    import pickle
+    import numpy as np
+    from pixelpick_amd.query import QuerySelector
+    from pixelpick_amd.synthetic import SyntheticDataset
+    ds = SyntheticDataset(7, 64, 96, 5, 5, n_init_pixels=10, seed=3)          # 7 images: ragged over 2 ranks
+    dl = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    args = _al_args(td, query_strategy=strategy, top_n_percent=top, reverse_order=rev)
+    qs = QuerySelector(args, dl, device=torch.device("cuda:0"))
+    torch.manual_seed(77)
+    np.random.seed(78)
+    dq = qs(nth_query=1, model=model)
+    stats = None
+    p = f"{td}/checkpoints/dist/1_query/query_stats.pkl"
+    if os.path.exists(p):
+        stats = pickle.load(open(p, "rb"))
+    return dq, stats, [q.copy() for q in ds.queries]
+
+
+def _acq_worker(rank, world, port, q, td):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    warnings.simplefilter("ignore")
+    from pixelpick_amd.utils.utils import get_model
+    torch.manual_seed(0)
+    model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=5, network_name="deeplab")).cuda()
+    cases = [("margin_sampling", 0.0, False), ("entropy", 0.05, False), ("least_confidence", 0.05, True), ("random", 0.0, False)]
+    single = [_round(f"{td}/single{rank}_{i}", *c, model) for i, c in enumerate(cases)]           # torch.distributed not initialised
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = []
+        for i, c in enumerate(cases):
+            dq, stats, queries = _round(f"{td}/sharded_{i}", *c, model)          # rank 0 writes the statistics file
+            dist.barrier()
+            dq1, stats1, queries1 = single[i]
+            same = list(dq.keys()) == list(dq1.keys())
+            for k in dq1:
+                same = same and np.array_equal(dq[k]["x_coords"], dq1[k]["x_coords"]) and np.array_equal(dq[k]["y_coords"], dq1[k]["y_coords"])
+            same = same and all(np.array_equal(a, b) for a, b in zip(queries, queries1))    # label_queries side effect on every rank
+            if rank == 0:
+                same = same and stats is not None and stats["label_distribution"] == stats1["label_distribution"]
+                for key in ("avg_entropy", "avg_n_unique_labels", "avg_spatial_coverage"):
+                    same = same and stats[key] == stats1[key]                      # bit-identical: merged in loader order
+            ok.append(bool(same))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_acquisition_round_equals_single_rank(tmp_path):
+    """Two ranks (gloo, sharing cuda:0) run QuerySelector.__call__ on the same 7-image dataset: dict_queries, the dataset's
+    merged masks on EVERY rank and rank 0's query_stats.pkl must equal the single-rank round bit for bit - for a plain
+    top-k strategy, the top-5 % + numpy sub-sample mode, reverse-order sampling and the host-RNG `random` strategy."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_acq_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert all(ok), f"rank {rank}: {ok}"
+
+
+def _driver_worker(rank, world, port, q, td):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    warnings.simplefilter("ignore")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pixelpick_amd.model import Model
+        from pixelpick_amd.synthetic import SyntheticDataset
+        torch.manual_seed(5)                                   # same seed on every rank: same shuffle order, disjoint shards
+        np.random.seed(5)
+        ds = SyntheticDataset(8, 64, 96, 5, 5, n_init_pixels=10, seed=1)
+        ds_val = SyntheticDataset(3, 64, 96, 5, 5, seed=2)
+        mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
+        m = Model(_al_args(td), mk(ds, 2, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device("cuda:0"))
+        assert m.world == 2
+        m()
+        picks = np.stack([qq for qq in ds.queries]).astype(np.uint8)
+        t = torch.from_numpy(picks)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        same_masks = all(torch.equal(parts[0], p) for p in parts[1:])
+        n_per_image = [int(qq.sum()) for qq in ds.queries]
+        files = sorted(os.listdir(f"{td}/checkpoints/dist/0_query")) if rank == 0 else None
+        q.put((rank, same_masks, n_per_image, [h for h in m.history if h[0] == "train"], files))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_driver_keeps_replicas_and_datasets_identical(tmp_path):
+    """Model(args)() on two ranks: sharded train batches with the gradient all-reduce, sharded validation with summed
+    confusion matrices, sharded acquisition; both ranks must end every stage with the same labelled masks and the same
+    logged scores, and only rank 0 writes the checkpoint / log / statistics files."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[0][2] == res[1][2] == [10 + 2 * 10] * 8            # initial 10 + two acquisition rounds of 10
+    assert res[0][3] == res[1][3] and len(res[0][3]) == 2           # identical train history (summed confusion matrices)
+    assert {"best_miou_model.pt", "log_train.txt", "log_val.txt", "query_stats.pkl"} <= set(res[0][4])
