@@ -169,6 +169,12 @@ class Model:
         scores = self.running_score.get_scores()[0]
         miou, pixel_acc = scores['Mean IoU'], scores['Pixel Acc']
         avg_loss = float(self.running_loss.avg) if torch.is_tensor(self.running_loss.avg) else self.running_loss.avg
+        if self.world > 1:                                                  # mean over the ranks' equally long shards
+            t = torch.tensor([avg_loss], dtype=torch.float64)
+            if torch.distributed.get_backend() == "nccl":
+                t = t.to(self.device)
+            torch.distributed.all_reduce(t)
+            avg_loss = float(t.item()) / self.world
         if self.rank == 0:
             write_log(self.log_train, list_entities=[epoch, miou, pixel_acc, avg_loss])
         self.history.append(("train", self.nth_query, epoch, miou, pixel_acc, avg_loss))

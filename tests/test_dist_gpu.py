@@ -205,8 +205,10 @@ def _acq_worker(rank, world, port, q, td):
             same = same and all(np.array_equal(a, b) for a, b in zip(queries, queries1))    # label_queries side effect on every rank
             if rank == 0:
                 same = same and stats is not None and stats["label_distribution"] == stats1["label_distribution"]
-                for key in ("avg_entropy", "avg_n_unique_labels", "avg_spatial_coverage"):
+                for key in ("avg_n_unique_labels", "avg_spatial_coverage"):
                     same = same and stats[key] == stats1[key]                      # bit-identical: merged in loader order
+                # entropies: an image forwarded in a batch of another size goes through other conv tilings (1e-7 on the logits)
+                same = same and abs(stats["avg_entropy"] - stats1["avg_entropy"]) <= 1e-5 * abs(stats1["avg_entropy"])
             ok.append(bool(same))
         q.put((rank, ok))
     finally:
@@ -215,7 +217,8 @@ def _acq_worker(rank, world, port, q, td):
 
 def test_sharded_acquisition_round_equals_single_rank(tmp_path):
     """Two ranks (gloo, sharing cuda:0) run QuerySelector.__call__ on the same 7-image dataset: dict_queries, the dataset's
-    merged masks on EVERY rank and rank 0's query_stats.pkl must equal the single-rank round bit for bit - for a plain
+    merged masks on EVERY rank and rank 0's query_stats.pkl must equal the single-rank round (coordinates, counts and
+    coverage bit for bit; the mean entropy to 1e-5: batch composition changes the conv tiling) - for a plain
     top-k strategy, the top-5 % + numpy sub-sample mode, reverse-order sampling and the host-RNG `random` strategy."""
     world = 2
     ctx = mp.get_context("spawn")
