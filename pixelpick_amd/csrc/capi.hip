@@ -20,7 +20,7 @@ int fail(int code, const char* fmt, ...)
 
 EventHook& event_hook()
 {
-    static EventHook h{nullptr, nullptr, 0, 0};
+    static thread_local EventHook h{nullptr, nullptr, 0, 0};   // per calling thread, like every other debugging knob
     return h;
 }
 

@@ -27,10 +27,10 @@ namespace pp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static int g_conv_xcd_remap = 1;
-static int g_conv_novec = 0;
-static int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
-static int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
+static thread_local int g_conv_xcd_remap = 1;
+static thread_local int g_conv_novec = 0;
+static thread_local int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
+static thread_local int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
 
 constexpr int kThreads = 256;
 constexpr int BK = 16;
@@ -1578,21 +1578,21 @@ struct ConvPlan {
     bool bn64;          // cfg 1 with 128x64 tiles
 };
 
-static int g_conv_splitk = 1;
-static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_splitk_min_iters = 4;
+static thread_local int g_conv_splitk = 1;
+static thread_local int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_splitk_min_iters = 4;
 
-static int g_conv_deepk = 1;
-static int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
-static int g_conv_dma = 1;         // 128-row tiles, LDS-DMA three-stage kernel: 0 off, 1 (default) forward + backward-data, 2 forward only,
+static thread_local int g_conv_deepk = 1;
+static thread_local int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
+static thread_local int g_conv_dma = 1;         // 128-row tiles, LDS-DMA three-stage kernel: 0 off, 1 (default) forward + backward-data, 2 forward only,
                                    // 3 forward + the backward-data of the 128x64-tiled layers only.  History: before the steady-state loop
                                    // lost its branches, backward-data through this kernel cost FPN 0.27 ms/step (48 KiB of LDS per block
                                    // beside the weight-gradient stream); after it: DeepLab 6.92 -> 6.89 ms/step, FPN 25.96 -> 26.02.
-static int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-DMA kernel: 0 off, 1 forward + backward-data (default: DeepLab 7.29 ->
+static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-DMA kernel: 0 off, 1 forward + backward-data (default: DeepLab 7.29 ->
                                    // 7.21 ms/step, FPN 28.06 -> 27.06), 2 forward only (7.25 / 27.42).  Replaces the 64-deep K step.
-static int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
-static int g_conv_n64 = 1;
-static int g_conv_tap_inner = 1;
-static int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
+static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
+static thread_local int g_conv_n64 = 1;
+static thread_local int g_conv_tap_inner = 1;
+static thread_local int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
 {
@@ -1697,7 +1697,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     return PP_OK;
 }
 
-static int g_narrow_rows_min = 16, g_narrow_splits_max = 4096;   // narrow-layer weight gradient: split geometry
+static thread_local int g_narrow_rows_min = 16, g_narrow_splits_max = 4096;   // narrow-layer weight gradient: split geometry
 // These kernels are latency-bound row walks (27 or fewer accumulators per thread), so more, shorter splits win as long as
 // the partials stay small: up to 4096 splits while splits x taps x Cin x Cout x 4 B <= 16 MiB, never fewer than 1024
 // (measured on the train step: 1024 -> 4096 splits for the stem and the 16/32-channel pointwise layers, 7.08 -> 7.05 ms).
@@ -1708,14 +1708,14 @@ static int64_t narrow_splits_max(int64_t floats_per_split)
     if (s < 1024) s = 1024;
     return s;
 }
-static int g_wgrad_narrow = 1;
-static int g_wgrad_m64 = 1;
-static int g_wgrad_xcd = 1;
-static int g_wgrad_dma = 1;          // LDS-DMA weight-gradient kernels: bit 0 = the 128-wide tiles (default on: DeepLab 7.17 -> 7.12 ms/step,
+static thread_local int g_wgrad_narrow = 1;
+static thread_local int g_wgrad_m64 = 1;
+static thread_local int g_wgrad_xcd = 1;
+static thread_local int g_wgrad_dma = 1;          // LDS-DMA weight-gradient kernels: bit 0 = the 128-wide tiles (default on: DeepLab 7.17 -> 7.12 ms/step,
                                      // FPN 26.86 -> 26.77), bit 1 = the 64x64 tiles (off: 7.17 -> 7.20)
 static const int g_wgrad_lds_pad_default = 0;
-static int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
-static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
+static thread_local int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
+static thread_local int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
 static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* dbias, bool* bias_done, void* workspace,

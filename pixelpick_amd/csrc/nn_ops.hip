@@ -69,7 +69,7 @@ struct ColReduceGeom {
     int nblk_cols;     // grid.y
 };
 
-static int g_dw_wgrad_blocks = 1024;    // row blocks aimed at by the depthwise weight gradient (pp_debug_set_dw_variant bits 1..)
+static thread_local int g_dw_wgrad_blocks = 1024;    // row blocks aimed at by the depthwise weight gradient (pp_debug_set_dw_variant bits 1..)
 
 static ColReduceGeom col_geom(int64_t M, int C, int target_blocks = 1024)
 {
@@ -312,8 +312,18 @@ struct BnFusedGeom {
     int64_t rows_per_chunk;
 };
 
-static int g_bn_target_blocks = 384;     // strips x row chunks aimed at (pp_debug_set_bn_target): measured in-process
+static thread_local int g_bn_target_blocks = 384;     // strips x row chunks aimed at (pp_debug_set_bn_target): measured in-process
                                          // 128: 7.77, 192: 7.47, 256-384: 7.30-7.36, 512: 7.36, 768: 7.60, 1024: 7.76 ms/step
+
+static thread_local int g_bn_bytes_per_block = 0;   // > 0: large maps get one block per this many bytes of x.  Off: measured neutral in
+                                                   // isolation (tools/bn_bench.py: 33.6 MB forward 33.4 us with 384 blocks, 33.2-35.8 us with 640)
+                                                   // and in the step (6.84 vs 6.86 ms) - a launch is ~13 us of fixed latency + bytes at ~5 TB/s
+
+// Blocks of the single-launch BatchNorm kernels that can be resident on the device at once (occupancy x CUs), queried
+// once per process (one process drives one GPU).  A launch never asks for more than HALF of it: the kernels wait for
+// sibling blocks, so all blocks of a launch must become resident while other spin-waiting launches (a second stream, a
+// second process on the same GPU) hold theirs - two such launches always fit side by side.  0: not known (no device).
+static int bn_fused_capacity();
 
 static BnFusedGeom bn_fused_geom(int64_t M, int C)
 {
@@ -326,7 +336,16 @@ static BnFusedGeom bn_fused_geom(int64_t M, int C)
     }
     g.nrl = kT / g.bq;
     g.nstrips = (int)cdiv(g.cq, g.bq);
-    int64_t R = g_bn_target_blocks / g.nstrips;
+    int64_t target = g_bn_target_blocks;
+    if (g_bn_bytes_per_block > 0) {
+        const int64_t by_bytes = M * (int64_t)C * 4 / g_bn_bytes_per_block;
+        if (by_bytes > target) target = by_bytes;
+    }
+    const int cap = bn_fused_capacity();
+    int64_t limit = cap > 0 ? cap / 2 : 1024;
+    if (limit > 1024) limit = 1024;
+    if (target > limit) target = limit;
+    int64_t R = target / g.nstrips;
     if (R > 256) R = 256;
     if (R < 1 || (int64_t)g.nstrips * R > 1024) R = 1;
     int64_t rpc = cdiv(cdiv(M, R), g.nrl) * g.nrl;
@@ -708,6 +727,25 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
         o.w = ga.w * is.w * (u.w - db.w * inv_count - (v.w - mu.w) * is.w * dg.w * inv_count);
         *reinterpret_cast<float4*>(dxq + r * a.lddx) = o;
     }
+}
+
+static int bn_fused_capacity()
+{
+    static const int cap = [] {
+        int dev = 0, cus = 0, a = 0, b = 0, c = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<false>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<true>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, bn_fused_bwd_kernel, kT, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        int per = a < b ? a : b;
+        per = per < c ? per : c;
+        return per * cus;
+    }();
+    return cap;
 }
 
 // ================================================================================================
@@ -1735,9 +1773,9 @@ __global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_
     }
 }
 
-static int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
-static int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
-static int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
+static thread_local int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
+static thread_local int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
+static thread_local int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
 
 static inline unsigned grid_for(int64_t total)
 {
@@ -1769,6 +1807,8 @@ void pp_debug_set_dw_variant(int v)
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
 void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 384; }
+void pp_debug_set_bn_bytes_per_block(int bytes) { g_bn_bytes_per_block = bytes > 0 ? bytes : 0; }
+int pp_bn_fused_capacity(void) { return bn_fused_capacity(); }
 
 // ---- batch norm -----------------------------------------------------------------------------------
 size_t pp_colreduce_workspace_bytes(int64_t M, int C)

@@ -328,7 +328,16 @@ def _wsbytes(fn_name: str, *args) -> int:
 
 # Single-launch BatchNorm (pp_bn_train_fwd_fused / pp_bn_bwd_fused).  PIXELPICK_BN_FUSED=0 selects the
 # three-launch form (partials -> finalize -> apply) for A/B timing.
+# PIXELPICK_BN_FUSED_DIST=0: three-launch form whenever torch.distributed runs with more than one rank (the fallback for a
+# multi-GPU box on which the single-launch kernels' sibling waits misbehave under a concurrent RCCL kernel)
 _BN_FUSED = os.environ.get("PIXELPICK_BN_FUSED", "1") != "0"
+_BN_FUSED_DIST = os.environ.get("PIXELPICK_BN_FUSED_DIST", "1") != "0"
+
+
+def disable_fused_bn_for_collectives():
+    """Called by the trainer when it runs data-parallel and PIXELPICK_BN_FUSED_DIST=0."""
+    global _BN_FUSED
+    _BN_FUSED = False
 _BN_FUSED_MAXM = int(os.environ.get("PIXELPICK_BN_FUSED_MAXM", str(1 << 62)))
 _BN_XCHG = {}
 _BN_XCHG_SYNC_INTS = 1 << 14          # 64 KiB of arrival counters (2048 strips: C <= 65536)
@@ -363,7 +372,9 @@ def _bn_exchange(device):
     persistent buffer (same addresses every launch).  Fine-grained memory is kept coherent by the hardware, so the
     exchange needs neither the L2 write-back nor the invalidate that a release/acquire pair on ordinary memory costs
     (11.9 vs 8.5 ms per step)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    # one area per (device, stream role): launches on one stream are ordered, launches on different streams may overlap
+    # and must not share partial slots or the launch epoch
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), _role[0])
     ex = _BN_XCHG.get(key)
     if ex is None:
         import ctypes

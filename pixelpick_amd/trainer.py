@@ -49,6 +49,8 @@ class FlatTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.collectives = self.world > 1 or (FORCE_COLLECTIVES and torch.distributed.is_available() and torch.distributed.is_initialized())
+        if self.collectives and not E._BN_FUSED_DIST:
+            E.disable_fused_bn_for_collectives()
         slow, fast = [], []
         seen = set()
         for name, p in model.named_parameters():

@@ -330,7 +330,7 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
     dev = torch.device(DEV)
     sync, ws = E._bn_exchange(dev)
     st = torch.cuda.current_stream().cuda_stream
-    for (M, C) in [(2048, 960), (8192, 192), (32768, 24), (100, 304)]:
+    for (M, C) in [(2048, 960), (8192, 192), (32768, 24), (100, 304), (4 * 64 * 128, 256)]:
         assert L.pp_bn_fused_workspace_bytes(M, C) <= ws.numel() and L.pp_bn_fused_sync_ints(C) <= sync.numel()
         gen = torch.Generator(device=DEV).manual_seed(9)
         xs = [torch.randn(M, C, device=DEV, generator=gen) * (1 + i % 3) + i for i in range(6)]
@@ -381,6 +381,64 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
         assert L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
                                  invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
                                  None, 0, 1.0, None, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
+
+
+def test_two_single_launch_batchnorms_on_two_streams_do_not_interfere():
+    """Two spin-waiting BatchNorm launches in flight at once (main + side stream, each with its own exchange area from
+    engine._bn_exchange): every launch asks for at most half of the co-resident capacity (pp_bn_fused_capacity), so both
+    become resident whatever the interleaving - no hang - and the results equal the one-stream results bit for bit.
+    Shapes include the 33 / 51 MB maps whose grid is sized from bytes."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    dev = torch.device(DEV)
+    cap = L.pp_bn_fused_capacity()
+    assert cap >= 512, cap
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    E.refresh_stream()
+    ex_main = E._bn_exchange(dev)
+    E._role[0] = 1
+    try:
+        ex_side = E._bn_exchange(dev)
+    finally:
+        E._role[0] = 0
+    assert ex_main[0].data_ptr() != ex_side[0].data_ptr()
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(4 * 64 * 128, 256), (4 * 130 * 258, 96), (2448, 960), (4 * 128 * 256, 32)]
+    data = []
+    for (M, C) in shapes:
+        x = torch.randn(M, C, device=DEV, generator=gen)
+        dy = torch.randn(M, C, device=DEV, generator=gen)
+        gamma, beta = torch.rand(C, device=DEV, generator=gen) + 0.5, torch.randn(C, device=DEV, generator=gen)
+        data.append((M, C, x, dy, gamma, beta))
+
+    def run(item, ex, st):
+        M, C, x, dy, gamma, beta = item
+        sync, ws = ex
+        assert L.pp_bn_fused_workspace_bytes(M, C) <= ws.numel()
+        mean, invstd, dg, db = (torch.empty(C, device=DEV) for _ in range(4))
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(L.pp_bn_train_fwd_fused(x.data_ptr(), C, M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                                           mean.data_ptr(), invstd.data_ptr(), None, 0, 2, 0.0, 0, None, y.data_ptr(), C, ws.data_ptr(),
+                                           ws.numel(), sync.data_ptr(), sync.numel(), st.cuda_stream), "fwd")
+        _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, y.data_ptr(), C, 2, M, C, mean.data_ptr(),
+                                     invstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C,
+                                     None, 0, 1.0, None, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), st.cuda_stream), "bwd")
+        return mean, invstd, dg, db, y, dx
+
+    ref = [run(it, ex_main, main) for it in data]
+    torch.cuda.synchronize()
+    side.wait_stream(main)
+    outs_a, outs_b = [], []
+    for rep in range(20):
+        for i in range(len(data)):
+            outs_a.append((i, run(data[i], ex_main, main)))
+            outs_b.append(((i + 1) % len(data), run(data[(i + 1) % len(data)], ex_side, side)))
+    main.wait_stream(side)
+    torch.cuda.synchronize()                      # a deadlock between the two launches would hang here (pytest-timeout)
+    for i, got in outs_a + outs_b:
+        for u, v in zip(got, ref[i]):
+            assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize("act", [1, 2])
