@@ -72,6 +72,13 @@ int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64
                      int64_t sB, int64_t sC, int64_t sH, int64_t sW,
                      const uint8_t* exclude, int strategy, float* out_map, pp_stream_t stream);
 
+/* MC-dropout accumulation (query.py:181-187 `uc_map += uc_map_; prob += prob_`, then / mc_n_steps): over the T passes in
+ * logits [T,C,H,W] (element strides sT,sC,sH,sW), prob_out [C,H,W] (+)= scale * sum_t softmax(logits[t]) and
+ * uc_out [H,W] (+)= scale * sum_t score(softmax(logits[t])) with the strategy's formula on the probabilities; either
+ * output may be NULL; accumulate == 0 overwrites.  No [T,C,H,W] probability tensor exists. */
+int pp_acq_softmax_sum(const float* logits, int64_t T, int64_t C, int64_t H, int64_t W, int64_t sT, int64_t sC, int64_t sH,
+                       int64_t sW, float* prob_out, float* uc_out, int strategy, float scale, int accumulate, pp_stream_t stream);
+
 /* query.py:246-247 UncertaintySampler.__call__(prob): prob f32 [B,C,H,W] (already softmaxed, any
  * strides) -> out_map f32 [B,H,W]; formulas of query.py:229-239 verbatim (no exclusion). */
 int pp_uncertainty_from_prob(const float* prob, int64_t B, int64_t C, int64_t H, int64_t W,
@@ -289,6 +296,12 @@ int pp_image_broadcast(const float* v, int64_t ldv, int B, int64_t P, int C, flo
  * draws a fresh mask on every replay once the host bumps that word. */
 int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed,
                const uint64_t* seed_dev, pp_stream_t stream);
+
+/* nn.Dropout2d (mobilenet_v2.py:114-115 on the high-level features in MC-dropout TRAINING, :127,133-134 on the low-level
+ * features): x, y [B,P,C] channels-last; one keep/drop draw per (sample, channel) from the hash of (seed, b*C + c).  The
+ * backward pass calls it again on dy with the same seed. */
+int pp_dropout2d(const float* x, int64_t ldx, float* y, int64_t ldy, int B, int64_t P, int C, float p, uint64_t seed,
+                 const uint64_t* seed_dev, pp_stream_t stream);
 
 /* F.cross_entropy(logits, target, ignore_index) (model.py:116) on NCHW logits (plane stride 1 within a
  * class: element (b,c,pix) at b*sB + c*sC + pix): *loss = mean over labelled pixels, *count = their

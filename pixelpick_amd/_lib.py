@@ -22,6 +22,7 @@ SIGNATURES = {
     "pp_acq_workspace_bytes": (_sz, [_i64] * 5),
     "pp_acq_score_topk": (_int, [_p] + [_i64] * 8 + [_p, _int, _i64, _p, _p, _p, _p, _sz, _p]),
     "pp_acq_score_map": (_int, [_p] + [_i64] * 8 + [_p, _int, _p, _p]),
+    "pp_acq_softmax_sum": (_int, [_p] + [_i64] * 8 + [_p, _p, _int, _f, _int, _p]),
     "pp_uncertainty_from_prob": (_int, [_p] + [_i64] * 8 + [_int, _p, _p]),
     "pp_topk_workspace_bytes": (_sz, [_i64] * 3),
     "pp_topk_select": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p, _sz, _p]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "pp_image_colsum": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
     "pp_image_broadcast": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
     "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p, _p]),
+    "pp_dropout2d": (_int, [_p, _i64, _p, _i64, _int, _i64, _int, _f, ctypes.c_uint64, _p, _p]),
     "pp_sparse_ce_workspace_bytes": (_sz, []),
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "pp_sparse_ce_lowres_workspace_bytes": (_sz, []),

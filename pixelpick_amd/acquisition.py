@@ -113,6 +113,25 @@ def uncertainty_from_prob(prob: torch.Tensor, strategy: str) -> torch.Tensor:
     return omap
 
 
+def mc_accumulate_(logits: torch.Tensor, prob_out: Optional[torch.Tensor], uc_out: Optional[torch.Tensor], strategy: str,
+                   scale: float, accumulate: bool = True):
+    """MC-dropout accumulation (query.py:181-187) in one kernel pass over logits [T,C,H,W]: prob_out [C,H,W] (+)= scale *
+    sum_t softmax(logits[t]), uc_out [H,W] (+)= scale * sum_t strategy-score(softmax(logits[t])).  Either may be None."""
+    _require_cuda_f32(logits, "logits", 4)
+    T, C, H, W = logits.shape
+    for t, shape in ((prob_out, (C, H, W)), (uc_out, (H, W))):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32 or t.device != logits.device):
+            raise ValueError(f"output must be a contiguous float32 {shape} tensor on the logits' device")
+    sT, sC, sH, sW = logits.stride()
+    sid = strategy_id(strategy) if uc_out is not None else 0
+    with torch.cuda.device(logits.device):
+        rc = _lib.lib().pp_acq_softmax_sum(logits.data_ptr(), T, C, H, W, sT, sC, sH, sW,
+                                           prob_out.data_ptr() if prob_out is not None else None,
+                                           uc_out.data_ptr() if uc_out is not None else None, sid, float(scale),
+                                           int(bool(accumulate)), _lib.current_stream_ptr(logits.device))
+    _lib.check(rc, "pp_acq_softmax_sum")
+
+
 def topk_select(scores: torch.Tensor, k: int, largest: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """scores [B,N] f32 -> (idx int32 [B,k], val f32 [B,k]); uc_map.flatten().topk (query.py:57-61)."""
     _require_cuda_f32(scores, "scores", 2)

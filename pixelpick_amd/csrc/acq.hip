@@ -764,6 +764,44 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
+// Sum over T forward passes of softmax(logits[t]) per pixel and of the strategy's score of each pass (the MC-dropout
+// branch, query.py:181-187: `uc_map += uc_map_; prob += prob_`), scaled: p_c = exp(x_c - m) / S and the score formulas in
+// the reference's operation order (libm expf / logf), one thread per pixel, any strides.
+__global__ __launch_bounds__(kBlock) void softmax_sum_kernel(const float* logits, int T, int C, int W, int64_t N, int64_t sT, int64_t sC,
+                                                            int64_t sH, int64_t sW, float* out, float* uc_out, int strategy, float scale,
+                                                            int accumulate)
+{
+    const int64_t pix = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= N) return;
+    const int64_t hh = pix / W, ww = pix - hh * W;
+    const float* base = logits + hh * sH + ww * sW;
+    float acc[PP_ACQ_MAX_CLASSES];
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    float uc = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const float* xt = base + (int64_t)t * sT;
+        float m = xt[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, xt[(int64_t)c * sC]);
+        float S = 0.0f;
+        for (int c = 0; c < C; ++c) S += expf(xt[(int64_t)c * sC] - m);
+        float ent = 0.0f, t1 = -INFINITY, t2 = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float pc = expf(xt[(int64_t)c * sC] - m) / S;
+            acc[c] += pc;
+            ent += (-pc) * logf(pc);
+            t2 = fmaxf(t2, fminf(t1, pc));
+            t1 = fmaxf(t1, pc);
+        }
+        uc += strategy == PP_ACQ_ENTROPY ? ent : (strategy == PP_ACQ_LEAST_CONFIDENCE ? 1.0f - t1 : fabsf(t1 - t2));
+    }
+    if (out)
+        for (int c = 0; c < C; ++c) {
+            const int64_t o = (int64_t)c * N + pix;
+            out[o] = accumulate ? fmaf(scale, acc[c], out[o]) : scale * acc[c];
+        }
+    if (uc_out) uc_out[pix] = accumulate ? fmaf(scale, uc, uc_out[pix]) : scale * uc;
+}
+
 static int next_pow2(int64_t v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct Plan {
@@ -1085,6 +1123,18 @@ int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64
     AcqParams p{logits, exclude, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
                 strategy, g_reduce_mode, 0};
     return dispatch_acq(p, pl, B, as_stream(stream));
+}
+
+int pp_acq_softmax_sum(const float* logits, int64_t T, int64_t C, int64_t H, int64_t W, int64_t sT, int64_t sC, int64_t sH,
+                       int64_t sW, float* prob_out, float* uc_out, int strategy, float scale, int accumulate, pp_stream_t stream)
+{
+    if (int rc = validate(logits, T, C, H, W, strategy)) return rc;
+    if (!prob_out && !uc_out) return fail(PP_ERR_BAD_ARG, "softmax_sum: both outputs are null");
+    const int64_t N = H * W;
+    const int64_t blocks = (N + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(softmax_sum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), logits, (int)T, (int)C, (int)W, N,
+                       sT, sC, sH, sW, prob_out, uc_out, strategy, scale, accumulate);
+    return check_launch("softmax_sum_kernel");
 }
 
 int pp_uncertainty_from_prob(const float* prob, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC,

@@ -1474,6 +1474,22 @@ __global__ __launch_bounds__(kT) void dropout4_kernel(const float* x, int64_t ld
     }
 }
 
+// nn.Dropout2d (mobilenet_v2.py:114-115,127,133-134): ONE draw per (sample, channel) zeroes the whole feature map of that
+// channel; same counter-based hash as the element dropout, indexed by b*C + c.
+__global__ __launch_bounds__(kT) void dropout2d_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int B, int64_t P, int C,
+                                                      float p, float inv_keep, uint64_t seed, const uint64_t* seed_dev)
+{
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+    const int64_t total = (int64_t)B * P * C;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        const int64_t r = e / C;                 // pixel row b*P + pix
+        const int c = (int)(e - r * C);
+        const int64_t b = r / P;
+        const float u = (float)(hash_rng(seed, (uint64_t)(b * C + c)) >> 8) * (1.0f / 16777216.0f);
+        y[r * ldy + c] = u >= p ? x[r * ldx + c] * inv_keep : 0.0f;
+    }
+}
+
 __global__ __launch_bounds__(kT) void dropout_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C,
                                                     float p, float inv_keep, uint64_t seed, const uint64_t* seed_dev)
 {
@@ -2243,6 +2259,17 @@ int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, in
         hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(M * C)), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, M, C, p,
                            1.0f / (1.0f - p), seed, seed_dev);
     return check_launch("dropout_kernel");
+}
+
+int pp_dropout2d(const float* x, int64_t ldx, float* y, int64_t ldy, int B, int64_t P, int C, float p, uint64_t seed,
+                 const uint64_t* seed_dev, pp_stream_t stream)
+{
+    if (!x || !y) return fail(PP_ERR_BAD_ARG, "dropout2d: null");
+    if (p < 0.0f || p >= 1.0f) return fail(PP_ERR_BAD_ARG, "dropout2d: p=%f outside [0,1)", (double)p);
+    if (B <= 0 || P <= 0 || C <= 0) return fail(PP_ERR_BAD_ARG, "dropout2d: B=%d P=%lld C=%d", B, (long long)P, C);
+    hipLaunchKernelGGL(dropout2d_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(kT), 0, as_stream(stream), x, ldx, y, ldy, B, P, C,
+                       p, 1.0f / (1.0f - p), seed, seed_dev);
+    return check_launch("dropout2d_kernel");
 }
 
 // ---- loss ----------------------------------------------------------------------------------------------------------

@@ -994,6 +994,36 @@ def _dropout_bwd(tape: Tape, dy, x: Var, p, seed):
     _acc(x, dx)
 
 
+def dropout2d(tape: Tape, x: Var, p: float, training: bool) -> Var:
+    """nn.Dropout2d: whole channels of a sample are zeroed (mobilenet_v2.py:114-115,133-134).  Identity in eval mode."""
+    if not training or p <= 0.0:
+        return x
+    B, H, W, C, ldx = _geom(x.t)
+    _dropout_counter[0] += 1
+    seed = (_dropout_counter[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.t.device)
+    sd = _dropout_seed_dev[0]
+    rc = _lib.lib().pp_dropout2d(x.t.data_ptr(), ldx, y.data_ptr(), C, B, H * W, C, float(p), seed,
+                                 sd.data_ptr() if sd is not None else None, _stream())
+    _lib.check(rc, "pp_dropout2d")
+    out = Var(y, needs_grad=x.needs_grad)
+    tape.record(_dropout2d_bwd, (x, p, seed), out)
+    return out
+
+
+def _dropout2d_bwd(tape: Tape, dy, x: Var, p, seed):
+    if not x.needs_grad:
+        return
+    B, H, W, C, _ = _geom(x.t)
+    _, _, _, _, lddy = _geom(dy)
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    sd = _dropout_seed_dev[0]
+    rc = _lib.lib().pp_dropout2d(dy.data_ptr(), lddy, dx.data_ptr(), C, B, H * W, C, float(p), seed,
+                                 sd.data_ptr() if sd is not None else None, _stream())
+    _lib.check(rc, "pp_dropout2d")
+    _acc(x, dx)
+
+
 # ------------------------------------------------------------------------------------------------- concat (zero-copy)
 def concat_alias(tape: Tape, buf: torch.Tensor, parts: Sequence[Var]) -> Var:
     """torch.cat(dim=channel) without a copy: every part was produced directly into its channel slice of

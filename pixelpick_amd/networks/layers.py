@@ -154,6 +154,25 @@ class ReLU6(_Placeholder):
         super().__init__()
 
 
+class Dropout2d(nn.Module):
+    """nn.Dropout2d(p): whole channels of a sample are dropped.  NOT an instance of `Dropout`, so turn_on_dropout() /
+    turn_off_dropout() (deeplab.py:33-41, `isinstance(m, torch.nn.Dropout)`) leave it alone, exactly as in the reference:
+    it is active in train mode only."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def run(self, tape, x):
+        return E.dropout2d(tape, x, self.p, self.training)
+
+    def forward(self, x):
+        return x
+
+    def extra_repr(self):
+        return f"p={self.p}"
+
+
 class Dropout(nn.Module):
     """nn.Dropout(p).  isinstance(m, Dropout) is what turn_on_dropout() toggles (deeplab.py:33-41)."""
 

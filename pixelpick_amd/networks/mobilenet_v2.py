@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine as E
-from .layers import BatchNorm2d, Conv2d, ReLU6
+from .layers import BatchNorm2d, Conv2d, Dropout2d, ReLU6
 
 
 FOLD_FIXED_PADDING = os.environ.get("PIXELPICK_FOLD_PAD", "1") != "0"
@@ -85,9 +85,6 @@ class MobileNetV2(nn.Module):
     def __init__(self, output_stride=8, BatchNorm=None, width_mult=1., pretrained=True, mc_dropout=False, mc_dropout_p=0.2):
         super().__init__()
         BatchNorm = BatchNorm or BatchNorm2d
-        if mc_dropout:
-            raise NotImplementedError("nn.Dropout2d (MC-dropout training variant, mobilenet_v2.py:114-115,133-134) "
-                                      "is not part of the accelerated path")
         block = InvertedResidual
         input_channel = 32
         current_stride = 1
@@ -107,11 +104,14 @@ class MobileNetV2(nn.Module):
             for i in range(n):
                 features.append(block(input_channel, output_channel, stride if i == 0 else 1, dilation, t, BatchNorm))
                 input_channel = output_channel
+        if mc_dropout:                                   # mobilenet_v2.py:114-115: last feature, for MC train
+            features.append(Dropout2d(p=mc_dropout_p))
         self.features = nn.Sequential(*features)
         if pretrained:
             self._load_pretrained_model()
         self.low_level_features = self.features[0:4]
         self.high_level_features = self.features[4:]
+        self.dropout = Dropout2d(p=mc_dropout_p)         # mobilenet_v2.py:127: on the low-level features, for MC test
         self.mc_dropout = mc_dropout
 
     def _load_pretrained_model(self):
@@ -127,7 +127,7 @@ class MobileNetV2(nn.Module):
     @staticmethod
     def _run_features(tape, seq, x):
         for m in seq:
-            if isinstance(m, InvertedResidual):
+            if isinstance(m, (InvertedResidual, Dropout2d)):
                 x = m.run(tape, x)
             else:  # stem conv_bn
                 x = m[1].run(tape, m[0].run(tape, x), E.ACT_RELU6)
@@ -136,4 +136,6 @@ class MobileNetV2(nn.Module):
     def run(self, tape, x):
         low = self._run_features(tape, self.low_level_features, x)
         high = self._run_features(tape, self.high_level_features, low)
+        if self.mc_dropout:                              # mobilenet_v2.py:133-134
+            low = self.dropout.run(tape, low)
         return high, low

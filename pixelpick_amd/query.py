@@ -354,21 +354,20 @@ class QuerySelector:
                     # mean uncertainty / mean probability over mc_n_steps stochastic passes: the passes differ only in their
                     # dropout masks (eval-mode BatchNorm is per sample), so they run as ONE forward over mc_n_steps copies of
                     # the image instead of mc_n_steps launch-bound forwards at batch 1 (`mc_chunk` copies at a time)
-                    uc_map = torch.zeros((h, w), device=self.device)
-                    prob = torch.zeros((1, self.n_classes, h, w), device=self.device)
-                    left = self.mc_n_steps
+                    uc_map = torch.empty((h, w), dtype=torch.float32, device=self.device)
+                    prob = torch.empty((1, self.n_classes, h, w), dtype=torch.float32, device=self.device)
+                    left, first = self.mc_n_steps, True
                     while left > 0:
                         t = min(left, self.mc_chunk)
                         logits = self._forward_logits(model, it.x.expand(t, -1, -1, -1).contiguous(), h, w)
-                        if not is_random:
-                            uc_map += acq.score_map(logits, None, self.query_strategy).sum(dim=0)
-                        prob += F.softmax(logits, dim=1).sum(dim=0, keepdim=True)
+                        # uc_map += score(softmax(logits)) / n ; prob += softmax(logits) / n   (query.py:181-187), one HIP pass
+                        acq.mc_accumulate_(logits, prob[0], None if is_random else uc_map, "entropy" if is_random else self.query_strategy,
+                                           1.0 / self.mc_n_steps, accumulate=not first)
                         left -= t
-                    prob /= self.mc_n_steps
+                        first = False
                     if is_random:                       # the drawn map is already the mean of the mc_n_steps host draws
                         idx_sorted = self._random_topk(it.draws["rmap"][None], excl_j[None], self._k_launch(h, w))[0]
                     else:
-                        uc_map /= self.mc_n_steps
                         uc_map[torch.from_numpy(excl_j).to(self.device)] = 0.0 if self._largest else 1.0
                         idx_t, _ = acq.topk_select(uc_map.reshape(1, h * w), self._k_launch(h, w), self._largest)
                         idx_sorted = idx_t[0].cpu().numpy().astype(np.int64)

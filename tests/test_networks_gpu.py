@@ -296,3 +296,35 @@ def test_flat_trainer_sgd_is_torch_sgd_with_the_voc_groups():
         tr.step_count = step
         tr.optimizer_step()
         assert (tr.flat_p.cpu() - torch.cat([pa.detach(), pb.detach()])).abs().max().item() < 2e-6
+
+
+def test_mc_dropout_training_variant_runs_through_dropout2d():
+    """--use_mc_dropout (mobilenet_v2.py:114-115,133-134): nn.Dropout2d on the high-level and low-level encoder features in
+    train mode.  A step is finite, bit-reproducible for a fixed seed, differs from the plain model's (the masks are live),
+    and in eval mode (Dropout2d inactive, as the reference) the logits equal the plain model's with the same weights."""
+    from pixelpick_amd import engine as E
+    a = _args(19)
+    a.use_mc_dropout = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mc = get_model(a)
+    sd = fi.formula_state_dict(mc.state_dict())
+    mc.load_state_dict(sd)
+    plain = _build(19)
+    for mod in mc.modules():
+        if isinstance(mod, Dropout):
+            mod.p = 0.0                                   # only the two Dropout2d stay stochastic
+    mc = mc.to(DEV)
+    x = fi.formula_input(2, 64, 96, key="mc").to(DEV)
+    y = fi.formula_labels(2, 64, 96, 19, 19, 20, key="mc").to(DEV)
+    with torch.no_grad():
+        assert torch.equal(mc.eval()(x)["pred"], plain.eval()(x)["pred"])
+    losses, grads = [], []
+    for rep in range(2):
+        E.set_dropout_seed(7)
+        tr = FlatTrainer(mc.train(), ignore_index=19)
+        losses.append(tr.forward_backward(x, y).item())
+        grads.append(tr.flat_g.clone())
+    assert np.isfinite(losses[0]) and losses[0] == losses[1] and torch.equal(grads[0], grads[1])
+    tp = FlatTrainer(plain.train(), ignore_index=19)
+    assert abs(tp.forward_backward(x, y).item() - losses[0]) > 1e-6

@@ -613,6 +613,49 @@ def test_dropout_statistics_and_backward():
     assert E.dropout(E.Tape(False), xv, 0.5, False) is xv   # eval: identity
 
 
+def test_dropout2d_drops_whole_channels_and_backward_uses_the_same_mask():
+    """nn.Dropout2d (mobilenet_v2.py:114-115,133-134): one draw per (sample, channel); kept channels are scaled by 1/(1-p);
+    the backward pass applies the identical mask to the gradient; eval mode / p = 0 is the identity."""
+    torch.manual_seed(0)
+    B, H, W, C, p = 6, 9, 11, 320, 0.2
+    x = torch.randn(B, H, W, C, device=DEV) + 3.0            # no zeros in the input
+    E.set_dropout_seed(123)
+    tape = E.Tape(True)
+    xv = E.Var(x)
+    yv = E.dropout2d(tape, xv, p, True)
+    y = yv.t
+    per_map = (y != 0).reshape(B, H * W, C)
+    assert (per_map.all(dim=1) | (~per_map).all(dim=1)).all(), "a channel map must be kept or dropped as a whole"
+    kept = per_map[:, 0, :]
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - p) < 0.04, frac                        # 1920 draws: sigma = 0.009
+    assert not torch.equal(kept[0], kept[1])                 # samples draw independently
+    torch.testing.assert_close(y[kept[:, None, None, :].expand_as(y)], (x / (1 - p))[kept[:, None, None, :].expand_as(y)])
+    dy = torch.randn_like(x)
+    tape.backward(yv, dy)
+    dx = xv.grad
+    assert torch.equal(dx != 0, y != 0)
+    torch.testing.assert_close(dx[y != 0], (dy / (1 - p))[y != 0])
+    assert E.dropout2d(E.Tape(False), xv, p, False) is xv and E.dropout2d(E.Tape(False), xv, 0.0, True) is xv
+
+
+def test_mc_accumulate_matches_torch_softmax_and_scores():
+    """pp_acq_softmax_sum (query.py:181-187): mean probability and mean per-pass score over T stochastic passes."""
+    from pixelpick_amd import acquisition as acq
+    torch.manual_seed(1)
+    T, C, H, W = 5, 21, 13, 17
+    logits = torch.randn(T + 3, C, H, W + 2, device=DEV)[:T, :, :, :W] * 3       # strided view
+    prob = torch.softmax(logits, dim=1)
+    for st, ref_uc in (("entropy", (-prob * prob.log()).sum(1)), ("least_confidence", 1 - prob.max(1)[0]),
+                       ("margin_sampling", (prob.topk(2, dim=1).values[:, 0] - prob.topk(2, dim=1).values[:, 1]).abs())):
+        p_out = torch.empty(C, H, W, device=DEV)
+        u_out = torch.empty(H, W, device=DEV)
+        acq.mc_accumulate_(logits[:2], p_out, u_out, st, 1.0 / T, accumulate=False)
+        acq.mc_accumulate_(logits[2:], p_out, u_out, st, 1.0 / T, accumulate=True)
+        torch.testing.assert_close(p_out, prob.mean(0), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(u_out, ref_uc.mean(0), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("B,C,H,W,n_lab,ign", [(4, 19, 64, 128, 20, 19), (2, 21, 33, 47, 10, 255), (1, 11, 20, 24, 480, 11)])
 def test_cross_entropy(B, C, H, W, n_lab, ign):
     torch.manual_seed(8)
