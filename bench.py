@@ -125,6 +125,15 @@ def cpu_baseline_acq(C, H, W, k, strategy, budget_s=8.0):
     return round(done * H * W / el / 1e6, 3), f"{done} images {H}x{W}x{C} one at a time (query.py:159 loop), {el:.1f} s"
 
 
+def _acq_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in ("acq.hip", "pp_common.h"):
+        h.update(open(os.path.join(here, "pixelpick_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +246,25 @@ def main():
         train = {"img_per_s": world * TB * a.steps / el, "ms_per_step": el / a.steps * 1e3, "loss_after": loss,
                  "launch": "hipGraph replay" if a.graph else "eager, weight gradients on a second stream",
                  "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
+        if dist is not None:
+            # what the communicator really is, and what the gradient exchange costs on its own (both buckets back to back,
+            # nothing else running): the overlapped step hides most of the first bucket under the encoder backward
+            ar = []
+            for _ in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                barrier()
+                e0.record()
+                dist.all_reduce(tr.flat_g[tr.n_split:])
+                dist.all_reduce(tr.flat_g[:tr.n_split])
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ar.append(e0.elapsed_time(e1))
+            ar_ms = max_over_ranks(sorted(ar[1:])[len(ar[1:]) // 2])
+            line["distributed"] = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                                   "allreduce_bytes_per_step": tr.n * 4, "buckets": [int((tr.n - tr.n_split) * 4), int(tr.n_split * 4)],
+                                   "allreduce_alone_ms": round(ar_ms, 4),
+                                   "allreduce_alone_GBps_per_rank": round(tr.n * 4 / (ar_ms * 1e-3) / 1e9, 1),
+                                   "overlapped": bool(__import__("pixelpick_amd.trainer", fromlist=["x"]).OVERLAP_ALLREDUCE)}
 
         # dominant train kernel vs the fp32 MFMA roofline: SegmentHead conv 3x3 304->256 on [TB,64,128] (decoders.py:107)
         Hq, Wq = H // 4, W // 4
@@ -332,15 +360,25 @@ def main():
         acqr = {"value": round(world * B * H * W * a.steps / el / 1e6, 1), "unit": "Mpixels/s",
                 "ms_per_step": round(el / a.steps * 1e3, 4), "images_per_launch_per_gpu": B, "k": k,
                 "strategy": a.strategy, "layout": a.layout}
-        # HBM traffic per launch from the PMC passes of this very configuration (profiles/r01_acq_pmc.txt: rocprofv3
-        # --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for
-        # gfx950).  A counter pass cannot run inside this process, so the figure is quoted only for the profiled config.
-        traffic = None
-        if (B, C, H, W, k, a.strategy, a.layout) == (256, 19, 256, 512, 20, "entropy", "nchw"):
-            traffic = 2 * 1261741.69 * 1024 + 10841.89 * 1024
+        # HBM traffic per launch: a counter pass cannot run inside this process, so it comes from the record a committed
+        # script writes (tools/measure_acq_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950).  The record carries the hash of the kernel source it measured; if this
+        # build's source differs, or the configuration is another one, the line says null instead of a stale number.
+        traffic, traffic_src = None, None
+        rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "acq_traffic.json")
+        if os.path.exists(rec_path):
+            rec = json.load(open(rec_path))
+            cfg = rec.get("config", {})
+            same_cfg = (cfg.get("B"), cfg.get("C"), cfg.get("H"), cfg.get("W"), cfg.get("k"), cfg.get("strategy"), cfg.get("layout")) == \
+                       (B, C, H, W, k, a.strategy, a.layout)
+            if same_cfg and rec.get("acq_source_sha256") == _acq_source_hash():
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/acq_traffic.json ({rec['kernel'].split('(')[0]}, measured {rec['measured_unix']})"
+            elif same_cfg:
+                traffic_src = "profiles/acq_traffic.json is for another build of csrc/acq.hip: re-run tools/measure_acq_traffic.py"
         line["roofline"] = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                            "traffic_source": "profiles/r01_acq_pmc.txt (rocprofv3 PMC, round 1)" if traffic else None,
+                            "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
                             "kernel_ms_min": round(min(kms), 4)}
 

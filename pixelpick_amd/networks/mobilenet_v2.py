@@ -116,8 +116,10 @@ class MobileNetV2(nn.Module):
 
     def _load_pretrained_model(self):
         path = os.environ.get("PIXELPICK_MNV2_WEIGHTS", "")
-        if path and os.path.isfile(path):
-            pretrain_dict = torch.load(path, map_location="cpu")
+        if path and not os.path.isfile(path):
+            raise FileNotFoundError(f"PIXELPICK_MNV2_WEIGHTS={path}: no such file (unset it to start from a random backbone)")
+        if path:
+            pretrain_dict = torch.load(path, map_location="cpu", weights_only=True)
             own = self.state_dict()
             self.load_state_dict({k: v for k, v in pretrain_dict.items() if k in own}, strict=False)
         else:

@@ -87,9 +87,12 @@ class FlatTrainer:
         self.last_logits: Optional[torch.Tensor] = None
         # run-time hyper-parameters live in device memory so that the whole step can be a replayed hipGraph:
         # hyper = [lr_backbone, lr_head, 1-beta1^t, sqrt(1-beta2^t)], seed = per-step dropout base seed
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        # (a ring of pinned staging slots: the host runs ahead of graph replays, so a slot is only rewritten once the copy
+        # that read it has executed - its event is waited for first)
+        self._stage = [(torch.zeros(4, dtype=torch.float32).pin_memory(), torch.zeros(1, dtype=torch.int64).pin_memory(),
+                        torch.cuda.Event()) for _ in range(4)]
+        self._stage_used = [False] * len(self._stage)
         self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
         self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self._graph = None
         self._gx = self._gy = None
@@ -159,13 +162,19 @@ class FlatTrainer:
     def _stage_hyper(self):
         """Host -> pinned -> device copies of the per-step scalars (enqueued on the current stream)."""
         t = self.step_count
-        self._hyper_host[0] = self.slow_lr * self.lr_factor
-        self._hyper_host[1] = self.lr * self.lr_factor
-        self._hyper_host[2] = 1.0 - self.betas[0] ** t
-        self._hyper_host[3] = (1.0 - self.betas[1] ** t) ** 0.5
-        self._seed_host[0] = 0x5DEECE66D * t + 11
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
-        self._seed_dev.copy_(self._seed_host, non_blocking=True)
+        slot = t % len(self._stage)
+        hyper_host, seed_host, ev = self._stage[slot]
+        if self._stage_used[slot]:
+            ev.synchronize()                              # the H2D copies of step t-4 have read this slot
+        hyper_host[0] = self.slow_lr * self.lr_factor
+        hyper_host[1] = self.lr * self.lr_factor
+        hyper_host[2] = 1.0 - self.betas[0] ** t
+        hyper_host[3] = (1.0 - self.betas[1] ** t) ** 0.5
+        seed_host[0] = 0x5DEECE66D * t + 11
+        self._hyper_dev.copy_(hyper_host, non_blocking=True)
+        self._seed_dev.copy_(seed_host, non_blocking=True)
+        ev.record()
+        self._stage_used[slot] = True
 
     def optimizer_step(self, use_device_hyper: bool = False):
         L = _lib.lib()
@@ -244,6 +253,22 @@ class FlatTrainer:
         for b in bufs:
             b.copy_(flat[off:off + b.numel()].view_as(b))
             off += b.numel()
+
+    def disable_graph(self):
+        """Back to eager steps; also removes the process-wide device seed word enable_graph() installed, so that later
+        eager trainers / MC-dropout forwards draw their masks from the host counter again."""
+        if self._graph is not None:
+            self._graph = None
+            self._gx = self._gy = None
+        if E._dropout_seed_dev[0] is self._seed_dev:
+            E.set_dropout_device_seed(None)
+
+    def __del__(self):
+        try:
+            if E._dropout_seed_dev[0] is self._seed_dev:
+                E.set_dropout_device_seed(None)
+        except Exception:
+            pass
 
     def set_poly_lr(self, T: int, N: int, power: float = 0.9):
         """utils/lr_scheduler.py:15-17 applied to both segments."""

@@ -284,3 +284,55 @@ def test_two_rank_driver_keeps_replicas_and_datasets_identical(tmp_path):
     assert res[0][2] == res[1][2] == [10 + 2 * 10] * 8            # initial 10 + two acquisition rounds of 10
     assert res[0][3] == res[1][3] and len(res[0][3]) == 2           # identical train history (summed confusion matrices)
     assert {"best_miou_model.pt", "log_train.txt", "log_val.txt", "query_stats.pkl"} <= set(res[0][4])
+
+
+def _long_worker(rank, world, port, q, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pixelpick_amd.trainer as T
+        from pixelpick_amd import engine as E
+        assert T.OVERLAP_ALLREDUCE and E.Tape.overlap_wgrad and E._BN_FUSED
+        from pixelpick_amd.utils.utils import get_model
+        from pixelpick_amd.trainer import FlatTrainer
+        torch.manual_seed(rank)                                  # DIFFERENT initial weights per rank: the constructor must
+        with warnings.catch_warnings():                          # broadcast rank 0's
+            warnings.simplefilter("ignore")
+            m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=7, network_name="deeplab")).cuda().train()
+        tr = FlatTrainer(m, ignore_index=7)                      # dropout ON (p = 0.5 / 0.2): per-rank masks, same parameters
+        E.set_dropout_seed(1000 + rank)
+        batches = [_batch(300 + 10 * rank + i) for i in range(4)]
+        checks = []
+        for s in range(steps):
+            tr.train_step(*batches[s % 4])
+            if (s + 1) % 50 == 0:
+                others = [torch.empty_like(tr.flat_p) for _ in range(world)]
+                dist.all_gather(others, tr.flat_p)
+                checks.append(all(torch.equal(others[0], o) for o in others[1:]))
+        torch.cuda.synchronize()
+        q.put((rank, checks, bool(torch.isfinite(tr.flat_p).all().item()), float(tr.last_loss.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_200_steps_with_spin_barrier_batchnorm_side_stream_and_overlapped_buckets():
+    """200 optimisation steps on two ranks sharing one GPU (gloo): the single-launch (spin-waiting) BatchNorm of BOTH
+    processes, the weight-gradient side streams and the overlapped two-bucket all-reduce all run concurrently on the same
+    device - the co-residency cap (pp_bn_fused_capacity / 2 per launch) must keep that from hanging - and the replicas,
+    started from different random initialisations, stay bit-identical (checked every 50 steps)."""
+    world, steps = 2, 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_long_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, checks, finite, loss in res:
+        assert len(checks) == 4 and all(checks), f"rank {rank}: replicas diverged {checks}"
+        assert finite and loss == loss
