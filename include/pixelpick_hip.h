@@ -297,6 +297,31 @@ int pp_image_broadcast(const float* v, int64_t ldv, int B, int64_t P, int C, flo
 int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int C, float p, uint64_t seed,
                const uint64_t* seed_dev, pp_stream_t stream);
 
+/* ---- training-time augmentation on the device (datasets/base_dataset.py:48-141) -----------------
+ * Images are HWC uint8 RGB (what PIL hands the reference), label maps / query masks [H,W] uint8.  The host builds the
+ * resampling tables (pixelpick_amd/augment.py restates libImaging's precompute_coeffs / nearest index rules and torch's
+ * nearest rule); the kernels evaluate them bit-exactly: clip8((2^21 + sum px*k) >> 22) per pass.
+ *   pp_aug_resample_h   TF.resize(x, BILINEAR), horizontal pass: src [H,W,3] -> dst [H,Wout,3]; bounds [Wout,2] (first
+ *                       source column, count), kk [Wout,ksize] 22-bit fixed-point coefficients.
+ *   pp_aug_vcrop        vertical pass evaluated only where TF.pad(fill) -> TF.crop(start, size) -> TF.hflip look:
+ *                       tmp [h_in, w_rs, 3] -> out [ch,cw,3]; rows/columns beyond (h_rs, w_rs) take the fill colour.
+ *   pp_aug_labels       label map through PIL-NEAREST tables (ty, tx), query mask through torch-nearest tables (qy, qx),
+ *                       same pad (ignore_index / 0) / crop / flip; y_out int64 [ch,cw], q_out uint8 0/1 (base_dataset.py:114).
+ *   pp_aug_jitter       in place; op 0 brightness, 1 contrast, 2 saturation (PIL ImageEnhance blends), 3 hue (PIL RGB->HSV,
+ *                       uint8 wrap-around shift, HSV->RGB), 4 RandomGrayscale (convert("L") x3); contrast needs 8 scratch bytes.
+ *   pp_aug_blur         cv2.GaussianBlur(img, (ks,ks), sigma) with a host-built float kernel; scratch [H*W*3] floats.
+ *   pp_aug_to_tensor    TF.normalize(TF.to_tensor(x), mean, std): HWC uint8 -> CHW float32; mean3 / std3 are HOST arrays. */
+int pp_aug_resample_h(const uint8_t* src, int H, int W, const int32_t* bounds, const int32_t* kk, int ksize, int Wout, uint8_t* dst,
+                      pp_stream_t stream);
+int pp_aug_vcrop(const uint8_t* tmp, const int32_t* bounds, const int32_t* kk, int ksize, int h_rs, int w_rs, int start_h, int start_w,
+                 int ch, int cw, int flip, int fill_r, int fill_g, int fill_b, uint8_t* out, pp_stream_t stream);
+int pp_aug_labels(const uint8_t* y, const uint8_t* q, int W, const int32_t* ty, const int32_t* tx, const int32_t* qy, const int32_t* qx,
+                  int h_rs, int w_rs, int start_h, int start_w, int ch, int cw, int flip, int ignore_index, int64_t* y_out,
+                  uint8_t* q_out, pp_stream_t stream);
+int pp_aug_jitter(uint8_t* img, int64_t n_pixels, int op, float factor, unsigned long long* scratch_sum, pp_stream_t stream);
+int pp_aug_blur(uint8_t* img, int H, int W, const float* kernel, int ks, float* scratch, pp_stream_t stream);
+int pp_aug_to_tensor(const uint8_t* img, int64_t n_pixels, const float* mean3, const float* std3, float* out, pp_stream_t stream);
+
 /* nn.Dropout2d (mobilenet_v2.py:114-115 on the high-level features in MC-dropout TRAINING, :127,133-134 on the low-level
  * features): x, y [B,P,C] channels-last; one keep/drop draw per (sample, channel) from the hash of (seed, b*C + c).  The
  * backward pass calls it again on dy with the same seed. */

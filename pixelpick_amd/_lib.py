@@ -66,6 +66,12 @@ SIGNATURES = {
     "pp_image_broadcast": (_int, [_p, _i64, _int, _i64, _int, _f, _p, _i64, _p]),
     "pp_dropout": (_int, [_p, _i64, _p, _i64, _i64, _int, _f, ctypes.c_uint64, _p, _p]),
     "pp_dropout2d": (_int, [_p, _i64, _p, _i64, _int, _i64, _int, _f, ctypes.c_uint64, _p, _p]),
+    "pp_aug_resample_h": (_int, [_p, _int, _int, _p, _p, _int, _int, _p, _p]),
+    "pp_aug_vcrop": (_int, [_p, _p, _p] + [_int] * 11 + [_p, _p]),
+    "pp_aug_labels": (_int, [_p, _p, _int, _p, _p, _p, _p] + [_int] * 8 + [_p, _p, _p]),
+    "pp_aug_jitter": (_int, [_p, _i64, _int, _f, _p, _p]),
+    "pp_aug_blur": (_int, [_p, _int, _int, _p, _int, _p, _p]),
+    "pp_aug_to_tensor": (_int, [_p, _i64, ctypes.POINTER(_f), ctypes.POINTER(_f), _p, _p]),
     "pp_sparse_ce_workspace_bytes": (_sz, []),
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "pp_sparse_ce_lowres_workspace_bytes": (_sz, []),

@@ -1,0 +1,134 @@
+"""Device-side training augmentation (pixelpick_amd/augment.py + csrc/augment.hip) against the primitives the reference calls
+(datasets/base_dataset.py:48-141,181): PIL resize / pad / crop / flip, torch nearest for the query tensor, PIL ImageEnhance,
+convert("L"/"HSV") - bit-exact on uint8 - and the cv2.GaussianBlur restatement of oracle/augment.py."""
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import augment as orc
+from pixelpick_amd.augment import DeviceAugmenter, pil_bilinear_tables
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _data(rng, h, w, n_cls=19):
+    x = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    x[: h // 3] = (x[: h // 3].astype(np.int32) // 3 + np.linspace(0, 160, w)[None, :, None]).astype(np.uint8)   # smooth region
+    y = rng.randint(0, n_cls, (h, w)).astype(np.uint8)
+    y[rng.rand(h, w) < 0.05] = 255
+    q = (rng.rand(h, w) < 0.02).astype(np.uint8)
+    return x, y, q
+
+
+@pytest.mark.parametrize("h,w,crop", [(64, 96, (48, 80)), (40, 60, (48, 80)), (100, 72, (64, 64)), (128, 256, (128, 256))])
+def test_geometric_path_is_bit_exact_against_pil_and_torch(h, w, crop):
+    rng = np.random.RandomState(h * 1000 + w)
+    aug = DeviceAugmenter(crop, MEAN, STD, ignore_index=255, photometric=dict(random_color_jitter=False, random_grayscale=False,
+                                                                              random_gaussian_blur=False), device=DEV)
+    random.seed(h + w)
+    n_flip = n_pad = 0
+    for trial in range(12):
+        x, y, q = _data(rng, h, w)
+        p = aug.draw(h, w)
+        n_flip += p["flip"]
+        n_pad += p["h_rs"] < crop[0] or p["w_rs"] < crop[1]
+        out = aug([x], [y], [q], params=[p])
+        img, y_ref, q_ref = orc.geometric(x, y, q, p, crop, aug.mean_val, 255)
+        x_ref = orc.to_tensor_normalize(np.asarray(img), MEAN, STD)
+        assert torch.equal(out["x"][0].cpu(), x_ref), (trial, p)
+        assert np.array_equal(out["y"][0].cpu().numpy(), y_ref), (trial, p)
+        assert np.array_equal(out["queries"][0].cpu().numpy(), q_ref), (trial, p)
+    assert n_flip > 0 and (n_pad > 0 or min(h, w) >= 2 * max(crop))
+
+
+def test_draw_order_and_ranges_follow_the_reference():
+    aug = DeviceAugmenter((256, 512), MEAN, STD, ignore_index=19, device=DEV)
+    random.seed(3); torch.manual_seed(3); np.random.seed(3)
+    ps = [aug.draw(256, 512) for _ in range(200)]
+    random.seed(3)
+    rs = random.uniform(0.5, 2.0)                                     # first draw of the first image is the scale
+    assert (ps[0]["w_rs"], ps[0]["h_rs"]) == (int(512 * rs), int(256 * rs))
+    assert all(128 <= p["h_rs"] <= 512 for p in ps)
+    assert all(0 <= p["start_h"] <= max(p["h_rs"], 256) - 256 and 0 <= p["start_w"] <= max(p["w_rs"], 512) - 512 for p in ps)
+    frac_jit = np.mean([len([o for o in p["ops"] if o[0] < 4]) == 4 for p in ps])
+    frac_gray = np.mean([any(o[0] == 4 for o in p["ops"]) for p in ps])
+    frac_blur = np.mean([p["blur"] is not None for p in ps])
+    assert 0.7 < frac_jit < 0.9 and 0.1 < frac_gray < 0.3 and 0.38 < frac_blur < 0.62
+    for p in ps:
+        for op, f in p["ops"]:
+            assert (0.2 <= f <= 1.8) if op in (0, 1, 2) else (-0.2 <= f <= 0.2) if op == 3 else True
+        if p["blur"]:
+            assert p["blur"][0] == 25 and 0.1 <= p["blur"][1] < 2.0     # int(0.1 * 256 // 2 * 2 + 1)
+
+
+@pytest.mark.parametrize("op,factors", [(0, [0.2, 0.77, 1.0, 1.31, 1.8]), (1, [0.2, 0.9, 1.45, 1.8]), (2, [0.2, 0.6, 1.2, 1.8]),
+                                        (3, [-0.2, -0.07, 0.0, 0.11, 0.2]), (4, [0.0])])
+def test_photometric_ops_are_bit_exact_against_pil(op, factors):
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(op)
+    x, _, _ = _data(rng, 72, 104)
+    x[:4] = x[:4, :, :1]                                              # exactly grey pixels (s == 0 branch of the HSV code)
+    for f in factors:
+        d = torch.from_numpy(x.copy()).to(DEV)
+        scratch = torch.zeros(1, dtype=torch.int64, device=DEV)
+        _lib.check(L.pp_aug_jitter(d.data_ptr(), 72 * 104, op, float(f), scratch.data_ptr(), _lib.current_stream_ptr()), "jitter")
+        ref = np.asarray(orc.jitter(Image.fromarray(x), op, f))
+        got = d.cpu().numpy()
+        assert np.array_equal(got, ref), (op, f, np.abs(got.astype(int) - ref).max(), (got != ref).mean())
+
+
+@pytest.mark.parametrize("ks,sigma", [(25, 0.1), (25, 0.83), (25, 1.97), (7, 1.2)])
+def test_gaussian_blur_matches_the_cv2_restatement(ks, sigma):
+    from pixelpick_amd import _lib
+    from pixelpick_amd.augment import cv2_gaussian_kernel
+    L = _lib.lib()
+    rng = np.random.RandomState(ks)
+    x, _, _ = _data(rng, 48, 80)
+    d = torch.from_numpy(x.copy()).to(DEV)
+    k = torch.from_numpy(cv2_gaussian_kernel(ks, sigma)).to(DEV)
+    fb = torch.empty(48 * 80 * 3, dtype=torch.float32, device=DEV)
+    _lib.check(L.pp_aug_blur(d.data_ptr(), 48, 80, k.data_ptr(), ks, fb.data_ptr(), _lib.current_stream_ptr()), "blur")
+    ref = orc.gaussian_blur(x, ks, sigma)
+    got = d.cpu().numpy()
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3               # fma vs mul+add may tip a value sitting on .5
+    assert abs(float(cv2_gaussian_kernel(ks, sigma).sum()) - 1.0) < 1e-6
+
+
+def test_full_pipeline_batch_shapes_and_determinism():
+    aug = DeviceAugmenter((64, 96), MEAN, STD, ignore_index=255, device=DEV)
+    rng = np.random.RandomState(0)
+    imgs, labs, qs = zip(*[_data(rng, 80, 120) for _ in range(4)])
+    outs = []
+    for rep in range(2):
+        random.seed(1); torch.manual_seed(1); np.random.seed(1)
+        outs.append(aug(list(imgs), list(labs), list(qs)))
+    a, b = outs
+    assert a["x"].shape == (4, 3, 64, 96) and a["y"].shape == (4, 64, 96) and a["queries"].shape == (4, 64, 96)
+    assert torch.equal(a["x"], b["x"]) and torch.equal(a["y"], b["y"]) and torch.equal(a["queries"], b["queries"])
+    assert torch.isfinite(a["x"]).all() and a["y"].dtype == torch.int64 and set(a["queries"].unique().tolist()) <= {0, 1}
+    # the whole chain for one image against the oracle (geometric -> jitter ops -> blur -> to_tensor)
+    p = a["params"][2]
+    img, y_ref, q_ref = orc.geometric(imgs[2], labs[2], qs[2], p, (64, 96), aug.mean_val, 255)
+    for op, f in p["ops"]:
+        img = orc.jitter(img, op, f)
+    arr = np.asarray(img)
+    if p["blur"] is not None:
+        arr = orc.gaussian_blur(arr, *p["blur"])
+    x_ref = orc.to_tensor_normalize(arr, MEAN, STD)
+    tol = (1.5 / 255) / min(STD) if p["blur"] is not None else 0.0
+    assert (a["x"][2].cpu() - x_ref).abs().max().item() <= tol + 1e-7
+    assert np.array_equal(a["y"][2].cpu().numpy(), y_ref) and np.array_equal(a["queries"][2].cpu().numpy(), q_ref)
+
+
+def test_tables_reproduce_pil_on_the_host():
+    """The coefficient tables alone (no GPU arithmetic involved beyond the integer sums the other tests cover)."""
+    b, k, ks = pil_bilinear_tables(100, 37)
+    assert ks == 2 * int(np.ceil(100 / 37)) + 1 and b.shape == (37, 2) and k.shape == (37, ks)
+    assert (k.sum(axis=1) - (1 << 22)).__abs__().max() <= ks           # rows sum to 1.0 in 22-bit fixed point, up to rounding
