@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "pp_common.h"
+#include <type_traits>
 
 namespace pp {
 
@@ -763,6 +764,235 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* 
     }
 }
 
+
+// ---- large-k, multi-block: the radix select of topk_large_kernel taken out of the one-block-per-image kernel -------------
+// Four histogram passes over the score map (8 key bits each, 256 bins), every pass a grid of blocks_per_image x B
+// blocks that add their LDS histograms into the image's global one with integer atomics (order-independent, exact).  No
+// separate scan launch: the blocks of pass p (and the final kernel) re-derive the digits chosen so far from the earlier
+// histograms - a 256-bin scan per earlier pass.  The final one-block-per-image kernel then knows the threshold key T, how
+// many keys equal to T it must take and how many exist, compacts in one barrier-free sweep and sorts.
+constexpr int kSelBins = 256;         // 8-bit digits, four passes: 8 KiB of LDS histograms per block instead of 64 KiB (the 2048-bin
+constexpr int kSelPasses = 4;         // / three-pass form spent most of a pass zeroing and flushing its LDS: 84 us per pass)
+constexpr int kSelSub = 8;            // sub-histograms per block (lane & 7): same-address LDS atomics conflict 8x less
+
+__device__ __forceinline__ uint32_t sel_digit(uint32_t key, int pass) { return (key >> (24 - 8 * pass)) & 255u; }
+__device__ __forceinline__ int sel_shift(int pass) { return 24 - 8 * pass; }
+__device__ __forceinline__ uint32_t sel_mask(int pass) { return pass == 0 ? 0u : (0xFFFFFFFFu << (32 - 8 * pass)); }
+
+// From the top bin down: the digit d with  #(bins above d) < remaining <= #(bins above d) + hist[d].
+// out[0] = d, out[1] = remaining - #above, out[2] = hist[d].
+__device__ __forceinline__ void sel_scan(const uint32_t* hist, uint32_t remaining, uint32_t* sh /*[kSelBins]*/, uint32_t* out /*[3]*/)
+{
+    const int t = threadIdx.x;
+    if (t < kSelBins) sh[t] = hist[t];
+    __syncthreads();
+    if (t == 0) {
+        uint32_t cum = 0;
+        int d = kSelBins - 1;
+        for (; d > 0; --d) {
+            const uint32_t cnt = sh[d];
+            if (cum + cnt >= remaining) break;
+            cum += cnt;
+        }
+        out[0] = (uint32_t)d;
+        out[1] = remaining - cum;
+        out[2] = sh[d];
+    }
+    __syncthreads();
+}
+
+// hist: [B][kSelPasses][kSelBins] (zeroed by the host before pass 0)
+__global__ __launch_bounds__(kBlock) void select_hist_kernel(const float* scores, int64_t N, int k, int largest, int pass, uint32_t* hist)
+{
+    __shared__ uint32_t lh[kSelSub][kSelBins];
+    __shared__ uint32_t sh[kBlock];
+    __shared__ uint32_t res[3];
+    const int b = blockIdx.y;
+    const float* s = scores + (int64_t)b * N;
+    uint32_t* H = hist + (int64_t)b * kSelPasses * kSelBins;
+    const bool lg = largest != 0;
+    uint32_t prefix = 0, remaining = (uint32_t)k;
+    for (int q = 0; q < pass; ++q) {
+        sel_scan(H + q * kSelBins, remaining, sh, res);
+        prefix |= res[0] << sel_shift(q);
+        remaining = res[1];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < kSelSub * kSelBins; i += kBlock) (&lh[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t mask = sel_mask(pass);
+    const int sub = threadIdx.x & (kSelSub - 1);
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+    int64_t i = i0 + threadIdx.x;
+    for (; i + 3 * kBlock < i1; i += 4 * kBlock) {            // four loads in flight per thread
+        const float v0 = s[i], v1 = s[i + kBlock], v2 = s[i + 2 * kBlock], v3 = s[i + 3 * kBlock];
+        const uint32_t k0 = order_key(v0, lg), k1 = order_key(v1, lg), k2 = order_key(v2, lg), k3 = order_key(v3, lg);
+        if ((k0 & mask) == prefix) atomicAdd(&lh[sub][sel_digit(k0, pass)], 1u);
+        if ((k1 & mask) == prefix) atomicAdd(&lh[sub][sel_digit(k1, pass)], 1u);
+        if ((k2 & mask) == prefix) atomicAdd(&lh[sub][sel_digit(k2, pass)], 1u);
+        if ((k3 & mask) == prefix) atomicAdd(&lh[sub][sel_digit(k3, pass)], 1u);
+    }
+    for (; i < i1; i += kBlock) {
+        const uint32_t key = order_key(s[i], lg);
+        if ((key & mask) == prefix) atomicAdd(&lh[sub][sel_digit(key, pass)], 1u);
+    }
+    __syncthreads();
+    uint32_t* Hp = H + pass * kSelBins;
+    for (int d = threadIdx.x; d < kSelBins; d += kBlock) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < kSelSub; ++u) c += lh[u][d];
+        if (c) atomicAdd(&Hp[d], c);
+    }
+}
+
+// One 1024-thread block per image: threshold from the three histograms, barrier-free compaction, bitonic sort.
+__global__ __launch_bounds__(kLargeThreads) void topk_large_sel_kernel(const float* scores, int64_t N, int k, int largest, const uint32_t* hist,
+                                                                      uint64_t* gbuf, int P, int32_t* out_idx, float* out_val)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* shs = reinterpret_cast<uint32_t*>(smem);            // 256: scan partials
+    uint32_t* misc = shs + 256;                                    // 64
+    uint64_t* buf = gbuf ? gbuf + (int64_t)blockIdx.x * P : reinterpret_cast<uint64_t*>(smem + (256 + 64) * 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = scores + (int64_t)blockIdx.x * N;
+    const uint32_t* H = hist + (int64_t)blockIdx.x * kSelPasses * kSelBins;
+    const bool lg = largest != 0;
+    uint32_t T = 0, need_eq = (uint32_t)k, total_eq = 0;
+    for (int q = 0; q < kSelPasses; ++q) {
+        sel_scan(H + q * kSelBins, need_eq, shs, misc);
+        T |= misc[0] << sel_shift(q);
+        need_eq = misc[1];
+        total_eq = misc[2];
+        __syncthreads();
+    }
+    if (tid == 0) { misc[4] = 0; /* out count */ misc[5] = 0; /* eq seen so far (ordered path) */ }
+    __syncthreads();
+    const bool all_eq = need_eq == total_eq;          // every key equal to T is taken: their order is irrelevant (the sort fixes it)
+    auto push = [&](uint32_t key, int64_t i, bool valid) {
+        const bool take = valid && (key > T || (all_eq && key == T));
+        const unsigned long long bal = __ballot(take);
+        if (bal) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&misc[4], (uint32_t)__popcll(bal));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (take) buf[wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+        }
+    };
+    {
+        int64_t base = 0;
+        for (; base + 4 * kLargeThreads <= N; base += 4 * kLargeThreads) {        // four loads in flight per thread
+            const int64_t i = base + tid;
+            const float v0 = s[i], v1 = s[i + kLargeThreads], v2 = s[i + 2 * kLargeThreads], v3 = s[i + 3 * kLargeThreads];
+            push(order_key(v0, lg), i, true);
+            push(order_key(v1, lg), i + kLargeThreads, true);
+            push(order_key(v2, lg), i + 2 * kLargeThreads, true);
+            push(order_key(v3, lg), i + 3 * kLargeThreads, true);
+        }
+        for (; base < N; base += kLargeThreads) {
+            const int64_t i = base + tid;
+            push(i < N ? order_key(s[i], lg) : 0u, i, i < N);
+        }
+    }
+    __syncthreads();
+    if (!all_eq) {
+        // ties at the threshold (constant regions): the need_eq keys == T with the LOWEST indices, found in index order
+        for (int64_t base = 0; base < N; base += kLargeThreads) {
+            const int64_t i = base + tid;
+            const bool eq = i < N && order_key(s[i], lg) == T;
+            const unsigned long long bal = __ballot(eq);
+            if (lane == 0) misc[8 + wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = misc[5];
+            for (int q = 0; q < wave; ++q) before += misc[8 + q];
+            const uint32_t rank = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (eq && rank < need_eq) {
+                const uint32_t pos = atomicAdd(&misc[4], 1u);
+                buf[pos] = ((uint64_t)T << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tot = 0;
+                for (int q = 0; q < kLargeThreads / kWave; ++q) tot += misc[8 + q];
+                misc[5] += tot;
+            }
+            __syncthreads();
+            if (misc[5] >= need_eq) break;
+        }
+        __syncthreads();
+    }
+    for (int j = k + tid; j < P; j += kLargeThreads) buf[j] = 0ull;
+    __syncthreads();
+    // bitonic sort, descending.  Strides >= 8 exchange through `buf`; the three last stages of every size (strides 4, 2, 1)
+    // and the whole of sizes 2..8 run in registers on the thread's own 8 consecutive keys: 66 barrier phases instead of 91.
+    auto reg_stages = [&](int size, bool head) {
+        for (int g = tid; g < (P >> 3); g += kLargeThreads) {
+            uint64_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = buf[8 * g + j];
+            auto stage = [&](auto S_, int sz) {
+                constexpr int S = decltype(S_)::value;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if ((j & S) == 0) {
+                        const bool desc = ((8 * g + j) & sz) == 0;
+                        const uint64_t a = v[j], b = v[j + S];
+                        const bool sw = (a < b) == desc;
+                        v[j] = sw ? b : a;
+                        v[j + S] = sw ? a : b;
+                    }
+                }
+            };
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I4 = std::integral_constant<int, 4>;
+            if (head) {
+                stage(I1{}, 2);
+                stage(I2{}, 4); stage(I1{}, 4);
+                stage(I4{}, 8); stage(I2{}, 8); stage(I1{}, 8);
+            } else {
+                stage(I4{}, size); stage(I2{}, size); stage(I1{}, size);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf[8 * g + j] = v[j];
+        }
+        __syncthreads();
+    };
+    if (P >= 8) {
+        reg_stages(8, true);                                // sizes 2, 4, 8 entirely in registers
+        for (int size = 16; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride >= 8; stride >>= 1) {
+                for (int t = tid; t < (P >> 1); t += kLargeThreads) {
+                    const int pos = 2 * t - (t & (stride - 1));
+                    const uint64_t a = buf[pos], b = buf[pos + stride];
+                    const bool desc = (pos & size) == 0;
+                    if ((a < b) == desc) { buf[pos] = b; buf[pos + stride] = a; }
+                }
+                __syncthreads();
+            }
+            reg_stages(size, false);                        // strides 4, 2, 1 of this size
+        }
+    } else {
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (P >> 1); t += kLargeThreads) {
+                    const int pos = 2 * t - (t & (stride - 1));
+                    const uint64_t a = buf[pos], b = buf[pos + stride];
+                    const bool desc = (pos & size) == 0;
+                    if ((a < b) == desc) { buf[pos] = b; buf[pos + stride] = a; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int j = tid; j < k; j += kLargeThreads) {
+        const uint64_t v = buf[j];
+        out_idx[(int64_t)blockIdx.x * k + j] = (int32_t)(0xFFFFFFFFu - (uint32_t)v);
+        if (out_val) out_val[(int64_t)blockIdx.x * k + j] = key_to_float((uint32_t)(v >> 32), lg);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 // Sum over T forward passes of softmax(logits[t]) per pixel and of the strategy's score of each pass (the MC-dropout
 // branch, query.py:181-187: `uc_map += uc_map_; prob += prob_`), scaled: p_c = exp(x_c - m) / S and the score formulas in
@@ -873,21 +1103,49 @@ static int run_merge(uint64_t* cand, int64_t n_cand, uint64_t* other, int64_t B,
     }
 }
 
-static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int largest, uint64_t* gbuf,
+static thread_local int g_large_multiblock = 1;     // 0: the one-block-per-image radix select (pp_debug_set_reduce_mode bit 8), for A/B
+
+static size_t large_ws_bytes(int64_t B, int64_t k)
+{
+    const int P = next_pow2(k);
+    const size_t g = P <= kLargeLdsMaxP ? 256 : align_up((size_t)B * P * 8, 256);
+    return g + align_up((size_t)B * kSelPasses * kSelBins * 4, 256);
+}
+
+static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int largest, void* ws,
                      int32_t* out_idx, float* out_val, hipStream_t st)
 {
     const int P = next_pow2(k);
     const bool in_lds = P <= kLargeLdsMaxP;
+    uint64_t* gbuf = reinterpret_cast<uint64_t*>(ws);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + (in_lds ? 256 : align_up((size_t)B * P * 8, 256)));
     const size_t lds = (256 + 64) * 4 + (in_lds ? (size_t)P * 8 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_large_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_large_sel_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
         attr_set = true;
     }
-    hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest,
+    if (!g_large_multiblock || B > 65535) {
+        hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest,
+                           in_lds ? (uint64_t*)nullptr : gbuf, P, out_idx, out_val);
+        return check_launch("topk_large_kernel");
+    }
+    if (hipMemsetAsync(hist, 0, (size_t)B * kSelPasses * kSelBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+    // >= ~2048 blocks per pass, at least 4096 elements per block
+    int64_t bpi = cdiv(2048, B);
+    const int64_t by_size = cdiv(N, 4096);
+    if (bpi > by_size) bpi = by_size;
+    if (bpi < 1) bpi = 1;
+    for (int pass = 0; pass < kSelPasses; ++pass) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, (int)k, largest, pass, hist);
+        if (int rc = check_launch("select_hist_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(topk_large_sel_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest, hist,
                        in_lds ? (uint64_t*)nullptr : gbuf, P, out_idx, out_val);
-    return check_launch("topk_large_kernel");
+    return check_launch("topk_large_sel_kernel");
 }
 
 template <int CMAX, bool EXACT>
@@ -1077,7 +1335,12 @@ using namespace pp;
 
 extern "C" {
 
-void pp_debug_set_reduce_mode(int mode) { g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
+void pp_debug_set_reduce_mode(int mode)
+{
+    g_large_multiblock = (mode & 256) ? 0 : 1;      // bit 8: large-k selection through the one-block-per-image radix select (A/B)
+    mode &= 255;
+    g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0;
+}
 
 void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
 
@@ -1094,8 +1357,7 @@ size_t pp_topk_workspace_bytes(int64_t B, int64_t N, int64_t k)
         Plan pl = make_plan(B, N, false);
         return merge_ws_bytes(B, (int64_t)pl.waves_per_image * k, k);
     }
-    const int P = next_pow2(k);
-    return P <= kLargeLdsMaxP ? 256 : align_up((size_t)B * P * 8, 256);
+    return large_ws_bytes(B, k);
 }
 
 size_t pp_acq_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_t k)

@@ -118,6 +118,30 @@ def test_topk_select_vs_oracle(B, N, k, largest, reduce_mode):
         np.testing.assert_array_equal(val[b].cpu().numpy(), e_val)
 
 
+@pytest.mark.parametrize("largest", [True, False])
+@pytest.mark.parametrize("B,N,k,levels", [(3, 131072, 6553, 10), (2, 50000, 2500, 3), (5, 20000, 100, 1), (260, 8192, 409, 40)])
+def test_large_k_select_with_ties_at_the_threshold(B, N, k, levels, largest):
+    """The multi-block radix select (three histogram passes + one sorting block per image) on maps quantised to a few
+    levels, so that the k-th value sits inside a big group of equal keys: the lowest-index members of that group must be
+    taken, exactly as the oracle's stable sort does (void regions produce exactly this in the top-5 % mode)."""
+    rng = np.random.RandomState(B * 7 + levels)
+    s = (np.floor(rng.rand(B, N) * levels) / levels).astype(np.float32)
+    s[0, :50] = np.nan if B > 1 else 0.0
+    idx, val = acq.topk_select(torch.from_numpy(s).to(DEV), k, largest)
+    for b in range(min(B, 6)):
+        e_idx, e_val = orc.topk(s[b], k, largest)
+        assert idx[b].cpu().numpy().tolist() == e_idx.tolist()
+        np.testing.assert_array_equal(val[b].cpu().numpy(), e_val)
+    # the one-block-per-image kernel gives the same answer (A/B switch)
+    from pixelpick_amd import _lib
+    _lib.lib().pp_debug_set_reduce_mode(256)
+    try:
+        idx2, val2 = acq.topk_select(torch.from_numpy(s).to(DEV), k, largest)
+    finally:
+        _lib.lib().pp_debug_set_reduce_mode(0)
+    assert torch.equal(idx, idx2) and torch.equal(val.view(torch.int32), val2.view(torch.int32))
+
+
 @pytest.mark.parametrize("st", STRATS)
 def test_select_modes_golden(golden_dir, st):
     m = np.load(os.path.join(golden_dir, "acq_select_modes.npz"))
