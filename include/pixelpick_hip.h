@@ -198,6 +198,21 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
 /* drop_p > 0: the nn.Dropout(p) that follows BN -> ReLU (aspp.py:60-61, decoders.py:108-114) is applied in the same pass
  * with pp_dropout's mask stream (same seed / seed_dev -> same mask), act must be 0 or 1. */
 
+/* Training-mode BatchNorm whose statistics come from the PRODUCER of x (round 2): pp_conv2d_fwd_stats writes, next to the
+ * convolution output, per-wave (or, behind a split-K convolution, per reduce-block) column sums and sums of squares
+ * stats[rows][2][Cout] (rows = pp_conv2d_fwd_stats_rows(shape); 0 = this shape delivers none), and
+ * pp_bn_train_fwd_partials reduces them (fixed order, fp64) in every block and applies scale/shift (+ residual, activation,
+ * dropout) in one pass over x: no statistics pass, no exchange between blocks, no co-residency requirement
+ * (mobilenet_v2.py:42-43,56-57 conv -> BatchNorm pairs and every other dense conv -> BatchNorm pair of the networks). */
+int64_t pp_conv2d_fwd_stats_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pp_conv2d_fwd_stats(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                        int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                        size_t ws_bytes, float* stats, size_t stats_floats, pp_stream_t stream);
+int pp_bn_train_fwd_partials(const float* x, int64_t ldx, int64_t M, int C, const float* stats, int64_t stat_rows, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                             float* invstd, const float* residual, int64_t ldr, int act, float drop_p, uint64_t drop_seed,
+                             const uint64_t* drop_seed_dev, float* y, int64_t ldy, pp_stream_t stream);
+
 /* Depthwise 3x3 convolution + training-mode BatchNorm (+ residual) + activation in ONE launch (mobilenet_v2.py:38-40, 52-54):
  * the single-launch BatchNorm computes the convolution in its statistics pass, writes it to x_out [B,Ho,Wo,C] (BatchNorm's
  * input, needed by the backward pass) and applies the normalisation from there.  Bit-identical to pp_dwconv3x3_fwd followed

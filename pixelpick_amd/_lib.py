@@ -32,6 +32,9 @@ SIGNATURES = {
     "pp_conv2d_fwd_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_data_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p]),
+    "pp_conv2d_fwd_stats_rows": (_i64, [_int] * 10),
+    "pp_conv2d_fwd_stats": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p, _sz, _p]),
+    "pp_bn_train_fwd_partials": (_int, [_p, _i64, _i64, _int, _p, _i64, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _int, _f, _u64, _p, _p, _i64, _p]),
     "pp_conv2d_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int,
                                     _p, _i64, _int, _p, _sz, _p]),
     "pp_dwconv3x3_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int, _p, _i64, _p]),

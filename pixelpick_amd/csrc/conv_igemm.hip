@@ -65,6 +65,8 @@ struct ConvParams {
     Epilogue epi;     // inference only: folded BatchNorm + residual + activation (all NULL / 0 in training)
     int accumulate;   // y += result (backward-data into a gradient that already holds the residual branch's part)
     int tap_inner;    // K loop order (A/B knob)
+    float* stats;     // training forward in front of a BatchNorm: per-wave column sums / sums of squares of the stored outputs,
+                      // [rows_partial][2][Cn], rows_partial = m0 / (TM*32) + wm (see conv_epilogue); NULL: none
     ConvTaps taps;
 };
 
@@ -146,6 +148,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         const int act = final_pass ? p.epi.act : 0;
         float* out = p.splits > 1 ? p.part + (int64_t)blockIdx.y * p.M * p.Cn : p.y;
         const int64_t ldo = p.splits > 1 ? (int64_t)p.Cn : p.ldy;
+        float s1 = 0.0f, s2 = 0.0f;           // column sum / sum of squares of what this lane stores (BatchNorm statistics)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -156,8 +159,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     if (affine) o = fmaf(o, sc, sf);
                     if (res) o += res[m * p.epi.ldr + n];
                     if (final_pass && p.accumulate) o += out[m * ldo + n];
-                    out[m * ldo + n] = epi_act(o, act);
+                    o = epi_act(o, act);
+                    out[m * ldo + n] = o;
+                    s1 += o;
+                    s2 = fmaf(o, o, s2);
                 }
+            }
+        }
+        if (p.stats && final_pass) {
+            // lanes l and l+32 hold the same column (rows 4*hh apart): one fixed-order add, then one store per column
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (hh == 0) {
+                const int64_t pr = m0 / (TM * 32) + wm;
+                p.stats[(pr * 2 + 0) * p.Cn + n] = s1;
+                p.stats[(pr * 2 + 1) * p.Cn + n] = s2;
             }
         }
     }
@@ -810,6 +826,67 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
         if (epi.res) s += epi.res[m * epi.ldr + n];
         if (accumulate) s += y[m * ldy + n];
         y[m * ldy + n] = epi_act(s, epi.act);
+    }
+}
+
+// split-K second stage in front of a training BatchNorm: the same sums in the same order as splitk_reduce_kernel's vector
+// path, plus the column sums / sums of squares of the rows this block owns -> stats[blockIdx.x][2][Cn].
+// Threads: q = tid % cq (channel quad, fixed per thread so that its sums stay in registers), rl = tid / cq (row lane).
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* part, int splits, int64_t M, int Cn, const float* bias,
+                                                                  float* y, int64_t ldy, int accumulate, float* stats, int64_t rows_per_block)
+{
+    __shared__ float4 sh[2][256];
+    const int cq = Cn >> 2;
+    const int nrl = 256 / cq;
+    const int tid = threadIdx.x;
+    const int q = tid % cq, rl = tid / cq;
+    const bool active = rl < nrl;
+    const int64_t MN = M * Cn;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+    if (active) {
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t m = r0 + rl; m < r1; m += nrl) {
+            const float* src = part + m * Cn + q * 4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 4 <= splits; z += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)z * MN);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)(z + 1) * MN);
+                const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)(z + 2) * MN);
+                const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)(z + 3) * MN);
+                a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+                a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+                a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+                a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+            }
+            for (; z < splits; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)z * MN);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            float4 s = bv;
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(y + m * ldy + q * 4);
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            *reinterpret_cast<float4*>(y + m * ldy + q * 4) = s;
+            t1.x += s.x; t1.y += s.y; t1.z += s.z; t1.w += s.w;
+            t2.x = fmaf(s.x, s.x, t2.x); t2.y = fmaf(s.y, s.y, t2.y); t2.z = fmaf(s.z, s.z, t2.z); t2.w = fmaf(s.w, s.w, t2.w);
+        }
+    }
+    sh[0][tid] = t1;
+    sh[1][tid] = t2;
+    __syncthreads();
+    if (active && rl == 0) {
+        for (int l = 1; l < nrl; ++l) {                    // fixed order over the row lanes
+            const float4 a = sh[0][l * cq + q], b = sh[1][l * cq + q];
+            t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
+            t2.x += b.x; t2.y += b.y; t2.z += b.z; t2.w += b.w;
+        }
+        *reinterpret_cast<float4*>(stats + ((int64_t)blockIdx.x * 2 + 0) * Cn + q * 4) = t1;
+        *reinterpret_cast<float4*>(stats + ((int64_t)blockIdx.x * 2 + 1) * Cn + q * 4) = t2;
     }
 }
 
@@ -1635,6 +1712,21 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
     return pl;
 }
 
+// Partial-statistics rows a forward convolution with this plan writes (ConvParams::stats): one per wave row of the tile
+// grid, or one per block of the split-K reduce.  0: this shape cannot deliver statistics (the caller runs the plain BatchNorm).
+static int64_t splitk_stats_rows_per_block(int64_t M) { return M >= 8192 ? 64 : 16; }
+
+static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
+{
+    if (pl.splits > 1) {
+        if (Cn % 4 != 0 || Cn / 4 > 256) return 0;
+        return cdiv(M, splitk_stats_rows_per_block(M));
+    }
+    if (pl.cfg == 0) return cdiv(M, 128) * 4;                       // 128x32 tiles, four waves stacked along M
+    if (pl.cfg == 1 || pl.cfg == 4) return cdiv(M, 128) * 2;        // 128-row tiles, 2 x 2 waves
+    return cdiv(M, 64) * 2;                                          // 64x64 tiles, 2 x 2 waves
+}
+
 template <bool BWD>
 static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes, hipStream_t st)
 {
@@ -1686,6 +1778,12 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         else          hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, BWD, false>), grid, dim3(kThreads), 0, st, p);
     }
     if (int rc = check_launch("conv_igemm_kernel")) return rc;
+    if (pl.splits > 1 && p.stats) {
+        const int64_t rpb = splitk_stats_rows_per_block(p.M);
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)cdiv(p.M, rpb)), dim3(256), 0, st, p.part, pl.splits, p.M, p.Cn,
+                           p.bias, p.y, p.ldy, p.accumulate, p.stats, rpb);
+        return check_launch("splitk_reduce_stats_kernel");
+    }
     if (pl.splits > 1 && !(g_conv_ablate_reduce & (BWD ? 2 : 1))) {
         const bool plain = p.epi.gamma == nullptr && p.epi.res == nullptr && p.epi.act == 0 && p.Cn % 4 == 0 && p.ldy % 4 == 0;
         int64_t nb = cdiv(plain ? p.M * (p.Cn / 4) : p.M * p.Cn, 256);
@@ -1855,6 +1953,18 @@ size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cout * 4, 256) : 0;
 }
 
+int64_t pp_conv2d_fwd_stats_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return 0;
+    ConvTaps t;
+    build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+    return conv_stats_rows(pl, M, Cout);
+}
+
 size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
@@ -1869,7 +1979,7 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
 
 static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                            int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, const Epilogue& epi,
-                           void* workspace, size_t ws_bytes, pp_stream_t stream)
+                           void* workspace, size_t ws_bytes, pp_stream_t stream, float* stats = nullptr, size_t stats_floats = 0)
 {
     if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
@@ -1883,7 +1993,25 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
+    if (stats) {
+        const int64_t rows = pp_conv2d_fwd_stats_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, dil);
+        if (rows <= 0) return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape delivers no BatchNorm statistics");
+        if (stats_floats < (size_t)rows * 2 * Cout) return fail(PP_ERR_WORKSPACE, "conv fwd: statistics buffer too small");
+        const ConvPlan pl = plan_conv(p.M, Cout, Cin, p.taps.n, Cin % 4 == 0 && Cout % 4 == 0);
+        if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * Cout * 4))
+            return fail(PP_ERR_WORKSPACE, "conv fwd: the split-K workspace is required when statistics are requested");
+        p.stats = stats;
+    }
     return launch_conv<false>(p, workspace, ws_bytes, as_stream(stream));
+}
+
+int pp_conv2d_fwd_stats(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                        int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                        size_t ws_bytes, float* stats, size_t stats_floats, pp_stream_t stream)
+{
+    if (!stats) return fail(PP_ERR_BAD_ARG, "conv fwd: stats is null");
+    return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
+                           ws_bytes, stream, stats, stats_floats);
 }
 
 int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,

@@ -479,6 +479,8 @@ struct BnFwdArgs {
     // DW variant: x is not an input but the OUTPUT of a depthwise 3x3 convolution computed here (mobilenet_v2.py:38,52 -> :39,53)
     const float* dw_in; int64_t dw_ld; const float* dw_w; float* x_out;
     int dw_H, dw_W, dw_Ho, dw_Wo, dw_stride, dw_pad, dw_dil;
+    // PARTIALS variant: the statistics were accumulated by the producer (convolution epilogue / split-K reduce):
+    const float* stats; int stat_rows;      // [stat_rows][2][C] column sums and sums of squares
 };
 
 // one output quad of the depthwise 3x3 convolution, same tap order / fma chain as dwconv_fwd_kernel (bit-identical)
@@ -507,16 +509,22 @@ __device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int 
     return acc;
 }
 
-template <bool DW>
+// MODE 0: statistics + apply in one launch (blocks exchange partials, see above); MODE 1: the same with the depthwise
+// convolution computed in the statistics pass; MODE 2: the producer of x already wrote partial statistics - no first pass
+// over x, NO exchange between blocks and no co-residency requirement: every block reduces the stat_rows partial rows of its
+// channel strip itself (fixed order, fp64) and applies.
+template <int MODE>
 __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 {
+    constexpr bool DW = MODE == 1;
     __shared__ unsigned sh_tag;
     __shared__ float4 sh[2][kT];
     __shared__ double shd[kT];
     __shared__ double tot[64];
     __shared__ float aff[2][32];
     const BnFusedGeom g = a.g;
-    const unsigned tag = launch_tag(a.sync, &sh_tag);
+    unsigned tag = 0;
+    if constexpr (MODE != 2) tag = launch_tag(a.sync, &sh_tag);
     const int t = threadIdx.x;
     const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
     const int ql = t % g.bq, rl = t / g.bq;
@@ -525,6 +533,33 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
     const int64_t r0 = (int64_t)chunk * g.rows_per_chunk;
     const int64_t r1 = r0 + g.rows_per_chunk < a.M ? r0 + g.rows_per_chunk : a.M;
     const float* xq = a.x + q * 4;
+    const int nch = g.bq * 4, nout = nch * 2;
+    if constexpr (MODE == 2) {
+        // tot[stat * nch + cl] = sum over the partial rows, thread (sub, o): rows sub, sub + nsub, ... then the subs in order
+        const int nsub = kT / nout;
+        const int o = t % nout, sub = t / nout;
+        const int stat = o / nch, cl = o - stat * nch;
+        const int c = strip * nch + cl;
+        double s = 0.0;
+        if (sub < nsub && c < a.C) {
+            const float* p = a.stats + (int64_t)stat * a.C + c;
+            int r = sub;
+            for (; r + 3 * nsub < a.stat_rows; r += 4 * nsub) {
+                const float v0 = p[(int64_t)r * 2 * a.C], v1 = p[(int64_t)(r + nsub) * 2 * a.C];
+                const float v2 = p[(int64_t)(r + 2 * nsub) * 2 * a.C], v3 = p[(int64_t)(r + 3 * nsub) * 2 * a.C];
+                s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            }
+            for (; r < a.stat_rows; r += nsub) s += (double)p[(int64_t)r * 2 * a.C];
+        }
+        shd[t] = s;
+        __syncthreads();
+        if (t < nout) {
+            double acc = shd[t];
+            for (int k = 1; k < nsub; ++k) acc += shd[k * nout + t];
+            tot[t] = acc;
+        }
+        __syncthreads();
+    } else {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (active) {
         for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
@@ -551,12 +586,12 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
         }
     }
     rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
-    const int nch = g.bq * 4, nout = nch * 2;
     if (rl == 0) {
         publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1, tag);
     }
     strip_combine(a.part, strip, g.R, nout, tag, shd, tot);
     launch_done(a.sync);
+    }
     if (t < nch) {
         const int c = strip * nch + t;
         if (c < a.C) {
@@ -735,8 +770,8 @@ static int bn_fused_capacity()
         int dev = 0, cus = 0, a = 0, b = 0, c = 0;
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<false>, kT, 0) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<true>, kT, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<0>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<1>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, bn_fused_bwd_kernel, kT, 0) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
@@ -1891,9 +1926,28 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
     if (int rc = bn_fused_check("bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 reinterpret_cast<xword*>(workspace), sync, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev,
-                nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<false>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+                nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<0>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel");
+}
+
+int pp_bn_train_fwd_partials(const float* x, int64_t ldx, int64_t M, int C, const float* stats, int64_t stat_rows, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                             float* invstd, const float* residual, int64_t ldr, int act, float drop_p, uint64_t drop_seed,
+                             const uint64_t* drop_seed_dev, float* y, int64_t ldy, pp_stream_t stream)
+{
+    if (drop_p < 0.0f || drop_p >= 1.0f) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_partials: dropout p=%f outside [0,1)", (double)drop_p);
+    if (drop_p > 0.0f && act == 2) return fail(PP_ERR_UNSUPPORTED, "bn_train_fwd_partials: dropout after ReLU6 is not fusable");
+    if (!x || !gamma || !beta || !mean || !invstd || !y || !stats) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_partials: null");
+    if (M < 1 || stat_rows < 1 || stat_rows > 0x7FFFFFFFll) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_partials: M / stat_rows");
+    if (int rc = need_c4(C, "bn_train_fwd_partials")) return rc;
+    if (ldx % 4 || ldy % 4 || (residual && ldr % 4)) return fail(PP_ERR_BAD_ARG, "bn_train_fwd_partials: ld must be multiples of 4");
+    BnFusedGeom g = bn_fused_geom(M, C);
+    BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
+                nullptr, nullptr, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev,
+                nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, stats, (int)stat_rows};
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<2>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    return check_launch("bn_fused_fwd_kernel<partials>");
 }
 
 int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H, int W, int C, const float* w, int stride, int pad,
@@ -1914,8 +1968,8 @@ int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H
     if (int rc = bn_fused_check("dwconv_bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnFwdArgs a{x_out, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 reinterpret_cast<xword*>(workspace), sync, g, 0.0f, 1.0f, 0ull, nullptr,
-                in, ld_in, w, x_out, H, W, Ho, Wo, stride, pad, dil};
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<true>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+                in, ld_in, w, x_out, H, W, Ho, Wo, stride, pad, dil, nullptr, 0};
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<1>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel<dw>");
 }
 

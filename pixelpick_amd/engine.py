@@ -62,6 +62,12 @@ _FUSE_EVAL = os.environ.get("PIXELPICK_FUSE_EVAL", "1") != "0"
 # (pp_dwconv3x3_bn_train_fwd_fused; bit-identical).  Off by default: measured 7.16-7.18 vs 7.05 ms/step - the BatchNorm grid
 # (384 blocks) is too small for the nine-tap gather, the 17 saved launches do not pay for it.
 _FUSE_DW_BN = os.environ.get("PIXELPICK_FUSE_DW_BN", "0") == "1"
+# PIXELPICK_CONV_BN_STATS=1: a training BatchNorm behind a dense convolution takes its statistics from partial sums the
+# convolution's epilogue (or its split-K reduce) wrote, and only applies - no statistics pass, no exchange between blocks, no
+# co-residency requirement.  OFF by default: measured 6.96-6.98 vs 6.86-6.87 ms/step (profiles/r02_train_ablation.txt) - every
+# block re-reducing the 64..128 partial rows of its channel strip costs what the exchange of the single-launch kernel costs
+# (7-10 us per layer on the 1/16-resolution maps either way), and the extra allocations add 0.35 ms of host time per step.
+_CONV_BN_STATS = os.environ.get("PIXELPICK_CONV_BN_STATS", "0") == "1"
 
 
 def _launch_deferred(v: "Var", bn):
@@ -587,6 +593,14 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
         out = Var(None, needs_grad=False)
         out._pending = ("conv", x, w, bias, stride, pad, dil)
         return out
+    if _CONV_BN_STATS and tape.enabled and dst is None:
+        # training: deferred as well - a training-mode BatchNorm right behind it launches the convolution with a statistics
+        # epilogue (pp_conv2d_fwd_stats) and then only applies (pp_bn_train_fwd_partials); any other consumer's `.t`
+        # launches the plain convolution
+        out = Var(None)
+        out._pending = ("conv", x, w, bias, stride, pad, dil)
+        tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil), out)
+        return out
     Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
     y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.t.device)
     _, _, _, _, ldy = _geom(y)
@@ -708,6 +722,68 @@ def _dw_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_va
     return out
 
 
+_CONV_BN_STATS_MAX_ROWS = int(os.environ.get("PIXELPICK_CONV_BN_STATS_MAX_ROWS", "160"))
+
+
+def _launch_conv_stats(x: Var):
+    """x is a DEFERRED dense convolution: launch it with the BatchNorm-statistics epilogue.  -> (stats [rows,2,Cout], rows), or
+    None when this shape delivers no statistics (x stays deferred)."""
+    _, xin, w, bias, stride, pad, dil = x._pending
+    B, H, W, Cin, ldx = _geom(xin.t)
+    kh, kw, _, Cout = w.shape
+    rows = _wsbytes("pp_conv2d_fwd_stats_rows", B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+    if rows <= 0 or rows > _CONV_BN_STATS_MAX_ROWS or Cout % 4:
+        return None                                 # (large maps: thousands of partial rows - the stem BatchNorm took 93 us instead of 22)
+    dev = xin.t.device
+    Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+    stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=dev)
+    ws, wsn = _conv_ws(False, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+    rc = _lib.lib().pp_conv2d_fwd_stats(xin.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        kh, kw, stride, pad, dil, y.data_ptr(), Cout, Cout, ws, wsn, stats.data_ptr(), stats.numel(),
+                                        _stream())
+    _lib.check(rc, "pp_conv2d_fwd_stats")
+    x._pending = None
+    x._t = y
+    return stats, rows
+
+
+def _conv_bn_train_partials(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst, dropout_p):
+    """Dense convolution -> training BatchNorm (+ residual, activation, dropout): the convolution's epilogue delivers the
+    statistics, the BatchNorm kernel only applies.  None: not applicable (the caller takes the ordinary path)."""
+    if dropout_p > 0.0 and act == ACT_RELU6:
+        return None
+    got = _launch_conv_stats(x)
+    if got is None:
+        return None
+    stats, rows = got
+    B, H, W, C, ldx = _geom(x.t)
+    M = B * H * W
+    dev = x.t.device
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    y = dst if dst is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    _, _, _, _, ldy = _geom(y)
+    rptr, ldr = (None, 0)
+    if residual is not None:
+        _, _, _, _, ldr = _geom(residual.t)
+        rptr = residual.t.data_ptr()
+    dseed, sd = 0, None
+    if dropout_p > 0.0:                               # same seed sequence as dropout()
+        _dropout_counter[0] += 1
+        dseed = (_dropout_counter[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        sd = _dropout_seed_dev[0]
+    rc = _lib.lib().pp_bn_train_fwd_partials(x.t.data_ptr(), ldx, M, C, stats.data_ptr(), rows, gamma.data_ptr(), beta.data_ptr(), eps,
+                                             momentum, running_mean.data_ptr() if running_mean is not None else None,
+                                             running_var.data_ptr() if running_var is not None else None, mean.data_ptr(),
+                                             invstd.data_ptr(), rptr, ldr, act, float(dropout_p), dseed,
+                                             sd.data_ptr() if sd is not None else None, y.data_ptr(), ldy, _stream())
+    _lib.check(rc, "pp_bn_train_fwd_partials")
+    out = Var(y)
+    tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0 / (1.0 - dropout_p)), out)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- batch norm (+act, +residual)
 def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE,
                    residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
@@ -721,6 +797,10 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         _launch_deferred(x, (gamma, beta, running_mean, running_var, eps, act, residual, dst))
         return Var(x._t, needs_grad=False)
     L = _lib.lib()
+    if training and x._pending is not None and x._pending[0] == "conv" and tape.enabled and _CONV_BN_STATS:
+        out = _conv_bn_train_partials(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst, dropout_p)
+        if out is not None:
+            return out
     if (training and x._pending is not None and x._pending[0] == "dw" and tape.enabled and dropout_p == 0.0 and _BN_FUSED
             and _bn_exchange_ok(x._pending[1].t.device)):
         fused = _dw_bn_train_fused(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst)

@@ -108,6 +108,8 @@ class LayerwiseParity:
         self.rec = []                  # (kind, name, error, numel)
         self.flips = {}                # norm name -> (flipped units, units)
         self.res_nodes = {}            # norm name -> node adds a residual
+        self._deferred = {}            # id(Var) of a deferred convolution -> (conv name, Var)
+        self.n_stats_convs = 0         # convolutions launched with the BatchNorm-statistics epilogue
         self.dev = next(hip_model.parameters()).device
 
     # ------------------------------------------------------------------ forward sites
@@ -148,8 +150,30 @@ class LayerwiseParity:
         def conv_run_p(self, tape, x, dst=None, extra_pad=0):
             out = conv_run(self, tape, x, dst, extra_pad)
             n = me.mod_name[id(self)]
-            me._fwd_site("conv", n, n, out)
+            if out._pending is not None:
+                # deferred (the engine launches it when its consumer is known - with the statistics epilogue when that is a
+                # training BatchNorm): compared / forced right after that launch, see launch_deferred_p / launch_stats_p
+                me._deferred[id(out)] = (n, out)
+            else:
+                me._fwd_site("conv", n, n, out)
             return out
+
+        launch_deferred, launch_stats = E._launch_deferred, E._launch_conv_stats
+
+        def launch_deferred_p(v, bn):
+            launch_deferred(v, bn)
+            ent = me._deferred.pop(id(v), None)
+            if ent is not None and bn is None:
+                me._fwd_site("conv", ent[0], ent[0], v)
+
+        def launch_stats_p(x):
+            got = launch_stats(x)
+            if got is not None:
+                ent = me._deferred.pop(id(x), None)
+                if ent is not None:
+                    me.n_stats_convs += 1
+                    me._fwd_site("conv", ent[0], ent[0], x)
+            return got
 
         def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None):
             out = bn_run(self, tape, x, act, residual, dst, dropout)
@@ -195,10 +219,13 @@ class LayerwiseParity:
 
         L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run = conv_run_p, bn_run_p, gn_run_p
         E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd = conv_bwd_p, dw_bwd_p, bn_bwd_p, gn_bwd_p
+        self._saved_launch = (launch_deferred, launch_stats)
+        E._launch_deferred, E._launch_conv_stats = launch_deferred_p, launch_stats_p
         return self
 
     def __exit__(self, *exc):
         (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd) = self._saved
+        E._launch_deferred, E._launch_conv_stats = self._saved_launch
         return False
 
     # ------------------------------------------------------------------ after the sweep

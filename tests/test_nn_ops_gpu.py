@@ -383,6 +383,56 @@ def test_batchnorm_single_launch_exchange_is_coherent_deterministic_and_rearms()
                                  None, 0, 1.0, None, ws.data_ptr(), 16, sync.data_ptr(), sync.numel(), st) != 0
 
 
+@pytest.mark.parametrize("shape", [(4, 18, 34, 160, 960, 1, 0, 1), (4, 16, 32, 960, 160, 1, 0, 1), (4, 16, 32, 1280, 256, 1, 0, 1),
+                                   (4, 16, 32, 320, 256, 3, 6, 6), (2, 64, 128, 304, 256, 3, 1, 1), (4, 64, 128, 24, 48, 1, 0, 1),
+                                   (2, 128, 256, 3, 32, 3, 1, 1), (3, 23, 30, 64, 384, 1, 0, 1), (4, 32, 64, 256, 1024, 1, 0, 1)])
+@pytest.mark.parametrize("act,with_res,drop", [(E.ACT_RELU6, False, 0.0), (E.ACT_NONE, True, 0.0), (E.ACT_RELU, False, 0.5)])
+def test_conv_epilogue_statistics_feed_the_batchnorm(shape, act, with_res, drop, monkeypatch):
+    """Dense convolution -> training BatchNorm with the statistics taken from the convolution's epilogue (pp_conv2d_fwd_stats:
+    per-wave column sums, or the split-K reduce's per-block sums) and applied by pp_bn_train_fwd_partials, against the same
+    pair through the self-contained single-launch BatchNorm: same convolution output bit for bit, statistics / outputs /
+    running statistics / all gradients within 2e-5, identical dropout mask; every tile configuration and the split-K path."""
+    B, H, W, Cin, Cout, k, pad, dil = shape
+    if with_res and act != E.ACT_NONE:
+        pytest.skip("combination not used")
+    gen = torch.Generator(device=DEV).manual_seed(B * 100 + Cout)
+    x = torch.randn(B, H, W, Cin, device=DEV, generator=gen)
+    w = (torch.randn(k, k, Cin, Cout, device=DEV, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5).requires_grad_(True)
+    gamma = (torch.rand(Cout, device=DEV, generator=gen) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cout, device=DEV, generator=gen).requires_grad_(True)
+    Ho, Wo = E.out_size(H, k, 1, pad, dil), E.out_size(W, k, 1, pad, dil)
+    res = torch.randn(B, Ho, Wo, Cout, device=DEV, generator=gen) if with_res else None
+    dy = torch.randn(B, Ho, Wo, Cout, device=DEV, generator=gen)
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(E, "_CONV_BN_STATS", mode)
+        monkeypatch.setattr(E, "_CONV_BN_STATS_MAX_ROWS", 1 << 30)
+        E.set_dropout_seed(77)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        tape = E.Tape(True)
+        xv = E.Var(x.clone())
+        rvv = E.Var(res.clone()) if with_res else None
+        cv = E.conv2d(tape, xv, w, None, 1, pad, dil)
+        assert (cv._pending is not None) == mode
+        yv = E.batch_norm_act(tape, cv, gamma, beta, rm, rv, True, act, rvv, dropout_p=drop)
+        tape.backward(yv, dy.clone())
+        torch.cuda.synchronize()
+        outs[mode] = dict(conv=cv.t.clone(), y=yv.t.clone(), rm=rm, rv=rv, dx=xv.grad.clone(), dw=tape.param_grads[id(w)].clone(),
+                          dg=tape.param_grads[id(gamma)].clone(), db=tape.param_grads[id(beta)].clone())
+    a, b = outs[True], outs[False]
+    assert torch.equal(a["conv"], b["conv"])                               # the epilogue does not change what is stored
+    assert torch.equal(a["y"] == 0, b["y"] == 0) or drop == 0.0            # same dropout mask (same seed stream)
+    for key, tol in (("y", 2e-5), ("rm", 2e-6), ("rv", 2e-6), ("dx", 5e-5), ("dw", 5e-5), ("dg", 5e-5), ("db", 5e-5)):
+        close(a[key], b[key], tol=tol, what=key)
+    rows = int(L().pp_conv2d_fwd_stats_rows(B, H, W, Cin, Cout, k, k, 1, pad, dil))
+    assert rows > 0
+
+
+def L():
+    from pixelpick_amd import _lib
+    return _lib.lib()
+
+
 def test_two_single_launch_batchnorms_on_two_streams_do_not_interfere():
     """Two spin-waiting BatchNorm launches in flight at once (main + side stream, each with its own exchange area from
     engine._bn_exchange): every launch asks for at most half of the co-resident capacity (pp_bn_fused_capacity), so both
