@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import acquisition as acq
+from . import dist_utils
 
 _LARGEST_STRATEGIES = ("entropy", "least_confidence")
 # PIXELPICK_FUSED_LOWRES=0: always materialise the full-resolution logits (model(x)["pred"]) before scoring
@@ -167,11 +168,9 @@ class QuerySelector:
     def _dist(self):
         """(rank, world, group) of the acquisition round.  `self.process_group` (None = the default group) is used when
         torch.distributed is initialised; otherwise the round is single-rank."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            g = getattr(self, "process_group", None)
-            return dist.get_rank(g), dist.get_world_size(g), g
-        return 0, 1, None
+        g = getattr(self, "process_group", None)
+        rank, world = dist_utils.rank_world(g)
+        return rank, world, g
 
     def _draw(self, h: int, w: int) -> dict:
         """Every host random number ONE image consumes, drawn when the loop reaches the image - the reference's order
@@ -405,7 +404,7 @@ class QuerySelector:
                 h, w = dict_data['x'].shape[2:]
                 draws = self._draw(h, w)                       # every rank advances the host RNG streams for every image
                 y = dict_data.get('y', None)
-                if world > 1 and batch_ind % world != rank:
+                if dist_utils.owner_rank(batch_ind, world) != rank:
                     continue                                   # another rank's image (i -> rank i mod W)
                 if pipelined and not dict_data['x'].is_cuda:
                     with torch.cuda.stream(copy_stream):       # the upload must not queue behind the previous batch's kernels
@@ -441,12 +440,7 @@ class QuerySelector:
             if inflight:
                 finish(inflight.pop())
 
-        if world > 1:
-            import torch.distributed as dist
-            gathered = [None] * world
-            dist.all_gather_object(gathered, records, group=group)      # ~100 B per image; the only exchange of the round
-            records = [r for part in gathered for r in part]
-        records.sort(key=lambda r: r[0])                               # loader order, as the single-rank loop
+        records = dist_utils.gather_records(records, world, group)     # ~100 B per image, the only exchange of the round; loader order
         assert len(records) == n_seen and n_seen > 0, f"no queries are chosen!" if n_seen == 0 else (len(records), n_seen)
         dict_queries: dict = dict()
         n_pixels = 0
