@@ -779,26 +779,44 @@ __device__ __forceinline__ uint32_t sel_digit(uint32_t key, int pass) { return (
 __device__ __forceinline__ int sel_shift(int pass) { return 24 - 8 * pass; }
 __device__ __forceinline__ uint32_t sel_mask(int pass) { return pass == 0 ? 0u : (0xFFFFFFFFu << (32 - 8 * pass)); }
 
-// From the top bin down: the digit d with  #(bins above d) < remaining <= #(bins above d) + hist[d].
-// out[0] = d, out[1] = remaining - #above, out[2] = hist[d].
-__device__ __forceinline__ void sel_scan(const uint32_t* hist, uint32_t remaining, uint32_t* sh /*[kSelBins]*/, uint32_t* out /*[3]*/)
+// From the top bin down: the digit d with  #(bins above d) < remaining <= #(bins above d) + hist[d]  (d = 0 if the bins above
+// it hold fewer than `remaining`).  Parallel: thread t < 256 owns bin 255 - t, an inclusive scan over the threads gives the
+// count of bins at or above each one (a serial walk with its dependent LDS reads costs ~10 us per 256-bin histogram).
+// h: 256 words in LDS or global; sh: >= 8 words of LDS; out[0] = d, out[1] = remaining - #above, out[2] = hist[d].
+// Must be called by all threads of the block (two barriers); blocks of 256 or more threads.
+__device__ __forceinline__ void sel_find_digit(const uint32_t* h, uint32_t remaining, uint32_t* sh, uint32_t* out)
 {
-    const int t = threadIdx.x;
-    if (t < kSelBins) sh[t] = hist[t];
-    __syncthreads();
-    if (t == 0) {
-        uint32_t cum = 0;
-        int d = kSelBins - 1;
-        for (; d > 0; --d) {
-            const uint32_t cnt = sh[d];
-            if (cum + cnt >= remaining) break;
-            cum += cnt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t own = 0, incl = 0;
+    if (t < kSelBins) {
+        own = h[kSelBins - 1 - t];
+        incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += v;
         }
-        out[0] = (uint32_t)d;
-        out[1] = remaining - cum;
-        out[2] = sh[d];
+        if (lane == 63) sh[wave] = incl;
     }
     __syncthreads();
+    if (t < kSelBins) {
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += sh[w];
+        incl += base;
+        const uint32_t excl = incl - own;
+        const bool hit = excl < remaining && remaining <= incl;
+        if ((hit && t < kSelBins - 1) || (t == kSelBins - 1 && excl < remaining)) {      // bin 0 takes whatever is left
+            out[0] = (uint32_t)(kSelBins - 1 - t);
+            out[1] = remaining - excl;
+            out[2] = own;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sel_scan(const uint32_t* hist, uint32_t remaining, uint32_t* sh /*[kSelBins]*/, uint32_t* out /*[3]*/)
+{
+    sel_find_digit(hist, remaining, sh, out);
 }
 
 // hist: [B][kSelPasses][kSelBins] (zeroed by the host before pass 0)
@@ -992,6 +1010,7 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_sel_kernel(const flo
         if (out_val) out_val[(int64_t)blockIdx.x * k + j] = key_to_float((uint32_t)(v >> 32), lg);
     }
 }
+
 
 // ---- host side ---------------------------------------------------------------------------------------
 // Sum over T forward passes of softmax(logits[t]) per pixel and of the strategy's score of each pass (the MC-dropout
