@@ -773,6 +773,106 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
+// ---- pointwise (1x1, stride 1) convolutions on few rows: operands straight from L1/L2 into MFMA fragments ---------------------
+// The 1/16-resolution layers of MobileNetV2 / ASPP are 1x1 convolutions over 2048-2448 rows (mobilenet_v2.py:42,56,
+// aspp.py:49,73-75).  With 256-640 reduction channels and a narrow output (384 -> 64, 576 -> 96/160, 320 -> 256 and the
+// backward-data of 64 -> 384, 96 -> 576) the LDS-staged kernels are dominated by fixed costs: pipeline fill, one barrier per
+// K step, and a split-K pass through global memory plus a second launch.  Here a block owns ONE 32x32 output tile, wave w
+// reduces channels [w*K/4, (w+1)*K/4) reading its A rows (float4 per lane: 4 consecutive channels of one pixel) and B columns
+// directly in fragment order (the permuted K order of mma_step: lane half h consumes k = 8q + 4h + j), CH K steps ahead, and
+// the four partial tiles are added through LDS in wave order (deterministic) - split-K without a second launch.
+// Measured (profiles/r02_train_ablation.txt): 3-5 us per call faster than split-K + reduce in that K range; slower above it
+// (the per-lane row reads are uncoalesced, 32 cache lines per instruction, and a 32x32 tile re-reads both operands too often),
+// and a whole-K-per-wave variant for wide outputs (160 -> 960) lost 2x to the staged kernel - so neither is dispatched.
+// BWD: backward-data of the same convolution (A = dY, B = W transposed: float4 along Cout).  Padding of a 1x1 convolution
+// (the folded fixed_padding of mobilenet_v2.py:15-21) only shifts / blanks rows: handled by the row decode.
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void conv1x1_direct_kernel(ConvParams p)
+{
+    constexpr int CH = 8;                                   // K steps (of 8 channels) per register chunk
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+    const int64_t m0 = (int64_t)mt * 32;
+    const int n0 = nt * 32;
+    // A row of this lane
+    const int64_t m = m0 + l31;
+    const float* arow = nullptr;
+    if (m < p.M) {
+        const unsigned mu = (unsigned)m;
+        const unsigned t = mu / (unsigned)p.Wo;
+        const int ow = (int)(mu - t * (unsigned)p.Wo);
+        const unsigned bb = t / (unsigned)p.Ho;
+        const int oh = (int)(t - bb * (unsigned)p.Ho);
+        const int ih = oh + p.taps.dh[0], iw = ow + p.taps.dw[0];
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) arow = p.x + (((int64_t)bb * p.H + ih) * p.W + iw) * p.ldx;
+    }
+    const int col = n0 + l31;
+    const bool col_ok = col < p.Cn;
+    const float* wbase = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout;
+    // K range of this wave, in steps of 8 channels
+    const int nsteps = (p.Ck + 7) / 8;
+    const int per = (nsteps + 3) / 4;
+    const int s_beg = wave * per;
+    const int s_end = s_beg + per < nsteps ? s_beg + per : nsteps;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float4 a[2][CH];
+    float b[2][CH][4];
+    auto load_chunk = [&](int buf, int s0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int k = (s0 + u) * 8 + 4 * h;
+            const bool kin = (s0 + u) < s_end && k < p.Ck;
+            a[buf][u] = (kin && arow) ? *reinterpret_cast<const float4*>(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (BWD) {
+                const float4 v = (kin && col_ok) ? *reinterpret_cast<const float4*>(wbase + (int64_t)col * p.Cout + k)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                b[buf][u][0] = v.x; b[buf][u][1] = v.y; b[buf][u][2] = v.z; b[buf][u][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[buf][u][j] = (kin && col_ok) ? wbase[(int64_t)(k + j) * p.Cout + col] : 0.0f;
+            }
+        }
+    };
+    auto mma_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].x, b[buf][u][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].y, b[buf][u][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].z, b[buf][u][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].w, b[buf][u][3], acc, 0, 0, 0);
+        }
+    };
+    if (s_beg < s_end) {
+        load_chunk(0, s_beg);
+        for (int s0 = s_beg; s0 < s_end; s0 += 2 * CH) {
+            if (s0 + CH < s_end) load_chunk(1, s0 + CH);
+            mma_chunk(0);
+            if (s0 + CH < s_end) {
+                if (s0 + 2 * CH < s_end) load_chunk(0, s0 + 2 * CH);
+                mma_chunk(1);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
+    f32x16 accs[1][1];
+    accs[0][0] = acc;
+    conv_epilogue<1, 1>(p, accs, m0, n0, 0, 0);
+}
+
 // split-K second stage: y[m][n] = epilogue(bias[n] + sum_z part[z][m][n]), z in fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int splits, int64_t M, int Cn,
                                                             const float* bias, float* y, int64_t ldy, Epilogue epi, int accumulate)
@@ -1669,6 +1769,7 @@ static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-D
 static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
+static thread_local int g_conv_direct1x1 = 1, g_direct_rows_max = 4096, g_direct_k_max = 640;   // pp_debug_set_conv_variant bit 23 switches the direct 1x1 kernel off (A/B)
 static thread_local int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
@@ -1738,6 +1839,20 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n, vec);
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
+    }
+    // few-row pointwise layers: the direct kernel (no LDS staging, in-block split-K), see conv1x1_direct_kernel
+    if (g_conv_direct1x1 && vec && !p.stats && p.taps.n == 1 && p.stride == 1 && p.bwd_stride <= 1 && p.M <= g_direct_rows_max &&
+        p.Ck >= 32 && p.Cn >= 32 && p.Ck % 4 == 0 && (BWD ? p.Cout % 4 == 0 : true) && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) {
+        const int64_t t64 = cdiv(p.M, 64) * cdiv(p.Cn, 64);
+        if (t64 < 256 && p.Ck >= 256 && p.Ck <= g_direct_k_max) {   // too few 64x64 tiles for 256 CUs, a reduction worth splitting four ways
+            p.splits = 1;
+            p.ks_per_split = 0;
+            p.part = nullptr;
+            p.n_tiles = (int)cdiv(p.Cn, 32);
+            const int64_t blocks = cdiv(p.M, 32) * p.n_tiles;
+            hipLaunchKernelGGL((conv1x1_direct_kernel<BWD>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p);
+            return check_launch("conv1x1_direct_kernel");
+        }
     }
     p.tap_inner = g_conv_tap_inner;
     p.n_tiles = pl.n_tiles;
@@ -1937,6 +2052,7 @@ void pp_debug_set_conv_variant(int v)
     g_conv_dma64 = (v & 262144) ? 0 : ((v & 524288) ? 2 : 1);   // bit 18: LDS-DMA kernel of the 64x64 tiles off; bit 19: forward only
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
+    g_conv_direct1x1 = (v & 8388608) ? 0 : 1;   // bit 23: direct (LDS-free) kernel of the few-row 1x1 layers off (A/B)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
 }

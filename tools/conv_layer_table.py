@@ -41,6 +41,7 @@ def main():
     torch.cuda.synchronize()
     engine.conv2d = orig
     L = _lib.lib()
+    L.pp_debug_set_conv_variant(int(os.environ.get("CONV_VARIANT", 0)))      # A/B of the kernel choices (conv_igemm.hip)
     st = torch.cuda.current_stream().cuda_stream
 
     def timeit(fn, n=20):
