@@ -128,7 +128,94 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
-    return _lib
+    return _recording[0] or _lib
+
+
+# ------------------------------------------------------------------------------------------------ launch plans
+# A train step is ~415 launches through this binding plus ~110 stream fork / join operations, each with a few microseconds of
+# Python around it (shape arithmetic, tape bookkeeping, workspace look-ups): 5.4 ms of host time for a 6.85 ms step.  With
+# static shapes and stable addresses (FlatTrainer.enable_replay runs the step inside a private torch memory pool) every one
+# of those calls repeats with identical arguments, so the step is recorded ONCE as a flat list of (function, converted
+# arguments) and re-issued from a tight loop.  Unlike a hipGraph the replay keeps the two-queue eager schedule (main stream +
+# weight-gradient stream, the all-reduce under the encoder backward) - profiles/r02_graph_replay.txt shows why the graph loses.
+_NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity")
+
+
+def _is_launch(name: str) -> bool:
+    return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints")))
+
+
+class LaunchPlan:
+    """The recorded step: `calls` = [(callable, args tuple)].  C-ABI entries return 0 on success, stream operations None."""
+    __slots__ = ("calls",)
+
+    def __init__(self):
+        self.calls = []
+
+    def replay(self):
+        for fn, args in self.calls:
+            if fn(*args):
+                raise PixelPickHipError(f"{getattr(fn, '__name__', fn)} failed during replay: "
+                                        f"{lib().pp_last_error().decode('utf-8', 'replace')}")
+
+    def __len__(self):
+        return len(self.calls)
+
+
+class _RecordingLib:
+    """What lib() returns while a plan is being recorded: every launch is executed AND appended to the plan."""
+
+    def __init__(self, real, plan):
+        self.__dict__["_real"] = real
+        self.__dict__["_plan"] = plan
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not _is_launch(name):
+            return fn
+        calls, argtypes = self._plan.calls, fn.argtypes
+
+        def rec(*args):
+            rc = fn(*args)
+            if rc == 0:
+                # converted once: ctypes passes instances of the declared types straight through
+                calls.append((fn, tuple(a if isinstance(a, (ctypes._SimpleCData, ctypes._Pointer, ctypes.Array)) else t(a)
+                                        for t, a in zip(argtypes, args))))
+            return rc
+
+        self.__dict__[name] = rec
+        return rec
+
+
+_recording = [None]
+
+
+class record_plan:
+    """with record_plan() as plan: ...   (not re-entrant, calling thread only)"""
+
+    def __enter__(self):
+        if _recording[0] is not None:
+            raise RuntimeError("a launch plan is already being recorded")
+        plan = LaunchPlan()
+        _recording[0] = _RecordingLib(lib(), plan)
+        return plan
+
+    def __exit__(self, *exc):
+        _recording[0] = None
+        return False
+
+
+def plan_note(fn, *args):
+    """Run fn(*args) (a stream fork / join, a collective, a host-side counter: must return None) and, while a plan is being
+    recorded, make it part of the replay."""
+    rec = _recording[0]
+    if rec is not None:
+        rec._plan.calls.append((fn, args))
+    return fn(*args)
+
+
+def recording() -> bool:
+    return _recording[0] is not None
 
 
 def check(rc: int, what: str):

@@ -182,8 +182,8 @@ class Tape:
         self._side_rr = (i + 1) % N_SIDE_STREAMS
         side = _side_stream(dev, i)
         ev = _fork_event(dev)
-        ev.record(_main_stream_obj())
-        side.wait_event(ev)
+        _lib.plan_note(ev.record, _main_stream_obj())         # (plan_note: also part of a recorded launch plan, _lib.LaunchPlan)
+        _lib.plan_note(side.wait_event, ev)
         self._keepalive.extend(tensors)
         if self._side is None:
             self._side = {}
@@ -212,7 +212,7 @@ class Tape:
             Tape.trace.append(("bwd_main_end", _mark()))
         if self._side is not None:    # join: the optimiser / all-reduce must see every weight gradient
             for side in self._side.values():
-                _main_stream_obj().wait_stream(side)
+                _lib.plan_note(_main_stream_obj().wait_stream, side)
             self._side = None
         if Tape.trace is not None:
             Tape.trace.append(("joined", _mark()))

@@ -95,6 +95,8 @@ class FlatTrainer:
         self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
         self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self._graph = None
+        self._graph_bn = []
+        self._plan = self._plan_pool = self._plan_stream = None
         self._gx = self._gy = None
 
     # -----------------------------------------------------------------------------------------------
@@ -132,6 +134,9 @@ class FlatTrainer:
         return loss
 
     def _early_all_reduce(self, tape):
+        _lib.plan_note(self._early_all_reduce_on, tuple(tape.side_streams_in_use()))
+
+    def _early_all_reduce_on(self, sides):
         """Backward hook at the encoder boundary: the gradients of everything BEHIND the encoder (flat_g[n_split:], 16 of
         the 23 MB for DeepLabv3+-MNv2) are complete once the work already enqueued on the main and the weight-gradient
         streams has run, while the whole encoder backward (~3 ms) is still ahead.  Their all-reduce is issued now from a
@@ -142,7 +147,7 @@ class FlatTrainer:
         if comm is None:
             comm = self.__dict__["_comm_stream"] = torch.cuda.Stream(device=self.flat_g.device)
         comm.wait_stream(main)
-        for s in tape.side_streams_in_use():
+        for s in sides:
             comm.wait_stream(s)
         with torch.cuda.stream(comm):
             self._early_work = torch.distributed.all_reduce(self.flat_g[self.n_split:], op=torch.distributed.ReduceOp.SUM,
@@ -196,7 +201,7 @@ class FlatTrainer:
     def _step_body(self, x, y, keep_logits, device_hyper):
         E.begin_step()
         loss = self.forward_backward(x, y, keep_logits)
-        self.all_reduce_grads()
+        _lib.plan_note(self.all_reduce_grads)
         self.optimizer_step(device_hyper)
         return loss
 
@@ -204,13 +209,47 @@ class FlatTrainer:
         """One optimisation step (model.py:101-122).  After enable_graph() the step is a hipGraph replay."""
         self._ensure_train_mode()
         self.step_count += 1
-        if self._graph is not None:
+        if self._graph is not None or self._plan is not None:
             self._gx.copy_(x, non_blocking=True)
             self._gy.copy_(y, non_blocking=True)
             self._stage_hyper()
-            self._graph.replay()
+            if self._plan is not None:
+                if torch.cuda.current_stream().cuda_stream != self._plan_stream:
+                    raise RuntimeError("train_step after enable_replay() must run on the stream the plan was recorded on")
+                self._plan.replay()
+            else:
+                for d in self._graph_bn:                  # host-side num_batches_tracked bookkeeping the graph cannot hold
+                    d["_nbt_pending"] += 1
+                self._graph.replay()
             return self.last_loss
         return self._step_body(x, y, keep_logits, False)
+
+    def enable_replay(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 1):
+        """Record the launches of one step for this input shape (~415 C-ABI calls, ~110 stream fork / join operations, the
+        all-reduces at N > 1) as a _lib.LaunchPlan and re-issue them from a tight loop in every later train_step(): the
+        Python around each launch (5.4 ms per 6.85 ms step) is paid once.  The GPU schedule is the eager one - main stream,
+        weight-gradient stream, all-reduce under the encoder backward - which a captured hipGraph does not keep
+        (profiles/r02_graph_replay.txt).  As for enable_graph(): the step runs on private copies of x / y, per-step scalars
+        (learning rates, Adam bias corrections, dropout seed) are read from device memory, and the recorded step allocates
+        from a private memory pool that is kept, so every address in the plan stays valid and is never handed to another
+        tensor.  `warmup` eager steps (real optimisation steps, as is the recorded one) first grow the scratch buffers."""
+        assert self._graph is None and self._plan is None
+        self.model.train()
+        E.set_dropout_device_seed(self._seed_dev)
+        self._gx, self._gy = x.clone(), y.clone()
+        for _ in range(warmup):
+            self.step_count += 1
+            self._stage_hyper()
+            self._step_body(self._gx, self._gy, True, True)
+        self.step_count += 1
+        self._stage_hyper()
+        pool = torch.cuda.MemPool()
+        with torch.cuda.use_mem_pool(pool, device=x.device):
+            with _lib.record_plan() as plan:
+                self._step_body(self._gx, self._gy, True, True)
+        self._plan, self._plan_pool = plan, pool
+        self._plan_stream = torch.cuda.current_stream(x.device).cuda_stream
+        return self
 
     def enable_graph(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2):
         """Capture forward + loss + backward (+ all-reduce) + Adam for this input shape into ONE hipGraph (~700 kernel
@@ -234,6 +273,7 @@ class FlatTrainer:
         with torch.cuda.graph(g):
             self._step_body(self._gx, self._gy, True, True)
         self._graph = g
+        self._graph_bn = [m.__dict__ for m in self.model.modules() if "_nbt_pending" in m.__dict__ and m.training]
         return self
 
     def sync_buffers(self, src: int = 0):
@@ -257,11 +297,15 @@ class FlatTrainer:
     def disable_graph(self):
         """Back to eager steps; also removes the process-wide device seed word enable_graph() installed, so that later
         eager trainers / MC-dropout forwards draw their masks from the host counter again."""
-        if self._graph is not None:
-            self._graph = None
+        if self._graph is not None or self._plan is not None:
+            if self._plan is not None:
+                self.last_loss = self.last_logits = None  # they live in the plan's memory pool
+            self._graph = self._plan = self._plan_pool = None
             self._gx = self._gy = None
         if E._dropout_seed_dev[0] is self._seed_dev:
             E.set_dropout_device_seed(None)
+
+    disable_replay = disable_graph
 
     def __del__(self):
         try:

@@ -166,3 +166,52 @@ def test_numpy_choice_over_an_array_equals_choice_over_its_positions():
         pos = np.random.choice(len(a), 10, False)
         nxt2 = np.random.rand()
         assert (a[pos] == r1).all() and nxt1 == nxt2
+
+
+def test_launch_plan_records_and_replays_in_order():
+    """_lib.LaunchPlan mechanics without a GPU: launches are recorded with converted arguments, queries (workspace sizes,
+    debug knobs) are not, plan_note() callables ride in order, a failing call is reported on replay."""
+    import ctypes
+    from pixelpick_amd import _lib
+
+    log = []
+
+    class _Fn:
+        def __init__(self, name, argtypes, rc=0):
+            self.__name__, self.argtypes, self.rc = name, argtypes, rc
+
+        def __call__(self, *args):
+            log.append((self.__name__, tuple(getattr(a, "value", a) for a in args)))
+            return self.rc
+
+    class _Fake:
+        pp_add2d = _Fn("pp_add2d", [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float])
+        pp_topk_workspace_bytes = _Fn("pp_topk_workspace_bytes", [ctypes.c_int64])
+        pp_bad = _Fn("pp_bad", [ctypes.c_int], rc=-3)
+
+        @staticmethod
+        def pp_last_error():
+            return b"boom"
+
+    plan = _lib.LaunchPlan()
+    rec = _lib._RecordingLib(_Fake, plan)
+    _lib._recording[0] = rec
+    try:
+        assert _lib.recording()
+        rec.pp_add2d(None, 7, 0.5)
+        rec.pp_topk_workspace_bytes(3)                 # a query: executed, not recorded
+        _lib.plan_note(log.append, "note")
+        rec.pp_add2d(1234, 8, 1.5)
+        assert rec.pp_bad(1) == -3                     # failed launches are not recorded
+    finally:
+        _lib._recording[0] = None
+    assert len(plan) == 3
+    assert all(isinstance(a, ctypes._SimpleCData) for a in plan.calls[0][1])
+    first = list(log)
+    del log[:]
+    plan.replay()
+    assert log == [("pp_add2d", (None, 7, 0.5)), "note", ("pp_add2d", (1234, 8, 1.5))]
+    assert [e for e in first if e != ("pp_topk_workspace_bytes", (3,)) and e != ("pp_bad", (1,))] == log
+    plan.calls.append((_Fake.pp_bad, (ctypes.c_int(1),)))
+    with pytest.raises(_lib.PixelPickHipError):
+        plan.replay()

@@ -218,6 +218,50 @@ def test_graph_replay_matches_eager_steps():
     assert torch.equal(p_eager, p_graph)
 
 
+@pytest.mark.parametrize("network", ["deeplab", "FPN"])
+def test_launch_plan_replay_matches_eager_steps(network):
+    """FlatTrainer.enable_replay: the recorded launch list (C-ABI calls + stream forks / joins, re-issued from a loop) must
+    walk the same parameter trajectory as eager steps, bit for bit, with inputs that change from step to step, dropout
+    active (device-side seed) and the BatchNorm step counters still advancing."""
+    from pixelpick_amd import engine as E
+    from pixelpick_amd.networks.layers import BatchNorm2d
+    C, B, H, W = 19, 2, 64, 96
+    data = [(fi.formula_input(B, H, W, key=f"r{i}").to(DEV), fi.formula_labels(B, H, W, C, C, 20, key=f"r{i}").to(DEV)) for i in range(3)]
+
+    def run(use_plan):
+        m = _build(C, network)
+        for mod in m.modules():
+            if isinstance(mod, Dropout):
+                mod.p = 0.3
+        tr = FlatTrainer(m.train(), ignore_index=C)
+        E.set_dropout_device_seed(tr._seed_dev)
+        losses = []
+        for i in range(5):
+            xb, yb = data[i % 3]
+            if not use_plan:
+                tr.step_count += 1
+                tr._stage_hyper()
+                losses.append(tr._step_body(xb, yb, False, True).item())
+            elif i == 0:
+                tr.enable_replay(xb, yb, warmup=0)          # the recorded step is a real step
+                assert len(tr._plan) > 100
+                losses.append(tr.last_loss.item())
+            else:
+                losses.append(tr.train_step(xb, yb).item())
+        nbt = [int(mod.state_dict()["num_batches_tracked"]) for mod in m.modules() if isinstance(mod, BatchNorm2d)]
+        p = tr.flat_p.clone()
+        if use_plan:
+            tr.disable_replay()
+        E.set_dropout_device_seed(None)
+        return p, losses, nbt
+
+    p_eager, l_eager, n_eager = run(False)
+    p_plan, l_plan, n_plan = run(True)
+    assert l_eager == l_plan
+    assert torch.equal(p_eager, p_plan)
+    assert n_eager == n_plan and (not n_eager or set(n_eager) == {5})
+
+
 @pytest.mark.parametrize("network,shape", [("deeplab", (2, 72, 88)), ("deeplab", (1, 128, 192)), ("FPN", (2, 64, 96))])
 def test_inference_with_fused_conv_bn_act_is_bit_identical(network, shape):
     """Inference folds eval-mode BatchNorm (+ residual + activation) into the producing convolution's epilogue
