@@ -315,6 +315,8 @@ struct BnFusedGeom {
 static thread_local int g_bn_target_blocks = 384;     // strips x row chunks aimed at (pp_debug_set_bn_target): measured in-process
                                          // 128: 7.77, 192: 7.47, 256-384: 7.30-7.36, 512: 7.36, 768: 7.60, 1024: 7.76 ms/step
 
+constexpr int kBnRowCache = 8;                    // rows per thread the single-launch BatchNorm kernels may keep in registers between passes
+static thread_local int g_bn_row_cache = 1;       // pp_debug_set_bn_bytes_per_block(-1) switches the register-cached variants off (A/B)
 static thread_local int g_bn_bytes_per_block = 0;   // > 0: large maps get one block per this many bytes of x.  Off: measured neutral in
                                                    // isolation (tools/bn_bench.py: 33.6 MB forward 33.4 us with 384 blocks, 33.2-35.8 us with 640)
                                                    // and in the step (6.84 vs 6.86 ms) - a launch is ~13 us of fixed latency + bytes at ~5 TB/s
@@ -401,12 +403,17 @@ __device__ __forceinline__ void publish_partial(xword* p, int nch, const float4&
     xchg_put(p + nch + 0, s1.x, tag); xchg_put(p + nch + 1, s1.y, tag); xchg_put(p + nch + 2, s1.z, tag); xchg_put(p + nch + 3, s1.w, tag);
 }
 
-// this launch's tag, read once per block (before any block of the launch can have advanced the epoch)
-__device__ __forceinline__ unsigned launch_tag(const int* sync, unsigned* sh_tag)
+// this launch's tag, read once per block (before any block of the launch can have advanced the epoch: the epoch moves
+// only when every block has gone through launch_done).  The load is issued at kernel entry by thread 0 and only consumed
+// after the statistics pass (tag_share in front of rowlane_tree, whose barriers publish it): its ~1 us of latency runs
+// under the pass instead of in front of it.
+__device__ __forceinline__ unsigned tag_issue(const int* sync)
 {
-    if (threadIdx.x == 0) *sh_tag = (unsigned)__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    __syncthreads();
-    return *sh_tag;
+    return threadIdx.x == 0 ? (unsigned)__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+}
+__device__ __forceinline__ void tag_share(unsigned tag0, unsigned* sh_tag)
+{
+    if (threadIdx.x == 0) *sh_tag = tag0;
 }
 
 // called by every block after its last xchg_get: the last one through advances the epoch and re-arms the counter
@@ -513,18 +520,22 @@ __device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int 
 // convolution computed in the statistics pass; MODE 2: the producer of x already wrote partial statistics - no first pass
 // over x, NO exchange between blocks and no co-residency requirement: every block reduces the stat_rows partial rows of its
 // channel strip itself (fixed order, fp64) and applies.
-template <int MODE>
+// NC > 0 (MODE 0 only): a thread's rows of its chunk (at most NC, launcher-checked) stay in registers between the statistics
+// pass and the apply pass - same sums in the same order, no second read of x (one L2 round trip less per launch).
+template <int MODE, int NC = 0>
 __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 {
     constexpr bool DW = MODE == 1;
+    static_assert(NC == 0 || (MODE == 0 && NC % 4 == 0), "row cache: plain BatchNorm only");
+    float4 keep[NC > 0 ? NC : 1];
     __shared__ unsigned sh_tag;
     __shared__ float4 sh[2][kT];
     __shared__ double shd[kT];
     __shared__ double tot[64];
     __shared__ float aff[2][32];
     const BnFusedGeom g = a.g;
-    unsigned tag = 0;
-    if constexpr (MODE != 2) tag = launch_tag(a.sync, &sh_tag);
+    unsigned tag = 0, tag0 = 0;
+    if constexpr (MODE != 2) tag0 = tag_issue(a.sync);
     const int t = threadIdx.x;
     const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
     const int ql = t % g.bq, rl = t / g.bq;
@@ -561,31 +572,44 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
         __syncthreads();
     } else {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    if (active) {
-        for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
-            float4 v[4];
-            float w[4];
+    auto stat_group = [&](int64_t r, float4* v) {          // four rows r, r + nrl, ...: the accumulation order of every variant
+        float w[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t rr = r + (int64_t)j * g.nrl;
-                w[j] = rr < r1 ? 1.0f : 0.0f;
-                if constexpr (DW) {
-                    v[j] = dw_point(a, rr < r1 ? rr : r1 - 1, q);
-                    if (rr < r1) *reinterpret_cast<float4*>(a.x_out + rr * a.ldx + q * 4) = v[j];   // BN's input, kept for backward
-                } else {
-                    v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);
-                }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = r + (int64_t)j * g.nrl;
+            w[j] = rr < r1 ? 1.0f : 0.0f;
+            if constexpr (DW) {
+                v[j] = dw_point(a, rr < r1 ? rr : r1 - 1, q);
+                if (rr < r1) *reinterpret_cast<float4*>(a.x_out + rr * a.ldx + q * 4) = v[j];   // BN's input, kept for backward
+            } else {
+                v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);
             }
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 u = make_float4(v[j].x * w[j], v[j].y * w[j], v[j].z * w[j], v[j].w * w[j]);
-                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
-                s1.x = fmaf(u.x, u.x, s1.x); s1.y = fmaf(u.y, u.y, s1.y);
-                s1.z = fmaf(u.z, u.z, s1.z); s1.w = fmaf(u.w, u.w, s1.w);
+        for (int j = 0; j < 4; ++j) {
+            const float4 u = make_float4(v[j].x * w[j], v[j].y * w[j], v[j].z * w[j], v[j].w * w[j]);
+            s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            s1.x = fmaf(u.x, u.x, s1.x); s1.y = fmaf(u.y, u.y, s1.y);
+            s1.z = fmaf(u.z, u.z, s1.z); s1.w = fmaf(u.w, u.w, s1.w);
+        }
+    };
+    if (active) {
+        if constexpr (NC > 0) {
+#pragma unroll
+            for (int it = 0; it < NC / 4; ++it) {
+                const int64_t r = r0 + rl + (int64_t)it * g.nrl * 4;
+                if (r < r1) stat_group(r, &keep[it * 4]);
+            }
+        } else {
+            for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
+                float4 v[4];
+                stat_group(r, v);
             }
         }
     }
+    tag_share(tag0, &sh_tag);
     rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
+    tag = sh_tag;
     if (rl == 0) {
         publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1, tag);
     }
@@ -624,6 +648,24 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
     const bool drop = a.drop_p > 0.0f;
     uint64_t dseed = a.drop_seed;
     if (drop && a.drop_seed_dev) dseed += *a.drop_seed_dev * 0x9E3779B97F4A7C15ull;      // as dropout4_kernel
+    if constexpr (NC > 0) {
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            const int64_t r = r0 + rl + (int64_t)e * g.nrl;
+            if (r >= r1) break;
+            const float4 va = keep[e];
+            float4 oa;
+            oa.x = fmaf(va.x, sc.x, sf.x); oa.y = fmaf(va.y, sc.y, sf.y); oa.z = fmaf(va.z, sc.z, sf.z); oa.w = fmaf(va.w, sc.w, sf.w);
+            if (rq) {
+                const float4 ra = *reinterpret_cast<const float4*>(rq + r * a.ldr);
+                oa.x += ra.x; oa.y += ra.y; oa.z += ra.z; oa.w += ra.w;
+            }
+            oa.x = act_fwd(oa.x, act); oa.y = act_fwd(oa.y, act); oa.z = act_fwd(oa.z, act); oa.w = act_fwd(oa.w, act);
+            if (drop) drop4(oa, (uint64_t)(r * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
+            *reinterpret_cast<float4*>(yq + r * a.ldy) = oa;
+        }
+        return;
+    }
     for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
         const int64_t rb = r + g.nrl;
         const bool two = rb < r1;
@@ -649,6 +691,14 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
     }
 }
 
+// dx of one element; no fma contraction, so that every kernel variant (and the mask / dropout scaling in front of it, which
+// the row-cached variant applies in the reduction pass) rounds identically
+__device__ __forceinline__ float bn_dx(float u, float v, float mu, float is, float ga, float db, float dg, float inv_count)
+{
+#pragma clang fp contract(off)
+    return ga * is * (u - db * inv_count - (v - mu) * is * dg * inv_count);
+}
+
 struct BnBwdArgs {
     const float* x; int64_t ldx; const float* dy; int64_t lddy; const float* yact; int64_t ldya; int act;
     int64_t M; int C; const float* mean; const float* invstd; const float* gamma; float* dgamma; float* dbeta;
@@ -657,6 +707,9 @@ struct BnBwdArgs {
     const float* beta_mask;   // non-NULL (and yact NULL): the activation mask is recomputed from x, z = x*scale + shift
 };
 
+// NC > 0: a thread's (at most NC, launcher-checked) rows of x and of the masked, scaled dy stay in registers between the
+// reduction pass and the dx pass (same values, same order; the mask source is not read twice either).
+template <int NC>
 __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
 {
     __shared__ unsigned sh_tag;
@@ -664,8 +717,10 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
     __shared__ double shd[kT];
     __shared__ double tot[64];
     __shared__ float red[2][32];
+    static_assert(NC % 2 == 0, "row cache: pairs of rows");
+    float4 keepx[NC > 0 ? NC : 1], keepu[NC > 0 ? NC : 1];
     const BnFusedGeom g = a.g;
-    const unsigned tag = launch_tag(a.sync, &sh_tag);
+    const unsigned tag0 = tag_issue(a.sync);
     const int t = threadIdx.x;
     const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
     const int ql = t % g.bq, rl = t / g.bq;
@@ -689,7 +744,8 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
             zsc = make_float4(gm.x * is.x, gm.y * is.y, gm.z * is.z, gm.w * is.w);
             zsf = make_float4(be.x - mu.x * zsc.x, be.y - mu.y * zsc.y, be.z - mu.z * zsc.z, be.w - mu.w * zsc.w);
         }
-        for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
+        // two rows r, r + nrl: the accumulation order of every variant; vk / uk (row cache) receive x and mask * dy * gscale
+        auto red_group = [&](int64_t r, float4* vk, float4* uk) {
             float4 v[2], gg[2], ya[2];
             float w[2];
 #pragma unroll
@@ -711,15 +767,30 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
                     u.x *= act_mask(ya[j].x, act); u.y *= act_mask(ya[j].y, act);
                     u.z *= act_mask(ya[j].z, act); u.w *= act_mask(ya[j].w, act);
                 }
+                if constexpr (NC > 0) {
+                    vk[j] = v[j];
+                    uk[j] = make_float4(u.x * a.gscale, u.y * a.gscale, u.z * a.gscale, u.w * a.gscale);   // what the dx pass computes
+                }
                 const float ws_ = w[j] * a.gscale;
                 u.x *= ws_; u.y *= ws_; u.z *= ws_; u.w *= ws_;
                 s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
                 s1.x = fmaf(u.x, (v[j].x - mu.x) * is.x, s1.x); s1.y = fmaf(u.y, (v[j].y - mu.y) * is.y, s1.y);
                 s1.z = fmaf(u.z, (v[j].z - mu.z) * is.z, s1.z); s1.w = fmaf(u.w, (v[j].w - mu.w) * is.w, s1.w);
             }
+        };
+        if constexpr (NC > 0) {
+#pragma unroll
+            for (int it = 0; it < NC / 2; ++it) {
+                const int64_t r = r0 + rl + (int64_t)it * g.nrl * 2;
+                if (r < r1) red_group(r, &keepx[it * 2], &keepu[it * 2]);
+            }
+        } else {
+            for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) red_group(r, nullptr, nullptr);
         }
     }
+    tag_share(tag0, &sh_tag);
     rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
+    const unsigned tag = sh_tag;
     const int nch = g.bq * 4, nout = nch * 2;
     if (rl == 0) {
         publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1, tag);
@@ -744,6 +815,22 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + q * 4);
     float* dxq = a.dx + q * 4;
     float* drq = a.dres ? a.dres + q * 4 : nullptr;
+    if constexpr (NC > 0) {
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            const int64_t r = r0 + rl + (int64_t)e * g.nrl;
+            if (r >= r1) break;
+            const float4 u = keepu[e], v = keepx[e];
+            if (drq) *reinterpret_cast<float4*>(drq + r * a.lddr) = u;
+            float4 o;
+            o.x = bn_dx(u.x, v.x, mu.x, is.x, ga.x, db.x, dg.x, inv_count);
+            o.y = bn_dx(u.y, v.y, mu.y, is.y, ga.y, db.y, dg.y, inv_count);
+            o.z = bn_dx(u.z, v.z, mu.z, is.z, ga.z, db.z, dg.z, inv_count);
+            o.w = bn_dx(u.w, v.w, mu.w, is.w, ga.w, db.w, dg.w, inv_count);
+            *reinterpret_cast<float4*>(dxq + r * a.lddx) = o;
+        }
+        return;
+    }
     for (int64_t r = r0 + rl; r < r1; r += g.nrl) {
         float4 u = *reinterpret_cast<const float4*>(gq + r * a.lddy);
         const float4 v = *reinterpret_cast<const float4*>(xq + r * a.ldx);
@@ -756,10 +843,10 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
         u.x *= a.gscale; u.y *= a.gscale; u.z *= a.gscale; u.w *= a.gscale;
         if (drq) *reinterpret_cast<float4*>(drq + r * a.lddr) = u;
         float4 o;
-        o.x = ga.x * is.x * (u.x - db.x * inv_count - (v.x - mu.x) * is.x * dg.x * inv_count);
-        o.y = ga.y * is.y * (u.y - db.y * inv_count - (v.y - mu.y) * is.y * dg.y * inv_count);
-        o.z = ga.z * is.z * (u.z - db.z * inv_count - (v.z - mu.z) * is.z * dg.z * inv_count);
-        o.w = ga.w * is.w * (u.w - db.w * inv_count - (v.w - mu.w) * is.w * dg.w * inv_count);
+        o.x = bn_dx(u.x, v.x, mu.x, is.x, ga.x, db.x, dg.x, inv_count);
+        o.y = bn_dx(u.y, v.y, mu.y, is.y, ga.y, db.y, dg.y, inv_count);
+        o.z = bn_dx(u.z, v.z, mu.z, is.z, ga.z, db.z, dg.z, inv_count);
+        o.w = bn_dx(u.w, v.w, mu.w, is.w, ga.w, db.w, dg.w, inv_count);
         *reinterpret_cast<float4*>(dxq + r * a.lddx) = o;
     }
 }
@@ -770,14 +857,19 @@ static int bn_fused_capacity()
         int dev = 0, cus = 0, a = 0, b = 0, c = 0;
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<0>, kT, 0) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<1>, kT, 0) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, bn_fused_bwd_kernel, kT, 0) != hipSuccess) {
+        int d = 0, e = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<0, 0>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<1, 0>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, bn_fused_bwd_kernel<0>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, bn_fused_fwd_kernel<0, kBnRowCache>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, bn_fused_bwd_kernel<kBnRowCache>, kT, 0) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
         int per = a < b ? a : b;
         per = per < c ? per : c;
+        per = per < d ? per : d;
+        per = per < e ? per : e;
         return per * cus;
     }();
     return cap;
@@ -1858,7 +1950,11 @@ void pp_debug_set_dw_variant(int v)
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
 void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 384; }
-void pp_debug_set_bn_bytes_per_block(int bytes) { g_bn_bytes_per_block = bytes > 0 ? bytes : 0; }
+void pp_debug_set_bn_bytes_per_block(int bytes)
+{
+    g_bn_bytes_per_block = bytes > 0 ? bytes : 0;
+    g_bn_row_cache = bytes == -1 ? 0 : 1;          // -1: the register-cached variants off (A/B)
+}
 int pp_bn_fused_capacity(void) { return bn_fused_capacity(); }
 
 // ---- batch norm -----------------------------------------------------------------------------------
@@ -1927,7 +2023,10 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 reinterpret_cast<xword*>(workspace), sync, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev,
                 nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<0>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    if (g_bn_row_cache && g.rows_per_chunk <= (int64_t)g.nrl * kBnRowCache)
+        hipLaunchKernelGGL((bn_fused_fwd_kernel<0, kBnRowCache>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL((bn_fused_fwd_kernel<0, 0>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel");
 }
 
@@ -1946,7 +2045,7 @@ int pp_bn_train_fwd_partials(const float* x, int64_t ldx, int64_t M, int C, cons
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 nullptr, nullptr, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev,
                 nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, stats, (int)stat_rows};
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<2>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    hipLaunchKernelGGL((bn_fused_fwd_kernel<2, 0>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel<partials>");
 }
 
@@ -1969,7 +2068,7 @@ int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H
     BnFwdArgs a{x_out, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 reinterpret_cast<xword*>(workspace), sync, g, 0.0f, 1.0f, 0ull, nullptr,
                 in, ld_in, w, x_out, H, W, Ho, Wo, stride, pad, dil, nullptr, 0};
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<1>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    hipLaunchKernelGGL((bn_fused_fwd_kernel<1, 0>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel<dw>");
 }
 
@@ -1989,7 +2088,10 @@ int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
     if (int rc = bn_fused_check("bn_bwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnBwdArgs a{x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr,
                 reinterpret_cast<xword*>(workspace), sync, g, grad_scale, y_act ? nullptr : beta};
-    hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    if (g_bn_row_cache && g.rows_per_chunk <= (int64_t)g.nrl * kBnRowCache)
+        hipLaunchKernelGGL(bn_fused_bwd_kernel<kBnRowCache>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(bn_fused_bwd_kernel<0>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_bwd_kernel");
 }
 

@@ -318,6 +318,42 @@ def test_batchnorm_train_fwd_bwd(shape, act, with_res, bn_fused):
         close(nchw(rv.grad), res.grad, what="dres")
 
 
+@pytest.mark.parametrize("act,with_res", [(0, False), (2, False), (1, True)])
+@pytest.mark.parametrize("shape", [(4, 18, 34, 96), (4, 16, 32, 960), (4, 32, 64, 192), (2, 23, 30, 256), (2, 9, 11, 100), (3, 1, 1, 256)])
+def test_batchnorm_register_cached_variant_is_bit_identical(shape, act, with_res):
+    """Maps small enough that a thread's rows fit in registers take the row-cached single-launch kernels (no second read of
+    x / dy): same sums in the same order as the two-pass kernels, selected off with pp_debug_set_bn_bytes_per_block(-1)."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    B, H, W, C = shape
+    torch.manual_seed(12)
+    x = torch.randn(B, H, W, C, device=DEV) * 2 + 0.5
+    res = torch.randn(B, H, W, C, device=DEV) if with_res else None
+    dy = torch.randn(B, H, W, C, device=DEV)
+    g0, b0 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+
+    def run(cached):
+        L.pp_debug_set_bn_bytes_per_block(0 if cached else -1)
+        try:
+            tape = E.Tape()
+            xv = E.Var(x.clone())
+            rv = E.Var(res.clone()) if with_res else None
+            g, bta = gparam(g0), gparam(b0)
+            rm, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            yv = E.batch_norm_act(tape, xv, g, bta, rm, rvar, True, act, rv)
+            y = yv.t.clone()
+            tape.backward(yv, dy.clone())
+            return y, xv.grad.clone(), tape.param_grads[id(g)].clone(), tape.param_grads[id(bta)].clone(), rm, rvar, \
+                (rv.grad.clone() if with_res else None)
+        finally:
+            L.pp_debug_set_bn_bytes_per_block(0)
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        if u is not None:
+            assert torch.equal(u, v)
+
+
 def _read_sync(sync):
     import ctypes
     probe = torch.empty(2, dtype=torch.int32, device=DEV)
