@@ -189,6 +189,10 @@ int pp_bn_train_fwd(const float* x, int64_t ldx, int64_t M, int C, const float* 
  * run-to-run differences were observed with ordinary memory; pixelpick_amd/engine.py `_bn_exchange` allocates the area
  * once per device).  They must not be shared by launches that can run concurrently.  Results are deterministic. */
 size_t pp_bn_fused_workspace_bytes(int64_t M, int C);
+/* 1 when a [M, C] map is small enough for the single-launch training BatchNorm kernels to keep every thread's rows in
+ * registers between their two passes (no second read of x / dy); then the depthwise convolution in front of a BatchNorm is
+ * also computed inside that launch (pp_dwconv3x3_bn_train_fwd_fused) at no extra traffic.  mobilenet_v2.py:38-39,52-53. */
+int pp_bn_fused_rows_cached(int64_t M, int C);
 size_t pp_bn_fused_sync_ints(int C);
 int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, float* mean, float* invstd,

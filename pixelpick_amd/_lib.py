@@ -48,6 +48,7 @@ SIGNATURES = {
     "pp_bn_bwd": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "pp_bn_fused_workspace_bytes": (_sz, [_i64, _int]),
     "pp_bn_fused_sync_ints": (_sz, [_int]),
+    "pp_bn_fused_rows_cached": (_int, [_i64, _int]),
     "pp_bn_train_fwd_fused": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _int, _f, _u64, _p, _p, _i64, _p, _sz, _p, _sz, _p]),
     "pp_dwconv3x3_bn_train_fwd_fused": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p, _p, _f, _f, _p, _p, _p, _p,
                                                _p, _i64, _int, _p, _i64, _p, _sz, _p, _sz, _p]),
@@ -138,7 +139,7 @@ def lib():
 # of those calls repeats with identical arguments, so the step is recorded ONCE as a flat list of (function, converted
 # arguments) and re-issued from a tight loop.  Unlike a hipGraph the replay keeps the two-queue eager schedule (main stream +
 # weight-gradient stream, the all-reduce under the encoder backward) - profiles/r02_graph_replay.txt shows why the graph loses.
-_NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity")
+_NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_fused_rows_cached")
 
 
 def _is_launch(name: str) -> bool:

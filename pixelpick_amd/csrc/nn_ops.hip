@@ -520,13 +520,13 @@ __device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int 
 // convolution computed in the statistics pass; MODE 2: the producer of x already wrote partial statistics - no first pass
 // over x, NO exchange between blocks and no co-residency requirement: every block reduces the stat_rows partial rows of its
 // channel strip itself (fixed order, fp64) and applies.
-// NC > 0 (MODE 0 only): a thread's rows of its chunk (at most NC, launcher-checked) stay in registers between the statistics
+// NC > 0 (MODE 0 / 1): a thread's rows of its chunk (at most NC, launcher-checked) stay in registers between the statistics
 // pass and the apply pass - same sums in the same order, no second read of x (one L2 round trip less per launch).
 template <int MODE, int NC = 0>
 __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 {
     constexpr bool DW = MODE == 1;
-    static_assert(NC == 0 || (MODE == 0 && NC % 4 == 0), "row cache: plain BatchNorm only");
+    static_assert(NC == 0 || (MODE != 2 && NC % 4 == 0), "row cache: the kernels with a statistics pass");
     float4 keep[NC > 0 ? NC : 1];
     __shared__ unsigned sh_tag;
     __shared__ float4 sh[2][kT];
@@ -857,12 +857,13 @@ static int bn_fused_capacity()
         int dev = 0, cus = 0, a = 0, b = 0, c = 0;
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        int d = 0, e = 0;
+        int d = 0, e = 0, f = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<0, 0>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<1, 0>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, bn_fused_bwd_kernel<0>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, bn_fused_fwd_kernel<0, kBnRowCache>, kT, 0) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, bn_fused_bwd_kernel<kBnRowCache>, kT, 0) != hipSuccess) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, bn_fused_bwd_kernel<kBnRowCache>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, bn_fused_fwd_kernel<1, kBnRowCache>, kT, 0) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
@@ -870,6 +871,7 @@ static int bn_fused_capacity()
         per = per < c ? per : c;
         per = per < d ? per : d;
         per = per < e ? per : e;
+        per = per < f ? per : f;
         return per * cus;
     }();
     return cap;
@@ -1994,6 +1996,13 @@ size_t pp_bn_fused_workspace_bytes(int64_t M, int C)
     return align_up((size_t)g.nstrips * g.R * g.bq * 8 * 8, 256);     // one 64-bit {tag, value} word per partial
 }
 
+int pp_bn_fused_rows_cached(int64_t M, int C)
+{
+    if (M < 1 || C < 4 || C % 4) return 0;
+    BnFusedGeom g = bn_fused_geom(M, C);
+    return (g_bn_row_cache && g.rows_per_chunk <= (int64_t)g.nrl * kBnRowCache) ? 1 : 0;
+}
+
 size_t pp_bn_fused_sync_ints(int C) { (void)C; return 64; }      // [0] launch epoch, [1] blocks done; one 256-byte line
 
 static int bn_fused_check(const char* what, int64_t M, int C, const BnFusedGeom& g, const void* workspace, size_t ws_bytes,
@@ -2068,7 +2077,10 @@ int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H
     BnFwdArgs a{x_out, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 reinterpret_cast<xword*>(workspace), sync, g, 0.0f, 1.0f, 0ull, nullptr,
                 in, ld_in, w, x_out, H, W, Ho, Wo, stride, pad, dil, nullptr, 0};
-    hipLaunchKernelGGL((bn_fused_fwd_kernel<1, 0>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    if (g_bn_row_cache && g.rows_per_chunk <= (int64_t)g.nrl * kBnRowCache)
+        hipLaunchKernelGGL((bn_fused_fwd_kernel<1, kBnRowCache>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL((bn_fused_fwd_kernel<1, 0>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_fwd_kernel<dw>");
 }
 

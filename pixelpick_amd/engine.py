@@ -61,7 +61,24 @@ _FUSE_EVAL = os.environ.get("PIXELPICK_FUSE_EVAL", "1") != "0"
 # PIXELPICK_FUSE_DW_BN=1: compute a depthwise convolution inside the single-launch training BatchNorm behind it
 # (pp_dwconv3x3_bn_train_fwd_fused; bit-identical).  Off by default: measured 7.16-7.18 vs 7.05 ms/step - the BatchNorm grid
 # (384 blocks) is too small for the nine-tap gather, the 17 saved launches do not pay for it.
-_FUSE_DW_BN = os.environ.get("PIXELPICK_FUSE_DW_BN", "0") == "1"
+_FUSE_DW_BN = os.environ.get("PIXELPICK_FUSE_DW_BN", "0")          # "0" never, "1" always, "auto" where the rows stay in registers
+_FUSE_DW_BN = {"0": False, "1": True}.get(_FUSE_DW_BN, _FUSE_DW_BN)
+_ROWS_CACHED = {}
+
+
+def _dw_bn_fusable(M: int, C: int) -> bool:
+    if _FUSE_DW_BN != "auto":
+        return bool(_FUSE_DW_BN)
+    key = (M, C)
+    r = _ROWS_CACHED.get(key)
+    if r is None:
+        r = _ROWS_CACHED[key] = bool(_lib.lib().pp_bn_fused_rows_cached(M, C)) and _BN_FUSED
+    return r
+
+
+def _dw_out_rows(x: "Var", stride, pad, dil):
+    B, H, W, C = shape_of(x)
+    return B * out_size(H, 3, stride, pad, dil) * out_size(W, 3, stride, pad, dil), C
 # PIXELPICK_CONV_BN_STATS=1: a training BatchNorm behind a dense convolution takes its statistics from partial sums the
 # convolution's epilogue (or its split-K reduce) wrote, and only applies - no statistics pass, no exchange between blocks, no
 # co-residency requirement.  OFF by default: measured 6.96-6.98 vs 6.86-6.87 ms/step (profiles/r02_train_ablation.txt) - every
@@ -652,7 +669,7 @@ def dwconv3x3(tape: Tape, x: Var, w: torch.Tensor, stride=1, pad=0, dil=1) -> Va
         out = Var(None, needs_grad=False)
         out._pending = ("dw", x, w, None, stride, pad, dil)
         return out
-    if _FUSE_DW_BN and tape.enabled:
+    if _FUSE_DW_BN and tape.enabled and _dw_bn_fusable(*_dw_out_rows(x, stride, pad, dil)):
         # training: defer as well - a training-mode BatchNorm right behind it computes the convolution inside its own
         # single launch (pp_dwconv3x3_bn_train_fwd_fused); any other consumer's `.t` launches the plain convolution
         out = Var(None)
