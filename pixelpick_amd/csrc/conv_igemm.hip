@@ -1929,6 +1929,44 @@ static thread_local int g_wgrad_dma = 1;          // LDS-DMA weight-gradient ker
 static const int g_wgrad_lds_pad_default = 0;
 static thread_local int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
 static thread_local int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
+static thread_local int g_wgrad_balance = 1;     // pp_debug_set_wgrad_target bit 24: CU-balanced split choice of the MFMA-bound layers off (A/B)
+
+static int device_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return n;
+    }();
+    return cus;
+}
+
+// Split count of an MFMA-bound weight gradient (>= 8 GFLOP: the SegmentHead / ResNet 3x3 layers).  Blocks are handed to CUs
+// round-robin and a CU shares its MFMA pipes among its resident blocks, so the launch lasts as long as its busiest CU:
+// ceil(tiles * s / CUs) blocks of ceil(M / s) rows each.  The target-block rule (s = target / tiles) lands anywhere between
+// 70 % and 98 % balance (36 tiles: 29 slices = 1044 blocks = 4.08 per CU -> 5 on the busiest; 14 slices = 504 blocks -> 2 on
+// every CU); this picks the slice count with the least busiest-CU work plus the cost of reducing one more slice of partial
+// sums.  Measured on the two SegmentHead layers (4 x 64 x 128 rows): 383 -> 333 us and 482 -> 418 us.
+static int64_t wgrad_balanced_splits(int64_t tiles, int64_t M, int bm, int bn, int64_t dw_elems, int64_t max_splits)
+{
+    const int cus = device_cus();
+    const double t_row = 2.0 * bm * bn / 0.46e12;            // one tile row of MFMA work on a CU running at ~0.75 of its fp32 peak
+    const double t_red = (double)dw_elems * 8.0 / 4.0e12;    // one more slice of partials written and read back
+    int64_t s_lo = cdiv((int64_t)(1.8 * cus), tiles);        // at least ~two blocks per CU (latency hiding)
+    if (s_lo > max_splits) s_lo = max_splits;
+    if (s_lo < 1) s_lo = 1;
+    int64_t best = s_lo;
+    double best_cost = 1e30;
+    for (int64_t sp = s_lo; sp <= max_splits; ++sp) {
+        const int64_t rows = cdiv(cdiv(M, sp), BK) * BK;
+        const double cost = (double)cdiv(tiles * sp, cus) * rows * t_row + sp * t_red;
+        if (cost < best_cost * 0.999) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
 static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* dbias, bool* bias_done, void* workspace,
@@ -2024,6 +2062,7 @@ void pp_debug_set_wgrad_target(int v)
 {
     g_wgrad_target = (v & 0xFFFF) > 0 ? (v & 0xFFFF) : 1024;
     g_wgrad_lds_pad = v > 0 ? ((v >> 16) & 0xFF) * 1024 : g_wgrad_lds_pad_default;   // bits 16-23: KiB of LDS padding (A/B)
+    g_wgrad_balance = (v > 0 && ((v >> 24) & 1)) ? 0 : 1;                             // bit 24: CU-balanced split choice off
 }
 /* v = big_tile_min | wgrad_rows_min << 12 (0 fields: defaults 384 / 128) */
 void pp_debug_set_conv_thresholds(int v)
@@ -2225,6 +2264,8 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     if (splits > max_by_m) splits = max_by_m;
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
+    if (g_wgrad_balance && big && 2.0 * p.taps.n * Cin * Cout * (double)p.M >= 8e9)
+        splits = wgrad_balanced_splits(tiles, p.M, bm, bn, (int64_t)p.taps.n * Cin * Cout, max_by_m < 64 ? max_by_m : 64);
     p.m_per_split = cdiv(cdiv(p.M, splits), BK) * BK;
     splits = cdiv(p.M, p.m_per_split);
     const size_t need = (size_t)splits * p.taps.n * Cin * Cout * 4;

@@ -124,13 +124,14 @@ def _launch_deferred(v: "Var", bn):
 
 _side_streams = {}
 N_SIDE_STREAMS = int(os.environ.get("PIXELPICK_SIDE_STREAMS", "1"))
+SIDE_PRIORITY = int(os.environ.get("PIXELPICK_SIDE_PRIORITY", "0"))      # HIP stream priority of the weight-gradient stream(s)
 
 
 def _side_stream(device, i: int = 0) -> "torch.cuda.Stream":
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), i)
     st = _side_streams.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
         _side_streams[key] = st
     return st
 

@@ -42,6 +42,9 @@ def main():
     engine.conv2d = orig
     L = _lib.lib()
     L.pp_debug_set_conv_variant(int(os.environ.get("CONV_VARIANT", 0)))      # A/B of the kernel choices (conv_igemm.hip)
+    if os.environ.get("WGRAD_TARGET"):
+        L.pp_debug_set_wgrad_target(int(os.environ["WGRAD_TARGET"]))
+    only = os.environ.get("ONLY")          # e.g. ONLY=64x128x3: rows of that H x W x kernel only
     st = torch.cuda.current_stream().cuda_stream
 
     def timeit(fn, n=20):
@@ -58,6 +61,8 @@ def main():
     tot = [0.0, 0.0, 0.0]
     print(f"{'B,H,W':>12s} {'Cin':>5s} {'Cout':>5s} {'k':>3s} {'s':>2s} {'d':>3s} {'n':>3s} {'GF':>7s} | {'fwd us':>8s} {'TF':>6s} | {'bwdD us':>8s} {'TF':>6s} | {'bwdW us':>8s} {'TF':>6s}")
     for (Bn, Hh, Ww, Cin, Cout, kh, kw, s, p, d, ng), cnt in seen.items():
+        if only and only != f"{Hh}x{Ww}x{kh}":
+            continue
         Ho, Wo = engine.out_size(Hh, kh, s, p, d), engine.out_size(Ww, kw, s, p, d)
         xt = torch.randn(Bn, Hh, Ww, Cin, device="cuda")
         wt = torch.randn(kh, kw, Cin, Cout, device="cuda")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Quick timing of the DeepLabv3+-MNv2 train step (FlatTrainer) at the BASELINE config: B=4, 256x512, C=19."""
-import os, sys, time, json, warnings
+"""Quick timing of the DeepLabv3+-MNv2 (NET=FPN: FPNSeg-ResNet50) train step (FlatTrainer) at the BASELINE config: B=4, 256x512, C=19."""
+import contextlib, os, sys, time, json, warnings
 from argparse import Namespace
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -10,7 +10,8 @@ from pixelpick_amd.trainer import FlatTrainer
 def main():
     B, H, W, C = int(os.environ.get("B", 4)), 256, 512, 19
     steps, warm = int(os.environ.get("STEPS", 10)), 3
-    args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")
+    args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=os.environ.get("NET", "deeplab"), weight_type="random",
+                     n_layers=50, use_softmax=True, use_dilated_resnet=True, width_multiplier=1.0)
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -22,14 +23,17 @@ def main():
     for b in range(B):
         idx = torch.randperm(H * W, device="cuda", generator=g)[:20]
         y[b].view(-1)[idx] = torch.randint(0, C, (20,), device="cuda", generator=g)
-    for _ in range(warm):
-        loss = tr.train_step(x, y)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.train_step(x, y)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    mp = os.environ.get("MAIN_PRIORITY")              # run the step on a stream of this HIP priority (default: the current stream)
+    ctx = torch.cuda.stream(torch.cuda.Stream(priority=int(mp))) if mp is not None else contextlib.nullcontext()
+    with ctx:
+        for _ in range(warm):
+            loss = tr.train_step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.train_step(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
     print(json.dumps({"ms_per_step": dt * 1e3, "img_per_s": B / dt, "loss": loss.item()}))
 
 if __name__ == "__main__":
