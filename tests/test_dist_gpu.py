@@ -84,7 +84,20 @@ def _worker(rank, world, port, q):
             tr3.train_step(xs, ys)
         T.OVERLAP_ALLREDUCE = True
         overlap_equals_plain = torch.equal(tr3.flat_p, tr2.flat_p)
-        q.put((rank, same_as_single, replicas_equal, differs_from_a and overlap_equals_plain, losses))
+        # (D) launch-plan replay under collectives: the recorded step carries both all-reduces (the early bucket on the helper
+        #     stream included); three replayed steps equal three eager steps with device-side hyper-parameters
+        tr4, tr5 = _trainer(), _trainer()
+        tr4.enable_replay(xs, ys, warmup=0)
+        for _ in range(2):
+            tr4.train_step(xs, ys)
+        for _ in range(3):
+            tr5.step_count += 1
+            tr5._stage_hyper()
+            tr5._step_body(xs, ys, False, True)
+        torch.cuda.synchronize()
+        replay_equals_eager = torch.equal(tr4.flat_p, tr5.flat_p) and len(tr4._plan) > 100
+        tr4.disable_replay()
+        q.put((rank, same_as_single, replicas_equal, differs_from_a and overlap_equals_plain and replay_equals_eager, losses))
     finally:
         dist.destroy_process_group()
 

@@ -44,6 +44,8 @@ def main():
     L.pp_debug_set_conv_variant(int(os.environ.get("CONV_VARIANT", 0)))      # A/B of the kernel choices (conv_igemm.hip)
     if os.environ.get("WGRAD_TARGET"):
         L.pp_debug_set_wgrad_target(int(os.environ["WGRAD_TARGET"]))
+    if os.environ.get("SPLITK"):           # pp_debug_set_splitk word: tiles_threshold | target << 10 | min_k_steps << 20 | min_steps_per_slice << 26
+        L.pp_debug_set_splitk(int(os.environ["SPLITK"]))
     only = os.environ.get("ONLY")          # e.g. ONLY=64x128x3: rows of that H x W x kernel only
     st = torch.cuda.current_stream().cuda_stream
 
