@@ -46,6 +46,9 @@ class Model:
         self.best_miou = -1.0
         self.dataset_name = args.dataset_name
         self.debug = args.debug
+        # not in the reference: re-issue the train step's recorded launch list instead of walking the network in Python every
+        # step (args.replay_train_step / PIXELPICK_REPLAY_TRAIN=1; same parameters bit for bit, tests/test_networks_gpu.py)
+        self._replay_train = bool(getattr(args, "replay_train_step", False)) or os.environ.get("PIXELPICK_REPLAY_TRAIN", "0") == "1"
         self.device = device or torch.device("cuda:0")
         self.dir_checkpoints = f"{args.dir_root}/checkpoints/{args.experim_name}"
         self.experim_name = args.experim_name
@@ -159,7 +162,15 @@ class Model:
                 y = torch.where(mask != 0, y, torch.full_like(y, self.ignore_index))
             if self.lr_scheduler_type == "Poly":                           # per-iteration poly decay (lr_scheduler.py:15-17)
                 trainer.set_poly_lr((epoch - 1) * self._steps_per_epoch() + local_it, n_iters_total)
-            tape_pred = trainer.train_step(x, y, keep_logits=True)
+            if self._replay_train and trainer._plan is None and trainer._graph is None:
+                # static shapes (drop_last loader): record this step's launches once, re-issue them afterwards (halves the
+                # host cost of a step; FlatTrainer.enable_replay).  The recorded step IS this iteration's step.
+                trainer._ensure_train_mode()
+                trainer.enable_replay(x, y, warmup=0)
+            else:
+                if trainer._plan is not None and tuple(x.shape) != tuple(trainer._gx.shape):
+                    trainer.disable_replay()                                # a ragged batch: back to eager steps
+                trainer.train_step(x, y, keep_logits=True)
             self.running_score.update_from_logits(y, trainer.last_logits)  # device-side confusion matrix (L6)
             self.running_loss.update(trainer.last_loss)
             if self.debug:

@@ -106,3 +106,40 @@ def test_validation_batched_equals_per_image(tmp_path):
         assert cmx.sum() == res[0][0].sum() == 11 * 64 * 96 - int(sum((y == 5).sum() for y in ds_val.ys))
         assert np.abs(cmx - res[0][0]).sum() <= 4          # a near-tie argmax may flip with the summation order
         assert abs(miou - res[0][1]) < 1e-3 and abs(acc - res[0][2]) < 1e-3
+
+
+def test_active_learning_round_with_replayed_train_steps(tmp_path, monkeypatch):
+    """args.replay_train_step: the driver records the first train step of every round's trainer and re-issues its launch list
+    afterwards (FlatTrainer.enable_replay).  Same control flow and artefacts as the eager loop; a ragged last batch falls back
+    to eager steps."""
+    import warnings
+    from pixelpick_amd.trainer import FlatTrainer
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ds = SyntheticDataset(10, 64, 96, 5, 5, n_init_pixels=10, seed=1)          # 10 images, batch 4: two full batches + a ragged one
+    ds_val = SyntheticDataset(4, 64, 96, 5, 5, seed=2)
+    mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
+    args = _args(str(tmp_path), replay_train_step=True, max_budget=10)
+    seen = {"replayed": 0, "recorded": 0, "dropped": 0}
+    orig_enable, orig_disable = FlatTrainer.enable_replay, FlatTrainer.disable_graph
+
+    def enable(self, *a, **k):
+        seen["recorded"] += 1
+        return orig_enable(self, *a, **k)
+
+    def disable(self):
+        seen["dropped"] += int(self._plan is not None)
+        return orig_disable(self)
+
+    monkeypatch.setattr(FlatTrainer, "enable_replay", enable)
+    monkeypatch.setattr(FlatTrainer, "disable_graph", disable)
+    monkeypatch.setattr(FlatTrainer, "disable_replay", disable)
+    m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device(DEV))
+    m()
+    assert seen["recorded"] >= 2 and seen["dropped"] >= 1       # re-recorded after every ragged batch, in both rounds
+    losses = [h[5] for h in m.history if h[0] == "train"]
+    assert len(losses) == 4 and all(np.isfinite(l) for l in losses)
+    for i in range(len(ds)):
+        assert ds.queries[i].sum() == 10 + 2 * 10
+    assert (tmp_path / "checkpoints" / "synthetic" / "1_query" / "best_miou_model.pt").exists()
