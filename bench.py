@@ -149,9 +149,10 @@ def main():
     ap.add_argument("--strategy", default="entropy")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "acq"])
-    ap.add_argument("--network", default="deeplab", choices=["deeplab", "FPN"],
+    ap.add_argument("--network", default="deeplab", choices=["deeplab", "FPN", "deeplab_r50"],
                     help="train leg: deeplab = DeepLabv3+-MobileNetV2 (BASELINE configs[1], the default line); FPN = the "
-                         "reference's ResNet50 model (networks/model.py FPNSeg, configs[2])")
+                         "reference's ResNet50 model (networks/model.py FPNSeg, configs[2]); deeplab_r50 = the DeepLabv3+-ResNet50 "
+                         "assembled from the reference's parts (SURVEY.md 0.1, an extra: the reference never builds it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune-occ", type=int, default=0)
     ap.add_argument("--tune-ppt", type=int, default=0)
@@ -402,8 +403,11 @@ def main():
     if rank == 0:
         head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
-        net_desc = ("BASELINE configs[1]: Cityscapes {}x{}, C={}, DeepLabv3+-MobileNetV2" if a.network == "deeplab" else
-                    "BASELINE configs[2] (per GPU): Cityscapes {}x{}, C={}, ResNet50 model of the reference (FPNSeg)").format(H, W, C)
+        net_desc = {"deeplab": "BASELINE configs[1]: Cityscapes {}x{}, C={}, DeepLabv3+-MobileNetV2",
+                    "FPN": "BASELINE configs[2] (per GPU): Cityscapes {}x{}, C={}, ResNet50 model of the reference (FPNSeg)",
+                    "deeplab_r50": "BASELINE configs[2] as named (per GPU): Cityscapes {}x{}, C={}, DeepLabv3+-ResNet50 assembled from "
+                                   "the reference's parts (dilated ResNet50 + ASPP rates 12/24/36 + SegmentHead; not a reference model)"
+                    }[a.network].format(H, W, C)
         wl = (f"{net_desc}; train step per-GPU batch "
               f"{a.train_batch} with {a.n_labelled} labelled px/img + Adam; acquisition {a.strategy} top-k={k}, "
               f"B={a.batch} images/launch/GPU, {a.layout.upper()} fp32 logits")

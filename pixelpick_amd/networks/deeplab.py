@@ -63,13 +63,27 @@ class _NetFunction(torch.autograd.Function):
 
 
 class DeepLab(nn.Module):
+    """backbone='mobilenet' is the reference's model (deeplab.py:19 hard-wires MobileNetV2).  backbone='resnet' is the EXTRA
+    of SURVEY.md 0.1: a DeepLabv3+-ResNet50 assembled from reference PARTS - `ResNetBackbone('resnet50_dilated8')`
+    (resnet_backbone.py:141-144; c2 = low-level feature, c5 at 1/8 = high-level), `ASPP('resnet', 8)` (aspp.py:38-39,43-44:
+    2048 input channels, rates 1/12/24/36), `SegmentHead` - wired as deeplab.py:43-59 wires its MobileNetV2.  The reference
+    never instantiates it (its "ResNet50" model is FPNSeg), so it is pinned per component and against the same assembly of
+    the imported reference parts (tools/gen_golden_net.py --r50)."""
     LOWRES_LOGITS = True      # _run(..., upsample=False) stops in front of the final x4 bilinear (deeplab.py:55-56)
 
     def __init__(self, args, backbone='mobilenet', output_stride=16):
         super().__init__()
-        self.backbone = MobileNetV2(output_stride, BatchNorm2d, mc_dropout=args.use_mc_dropout)
+        self._resnet = backbone == 'resnet'
+        if self._resnet:
+            from .backbones.resnet_backbone import ResNetBackbone
+            if output_stride != 8:
+                raise NotImplementedError("the dilated ResNet backbone has output stride 8 (resnet_backbone.py:53-58)")
+            self.backbone = ResNetBackbone(backbone='resnet50_dilated8', pretrained=None)
+            low_level_inplanes = 256
+        else:
+            self.backbone = MobileNetV2(output_stride, BatchNorm2d, mc_dropout=args.use_mc_dropout)
+            low_level_inplanes = 24
         self.aspp = ASPP(backbone, output_stride, BatchNorm2d)
-        low_level_inplanes = 24
         self.low_level_conv = nn.Sequential(Conv2d(low_level_inplanes, 48, 1, bias=False), BatchNorm2d(48), ReLU())
         self.seg_head = SegmentHead(args)
         self.return_features = False
@@ -97,7 +111,11 @@ class DeepLab(nn.Module):
     def _run(self, tape, inputs, upsample=True):
         B, _, H, W = inputs.shape
         x = E.nchw_to_nhwc(inputs)
-        high, low = self.backbone.run(tape, x)
+        if self._resnet:
+            feats = self.backbone.run(tape, x)                  # [c2, c3, c4, c5]
+            high, low = feats[3], feats[0]
+        else:
+            high, low = self.backbone.run(tape, x)
         tape.mark("encoder_done")             # backward: every aspp / low-level / head gradient is enqueued at this point
         a = self.aspp.run(tape, high)
         _, Hl, Wl, _ = low.t.shape

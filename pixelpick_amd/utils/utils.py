@@ -8,6 +8,8 @@ def get_model(args):
     """utils/utils.py:15-51."""
     if args.network_name == "deeplab":
         return DeepLab(args)
+    if args.network_name == "deeplab_r50":        # not a reference choice (args.py:19): the assembled extra of SURVEY.md 0.1
+        return DeepLab(args, backbone='resnet', output_stride=8)
     if args.network_name == "FPN":
         from ..networks.model import FPNSeg
         return FPNSeg(args)

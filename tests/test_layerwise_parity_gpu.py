@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 import formula_init as fi
 from layerwise import LayerwiseParity, OracleTrace
-from oracle.net import OracleDeepLab, OracleFPN
+from oracle.net import OracleDeepLab, OracleDeepLabR50, OracleFPN
 from pixelpick_amd.networks.layers import Dropout
 from pixelpick_amd.trainer import FlatTrainer
 from pixelpick_amd.utils.utils import get_model
@@ -48,7 +48,8 @@ def _models(network, C, salt=""):
     for mod in m.modules():
         if isinstance(mod, Dropout):
             mod.p = 0.0
-    o = OracleDeepLab(C, 0.0, 0.0, 0.0) if network == "deeplab" else OracleFPN(C)
+    o = {"deeplab": lambda: OracleDeepLab(C, 0.0, 0.0, 0.0), "FPN": lambda: OracleFPN(C),
+         "deeplab_r50": lambda: OracleDeepLabR50(C, 0.0, 0.0, 0.0)}[network]()
     o.load_state_dict(sd)
     return m.to(DEV).train(), o.train()
 
@@ -105,6 +106,15 @@ def test_fpn_every_layer_forward_and_backward_matches_oracle():
     assert sum(f for f, _ in lp.flips.values()) <= 2, lp.flips
 
 
+def test_deeplab_r50_every_layer_forward_and_backward_matches_oracle():
+    """The assembled DeepLabv3+-ResNet50 (SURVEY.md 0.1 extra): dilated ResNet50 + ASPP at output stride 8 (rates 12/24/36) +
+    SegmentHead, every layer against the oracle of the same assembly (itself pinned to the reference's parts)."""
+    lp, loss, o_loss, m, o = _run("deeplab_r50", 19, 19, 4, 64, 96, 20)      # (the image-pooling BatchNorm sees only B rows: ill-conditioned below 4)
+    assert abs(loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss))
+    _assert_tight(lp, len(list(m.parameters())))
+    assert sum(f for f, _ in lp.flips.values()) <= 2, lp.flips
+
+
 def test_deeplab_every_layer_at_the_baseline_shape():
     """BASELINE configs[1]: 256x512, per-GPU batch 4, 20 labelled pixels per image (the shape bench.py times)."""
     lp, loss, o_loss, m, o = _run("deeplab", 19, 19, 4, 256, 512, 20, key="base")
@@ -131,7 +141,8 @@ def test_free_running_noise_is_reported_and_bounded(network, n_params, B, H, W):
     assert len(errs) == n_params and np.median(errs) <= 5e-2
 
 
-@pytest.mark.parametrize("network,n_params,B,H,W", [("deeplab", 182, 4, 128, 192), ("deeplab", 182, 4, 256, 512), ("FPN", 213, 2, 64, 96)])
+@pytest.mark.parametrize("network,n_params,B,H,W", [("deeplab", 182, 4, 128, 192), ("deeplab", 182, 4, 256, 512), ("FPN", 213, 2, 64, 96),
+                                                    ("deeplab_r50", 188, 4, 64, 96)])
 def test_branch_forced_free_running_gradients_are_tight(network, n_params, B, H, W):
     """The whole network FREE-RUNNING (no tensor is overwritten, rounding compounds through all 60 layers forward and
     backward) with one intervention: the few ReLU/ReLU6 units whose branch differs from the oracle's run are put on the

@@ -123,3 +123,25 @@ def test_mc_dropout_variant_builds_with_the_reference_layout():
     mc.turn_on_dropout()
     assert all(m.training for m in mc.modules() if isinstance(m, Dropout))
     assert not any(m.training for m in mc.modules() if isinstance(m, Dropout2d))
+
+
+def test_deeplab_r50_extra_has_the_surface_of_the_assembled_reference_parts(golden_dir):
+    """network_name="deeplab_r50" (SURVEY.md 0.1 extra): state_dict keys / shapes equal those of the reference's
+    ResNetBackbone('resnet50_dilated8') + ASPP('resnet', 8) + low-level conv + SegmentHead assembly the goldens were generated
+    from, parameters are in the reference's order, and the optimiser groups of utils/utils.py:125-141 apply unchanged."""
+    import warnings
+    a = _args()
+    a.network_name = "deeplab_r50"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = get_model(a)
+    g = np.load(os.path.join(golden_dir, "net_deeplab_r50_cs64x96.npz"))
+    sd = m.state_dict()
+    assert len(sd) == int(g["n_state_keys"]) == 374
+    assert zlib.crc32("\n".join(f"{k}:{tuple(v.shape)}" for k, v in sd.items()).encode()) == int(g["state_keys_crc"])
+    assert [k for k, _ in m.named_parameters()] == [str(k) for k in g["grad_names"]]
+    n = lambda mod: sum(p.numel() for p in mod.parameters())
+    assert n(m) == 40351667 and n(m.backbone) == 23508032 and tuple(m.aspp.aspp2.atrous_conv.weight.shape) == (3, 3, 2048, 256)
+    assert m.aspp.aspp2.atrous_conv.dilation == 12 and m.aspp.aspp4.atrous_conv.dilation == 36      # aspp.py:43-44, output stride 8
+    opt = get_optimizer(a, m)
+    assert [gr["lr"] for gr in opt.param_groups] == [5e-5, 5e-4, 5e-4, 5e-4]

@@ -181,6 +181,44 @@ def test_fpn_train_step_matches_reference(golden_dir):
     print(f"[fpn {tag}] logits max err {err:.2e}; worst relative abs-sum gradient deviation {worst:.2e}")
 
 
+# ------------------------------------------------------------------------- DeepLabv3+-ResNet50 (assembled extra)
+def test_deeplab_r50_matches_the_assembly_of_reference_parts(golden_dir):
+    """network_name="deeplab_r50": dilated ResNet50 + ASPP('resnet', output stride 8: 2048 channels, rates 1/12/24/36) +
+    SegmentHead, against goldens generated from the reference's own classes wired as deeplab.py:43-56."""
+    g = np.load(os.path.join(golden_dir, "net_deeplab_r50_voc40x56.npz"))
+    B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
+    m = _build(C, "deeplab_r50").eval()
+    with torch.no_grad():
+        out = m(fi.formula_input(B, H, W, key="xvoc40x56").to(DEV))
+    assert out["pred"].shape == (B, C, H, W)
+    assert _rel(out["pred"].reshape(-1)[::STRIDE].cpu().numpy(), g["eval_pred_samples"]) < TOL
+    tag = "cs64x96"
+    g = np.load(os.path.join(golden_dir, f"net_deeplab_r50_{tag}.npz"))
+    B, H, W, C, ign, n_lab = [int(v) for v in g["shape"]]
+    m = _build(C, "deeplab_r50").train()
+    assert len(m.state_dict()) == int(g["n_state_keys"]) == 374
+    x = fi.formula_input(B, H, W, key=f"x{tag}").to(DEV)
+    y = fi.formula_labels(B, H, W, C, ign, n_lab, key=f"y{tag}").to(DEV)
+    pred = m(x)["pred"]
+    loss = F.cross_entropy(pred, y, ignore_index=ign)
+    loss.backward()
+    ref_s = g["train_pred_samples"]
+    err = np.abs(pred.detach().reshape(-1)[::STRIDE].cpu().numpy().astype(np.float64) - ref_s).max()
+    assert err <= TOL * np.abs(ref_s).max() + 4 * float(g["train_pred_noise"]), f"logits err {err}"
+    assert abs(loss.item() - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
+    worst = _check_grads(g, {k: p.grad for k, p in m.named_parameters()})
+    for k in g.files:
+        if k.startswith("rs:"):
+            assert _rel(m.state_dict()[k[3:]].cpu().numpy(), g[k]) < TOL, k
+    print(f"[deeplab_r50 {tag}] logits max err {err:.2e}; worst relative abs-sum gradient deviation {worst:.2e}")
+    # the flat trainer (sparse low-resolution CE, two streams) walks the same step
+    m2 = _build(C, "deeplab_r50").train()
+    tr = FlatTrainer(m2, ignore_index=ign)
+    l2 = tr.forward_backward(x, y)
+    assert abs(l2.item() - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
+    _check_grads(g, {k: tr._grad_view[id(p)] for k, p in m2.named_parameters()})
+
+
 def test_graph_replay_matches_eager_steps():
     """FlatTrainer.enable_graph: the replayed hipGraph step must walk the same parameter trajectory as eager steps
     (deterministic kernels; learning rate, Adam bias correction and dropout seed are read from device memory)."""

@@ -34,13 +34,39 @@ FULL_GRADS = ["backbone.features.0.0.weight", "backbone.features.2.conv.1.weight
 NETWORK = "deeplab"
 
 
+class _AssembledDeepLabR50(torch.nn.Module):
+    """DeepLabv3+-ResNet50 put together from the reference's OWN classes (the reference ships the parts -
+    resnet_backbone.py:141-144, aspp.py:38-39 with backbone='resnet', decoders.py:104-123 - and never assembles them); the
+    wiring below is deeplab.py:43-56 with c2 / c5 of the dilated ResNet in the places of MobileNetV2's two outputs."""
+
+    def __init__(self, args):
+        super().__init__()
+        from networks.aspp import ASPP
+        from networks.backbones.resnet_backbone import ResNetBackbone
+        from networks.decoders import SegmentHead
+        nn = torch.nn
+        self.backbone = ResNetBackbone(backbone='resnet50_dilated8', pretrained=None)
+        self.aspp = ASPP('resnet', 8, nn.BatchNorm2d)
+        self.low_level_conv = nn.Sequential(nn.Conv2d(256, 48, 1, bias=False), nn.BatchNorm2d(48), nn.ReLU())
+        self.seg_head = SegmentHead(args)
+
+    def forward(self, inputs):
+        feats = self.backbone(inputs)
+        x = self.aspp(feats[-1])
+        low_ = self.low_level_conv(feats[0])
+        x = F.interpolate(x, size=low_.size()[2:], mode='bilinear', align_corners=True)
+        d = self.seg_head(torch.cat((x, low_), dim=1))
+        d['pred'] = F.interpolate(d['pred'], size=inputs.size()[2:], mode='bilinear', align_corners=True)
+        return d
+
+
 def _fresh_model(n_classes):
     import contextlib, io
     args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=n_classes, network_name=NETWORK,
                      weight_type="random", use_dilated_resnet=True, n_layers=50, width_multiplier=1.0)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):      # resnet_models.py:124 prints layer1
-        model = get_model(args)
+        model = _AssembledDeepLabR50(args) if NETWORK == "deeplab_r50" else get_model(args)
     model.load_state_dict(fi.formula_state_dict(model.state_dict()))
     for m in model.modules():                       # dropout RNG cannot be matched: force p = 0 (SURVEY hard part d)
         if isinstance(m, torch.nn.Dropout):
@@ -104,23 +130,35 @@ def gen_deeplab(n_classes, ignore_index, B, H, W, tag, n_lab=20, train=True):
         out["grad_summary"] = np.stack(gsum)
         out["grad_noise"] = np.stack(gnoise)
         # a few full gradients (small tensors) incl. the first and last layers and a padded-border BN
-        for k in (FULL_GRADS if NETWORK == "deeplab" else FULL_GRADS_FPN):
+        for k in {"deeplab": FULL_GRADS, "FPN": FULL_GRADS_FPN, "deeplab_r50": FULL_GRADS_R50}[NETWORK]:
             out["g:" + k] = dict(model.named_parameters())[k].grad.numpy().copy()
             gk = dict(model.named_parameters())[k].grad
             out["gn:" + k] = np.float64(max((pg[k].grad - gk).abs().max().item() for pg in pgs))
         sdn = model.state_dict()
         rs_keys = ["backbone.features.2.conv.1.running_mean", "backbone.features.2.conv.1.running_var",
                    "backbone.features.17.conv.4.running_var", "aspp.bn1.running_mean", "seg_head.segment_head.5.running_var"]
-        if NETWORK != "deeplab":
+        if NETWORK == "FPN":
             rs_keys = ["encoder.base.prefix.bn1.running_mean", "encoder.base.layer2.0.downsample.1.running_var",
                        "encoder.base.layer4.2.bn3.running_var"]
+        if NETWORK == "deeplab_r50":
+            rs_keys = ["backbone.prefix.bn1.running_mean", "backbone.layer4.2.bn3.running_var", "aspp.aspp3.bn.running_var",
+                       "aspp.bn1.running_mean", "seg_head.segment_head.5.running_var"]
         for k in rs_keys:
             out["rs:" + k] = sdn[k].numpy().copy()
         out["n_state_keys"] = np.int64(len(sdn))
         out["state_keys_crc"] = np.int64(__import__("zlib").crc32("\n".join(f"{k}:{tuple(v.shape)}" for k, v in sdn.items()).encode()))
-    np.savez_compressed(os.path.join(OUT, f"net_{'deeplab' if NETWORK == 'deeplab' else 'fpn'}_{tag}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"net_{ {'deeplab': 'deeplab', 'FPN': 'fpn', 'deeplab_r50': 'deeplab_r50'}[NETWORK]}_{tag}.npz"), **out)
     print("written", tag, "keys", len(out))
 
+
+FULL_GRADS_R50 = ["backbone.prefix.conv1.weight", "backbone.layer1.0.bn1.bias", "backbone.layer4.2.bn3.weight", "aspp.aspp2.bn.weight",
+                  "aspp.global_avg_pool.2.bias", "low_level_conv.1.weight", "seg_head.classifier.weight", "seg_head.classifier.bias"]
+
+if __name__ == "__main__" and "--r50" in sys.argv:
+    NETWORK = "deeplab_r50"
+    gen_deeplab(19, 19, 2, 64, 96, "cs64x96")
+    gen_deeplab(21, 255, 1, 40, 56, "voc40x56", train=False)
+    sys.exit(0)
 
 if __name__ == "__main__" and "--fpn" in sys.argv:
     NETWORK = "FPN"
