@@ -493,8 +493,9 @@ def test_query_selector_mc_dropout_mean_of_maps(chunk):
 
 
 # ---------------------------------------------------------------- SURVEY.md §8f rank 1 through the real network
-@pytest.mark.parametrize("dataset,st,top_n", [("cs", "entropy", 0.0), ("voc", "margin_sampling", 0.0), ("cs", "least_confidence", 0.05)])
-def test_query_selector_fused_lowres_gives_identical_queries_and_stats(monkeypatch, dataset, st, top_n):
+@pytest.mark.parametrize("dataset,st,top_n,backbone", [("cs", "entropy", 0.0, "mobilenet"), ("voc", "margin_sampling", 0.0, "mobilenet"),
+                                                       ("cs", "least_confidence", 0.05, "mobilenet"), ("cs", "entropy", 0.0, "resnet")])
+def test_query_selector_fused_lowres_gives_identical_queries_and_stats(monkeypatch, dataset, st, top_n, backbone):
     """DeepLab exposes forward_lowres: the selector then scores straight from the 1/4-resolution classifier output
     (pp_acq_lowres_score_topk).  Coordinates and QueryStats must equal the full-resolution-logits path exactly —
     including the VOC reflect-pad / crop branch (query.py:171-174,190) and the top-n-percent mode (query.py:36,62-64)."""
@@ -503,7 +504,8 @@ def test_query_selector_fused_lowres_gives_identical_queries_and_stats(monkeypat
     h, w = (77, 90) if dataset == "voc" else (64, 96)
     torch.manual_seed(3)
     net_args = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, use_aspp=True, use_softmax=False, use_img_inp=False)
-    model = DeepLab(net_args).to(DEV)
+    # backbone "resnet": the assembled DeepLabv3+-ResNet50 (SURVEY.md 0.1 extra) takes the same acquisition path
+    model = (DeepLab(net_args) if backbone == "mobilenet" else DeepLab(net_args, backbone="resnet", output_stride=8)).to(DEV)
     n = 5
     xs, ys = torch.randn(n, 3, h, w), torch.randint(0, C + 1, (n, h, w))
     ys[ys == C] = 255 if dataset == "voc" else C
