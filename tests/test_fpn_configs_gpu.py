@@ -76,3 +76,56 @@ def test_fpn_full_resolution_forward_and_least_confidence_acquisition():
     assert (p2[:1] - p1).abs().max().item() <= 1e-4 * p1.abs().max().item()
     emb = out["emb"]                                                          # lazy [1,128,H,W] like decoders.py:75-77
     assert emb.shape == (1, 128, H, W)
+
+
+# ------------------------------------------------------------- the same configurations on the assembled DeepLabv3+-ResNet50
+def _r50(C=19):
+    a = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab_r50")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = get_model(a)
+    m.load_state_dict(fi.formula_state_dict(m.state_dict()))
+    return m.to(DEV)
+
+
+def test_deeplab_r50_train_step_at_the_baseline_shape_is_finite_and_bit_reproducible():
+    """configs[2] as BASELINE.json names it (DeepLabv3+-ResNet50, 256x512, per-GPU batch 4) on the assembled extra."""
+    B, H, W, C = 4, 256, 512, 19
+    x = fi.formula_input(B, H, W, key="r50full").to(DEV)
+    y = fi.formula_labels(B, H, W, C, C, 20, key="r50full").to(DEV)
+    runs = []
+    from pixelpick_amd import engine as E
+    for rep in range(2):
+        E.set_dropout_seed(4321)                                         # ASPP / SegmentHead dropout is active: same mask stream in both runs
+        tr = FlatTrainer(_r50().train(), ignore_index=C)
+        assert tr.n_split == 23508032 and tr.n == 40351667              # backbone at lr/10 (utils/utils.py:125-141)
+        losses = [tr.train_step(x, y).item() for _ in range(3)]
+        runs.append((losses, tr.flat_p.clone(), tr.flat_g.clone()))
+    assert all(np.isfinite(l) for l in runs[0][0]) and runs[0][0][2] < runs[0][0][0]
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    # rate-36 / rate-24 taps that never land inside the 32 x 64 map (aspp.py:43-44 at output stride 8) have exactly zero gradient
+    assert torch.isfinite(runs[0][2]).all() and (runs[0][2] != 0).float().mean().item() > 0.9
+
+
+def test_deeplab_r50_full_resolution_least_confidence_acquisition_from_lowres_logits():
+    """configs[4] (1024x2048, least-confidence) with the DeepLab head: the 1/4-resolution classifier output goes straight
+    into the fused interpolate + score + top-k kernel; its picks equal the two-step path (upsampled logits -> scorer)."""
+    C, H, W, k = 19, 1024, 2048, 20
+    m = _r50().eval()
+    x = fi.formula_input(1, H, W, key="r501024").to(DEV)
+    excl = torch.zeros((1, H, W), dtype=torch.uint8, device=DEV)
+    excl[0, ::7, ::5] = 1
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        low, size = m.forward_lowres(x)
+        idx_f, val_f, _ = acq.score_topk_lowres(low, size, excl, "least_confidence", k)
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        pred = m(x)["pred"]
+    assert tuple(low.shape) == (1, H // 4, W // 4, C) and torch.isfinite(low).all() and pred.shape == (1, C, H, W)
+    idx_t, val_t, omap = acq.score_topk(pred, excl, "least_confidence", k, return_map=True)
+    print(f"\\n[configs[4], DeepLabv3+-R50] eval forward + fused LC top-{k} at {H}x{W}: peak device memory {peak:.2f} GiB")
+    assert peak < 24.0
+    assert idx_f[0].cpu().numpy().tolist() == idx_t[0].cpu().numpy().tolist()
+    e_idx, _ = orc.topk(omap[0].cpu().numpy(), k, True)
+    assert idx_t[0].cpu().numpy().tolist() == e_idx.tolist()
+    assert not excl.reshape(-1)[idx_f[0].long()].any()
