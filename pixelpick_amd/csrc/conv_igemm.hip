@@ -1557,6 +1557,9 @@ __global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int
     const bool live = n < p.Cout;
     const float* __restrict__ xg = p.x;
     const float* __restrict__ dyg = p.dy;
+    // grid.y > 1: this block handles taps [tb, tb + NTAPS) of a larger kernel (the 7x7 stem: seven rows of seven taps,
+    // 21 accumulators per thread instead of 147)
+    const int tb = blockIdx.y * NTAPS;
     RowIter it;
     it.init(m0 < p.M ? m0 : 0, p.Wo, p.Ho);
     // U rows per trip: all their loads are issued before the first FMA (the rows are independent; one row at a time
@@ -1570,7 +1573,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int
             g[u] = (live && rv) ? dyg[(m + u) * p.lddy + n] : 0.0f;
 #pragma unroll
             for (int ti = 0; ti < NTAPS; ++ti) {
-                const int ih = it.oh * p.stride + p.taps.dh[ti], iw = it.ow * p.stride + p.taps.dw[ti];
+                const int ih = it.oh * p.stride + p.taps.dh[tb + ti], iw = it.ow * p.stride + p.taps.dw[tb + ti];
                 const bool ok = rv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const float* xr = xg + (ok ? (((int64_t)it.bb * p.H + ih) * p.W + iw) * p.ldx : 0);
 #pragma unroll
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int
             for (int j = 0; j < NTAPS * CIN; ++j) acc[j] = fmaf(xv[u][j], g[u], acc[j]);
     }
     if (live) {
-        float* out = p.part + split * (int64_t)(NTAPS * CIN) * p.Cout + n;
+        float* out = p.part + (split * (int64_t)p.taps.n + tb) * CIN * p.Cout + n;
 #pragma unroll
         for (int j = 0; j < NTAPS * CIN; ++j) out[(int64_t)j * p.Cout] = acc[j];
     }
@@ -1977,8 +1980,9 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
     int form = 0;            // 1: lanes over Cout (narrow input), 2: lanes over Cin (narrow output)
     // measured against the MFMA path (tools/conv_layer_table.py, B=4 256x512): wins for 3->32 3x3 (182 -> 136 us), 32->16
     // (78 -> 48), 16->96 (82 -> 44), 96->24 (35 -> 25), 144->24 (35 -> 31), 128->19 at full resolution (416 -> 214); loses
-    // for 24->144, 32->192, the 7x7 stem (147 accumulators per thread) and everything below 32 K pixels.
-    if ((p.Cin == 3 && nt == 9) || (nt == 1 && (p.Cin == 16 || p.Cin == 32) && p.Cout <= 128)) form = 1;
+    // for 24->144, 32->192 and everything below 32 K pixels.  The 7x7 stem of the ResNets (147 accumulators per thread as one
+    // block: slower than MFMA) runs as seven tap rows over grid.y: 763 us on the MFMA path.
+    if ((p.Cin == 3 && (nt == 9 || nt == 49)) || (nt == 1 && (p.Cin == 16 || p.Cin == 32) && p.Cout <= 128)) form = 1;
     else if (nt == 1 && kh == 1 && kw == 1 && (p.Cout == 16 || p.Cout == 19 || p.Cout == 24 || p.Cout == 32) && p.Cin <= 256) form = 2;
     if (form == 0 || p.M < 32768) return 1;
     const int lanes_dim = form == 1 ? p.Cout : p.Cin;
@@ -2002,6 +2006,8 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
     dim3 grid((unsigned)nblk), blk(256);
     if (form == 1) {
         if (p.Cin == 3 && nt == 9)        hipLaunchKernelGGL((wgrad_narrow_in_kernel<3, 9, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
+        else if (p.Cin == 3 && nt == 49)  // the 7x7 stems (resnet_models.py:115-117): one row of seven taps per grid.y slice
+            hipLaunchKernelGGL((wgrad_narrow_in_kernel<3, 7, 4>), dim3((unsigned)nblk, 7), blk, 0, st, p, NL, RL, rows_per_split);
         else if (p.Cin == 16)             hipLaunchKernelGGL((wgrad_narrow_in_kernel<16, 1, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
         else                              hipLaunchKernelGGL((wgrad_narrow_in_kernel<32, 1, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
     } else {

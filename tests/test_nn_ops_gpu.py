@@ -62,7 +62,8 @@ CONV_CASES = [
     (2, 128, 130, 16, 96, 1, 1, 1, 1, False),     # expand with the folded fixed_padding (1x1, padding 1)
     (2, 128, 136, 96, 24, 1, 1, 0, 1, False),     # narrow output
     (2, 128, 132, 144, 32, 1, 1, 0, 1, False),
-    (1, 128, 160, 3, 64, 7, 2, 3, 1, False),      # ResNet stem (stays on the MFMA path)
+    (1, 128, 160, 3, 64, 7, 2, 3, 1, False),      # ResNet stem below 32 K pixels (stays on the MFMA path)
+    (2, 256, 264, 3, 64, 7, 2, 3, 1, False),      # ResNet stem, 33792 pixels: seven tap rows of the narrow-input kernel over grid.y
     (3, 96, 128, 256, 19, 1, 1, 0, 1, True),      # classifier (bias), 36864 pixels
     (1, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead at Cityscapes-quarter size (128x128 tiles)
     (2, 23, 30, 1280, 256, 1, 1, 0, 1, False),    # ASPP fuse at CamVid size (M = 1380)
