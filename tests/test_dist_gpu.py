@@ -349,3 +349,29 @@ def test_two_ranks_200_steps_with_spin_barrier_batchnorm_side_stream_and_overlap
     for rank, checks, finite, loss in res:
         assert len(checks) == 4 and all(checks), f"rank {rank}: replicas diverged {checks}"
         assert finite and loss == loss
+
+
+def test_bench_line_from_two_ranks_through_torch_distributed_run():
+    """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N`), with two ranks sharing this box's one GPU over gloo (PIXELPICK_DIST_BACKEND: RCCL needs a device per rank):
+    rank 0 prints ONE JSON line whose value is the whole-job aggregate, with the distributed block filled in."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PIXELPICK_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "8", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 8                       # per-GPU batch 4 x 2 ranks
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    dd = d["distributed"]
+    assert dd["nranks"] == 2 and dd["backend"] == "gloo" and dd["allreduce_bytes_per_step"] == 4 * 5815539 and sum(dd["buckets"]) == 4 * 5815539
+    assert "roofline" in d and d["acquisition"]["value"] > 0
