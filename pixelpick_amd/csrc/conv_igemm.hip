@@ -1773,6 +1773,7 @@ static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep 
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
 static thread_local int g_conv_direct1x1 = 1, g_direct_rows_max = 4096, g_direct_k_max = 640;   // pp_debug_set_conv_variant bit 23 switches the direct 1x1 kernel off (A/B)
+static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
 static thread_local int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
@@ -2098,6 +2099,7 @@ void pp_debug_set_conv_variant(int v)
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     g_conv_direct1x1 = (v & 8388608) ? 0 : 1;   // bit 23: direct (LDS-free) kernel of the few-row 1x1 layers off (A/B)
+    g_bwd_phases = (v & 16777216) ? 0 : 1;      // bit 24: strided backward-data as one masked-tap launch instead of s*s phase problems
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
 }
@@ -2126,6 +2128,82 @@ int64_t pp_conv2d_fwd_stats_rows(int B, int H, int W, int Cin, int Cout, int kh,
     return conv_stats_rows(pl, M, Cout);
 }
 
+// ---- backward-data of a STRIDED convolution by phases -------------------------------------------------------------------------
+// dX(ih, iw) = sum_t dY((ih + pad - th*dil) / s, (iw + pad - tw*dil) / s) W[t] where both divisions are exact.  Run over all of
+// dX with every tap masked by divisibility the kernel does s*s times the useful MACs (a 1x1 stride-2 downsample: three of four
+// dX pixels are zero; a 3x3 stride-2: 9/4 live taps per pixel on average - resnet_models.py:63-64,142-144).  Instead the s*s
+// pixel classes (ih % s, iw % s) = (ph, pw) are s*s ordinary stride-1 problems: class row a <-> ih = a*s + ph reads
+// dY(a + (ph + pad - th*dil)/s, .) through exactly the taps whose offset divides, writes a dense [B, Ha, Wb, Cin] slab, and one
+// interleave pass puts the slabs (zeros for a class without taps) into dX.  Same sums, tap by tap in the same order.
+struct PhaseGeom { int Ha, Wb; ConvTaps taps; };
+
+static void bwd_phase_geom(PhaseGeom& g, int ph, int pw, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho, int Wo)
+{
+    g.Ha = ph < H ? (H - ph + stride - 1) / stride : 0;
+    g.Wb = pw < W ? (W - pw + stride - 1) / stride : 0;
+    g.taps.n = 0;
+    for (int th = 0; th < kh; ++th)
+        for (int tw = 0; tw < kw; ++tw) {
+            const int vh = ph + pad - th * dil, vw = pw + pad - tw * dil;
+            if (((vh % stride) + stride) % stride != 0 || ((vw % stride) + stride) % stride != 0) continue;
+            const int dh = vh >= 0 ? vh / stride : -((-vh) / stride), dw = vw >= 0 ? vw / stride : -((-vw) / stride);
+            // live: some class row / column lands inside dY
+            if (!(dh < Ho && dh + g.Ha - 1 >= 0 && dw < Wo && dw + g.Wb - 1 >= 0)) continue;
+            g.taps.dh[g.taps.n] = dh;
+            g.taps.dw[g.taps.n] = dw;
+            g.taps.widx[g.taps.n] = th * kw + tw;
+            ++g.taps.n;
+        }
+}
+
+struct PhaseSlabs { const float* slab[16]; int Ha[16], Wb[16]; };
+
+// dX[b, a*s + ph, bb*s + pw, :] (+)= slab[ph*s + pw][b, a, bb, :]  (a NULL slab is all zeros); one float4 per thread
+__global__ __launch_bounds__(256) void bwd_phase_interleave_kernel(PhaseSlabs ps, int s, int B, int H, int W, int cq, float* dx, int64_t lddx,
+                                                                   int accumulate)
+{
+    const int64_t total = (int64_t)B * H * W * cq;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int q = (int)(e % cq);
+        int64_t t = e / cq;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        const int ph = ih % s, pw = iw % s, k = ph * s + pw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ps.slab[k]) v = *reinterpret_cast<const float4*>(ps.slab[k] + ((((int64_t)b * ps.Ha[k] + ih / s) * ps.Wb[k] + iw / s) * cq + q) * 4);
+        float* o = dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4;
+        if (accumulate) {
+            const float4 d = *reinterpret_cast<const float4*>(o);
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+        }
+        *reinterpret_cast<float4*>(o) = v;
+    }
+}
+
+static bool bwd_phases_apply(int Cin, int Cout, int stride, int64_t lddx)
+{
+    return g_bwd_phases && stride > 1 && stride <= 4 && Cin % 4 == 0 && Cout % 4 == 0 && lddx % 4 == 0;
+}
+
+// workspace of the phase form: the slabs (as many floats as dX has) followed by the largest split-K need of a phase problem
+static size_t bwd_phases_workspace(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int Ho, int Wo,
+                                   size_t* slab_bytes)
+{
+    size_t split_need = 0;
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            PhaseGeom g;
+            bwd_phase_geom(g, ph, pw, kh, kw, stride, pad, dil, H, W, Ho, Wo);
+            if (g.taps.n == 0 || g.Ha == 0 || g.Wb == 0) continue;
+            const int64_t M = (int64_t)B * g.Ha * g.Wb;
+            const ConvPlan pl = plan_conv(M, Cin, Cout, g.taps.n, true);
+            if (pl.splits > 1) split_need = std::max(split_need, align_up((size_t)pl.splits * M * Cin * 4, 256));
+        }
+    *slab_bytes = align_up((size_t)B * H * W * Cin * 4, 256);
+    return *slab_bytes + split_need;
+}
+
 size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
@@ -2135,7 +2213,12 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
     build_taps(t, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
     const int64_t M = (int64_t)B * H * W;
     const ConvPlan pl = plan_conv(M, Cin, Cout, t.n, Cin % 4 == 0 && Cout % 4 == 0);
-    return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
+    size_t need = pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
+    if (bwd_phases_apply(Cin, Cout, stride, 4)) {
+        size_t slabs = 0;
+        need = std::max(need, bwd_phases_workspace(B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, &slabs));
+    }
+    return need;
 }
 
 static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
@@ -2202,6 +2285,39 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
     if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
         return fail(PP_ERR_BAD_ARG, "conv bwd_data: inconsistent sizes");
+    if (bwd_phases_apply(Cin, Cout, stride, lddx) && (int64_t)B * H * W <= 0x7FFFFFFFll) {
+        size_t slab_bytes = 0;
+        const size_t need = bwd_phases_workspace(B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, &slab_bytes);
+        if (workspace && ws_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
+            hipStream_t st = as_stream(stream);
+            float* slabs = reinterpret_cast<float*>(workspace);
+            char* split_ws = reinterpret_cast<char*>(workspace) + slab_bytes;
+            PhaseSlabs ps{};
+            size_t off = 0;
+            for (int ph = 0; ph < stride; ++ph)
+                for (int pw = 0; pw < stride; ++pw) {
+                    const int k = ph * stride + pw;
+                    PhaseGeom g;
+                    bwd_phase_geom(g, ph, pw, kh, kw, stride, pad, dil, H, W, Ho, Wo);
+                    ps.slab[k] = nullptr; ps.Ha[k] = g.Ha; ps.Wb[k] = g.Wb;
+                    if (g.taps.n == 0 || g.Ha == 0 || g.Wb == 0) continue;
+                    ConvParams q{};
+                    q.x = dy; q.w = w; q.bias = nullptr; q.y = slabs + off; q.ldx = lddy; q.ldy = Cin;
+                    q.B = B; q.H = Ho; q.W = Wo; q.Ho = g.Ha; q.Wo = g.Wb; q.Ck = Cout; q.Cn = Cin; q.Cin = Cin; q.Cout = Cout;
+                    q.stride = 1; q.M = (int64_t)B * g.Ha * g.Wb; q.bwd_stride = 1; q.accumulate = 0;
+                    q.taps = g.taps;
+                    if (int rc = launch_conv<true>(q, split_ws, ws_bytes - slab_bytes, st)) return rc;
+                    ps.slab[k] = slabs + off;
+                    off += (size_t)q.M * Cin;
+                }
+            const int64_t total = (int64_t)B * H * W * (Cin / 4);
+            int64_t blocks = cdiv(total, 256 * 4);
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(bwd_phase_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ps, stride, B, H, W, Cin / 4, dx, lddx,
+                               accumulate ? 1 : 0);
+            return check_launch("bwd_phase_interleave_kernel");
+        }
+    }
     ConvParams p{};
     p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.ldx = lddy; p.ldy = lddx;
     p.B = B; p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.Ck = Cout; p.Cn = Cin; p.Cin = Cin; p.Cout = Cout;

@@ -111,7 +111,8 @@ def test_conv2d_fwd_bwd(case):
         close(nchw(xv.grad), xr.grad, what="conv dX")
 
 
-STRIDED_BWD = [(2, 17, 23, 128, 128, 3, 2, 1, 1), (2, 16, 24, 256, 512, 1, 2, 0, 1), (1, 15, 15, 64, 96, 3, 2, 1, 1)]
+STRIDED_BWD = [(2, 17, 23, 128, 128, 3, 2, 1, 1), (2, 16, 24, 256, 512, 1, 2, 0, 1), (1, 15, 15, 64, 96, 3, 2, 1, 1),
+               (2, 19, 22, 32, 48, 3, 2, 2, 2), (1, 21, 20, 8, 32, 7, 2, 3, 1), (2, 14, 17, 16, 24, 3, 3, 0, 1), (2, 13, 11, 64, 64, 1, 2, 0, 1)]
 
 
 @pytest.mark.parametrize("case", STRIDED_BWD, ids=[str(c) for c in STRIDED_BWD])
@@ -132,6 +133,38 @@ def test_conv2d_strided_bwd_data(case):
     tape.backward(yv, nhwc(dy))
     close(nchw(xv.grad), x.grad, what="strided dX")
     close(oihw(tape.param_grads[id(wg)]), w.grad, what="strided dW")
+
+
+@pytest.mark.parametrize("case", STRIDED_BWD, ids=[str(c) for c in STRIDED_BWD])
+def test_conv2d_strided_bwd_data_by_phases_equals_masked_taps(case):
+    """pp_conv2d_bwd_data of a strided convolution runs as stride^2 stride-1 problems (one per pixel class ih % s, iw % s) plus an
+    interleave pass; pp_debug_set_conv_variant bit 24 selects the single launch with divisibility-masked taps.  Same dX, also
+    when accumulating into an existing gradient."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    B, H, W, Cin, Cout, k, stride, pad, dil = case
+    Ho, Wo = E.out_size(H, k, stride, pad, dil), E.out_size(W, k, stride, pad, dil)
+    torch.manual_seed(21)
+    dy = torch.randn(B, Ho, Wo, Cout, device=DEV)
+    w = torch.randn(k, k, Cin, Cout, device=DEV) / np.sqrt(Cin * k * k)
+    base = torch.randn(B, H, W, Cin, device=DEV)
+    ws = torch.empty(max(1, L.pp_conv2d_bwd_data_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad, dil)), dtype=torch.uint8, device=DEV)
+    assert ws.numel() >= B * H * W * Cin * 4
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for variant in (0, 16777216):
+        L.pp_debug_set_conv_variant(variant)
+        try:
+            for accumulate in (0, 1):
+                dx = base.clone()
+                _lib.check(L.pp_conv2d_bwd_data(dy.data_ptr(), Cout, B, Ho, Wo, Cout, w.data_ptr(), k, k, stride, pad, dil, dx.data_ptr(), Cin,
+                                                H, W, Cin, accumulate, ws.data_ptr(), ws.numel(), st), "bwd_data")
+                outs.append(dx)
+        finally:
+            L.pp_debug_set_conv_variant(0)
+    close(outs[0].cpu(), outs[2].cpu(), tol=2e-5, what="phases vs masked taps")
+    close(outs[1].cpu(), outs[3].cpu(), tol=2e-5, what="phases vs masked taps, accumulating")
+    close((outs[1] - base).cpu(), outs[0].cpu(), tol=2e-5, what="accumulate adds")
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 24, 128), (3, 9, 7, 128), (2, 32, 48, 128), (1, 5, 6, 64)])
