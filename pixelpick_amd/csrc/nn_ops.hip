@@ -312,10 +312,26 @@ struct BnFusedGeom {
     int64_t rows_per_chunk;
 };
 
-static thread_local int g_bn_target_blocks = 384;     // strips x row chunks aimed at (pp_debug_set_bn_target): measured in-process
-                                         // 128: 7.77, 192: 7.47, 256-384: 7.30-7.36, 512: 7.36, 768: 7.60, 1024: 7.76 ms/step
+static thread_local int g_bn_target_blocks = 0;       // strips x row chunks aimed at (pp_debug_set_bn_target); 0 = one block per CU.  Round 1, in-process:
+                                         // 128: 7.77, 192: 7.47, 256-384: 7.30-7.36, 512: 7.36, 768: 7.60, 1024: 7.76 ms/step (384 chosen).
+                                         // Round 2: the launches of the head's backward run beside the SegmentHead weight gradient, whose
+                                         // 168-VGPR / 48 KiB blocks sit two per CU and leave room for exactly ONE more block per CU; a
+                                         // 376-block launch then waits for weight-gradient blocks to retire (246 us instead of ~50 in the
+                                         // trace).  192: 6.85, 240-256: 6.69-6.73, 288: 6.74, 320: 6.77, 384: 6.76 ms/step.
+static int bn_device_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return n;
+    }();
+    return cus;
+}
 
-constexpr int kBnRowCache = 8;                    // rows per thread the single-launch BatchNorm kernels may keep in registers between passes
+constexpr int kBnRowCache = 12;                   // rows per thread the single-launch BatchNorm kernels may keep in registers between passes
 static thread_local int g_bn_row_cache = 1;       // pp_debug_set_bn_bytes_per_block(-1) switches the register-cached variants off (A/B)
 static thread_local int g_bn_bytes_per_block = 0;   // > 0: large maps get one block per this many bytes of x.  Off: measured neutral in
                                                    // isolation (tools/bn_bench.py: 33.6 MB forward 33.4 us with 384 blocks, 33.2-35.8 us with 640)
@@ -338,7 +354,7 @@ static BnFusedGeom bn_fused_geom(int64_t M, int C)
     }
     g.nrl = kT / g.bq;
     g.nstrips = (int)cdiv(g.cq, g.bq);
-    int64_t target = g_bn_target_blocks;
+    int64_t target = g_bn_target_blocks > 0 ? g_bn_target_blocks : bn_device_cus();
     if (g_bn_bytes_per_block > 0) {
         const int64_t by_bytes = M * (int64_t)C * 4 / g_bn_bytes_per_block;
         if (by_bytes > target) target = by_bytes;
@@ -1951,7 +1967,7 @@ void pp_debug_set_dw_variant(int v)
     const int sel = (v >> 1) & 7;                 // 0: default, 1: 512, 2: 256, 3: 128, 4: 2048 row blocks for the weight gradient
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
-void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 384; }
+void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 0; }
 void pp_debug_set_bn_bytes_per_block(int bytes)
 {
     g_bn_bytes_per_block = bytes > 0 ? bytes : 0;
