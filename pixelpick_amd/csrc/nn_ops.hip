@@ -588,8 +588,8 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
         __syncthreads();
     } else {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    auto stat_group = [&](int64_t r, float4* v) {          // four rows r, r + nrl, ...: the accumulation order of every variant
-        float w[4];
+    // four rows r, r + nrl, ...: loads, then the accumulation in the order every variant uses
+    auto stat_load = [&](int64_t r, float4* v, float* w) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t rr = r + (int64_t)j * g.nrl;
@@ -601,6 +601,8 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
                 v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);
             }
         }
+    };
+    auto stat_acc = [&](const float4* v, const float* w) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 u = make_float4(v[j].x * w[j], v[j].y * w[j], v[j].z * w[j], v[j].w * w[j]);
@@ -614,12 +616,29 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
 #pragma unroll
             for (int it = 0; it < NC / 4; ++it) {
                 const int64_t r = r0 + rl + (int64_t)it * g.nrl * 4;
-                if (r < r1) stat_group(r, &keep[it * 4]);
+                if (r < r1) {
+                    float w[4];
+                    stat_load(r, &keep[it * 4], w);
+                    stat_acc(&keep[it * 4], w);
+                }
             }
-        } else {
+        } else if constexpr (DW) {
             for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
                 float4 v[4];
-                stat_group(r, v);
+                float w[4];
+                stat_load(r, v, w);
+                stat_acc(v, w);
+            }
+        } else {
+            // large maps run ONE block per CU (beside the weight-gradient blocks): eight rows of loads in flight per thread, or the
+            // launch is bound by its own memory-level parallelism (256 blocks x 4 loads x 1 KiB = 1 MB in flight chip-wide)
+            for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 8) {
+                float4 va[4], vb[4];
+                float wa[4], wb[4];
+                stat_load(r, va, wa);
+                stat_load(r + (int64_t)g.nrl * 4, vb, wb);       // rows past r1: weight 0, clamped address
+                stat_acc(va, wa);
+                stat_acc(vb, wb);
             }
         }
     }
@@ -682,27 +701,25 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
         }
         return;
     }
-    for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) {
-        const int64_t rb = r + g.nrl;
-        const bool two = rb < r1;
-        const float4 va = *reinterpret_cast<const float4*>(xq + r * a.ldx);
-        const float4 vb = *reinterpret_cast<const float4*>(xq + (two ? rb : r) * a.ldx);
-        float4 oa, ob;
-        oa.x = fmaf(va.x, sc.x, sf.x); oa.y = fmaf(va.y, sc.y, sf.y); oa.z = fmaf(va.z, sc.z, sf.z); oa.w = fmaf(va.w, sc.w, sf.w);
-        ob.x = fmaf(vb.x, sc.x, sf.x); ob.y = fmaf(vb.y, sc.y, sf.y); ob.z = fmaf(vb.z, sc.z, sf.z); ob.w = fmaf(vb.w, sc.w, sf.w);
-        if (rq) {
-            const float4 ra = *reinterpret_cast<const float4*>(rq + r * a.ldr);
-            const float4 rbv = *reinterpret_cast<const float4*>(rq + (two ? rb : r) * a.ldr);
-            oa.x += ra.x; oa.y += ra.y; oa.z += ra.z; oa.w += ra.w;
-            ob.x += rbv.x; ob.y += rbv.y; ob.z += rbv.z; ob.w += rbv.w;
+    for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
+        float4 v[4], rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = r + (int64_t)j * g.nrl;
+            const int64_t rc = rr < r1 ? rr : r;
+            v[j] = *reinterpret_cast<const float4*>(xq + rc * a.ldx);
+            rv[j] = rq ? *reinterpret_cast<const float4*>(rq + rc * a.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        oa.x = act_fwd(oa.x, act); oa.y = act_fwd(oa.y, act); oa.z = act_fwd(oa.z, act); oa.w = act_fwd(oa.w, act);
-        if (drop) drop4(oa, (uint64_t)(r * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
-        *reinterpret_cast<float4*>(yq + r * a.ldy) = oa;
-        if (two) {
-            ob.x = act_fwd(ob.x, act); ob.y = act_fwd(ob.y, act); ob.z = act_fwd(ob.z, act); ob.w = act_fwd(ob.w, act);
-            if (drop) drop4(ob, (uint64_t)(rb * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
-            *reinterpret_cast<float4*>(yq + rb * a.ldy) = ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = r + (int64_t)j * g.nrl;
+            if (rr >= r1) break;
+            float4 o;
+            o.x = fmaf(v[j].x, sc.x, sf.x); o.y = fmaf(v[j].y, sc.y, sf.y); o.z = fmaf(v[j].z, sc.z, sf.z); o.w = fmaf(v[j].w, sc.w, sf.w);
+            if (rq) { o.x += rv[j].x; o.y += rv[j].y; o.z += rv[j].z; o.w += rv[j].w; }
+            o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+            if (drop) drop4(o, (uint64_t)(rr * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
+            *reinterpret_cast<float4*>(yq + rr * a.ldy) = o;
         }
     }
 }
@@ -760,10 +777,9 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
             zsc = make_float4(gm.x * is.x, gm.y * is.y, gm.z * is.z, gm.w * is.w);
             zsf = make_float4(be.x - mu.x * zsc.x, be.y - mu.y * zsc.y, be.z - mu.z * zsc.z, be.w - mu.w * zsc.w);
         }
-        // two rows r, r + nrl: the accumulation order of every variant; vk / uk (row cache) receive x and mask * dy * gscale
-        auto red_group = [&](int64_t r, float4* vk, float4* uk) {
-            float4 v[2], gg[2], ya[2];
-            float w[2];
+        // two rows r, r + nrl: loads, then the accumulation in the order every variant uses; vk / uk (row cache) receive x and
+        // mask * dy * gscale
+        auto red_load = [&](int64_t r, float4* v, float4* gg, float4* ya, float* w) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int64_t rr = r + (int64_t)j * g.nrl;
@@ -771,8 +787,10 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
                 const int64_t rc = rr < r1 ? rr : r1 - 1;
                 v[j] = *reinterpret_cast<const float4*>(xq + rc * a.ldx);
                 gg[j] = *reinterpret_cast<const float4*>(gq + rc * a.lddy);
-                if (act != 0 && !remask) ya[j] = *reinterpret_cast<const float4*>(aq + rc * a.ldya);
+                ya[j] = (act != 0 && !remask) ? *reinterpret_cast<const float4*>(aq + rc * a.ldya) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        };
+        auto red_acc = [&](const float4* v, const float4* gg, float4* ya, const float* w, float4* vk, float4* uk) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float4 u = gg[j];
@@ -798,10 +816,23 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
 #pragma unroll
             for (int it = 0; it < NC / 2; ++it) {
                 const int64_t r = r0 + rl + (int64_t)it * g.nrl * 2;
-                if (r < r1) red_group(r, &keepx[it * 2], &keepu[it * 2]);
+                if (r < r1) {
+                    float4 v[2], gg[2], ya[2];
+                    float w[2];
+                    red_load(r, v, gg, ya, w);
+                    red_acc(v, gg, ya, w, &keepx[it * 2], &keepu[it * 2]);
+                }
             }
         } else {
-            for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 2) red_group(r, nullptr, nullptr);
+            // large maps, one block per CU: four rows (8-12 float4 loads) in flight per thread (see the forward kernel)
+            for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
+                float4 va[2], ga[2], yaa[2], vb[2], gb[2], yab[2];
+                float wa[2], wb[2];
+                red_load(r, va, ga, yaa, wa);
+                red_load(r + (int64_t)g.nrl * 2, vb, gb, yab, wb);   // rows past r1: weight 0, clamped address
+                red_acc(va, ga, yaa, wa, nullptr, nullptr);
+                red_acc(vb, gb, yab, wb, nullptr, nullptr);
+            }
         }
     }
     tag_share(tag0, &sh_tag);
@@ -847,23 +878,37 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
         }
         return;
     }
-    for (int64_t r = r0 + rl; r < r1; r += g.nrl) {
-        float4 u = *reinterpret_cast<const float4*>(gq + r * a.lddy);
-        const float4 v = *reinterpret_cast<const float4*>(xq + r * a.ldx);
-        if (act != 0) {
-            const float4 ya = remask ? make_float4(fmaf(v.x, zsc.x, zsf.x), fmaf(v.y, zsc.y, zsf.y), fmaf(v.z, zsc.z, zsf.z),
-                                                   fmaf(v.w, zsc.w, zsf.w))
-                                     : *reinterpret_cast<const float4*>(aq + r * a.ldya);
-            u.x *= act_mask(ya.x, act); u.y *= act_mask(ya.y, act); u.z *= act_mask(ya.z, act); u.w *= act_mask(ya.w, act);
+    for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
+        float4 uu[4], vv[4], yy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = r + (int64_t)j * g.nrl;
+            const int64_t rc = rr < r1 ? rr : r;
+            uu[j] = *reinterpret_cast<const float4*>(gq + rc * a.lddy);
+            vv[j] = *reinterpret_cast<const float4*>(xq + rc * a.ldx);
+            yy[j] = (act != 0 && !remask) ? *reinterpret_cast<const float4*>(aq + rc * a.ldya) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        u.x *= a.gscale; u.y *= a.gscale; u.z *= a.gscale; u.w *= a.gscale;
-        if (drq) *reinterpret_cast<float4*>(drq + r * a.lddr) = u;
-        float4 o;
-        o.x = bn_dx(u.x, v.x, mu.x, is.x, ga.x, db.x, dg.x, inv_count);
-        o.y = bn_dx(u.y, v.y, mu.y, is.y, ga.y, db.y, dg.y, inv_count);
-        o.z = bn_dx(u.z, v.z, mu.z, is.z, ga.z, db.z, dg.z, inv_count);
-        o.w = bn_dx(u.w, v.w, mu.w, is.w, ga.w, db.w, dg.w, inv_count);
-        *reinterpret_cast<float4*>(dxq + r * a.lddx) = o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = r + (int64_t)j * g.nrl;
+            if (rr >= r1) break;
+            float4 u = uu[j];
+            const float4 v = vv[j];
+            if (act != 0) {
+                const float4 ya = remask ? make_float4(fmaf(v.x, zsc.x, zsf.x), fmaf(v.y, zsc.y, zsf.y), fmaf(v.z, zsc.z, zsf.z),
+                                                       fmaf(v.w, zsc.w, zsf.w))
+                                         : yy[j];
+                u.x *= act_mask(ya.x, act); u.y *= act_mask(ya.y, act); u.z *= act_mask(ya.z, act); u.w *= act_mask(ya.w, act);
+            }
+            u.x *= a.gscale; u.y *= a.gscale; u.z *= a.gscale; u.w *= a.gscale;
+            if (drq) *reinterpret_cast<float4*>(drq + rr * a.lddr) = u;
+            float4 o;
+            o.x = bn_dx(u.x, v.x, mu.x, is.x, ga.x, db.x, dg.x, inv_count);
+            o.y = bn_dx(u.y, v.y, mu.y, is.y, ga.y, db.y, dg.y, inv_count);
+            o.z = bn_dx(u.z, v.z, mu.z, is.z, ga.z, db.z, dg.z, inv_count);
+            o.w = bn_dx(u.w, v.w, mu.w, is.w, ga.w, db.w, dg.w, inv_count);
+            *reinterpret_cast<float4*>(dxq + rr * a.lddx) = o;
+        }
     }
 }
 
