@@ -314,6 +314,24 @@ def main():
             evg.destroy()
             return ms1, bool(wsb)
 
+        def time_lib_sgemm(bb, h1, w1, ci, co):
+            """Yardstick only (never on the product path): the vendor library's fp32 GEMM on the same M x K x N, torch.matmul
+            into a preallocated output, timed with torch events on the stream it runs on."""
+            m1 = bb * h1 * w1
+            xg = torch.randn((m1, ci), device=dev)
+            wg = torch.randn((ci, co), device=dev) * 0.05
+            yg = torch.empty((m1, co), device=dev)
+            for _ in range(5):
+                torch.matmul(xg, wg, out=yg)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            torch.cuda.synchronize(dev)
+            for e0, e1 in evs:
+                e0.record()
+                torch.matmul(xg, wg, out=yg)
+                e1.record()
+            torch.cuda.synchronize(dev)
+            return sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+
         rows1 = []
         BIG = 16 * TB          # the same layers at 16x the rows (e.g. a 64-image acquisition/validation forward): the
         for name, h1, w1, ci, co in graded:      # kernel's rate once the grid fills the chip
@@ -324,11 +342,16 @@ def main():
             by = 4.0 * (m1 * ci + ci * co + m1 * co)
             ceil_tf = min(MFMA_F32_PEAK_TF, fl / by * HBM_PEAK_GBS / 1e3)
             tfb = 16 * fl / (msb * 1e-3) / 1e12
+            lib_ms = time_lib_sgemm(TB, h1, w1, ci, co)
             rows1.append({"shape": name, "rows": m1, "split_k": split, "us": round(ms1 * 1e3, 2),
+                          "library_sgemm_us": round(lib_ms * 1e3, 2), "library_sgemm_tf": round(fl / (lib_ms * 1e-3) / 1e12, 2),
+                          "vs_library": round(lib_ms / ms1, 3),
                           "achieved": round(fl / (ms1 * 1e-3) / 1e12, 2), "ceiling": round(ceil_tf, 1),
                           "frac_of_mfma_peak": round(fl / (ms1 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
                           "achieved_at_16x_rows": round(tfb, 2), "frac_at_16x_rows": round(tfb / MFMA_F32_PEAK_TF, 4)})
-        line["roofline_mfma_1x1"] = {"unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "batch": TB, "batch_16x": BIG, "shapes": rows1}
+        line["roofline_mfma_1x1"] = {"unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "batch": TB, "batch_16x": BIG,
+                                     "yardstick": "library_sgemm_* = torch.matmul fp32 (vendor BLAS) on the same M x K x N, measurement only",
+                                     "shapes": rows1}
         del tr, model, xa, wa, ya
         torch.cuda.empty_cache()
 

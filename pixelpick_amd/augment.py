@@ -109,6 +109,41 @@ class DeviceAugmenter:
             raise _lib.PixelPickHipError("DeviceAugmenter runs on the GPU only (no CPU fallback)")
         self._mean_c = (ctypes.c_float * 3)(*self.mean)
         self._std_c = (ctypes.c_float * 3)(*self.std)
+        # resampling tables are pure functions of (rule, in_size, out_size): built once on the host, kept ON THE DEVICE (a few KB
+        # each; a random scale in [0.5, 2] of one dataset size yields a few hundred distinct sizes per axis), so that a warm
+        # batch loop uploads nothing but the images
+        self._tables = {}
+        self.n_table_uploads = 0
+
+    @classmethod
+    def from_args(cls, args, device="cuda:0", crop_size=None):
+        """The augmenter the reference's dataset classes configure from `args` (cityscapes.py:44-58, camvid.py, voc.py:
+        args.augmentations["geometric" / "photometric"], args.mean / args.std, args.ignore_index; crop size by dataset)."""
+        if crop_size is None:
+            crop_size = getattr(args, "crop_size", None)
+        if crop_size is None:
+            ds = getattr(args, "dataset_name", "cs")
+            crop_size = {"cs": (256, 512) if getattr(args, "downsample", 4) == 4 else (512, 1024), "cv": (360, 480), "voc": (320, 320)}[ds]
+        aug = getattr(args, "augmentations", None) or {}
+        return cls(crop_size, args.mean, args.std, args.ignore_index, geometric=aug.get("geometric"), photometric=aug.get("photometric"),
+                   device=device)
+
+    def _table(self, kind: str, in_size: int, out_size: int):
+        key = (kind, in_size, out_size)
+        t = self._tables.get(key)
+        if t is None:
+            if kind == "bilinear":
+                b, k, ks = pil_bilinear_tables(in_size, out_size) if in_size != out_size else identity_tables(in_size)
+                t = (self._dev_i32(b), self._dev_i32(k), ks)
+            elif kind == "pil_nearest":
+                t = self._dev_i32(pil_nearest_table(in_size, out_size))
+            else:
+                t = self._dev_i32(torch_nearest_table(in_size, out_size))
+            if len(self._tables) >= 8192:
+                self._tables.clear()
+            self._tables[key] = t
+            self.n_table_uploads += 1
+        return t
 
     # ---- random parameters: same generators and order as the reference -------------------------------------------
     def draw(self, h: int, w: int) -> dict:
@@ -150,8 +185,11 @@ class DeviceAugmenter:
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device, non_blocking=True)
 
     def apply(self, x_u8: torch.Tensor, y_u8: Optional[torch.Tensor], q_u8: Optional[torch.Tensor], p: dict,
-              x_out: torch.Tensor, y_out: Optional[torch.Tensor], q_out: Optional[torch.Tensor]):
-        """x_u8 [H,W,3] uint8, y_u8 / q_u8 [H,W] uint8 on the device; outputs are slots of the batch tensors."""
+              x_out: torch.Tensor, y_out: Optional[torch.Tensor], q_out: Optional[torch.Tensor],
+              lq_u8: Optional[torch.Tensor] = None, lq_out: Optional[torch.Tensor] = None):
+        """x_u8 [H,W,3] uint8, y_u8 / q_u8 / lq_u8 [H,W] uint8 on the device; outputs are slots of the batch tensors.
+        lq: the human-labelled query map (base_dataset.py:67-68,85-86,99-101,113-114): a TENSOR in the reference, so it is resized
+        with torch's nearest rule like the query mask, but padded with ignore_index like the label map."""
         L = _lib.lib()
         st = _lib.current_stream_ptr(self.device)
         h, w, h_rs, w_rs = p["h"], p["w"], p["h_rs"], p["w_rs"]
@@ -159,30 +197,33 @@ class DeviceAugmenter:
         assert tuple(x_u8.shape) == (h, w, 3) and x_u8.dtype == torch.uint8 and x_u8.is_contiguous() and x_u8.is_cuda
         # horizontal pass (skipped by PIL when the width is unchanged)
         if w_rs != w:
-            bw, kw, ksw = pil_bilinear_tables(w, w_rs)
+            bw_d, kw_d, ksw = self._table("bilinear", w, w_rs)
             tmp = torch.empty((h, w_rs, 3), dtype=torch.uint8, device=self.device)
-            bw_d, kw_d = self._dev_i32(bw), self._dev_i32(kw)
             _lib.check(L.pp_aug_resample_h(x_u8.data_ptr(), h, w, bw_d.data_ptr(), kw_d.data_ptr(), ksw, w_rs, tmp.data_ptr(), st),
                        "pp_aug_resample_h")
         else:
             tmp = x_u8
-        bh, kh, ksh = pil_bilinear_tables(h, h_rs) if h_rs != h else identity_tables(h)
-        bh_d, kh_d = self._dev_i32(bh), self._dev_i32(kh)
+        bh_d, kh_d, ksh = self._table("bilinear", h, h_rs)
         crop = torch.empty((ch, cw, 3), dtype=torch.uint8, device=self.device)
         _lib.check(L.pp_aug_vcrop(tmp.data_ptr(), bh_d.data_ptr(), kh_d.data_ptr(), ksh, h_rs, w_rs, p["start_h"], p["start_w"], ch, cw,
                                   int(p["flip"]), self.mean_val[0], self.mean_val[1], self.mean_val[2], crop.data_ptr(), st), "pp_aug_vcrop")
         if y_out is not None or q_out is not None:
             ty = tx = qy = qx = None
             if y_out is not None:
-                ty, tx = self._dev_i32(pil_nearest_table(h, h_rs)), self._dev_i32(pil_nearest_table(w, w_rs))
+                ty, tx = self._table("pil_nearest", h, h_rs), self._table("pil_nearest", w, w_rs)
             if q_out is not None:
-                qy, qx = self._dev_i32(torch_nearest_table(h, h_rs)), self._dev_i32(torch_nearest_table(w, w_rs))
+                qy, qx = self._table("torch_nearest", h, h_rs), self._table("torch_nearest", w, w_rs)
             _lib.check(L.pp_aug_labels(y_u8.data_ptr() if y_out is not None else None, q_u8.data_ptr() if q_out is not None else None, w,
                                        ty.data_ptr() if ty is not None else None, tx.data_ptr() if tx is not None else None,
                                        qy.data_ptr() if qy is not None else None, qx.data_ptr() if qx is not None else None,
                                        h_rs, w_rs, p["start_h"], p["start_w"], ch, cw, int(p["flip"]), self.ignore_index,
                                        y_out.data_ptr() if y_out is not None else None, q_out.data_ptr() if q_out is not None else None, st),
                        "pp_aug_labels")
+        if lq_out is not None:
+            # the label-map leg of the same kernel (gather + ignore_index pad) driven by torch-nearest tables
+            qy, qx = self._table("torch_nearest", h, h_rs), self._table("torch_nearest", w, w_rs)
+            _lib.check(L.pp_aug_labels(lq_u8.data_ptr(), None, w, qy.data_ptr(), qx.data_ptr(), None, None, h_rs, w_rs, p["start_h"],
+                                       p["start_w"], ch, cw, int(p["flip"]), self.ignore_index, lq_out.data_ptr(), None, st), "pp_aug_labels")
         n = ch * cw
         scratch = None
         for op, factor in p["ops"]:
@@ -199,23 +240,38 @@ class DeviceAugmenter:
         return crop
 
     # ---- a batch ---------------------------------------------------------------------------------------------------
-    def __call__(self, images: List, labels: Optional[List] = None, queries: Optional[List] = None, params: Optional[List[dict]] = None):
-        """images: list of [H,W,3] uint8 (numpy or torch, host or device); labels / queries: lists of [H,W] uint8 / bool.
-        -> {'x': f32 [B,3,ch,cw], 'y': int64 [B,ch,cw] | None, 'queries': uint8 [B,ch,cw] | None, 'params': [...]}."""
+    def __call__(self, images: List, labels: Optional[List] = None, queries: Optional[List] = None, params: Optional[List[dict]] = None,
+                 labelled_queries: Optional[List] = None):
+        """images: list of [H,W,3] uint8 (numpy or torch, host or device) or one stacked [B,H,W,3] tensor; labels / queries /
+        labelled_queries: lists (or stacked tensors) of [H,W] uint8 / bool / integer maps with values < 256.
+        -> {'x': f32 [B,3,ch,cw], 'y': int64 [B,ch,cw] | None, 'queries': uint8 [B,ch,cw] | None,
+            'labelled_queries': int64 [B,ch,cw] | None, 'params': [...]}  - the keys of the reference's batch dict
+        (base_dataset.py:190-196)."""
         B = len(images)
         ch, cw = self.crop_size
         x = torch.empty((B, 3, ch, cw), dtype=torch.float32, device=self.device)
         y = torch.empty((B, ch, cw), dtype=torch.int64, device=self.device) if labels is not None else None
         q = torch.empty((B, ch, cw), dtype=torch.uint8, device=self.device) if queries is not None else None
+        lq = torch.empty((B, ch, cw), dtype=torch.int64, device=self.device) if labelled_queries is not None else None
+
+        def u8(t):
+            t = torch.as_tensor(t)
+            t = t.view(torch.uint8) if t.dtype == torch.bool else (t if t.dtype == torch.uint8 else t.to(torch.uint8))
+            return t.to(self.device, non_blocking=True).contiguous()
+
+        def stacked(v):          # one upload for a whole batch of equal-sized maps (the collated form)
+            return u8(v) if (torch.is_tensor(v) or isinstance(v, np.ndarray)) else None
+
+        xs, ys, qs, lqs = stacked(images), stacked(labels) if labels is not None else None, \
+            stacked(queries) if queries is not None else None, stacked(labelled_queries) if labelled_queries is not None else None
         used = []
         for b in range(B):
-            img = torch.as_tensor(images[b]).to(self.device, non_blocking=True).contiguous()
-            lab = torch.as_tensor(labels[b]).to(torch.uint8).to(self.device, non_blocking=True).contiguous() if labels is not None else None
-            qq = None
-            if queries is not None:
-                qq = torch.as_tensor(queries[b])
-                qq = (qq.view(torch.uint8) if qq.dtype == torch.bool else qq.to(torch.uint8)).to(self.device, non_blocking=True).contiguous()
+            img = xs[b] if xs is not None else u8(images[b])
+            lab = (ys[b] if ys is not None else u8(labels[b])) if labels is not None else None
+            qq = (qs[b] if qs is not None else u8(queries[b])) if queries is not None else None
+            ll = (lqs[b] if lqs is not None else u8(labelled_queries[b])) if labelled_queries is not None else None
             p = params[b] if params is not None else self.draw(int(img.shape[0]), int(img.shape[1]))
-            self.apply(img, lab, qq, p, x[b], y[b] if y is not None else None, q[b] if q is not None else None)
+            self.apply(img, lab, qq, p, x[b], y[b] if y is not None else None, q[b] if q is not None else None,
+                       ll, lq[b] if lq is not None else None)
             used.append(p)
-        return {"x": x, "y": y, "queries": q, "params": used}
+        return {"x": x, "y": y, "queries": q, "labelled_queries": lq, "params": used}

@@ -36,3 +36,84 @@ def gather_records(records: list, world: int, group=None) -> list:
         dist.all_gather_object(parts, records, group=group)
         records = [r for part in parts for r in part]
     return sorted(records, key=lambda r: r[0])
+
+
+# ------------------------------------------------------------------------------------------------- host side of the loaders
+# SURVEY.md 8(e) asks for DistributedSampler-style disjoint shards.  Skipping other ranks' batches AFTER the loader has read,
+# augmented and collated them costs W times the host I/O of the single-process reference and makes the shards depend on every
+# rank holding identical python / numpy / torch RNG states.  The helpers below shard at the INDEX level: each rank's loader only
+# ever touches its own items, and the order comes from an explicit seed shared by construction.
+import torch
+from torch.utils.data import DataLoader, RandomSampler, Sampler
+
+
+class ShardedBatchSampler(Sampler):
+    """Batches of dataset indices for rank `rank` of `world`.
+
+    The GLOBAL batch sequence is the one a single process would draw - a permutation of range(n) from
+    `torch.Generator().manual_seed(seed + epoch)` when `shuffle`, else 0..n-1, cut into batches of `batch_size` - and global
+    batch i belongs to rank i mod world.  `equal_steps` (training): the ragged tail of global batches is dropped so that every
+    rank runs the same number of steps (a collective per step); validation / acquisition keep every item.
+    Only indices are materialised here; no rank loads another rank's items."""
+
+    def __init__(self, n_items: int, batch_size: int, rank: int, world: int, shuffle: bool = False, drop_last: bool = False,
+                 equal_steps: bool = False, seed: int = 0):
+        self.n, self.bs, self.rank, self.world = int(n_items), int(batch_size), int(rank), int(world)
+        self.shuffle, self.drop_last, self.equal_steps, self.seed = shuffle, drop_last, equal_steps, int(seed)
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def global_batches(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        batches = [order[i:i + self.bs] for i in range(0, self.n, self.bs)]
+        if self.drop_last and batches and len(batches[-1]) < self.bs:
+            batches.pop()
+        if self.equal_steps:
+            batches = batches[:len(batches) // self.world * self.world]
+        return batches
+
+    def global_index_of_local(self):
+        """Positions (in the global batch sequence) of this rank's batches."""
+        return list(range(self.rank, len(self.global_batches()), self.world))
+
+    def __iter__(self):
+        gb = self.global_batches()
+        return iter(gb[self.rank::self.world])
+
+    def __len__(self):
+        return len(range(self.rank, len(self.global_batches()), self.world))
+
+
+def shard_dataloader(dl, rank: int, world: int, equal_steps: bool, seed: int = 0):
+    """A DataLoader over the SAME dataset / collate / workers as `dl` whose batch sampler is this rank's ShardedBatchSampler.
+    Returns None when `dl` is not a torch DataLoader with an integer batch size (the caller then falls back to enumerating
+    the whole loader and skipping, with the identical-RNG requirement that implies)."""
+    if not isinstance(dl, DataLoader) or dl.batch_size is None:
+        return None
+    shuffle = isinstance(dl.sampler, RandomSampler)
+    bs = ShardedBatchSampler(len(dl.dataset), dl.batch_size, rank, world, shuffle=shuffle, drop_last=dl.drop_last,
+                             equal_steps=equal_steps, seed=seed)
+    kw = dict(batch_sampler=bs, collate_fn=dl.collate_fn, num_workers=dl.num_workers, pin_memory=dl.pin_memory,
+              worker_init_fn=dl.worker_init_fn)
+    if dl.num_workers > 0:
+        kw.update(persistent_workers=dl.persistent_workers, prefetch_factor=dl.prefetch_factor)
+    return DataLoader(dl.dataset, **kw)
+
+
+def dataset_image_sizes(dataset):
+    """[(h, w)] of every item WITHOUT loading it, if the dataset says so (`image_sizes` attribute or `image_size(i)` method),
+    else None.  A sharded acquisition round needs it to advance the host RNG streams past the images of other ranks."""
+    sizes = getattr(dataset, "image_sizes", None)
+    if sizes is not None:
+        return [tuple(int(v) for v in s) for s in sizes]
+    fn = getattr(dataset, "image_size", None)
+    if callable(fn):
+        return [tuple(int(v) for v in fn(i)) for i in range(len(dataset))]
+    return None

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import acquisition as acq
+from . import dist_utils
 from .query import QuerySelector
 from .trainer import FlatTrainer
 from .utils.metrics import AverageMeter, RunningScore
@@ -35,7 +36,7 @@ def write_log(fp, list_entities=None, header=None):
 
 
 class Model:
-    def __init__(self, args, dataloader, dataloader_query, dataloader_val, device=None):
+    def __init__(self, args, dataloader, dataloader_query, dataloader_val, device=None, augmenter=None):
         # Host threads: every remaining torch CPU op in the loop (DataLoader collate = torch.stack of 11 MB per batch)
         # forks torch's intra-op pool, whose workers then spin; with the default of one thread per core (128 on the
         # MI355X hosts) the main thread that feeds the GPU is starved: measured 98 images/s through this driver vs
@@ -73,6 +74,23 @@ class Model:
         self.rank, self.world = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        # Host side of the shards: every rank's loaders only enumerate (read, augment, collate) its OWN batches / images
+        # (dist_utils.ShardedBatchSampler: the global batch order comes from an explicit seed + epoch, identical on every rank
+        # by construction; batch i -> rank i mod W).  Loaders that are not torch DataLoaders fall back to enumerate-and-skip,
+        # which needs identical RNG states on all ranks and W times the host I/O.
+        self._train_loader = self._val_loader = None
+        if self.world > 1:
+            seed = int(getattr(args, "seed", 0))
+            self._train_loader = dist_utils.shard_dataloader(dataloader, self.rank, self.world, equal_steps=True, seed=seed)
+            self._val_loader = dist_utils.shard_dataloader(dataloader_val, self.rank, self.world, equal_steps=False)
+        # Device data path (datasets/base_dataset.py:48-141,151-190): when an augmenter is given (or
+        # args.device_augment is set) the TRAIN loader yields raw uint8 batches {'x_u8','y_u8','queries'} and the geometric /
+        # photometric augmentation, to_tensor and normalisation run on the GPU; the host only draws the random parameters.
+        self.augmenter = augmenter
+        if self.augmenter is None and getattr(args, "device_augment", False):
+            from .augment import DeviceAugmenter
+            self.augmenter = DeviceAugmenter.from_args(args, device=self.device)
+        self.on_train_batch = None        # optional callback(dict_data, x, y, mask, aug_params): tests / debugging
         self.running_loss, self.running_score = AverageMeter(), RunningScore(args.n_classes)
         self.history = []
 
@@ -94,7 +112,11 @@ class Model:
             self.nth_query = nth_query
             model = self._train()
             queries = self.query_selector(nth_query, model)
-            self.dataloader.dataset.label_queries(queries, nth_query + 1)
+            # base_dataset.py:43-45 dumps queries.pkl whenever nth_query is an int: only rank 0 may write the file, the other
+            # ranks merge in memory (nth_query=None skips the dump) and wait until the file is complete
+            self.dataloader.dataset.label_queries(queries, nth_query + 1 if self.rank == 0 else None)
+            if self.world > 1:
+                torch.distributed.barrier()
             if nth_query == n_stages - 1:
                 break
         return
@@ -136,30 +158,54 @@ class Model:
             # model.py:144-145 calls MultiStepLR([20, 40], 0.1).step(epoch=epoch-1) at the END of every epoch, so the rate
             # in force DURING epoch E is base * 0.1^#{m <= E-2}: the drops take effect from epochs 22 and 42
             trainer.lr_factor = 0.1 ** sum(1 for m in (20, 40) if m <= epoch - 2)
+        if self._train_loader is not None:
+            loader = self._train_loader
+            loader.batch_sampler.set_epoch(max(self.nth_query, 0) * self.n_epochs + epoch)   # a new shared permutation per epoch
+            skip = False
+        else:
+            loader = self.dataloader
+            skip = self.world > 1
+            if skip and len(loader) < self.world:
+                raise ValueError(f"{len(loader)} train batches for {self.world} ranks: every rank needs at least one step per epoch")
         n_batches = len(self.dataloader)
         n_local = n_batches // self.world if n_batches >= self.world else 0      # equal step counts on every rank
         local_it = -1
-        for it, dict_data in enumerate(self.dataloader):
-            if self.world > 1:
+        for it, dict_data in enumerate(loader):
+            if skip:
                 if it >= n_local * self.world:
                     break                                                   # ragged tail: dropped, like drop_last
                 if it % self.world != self.rank:
                     continue
             local_it += 1
-            # model.py:106-108 uploads on the compute stream: a pageable copy there queues behind the previous step's kernels
-            # and blocks the host until they finish, so the host could never enqueue ahead of the GPU.  Upload on a copy
-            # stream instead and let the compute stream wait for it.
-            mask = None
-            with self._upload():
-                x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
-                if self.n_pixels_by_us != 0:
-                    mask = dict_data['queries'].to(self.device)
-            self._uploaded(x, y, mask)
+            mask, aug_params = None, None
+            if self.augmenter is not None and 'x_u8' in dict_data:
+                # raw uint8 batch: upload once, then random scale / pad / crop / flip of image, label map and query mask,
+                # colour jitter / grayscale / blur, to_tensor + normalize - all on the device (csrc/augment.hip)
+                def up(v):                      # stacked tensor (default collate) or a list of per-image tensors (ragged sizes)
+                    return v.to(self.device) if torch.is_tensor(v) else [torch.as_tensor(t).to(self.device) for t in v]
+                with self._upload():            # 1.5 MB of uint8 per batch instead of 6.3 MB of floats, off the compute stream
+                    xu, yu = up(dict_data['x_u8']), up(dict_data['y_u8'])
+                    qu = up(dict_data['queries']) if self.n_pixels_by_us != 0 else None
+                flat = [t for v in (xu, yu, qu) if v is not None for t in (v if isinstance(v, list) else [v])]
+                self._uploaded(*flat)
+                out = self.augmenter(xu, yu, qu)
+                x, y, mask, aug_params = out['x'], out['y'], out['queries'], out['params']
+            else:
+                # model.py:106-108 uploads on the compute stream: a pageable copy there queues behind the previous step's
+                # kernels and blocks the host until they finish, so the host could never enqueue ahead of the GPU.  Upload on
+                # a copy stream instead and let the compute stream wait for it.
+                with self._upload():
+                    x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)
+                    if self.n_pixels_by_us != 0:
+                        mask = dict_data['queries'].to(self.device)
+                self._uploaded(x, y, mask)
             if self.n_pixels_by_us != 0:                                   # model.py:108-110
                 mask = mask.view(y.shape)
                 # same values as `y.flatten()[~mask.flatten()] = ignore_index`, without the nonzero() + host sync
                 # that boolean-index assignment performs on every step
                 y = torch.where(mask != 0, y, torch.full_like(y, self.ignore_index))
+            if self.on_train_batch is not None:
+                self.on_train_batch(dict_data, x, y, mask, aug_params)
             if self.lr_scheduler_type == "Poly":                           # per-iteration poly decay (lr_scheduler.py:15-17)
                 trainer.set_poly_lr((epoch - 1) * self._steps_per_epoch() + local_it, n_iters_total)
             if self._replay_train and trainer._plan is None and trainer._graph is None:
@@ -199,15 +245,22 @@ class Model:
         trainer = FlatTrainer(model, lr=lr, slow_lr=slow_lr, weight_decay=wd, optimizer=kind, momentum=momentum,
                               ignore_index=self.ignore_index)
         n_total = self.n_epochs * self._steps_per_epoch()
-        for e in range(1, 1 + self.n_epochs):
-            self._train_epoch(e, model, trainer, n_total)
-            self._val(e, model)
-            if self.debug:
-                break
+        try:
+            for e in range(1, 1 + self.n_epochs):
+                self._train_epoch(e, model, trainer, n_total)
+                self._val(e, model)
+                if self.debug:
+                    break
+        finally:
+            # a recorded launch plan owns a private memory pool (one step of activations) and installs a process-wide device
+            # dropout seed: release both NOW, not when the cyclic GC gets to the trainer - every round builds a new trainer
+            trainer.disable_replay()
         self.best_miou = -1.0
         return model
 
     def _steps_per_epoch(self) -> int:
+        if self._train_loader is not None:
+            return len(self._train_loader)
         n = len(self.dataloader)
         return n if self.world == 1 else (n // self.world if n >= self.world else 0)
 
@@ -249,8 +302,9 @@ class Model:
             pend_x.clear()
             pend_y.clear()
 
-        for iv, dict_data in enumerate(self.dataloader_val):
-            if self.world > 1 and iv % self.world != self.rank:
+        val_loader = self._val_loader if self._val_loader is not None else self.dataloader_val
+        for iv, dict_data in enumerate(val_loader):
+            if self._val_loader is None and self.world > 1 and iv % self.world != self.rank:
                 continue
             with self._upload():
                 x, y = dict_data['x'].to(self.device), dict_data['y'].to(self.device)

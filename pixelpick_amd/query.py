@@ -398,10 +398,35 @@ class QuerySelector:
                     emit(it, cand, ent)
             pending.clear()
 
+        # Host side of the shard: a rank's loader only reads and collates ITS images (index-level shard,
+        # dist_utils.ShardedBatchSampler).  The host RNG streams must still advance through EVERY image in loader order (random
+        # strategy, reverse-order candidates, top-5 % sub-sample are drawn per image); for images of other ranks that only needs
+        # (h, w), which the dataset provides as metadata (`image_sizes` / `image_size(i)`).  A dataset without it, in a mode that
+        # draws, falls back to enumerating the whole loader and skipping.
+        needs_rng = is_random or self.reverse_order or self.top_n_percent > 0.
+        sharded, sizes = None, None
+        if world > 1 and getattr(self.dataloader, "batch_size", None) == 1:
+            sizes = dist_utils.dataset_image_sizes(dataset)
+            if sizes is not None or not needs_rng:
+                sharded = dist_utils.shard_dataloader(self.dataloader, rank, world, equal_steps=False)
+
+        def indexed_batches():
+            if sharded is None:
+                yield from enumerate(self.dataloader)
+            else:
+                yield from zip([b[0] for b in sharded.batch_sampler], sharded)
+
+        next_draw = 0
         with torch.no_grad():
-            for batch_ind, dict_data in enumerate(self.dataloader):
-                n_seen += 1
+            for batch_ind, dict_data in indexed_batches():
                 h, w = dict_data['x'].shape[2:]
+                if sharded is not None:
+                    if needs_rng:
+                        for j in range(next_draw, batch_ind):  # other ranks' images: advance the streams from metadata only
+                            self._draw(*sizes[j])
+                    next_draw = batch_ind + 1
+                else:
+                    n_seen += 1
                 draws = self._draw(h, w)                       # every rank advances the host RNG streams for every image
                 y = dict_data.get('y', None)
                 if dist_utils.owner_rank(batch_ind, world) != rank:
@@ -439,6 +464,11 @@ class QuerySelector:
             flush()
             if inflight:
                 finish(inflight.pop())
+        if sharded is not None:
+            n_seen = len(dataset)
+            if needs_rng:
+                for j in range(next_draw, n_seen):             # trailing images of other ranks: leave the streams where a
+                    self._draw(*sizes[j])                      # single-rank round would leave them
 
         records = dist_utils.gather_records(records, world, group)     # ~100 B per image, the only exchange of the round; loader order
         assert len(records) == n_seen and n_seen > 0, f"no queries are chosen!" if n_seen == 0 else (len(records), n_seen)
@@ -450,12 +480,15 @@ class QuerySelector:
             n_pixels += len(sel)
             if contrib is not None:
                 self.query_stats.apply(contrib)
-        if not human_labels and y is not None:
+        if not human_labels and (y is not None or any(r[5] is not None for r in records)):
             if rank == 0:
                 self.query_stats.save(nth_query)
             print(f"{n_pixels} labelled pixels  are chosen by {self.query_strategy} strategy")
-            # updates labels for the query dataloader only (query.py:219-220)
-            dataset.label_queries(dict_queries, nth_query)
+            # updates labels for the query dataloader only (query.py:219-220).  The reference's datasets dump queries.pkl when
+            # nth_query is an int (base_dataset.py:43-45): in a sharded round only rank 0 writes, the others merge in memory
+            dataset.label_queries(dict_queries, nth_query if rank == 0 else None)
+            if world > 1:
+                torch.distributed.barrier(group=group)
         return dict_queries
 
 

@@ -31,6 +31,8 @@ class SyntheticDataset(torch.utils.data.Dataset):
             self.queries.append(q)
         self.n_pixels_total = int(sum(q.sum() for q in self.queries))
         self.labelled_rounds = []
+        self.image_sizes = [(height, width)] * n_images
+        self.n_getitem = 0
 
     def label_queries(self, queries, nth_query=None):
         """base_dataset.py:24-45: OR-merge the new masks into self.queries."""
@@ -45,4 +47,75 @@ class SyntheticDataset(torch.utils.data.Dataset):
         return len(self.xs)
 
     def __getitem__(self, i):
+        self.n_getitem += 1
         return {'x': self.xs[i], 'y': self.ys[i], 'queries': torch.from_numpy(self.queries[i]), 'p_img': self.names[i]}
+
+
+class RawSyntheticDataset(torch.utils.data.Dataset):
+    """The same surface over RAW data, for the device data path: what the reference's `__getitem__`
+    (base_dataset.py:151-196) holds BEFORE augmentation - an RGB uint8 image as PIL decodes it, a uint8 label map, the bool
+    query mask - instead of the augmented float tensors its DataLoader workers produce.
+
+    train=True   items are raw: {'x_u8': uint8 [H,W,3], 'y_u8': uint8 [H,W], 'queries': bool [H,W], 'p_img'} - augmentation,
+                 to_tensor and normalisation happen on the GPU (pixelpick_amd.augment.DeviceAugmenter, driven by Model).
+    train=False  the reference's val / query branch (base_dataset.py:178-181: no augmentation): 'x' = normalize(to_tensor(img)),
+                 'y' int64, 'queries' uint8.
+    `image_sizes` lists (h, w) of every item without loading it (a sharded acquisition round advances the host RNG streams of
+    other ranks' images from it); `n_getitem` counts the items this process really collated."""
+
+    def __init__(self, n_images, height, width, n_classes, ignore_index, mean, std, n_init_pixels=0, seed=0, void_fraction=0.03,
+                 train=True, sizes=None):
+        rng = np.random.RandomState(seed)
+        assert ignore_index < 256 and n_classes <= 256
+        self.n_classes, self.ignore_index, self.train = n_classes, ignore_index, train
+        self.mean, self.std = [float(v) for v in mean], [float(v) for v in std]
+        self.imgs, self.labels, self.names, self.image_sizes = [], [], [], []
+        proto = rng.randint(30, 226, size=(n_classes, 3))
+        for i in range(n_images):
+            h, w = (height, width) if sizes is None else sizes[i % len(sizes)]
+            coarse = rng.randint(0, n_classes, size=((h + 7) // 8, (w + 7) // 8))
+            y = np.kron(coarse, np.ones((8, 8), dtype=np.int64))[:h, :w]
+            x = np.clip(proto[y] + rng.randint(-25, 26, size=(h, w, 3)), 0, 255).astype(np.uint8)
+            y = y.astype(np.uint8)
+            y[rng.rand(h, w) < void_fraction] = ignore_index
+            self.imgs.append(x)
+            self.labels.append(y)
+            self.names.append(f"synthetic_raw/img_{i:04d}.png")
+            self.image_sizes.append((h, w))
+        self.queries = []
+        for i in range(n_images):
+            h, w = self.image_sizes[i]
+            q = np.zeros((h, w), dtype=np.bool_)
+            if n_init_pixels > 0:
+                q.reshape(-1)[rng.choice(h * w, n_init_pixels, replace=False)] = True
+            self.queries.append(q)
+        self.n_pixels_total = int(sum(q.sum() for q in self.queries))
+        self.labelled_rounds = []
+        self.list_labelled_queries = None
+        self.n_getitem = 0
+
+    def view(self, train: bool):
+        """Another dataset object over the same images (the reference builds separate train / query datasets over the same
+        files, each with its own `queries`, model.py:27-37)."""
+        import copy
+        v = copy.copy(self)
+        v.train = train
+        v.queries = [q.copy() for q in self.queries]
+        v.labelled_rounds = []
+        v.n_getitem = 0
+        return v
+
+    label_queries = SyntheticDataset.label_queries
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def __getitem__(self, i):
+        self.n_getitem += 1
+        if self.train:
+            return {'x_u8': torch.from_numpy(self.imgs[i]), 'y_u8': torch.from_numpy(self.labels[i]),
+                    'queries': torch.from_numpy(self.queries[i]), 'p_img': self.names[i]}
+        x = torch.from_numpy(self.imgs[i]).permute(2, 0, 1).float().div(255.0)            # TF.to_tensor
+        x = (x - torch.tensor(self.mean).view(3, 1, 1)) / torch.tensor(self.std).view(3, 1, 1)   # TF.normalize
+        return {'x': x, 'y': torch.from_numpy(self.labels[i].astype(np.int64)),
+                'queries': torch.from_numpy(self.queries[i].astype(np.uint8)), 'p_img': self.names[i]}

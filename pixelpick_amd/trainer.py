@@ -210,7 +210,10 @@ class FlatTrainer:
         self._ensure_train_mode()
         self.step_count += 1
         if self._graph is not None or self._plan is not None:
-            self._gx.copy_(x, non_blocking=True)
+            if tuple(x.shape) != tuple(self._gx.shape) or tuple(y.shape) != tuple(self._gy.shape):
+                raise ValueError(f"replayed train_step needs the recorded shapes {tuple(self._gx.shape)} / {tuple(self._gy.shape)}, "
+                                 f"got {tuple(x.shape)} / {tuple(y.shape)} (disable_replay() first)")
+            self._gx.copy_(x, non_blocking=True)              # copy_ converts strides / dtype into the recorded layout
             self._gy.copy_(y, non_blocking=True)
             self._stage_hyper()
             if self._plan is not None:
@@ -236,7 +239,9 @@ class FlatTrainer:
         assert self._graph is None and self._plan is None
         self.model.train()
         E.set_dropout_device_seed(self._seed_dev)
-        self._gx, self._gy = x.clone(), y.clone()
+        # the private copies have the layout the recorded launches read: torch-side conversions inside the step
+        # (x.contiguous(), target.to(int64)) run once at record time and are NOT part of the plan
+        self._gx, self._gy = x.contiguous().clone(), y.to(torch.int64).contiguous().clone()
         for _ in range(warmup):
             self.step_count += 1
             self._stage_hyper()
@@ -259,7 +264,7 @@ class FlatTrainer:
         assert self._graph is None
         self.model.train()
         E.set_dropout_device_seed(self._seed_dev)
-        self._gx, self._gy = x.clone(), y.clone()
+        self._gx, self._gy = x.contiguous().clone(), y.to(torch.int64).contiguous().clone()
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side):                      # warm-up on a side stream, as torch's capture recipe asks
@@ -300,6 +305,9 @@ class FlatTrainer:
         if self._graph is not None or self._plan is not None:
             if self._plan is not None:
                 self.last_loss = self.last_logits = None  # they live in the plan's memory pool
+                # the plan holds bound methods of this trainer (all_reduce_grads, _early_all_reduce_on): clear it so that no
+                # trainer <-> plan reference cycle keeps the memory pool (a full step of activations) alive until a GC pass
+                self._plan.calls.clear()
             self._graph = self._plan = self._plan_pool = None
             self._gx = self._gy = None
         if E._dropout_seed_dev[0] is self._seed_dev:

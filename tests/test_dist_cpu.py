@@ -66,3 +66,60 @@ def test_shard_indices_cover_everything_once():
 
 def test_single_rank_gather_is_a_sort():
     assert du.gather_records([(2, "c"), (0, "a"), (1, "b")], 1) == [(0, "a"), (1, "b"), (2, "c")]
+
+
+def test_sharded_batch_sampler_partitions_the_single_process_order():
+    """dist_utils.ShardedBatchSampler: the union of the ranks' batches IS the global batch sequence (batch i -> rank i mod W),
+    no index is loaded twice, training shards have equal step counts, a new epoch is a new shared permutation, and without
+    shuffling the order is the reference's sequential loader."""
+    from pixelpick_amd.dist_utils import ShardedBatchSampler as S
+    for n, bs, w in ((10, 4, 2), (2975, 4, 8), (7, 1, 2), (5, 2, 4)):
+        for shuffle in (False, True):
+            for equal in (False, True):
+                ranks = [S(n, bs, r, w, shuffle=shuffle, equal_steps=equal, seed=11) for r in range(w)]
+                for s in ranks:
+                    s.set_epoch(3)
+                glob = ranks[0].global_batches()
+                assert all(s.global_batches() == glob for s in ranks)
+                per = [list(s) for s in ranks]
+                assert all(len(p) == len(s) for p, s in zip(per, ranks))
+                inter = [b for i in range(max(len(p) for p in per)) for p in per if i < len(p) for b in [p[i]]]
+                assert inter == glob
+                flat = [i for b in glob for i in b]
+                assert len(flat) == len(set(flat))
+                if equal:
+                    assert len({len(p) for p in per}) == 1 and len(glob) % w == 0
+                else:
+                    assert sorted(flat) == list(range(n))
+                if not shuffle:
+                    assert flat == list(range(len(flat)))
+    a = S(100, 4, 0, 2, shuffle=True, seed=1)
+    e0 = list(a)
+    a.set_epoch(1)
+    assert list(a) != e0
+
+
+def test_shard_dataloader_loads_only_own_items():
+    import torch
+    from pixelpick_amd.dist_utils import shard_dataloader, dataset_image_sizes
+
+    class DS(torch.utils.data.Dataset):
+        image_sizes = [(4, 6)] * 9
+
+        def __init__(self):
+            self.loaded = []
+
+        def __len__(self):
+            return 9
+
+        def __getitem__(self, i):
+            self.loaded.append(i)
+            return {"x": torch.full((1,), float(i)), "p_img": f"{i}"}
+
+    ds = DS()
+    dl = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=True, drop_last=True)
+    sh = shard_dataloader(dl, 1, 2, equal_steps=True, seed=5)
+    got = [b["x"].tolist() for b in sh]
+    assert len(got) == 2 and len(ds.loaded) == 4                     # 4 global batches of 2 -> 2 per rank; 4 items touched
+    assert shard_dataloader([1, 2, 3], 0, 2, True) is None          # not a DataLoader: caller falls back
+    assert dataset_image_sizes(ds) == [(4, 6)] * 9 and dataset_image_sizes(object()) is None

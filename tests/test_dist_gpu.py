@@ -191,7 +191,7 @@ def _round(td, strategy, top, rev, model):
     p = f"{td}/checkpoints/dist/1_query/query_stats.pkl"
     if os.path.exists(p):
         stats = pickle.load(open(p, "rb"))
-    return dq, stats, [q.copy() for q in ds.queries]
+    return dq, stats, [q.copy() for q in ds.queries], ds.n_getitem
 
 
 def _acq_worker(rank, world, port, q, td):
@@ -209,10 +209,12 @@ def _acq_worker(rank, world, port, q, td):
     try:
         ok = []
         for i, c in enumerate(cases):
-            dq, stats, queries = _round(f"{td}/sharded_{i}", *c, model)          # rank 0 writes the statistics file
+            dq, stats, queries, n_loaded = _round(f"{td}/sharded_{i}", *c, model)          # rank 0 writes the statistics file
             dist.barrier()
-            dq1, stats1, queries1 = single[i]
+            dq1, stats1, queries1, n_loaded1 = single[i]
             same = list(dq.keys()) == list(dq1.keys())
+            # host side of the shard: this rank's loader collated ceil((7 - rank) / 2) images, the single-rank round all 7
+            same = same and n_loaded1 == 7 and n_loaded == len(range(rank, 7, world))
             for k in dq1:
                 same = same and np.array_equal(dq[k]["x_coords"], dq1[k]["x_coords"]) and np.array_equal(dq[k]["y_coords"], dq1[k]["y_coords"])
             same = same and all(np.array_equal(a, b) for a, b in zip(queries, queries1))    # label_queries side effect on every rank
@@ -260,12 +262,33 @@ def _driver_worker(rank, world, port, q, td):
         from pixelpick_amd.synthetic import SyntheticDataset
         torch.manual_seed(5)                                   # same seed on every rank: same shuffle order, disjoint shards
         np.random.seed(5)
-        ds = SyntheticDataset(8, 64, 96, 5, 5, n_init_pixels=10, seed=1)
+        class FileWritingDataset(SyntheticDataset):
+            """label_queries dumps queries.pkl whenever nth_query is an int, as the reference's datasets do (base_dataset.py:43-45)."""
+            writes = 0
+
+            def label_queries(self, queries, nth_query=None):
+                super().label_queries(queries, nth_query)
+                if isinstance(nth_query, int):
+                    import pickle
+                    os.makedirs(f"{td}/checkpoints/dist/{nth_query}_query", exist_ok=True)
+                    with open(f"{td}/checkpoints/dist/{nth_query}_query/queries.pkl", "wb") as f:
+                        pickle.dump(queries, f)
+                    FileWritingDataset.writes += 1
+
+        ds = FileWritingDataset(8, 64, 96, 5, 5, n_init_pixels=10, seed=1)
+        ds_q = FileWritingDataset(8, 64, 96, 5, 5, n_init_pixels=10, seed=1)
         ds_val = SyntheticDataset(3, 64, 96, 5, 5, seed=2)
         mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
-        m = Model(_al_args(td), mk(ds, 2, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device("cuda:0"))
+        m = Model(_al_args(td), mk(ds, 2, True), mk(ds_q, 1, False), mk(ds_val, 1, False), device=torch.device("cuda:0"))
         assert m.world == 2
         m()
+        # only rank 0 wrote queries.pkl (2 stages x (query dataset + train dataset)); the other rank merged in memory
+        assert FileWritingDataset.writes == (4 if rank == 0 else 0), FileWritingDataset.writes
+        import pickle
+        assert len(pickle.load(open(f"{td}/checkpoints/dist/1_query/queries.pkl", "rb"))) == 8      # complete file on every rank's view
+        # host side of the shards: per stage this rank collated 8/2 train images per epoch, 4 query images, ceil((3-rank)/2) val images
+        assert ds.n_getitem == 2 * 4 and ds_q.n_getitem == 2 * 4, (ds.n_getitem, ds_q.n_getitem)
+        assert ds_val.n_getitem == 2 * len(range(rank, 3, world)), ds_val.n_getitem
         picks = np.stack([qq for qq in ds.queries]).astype(np.uint8)
         t = torch.from_numpy(picks)
         parts = [torch.empty_like(t) for _ in range(world)]

@@ -143,3 +143,70 @@ def test_active_learning_round_with_replayed_train_steps(tmp_path, monkeypatch):
     for i in range(len(ds)):
         assert ds.queries[i].sum() == 10 + 2 * 10
     assert (tmp_path / "checkpoints" / "synthetic" / "1_query" / "best_miou_model.pt").exists()
+
+
+def test_active_learning_round_on_the_device_data_path(tmp_path):
+    """SURVEY.md 8f-4 wired end to end: the train loader yields RAW uint8 batches (RawSyntheticDataset), Model._train_epoch
+    augments them on the GPU (DeviceAugmenter: random scale / pad / crop / flip of image + label map + query mask, colour
+    jitter / grayscale / blur, to_tensor + normalize) and trains on the result; a full active-learning round runs on it.
+    Every train batch is replayed on the host with the primitives the reference calls (oracle/augment.py: PIL resize / expand /
+    crop / transpose, torch nearest for the query tensor - datasets/base_dataset.py:55-118) from the SAME draws: the sparse
+    label map the step trained on (labels at the warped query pixels, ignore_index elsewhere - model.py:108-110) must be
+    bit-identical, i.e. the warped query masks land on exactly the labelled pixels of the host pipeline; the image matches
+    bit for bit when no blur was drawn (blur: cv2 restatement, +-1.5 grey levels)."""
+    import warnings
+    from oracle import augment as orc
+    from pixelpick_amd.augment import DeviceAugmenter
+    from pixelpick_amd.synthetic import RawSyntheticDataset
+    warnings.simplefilter("ignore")
+    import random
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    crop = (64, 96)
+    ds = RawSyntheticDataset(8, 72, 104, 5, 5, MEAN, STD, n_init_pixels=12, seed=1, train=True)
+    ds_q = ds.view(train=False)
+    ds_val = RawSyntheticDataset(4, 64, 96, 5, 5, MEAN, STD, seed=2, train=False)
+    mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
+    aug = DeviceAugmenter(crop, MEAN, STD, ignore_index=5, device=DEV)
+    args = _args(str(tmp_path), max_budget=10, n_init_pixels=12, n_epochs=2)
+    m = Model(args, mk(ds, 4, True), mk(ds_q, 1, False), mk(ds_val, 1, False), device=torch.device(DEV), augmenter=aug)
+    seen = []
+    m.on_train_batch = lambda d, x, y, mask, params: seen.append(
+        (list(d['p_img']), d['queries'].numpy().copy(), x.cpu(), y.cpu(), mask.cpu(), params))
+    m()
+    assert len(seen) == 2 * 2 * 2                                  # 2 stages x 2 epochs x 2 batches of 4
+    name_to_i = {n: i for i, n in enumerate(ds.names)}
+    n_lab = n_blur = n_exact = n_scaled = 0
+    for names, q_in, x, y, mask, params in seen:
+        assert x.shape == (4, 3) + crop and y.shape == (4,) + crop and y.dtype == torch.int64
+        for b, (name, p) in enumerate(zip(names, params)):
+            i = name_to_i[name]
+            img, y_ref, q_ref = orc.geometric(ds.imgs[i], ds.labels[i], q_in[b].astype(np.uint8), p, crop, aug.mean_val, 5)
+            assert np.array_equal(mask[b].numpy(), q_ref), (name, p)
+            y_sparse = np.where(q_ref != 0, y_ref, 5)
+            assert np.array_equal(y[b].numpy(), y_sparse), (name, p)      # bit-exact: same labelled pixels, same labels
+            n_lab += int((y_sparse != 5).sum())
+            n_scaled += (p["h_rs"], p["w_rs"]) != (72, 104)
+            for op, f in p["ops"]:
+                img = orc.jitter(img, op, f)
+            arr = np.asarray(img)
+            if p["blur"] is not None:
+                arr = orc.gaussian_blur(arr, *p["blur"])
+                n_blur += 1
+            x_ref = orc.to_tensor_normalize(arr, MEAN, STD)
+            tol = (1.5 / 255) / min(STD) if p["blur"] is not None else 0.0
+            assert (x[b] - x_ref).abs().max().item() <= tol + 1e-7, (name, p)
+            n_exact += p["blur"] is None
+    assert n_lab > 0 and n_scaled > 0 and n_blur > 0 and n_exact > 0
+    # the round itself: labels grew by 10 px per image per stage on both dataset views, artefacts written
+    for i in range(len(ds)):
+        assert ds.queries[i].sum() == 12 + 2 * 10 and ds_q.queries[i].sum() == 12 + 2 * 10
+    for nth in range(2):
+        d = tmp_path / "checkpoints" / "synthetic" / f"{nth}_query"
+        assert (d / "best_miou_model.pt").exists() and (d / "query_stats.pkl").exists()
+    assert all(np.isfinite(h[5]) for h in m.history if h[0] == "train")
+    # warm loop uploads no tables: every (rule, in, out) table was built once and is cached on the device
+    n_up = aug.n_table_uploads
+    aug(torch.from_numpy(np.stack(ds.imgs[:2])), torch.from_numpy(np.stack(ds.labels[:2])), torch.from_numpy(np.stack(ds.queries[:2])),
+        params=seen[0][5][:2])
+    assert aug.n_table_uploads == n_up

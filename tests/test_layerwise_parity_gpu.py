@@ -154,3 +154,46 @@ def test_branch_forced_free_running_gradients_are_tight(network, n_params, B, H,
     print("[branch-forced] worst parameter gradients:", [(n, f"{e:.2e}") for e, n in errs[:5]])
     assert len(errs) == n_params
     assert errs[0][0] <= TOL_BRANCH, errs[:8]
+
+
+def _oracle_param_grads(network, C, ign, x, y, dtype):
+    """Parameter gradients of the oracle evaluated in `dtype` on the formula weights (a second, independent evaluation of the
+    SAME function: what two correct implementations of this train step differ by)."""
+    _, o = _models(network, C)
+    o = o.to(dtype)
+    F.cross_entropy(o(x.to(dtype)), y, ignore_index=ign).backward()
+    return {n: p.grad.float() for n, p in o.named_parameters()}
+
+
+@pytest.mark.parametrize("network,n_params,B,H,W", [("deeplab", 182, 4, 128, 192), ("FPN", 213, 2, 64, 96)])
+def test_free_running_dense_label_gradients_within_the_oracles_own_fp32_band(network, n_params, B, H, W):
+    """Free-running, UNINTERVENED run (nothing overwritten, no ReLU unit aligned) on DENSE labels (~63 % of the pixels:
+    formula_labels draws H*W positions with replacement), model.py:116-121.
+
+    Measured (profiles/r03_dense_free_running.txt): forward sites agree to <= 3e-5, the gradient arriving at the classifier and
+    at the last BatchNorm to 2e-5 - and the gradient LEAVING that BatchNorm is 4e-3 off, on every label density from 20 px/img
+    to all pixels.  The ~40 ReLU units (of 1.9e7) that sit within the fp32 forward noise (2.5e-5 of a standard deviation) of
+    their threshold take the other branch, and at the head a dense gradient lives on B*h*w*256/2 = 8e5 active units: ONE
+    flipped unit is 1/sqrt(8e5) = 1.1e-3 of the tensor, not 1e-5, so label density does not buy the literal 1e-3.  The same
+    holds between any two correct fp32 evaluations of this function; the yardstick used here is therefore the ORACLE AGAINST
+    ITSELF: oracle/net.py evaluated in fp64 vs in fp32 on the same weights and inputs.  Bar: the HIP run's deviation from the
+    fp32 oracle stays within 2.5x of that band in the median and in the maximum over all parameter gradients (measured ~1x),
+    flipped units are reported, not aligned.  The no-discontinuity bar (branch-aligned, <= 5e-4, no noise term) is the test
+    below this one."""
+    lp, loss, o_loss, m, o = _run(network, 19, 19, B, H, W, H * W, force=False, key="dense")
+    print("\n[dense free-running] " + lp.summary().replace("\n", "\n[dense free-running] "))
+    assert abs(loss - o_loss) <= 1e-4 * max(1.0, abs(o_loss))
+    x = fi.formula_input(B, H, W, key="xdense")
+    y = fi.formula_labels(B, H, W, 19, 19, H * W, key="ydense")
+    g32 = {n: p.grad for n, p in o.named_parameters()}
+    g64 = _oracle_param_grads(network, 19, 19, x, y, torch.float64)
+    from layerwise import rel_l2
+    band = np.array([rel_l2(g32[n], g64[n]) for n in g32])
+    errs = np.array([e for k, _, e, _ in lp.rec if k == "param_grad"])
+    assert len(errs) == n_params == len(band)
+    nfl = sum(f for f, _ in lp.flips.values())
+    print(f"[dense free-running] flipped units (reported, not aligned): {nfl} of {sum(u for _, u in lp.flips.values())}")
+    print(f"[dense free-running] HIP vs fp32 oracle: median {np.median(errs):.2e} max {errs.max():.2e} | "
+          f"fp32 oracle vs fp64 oracle: median {np.median(band):.2e} max {band.max():.2e}")
+    assert np.median(errs) <= 2.5 * np.median(band) and errs.max() <= 2.5 * band.max(), (np.median(errs), errs.max(), np.median(band), band.max())
+    assert errs.max() <= 5e-2
