@@ -132,12 +132,15 @@ def ResNetBackbone(backbone=None, width_multiplier=1.0, pretrained=None, multi_g
                         f"{backbone}: only resnet50_dilated8 / resnet101_dilated8 are built (the reference's configs select no other)")
     orig = ResNet(Bottleneck, depths[backbone], width_multiplier=width_multiplier)
     if pretrained is not None:
-        sd = torch.load(pretrained, map_location="cpu")
+        sd = torch.load(pretrained, map_location="cpu", weights_only=True)
         own = orig.state_dict()
         mapped = {}
-        for k, v in sd.items():                     # module_helper.py load_model: conv1/bn1 live under prefix.*
-            k2 = k if k in own else "prefix." + k
+        for k, v in sd.items():                     # module_helper.py:102-106 load_model: conv1/bn1 live under prefix.*
+            k2 = "prefix." + k if "prefix." + k in own else k
             if k2 in own:
-                mapped[k2] = v
+                mapped[k2] = v                      # (the ImageNet head fc.* has no counterpart: this ResNet keeps no fc)
+        missing = [k for k in own if k not in mapped and not k.endswith("num_batches_tracked")]
+        if missing:
+            raise KeyError(f"{pretrained}: {len(missing)} backbone tensors missing from the file, e.g. {missing[:4]}")
         orig.load_state_dict(mapped, strict=False)
     return DilatedResnetBackbone(orig, dilate_scale=8, multi_grid=multi_grid)

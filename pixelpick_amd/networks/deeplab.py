@@ -81,7 +81,10 @@ class DeepLab(nn.Module):
             self.backbone = ResNetBackbone(backbone='resnet50_dilated8', pretrained=None)
             low_level_inplanes = 256
         else:
-            self.backbone = MobileNetV2(output_stride, BatchNorm2d, mc_dropout=args.use_mc_dropout)
+            # deeplab.py:19 always starts from the ImageNet backbone (MobileNetV2(pretrained=True) downloads it); here the
+            # file comes from PIXELPICK_MNV2_WEIGHTS and a random backbone has to be asked for (weight_type "random")
+            self.backbone = MobileNetV2(output_stride, BatchNorm2d, mc_dropout=args.use_mc_dropout,
+                                        pretrained=getattr(args, "weight_type", None) != "random")
             low_level_inplanes = 24
         self.aspp = ASPP(backbone, output_stride, BatchNorm2d)
         self.low_level_conv = nn.Sequential(Conv2d(low_level_inplanes, 48, 1, bias=False), BatchNorm2d(48), ReLU())

@@ -16,10 +16,14 @@ class Encoder(nn.Module):
         n_layers = args.n_layers
         if load_pretrained:
             if weight_type == "supervised":
-                path = resnet[n_layers]
-                self.base = ResNetBackbone(backbone=f'resnet{n_layers}_dilated8', pretrained=path if os.path.isfile(path) else None)
-                print("Encoder initialised with supervised weights." if os.path.isfile(path) else
-                      f"Encoder: {path} not found, random initialisation.")
+                # encoder.py:28 + module_helper.py:86-107: a torchvision-layout ResNet file at a path relative to scripts/;
+                # PIXELPICK_RESNET_WEIGHTS overrides the path.  A missing file raises, as in the reference (module_helper.py:95)
+                path = os.environ.get("PIXELPICK_RESNET_WEIGHTS", "") or resnet[n_layers]
+                if not os.path.isfile(path):
+                    raise FileNotFoundError(f"{path} not exists. (weight_type='supervised'; set PIXELPICK_RESNET_WEIGHTS or use "
+                                            f"weight_type='random')")
+                self.base = ResNetBackbone(backbone=f'resnet{n_layers}_dilated8', pretrained=path)
+                print("Encoder initialised with supervised weights.")
             else:
                 self.base = ResNetBackbone(backbone='resnet50_dilated8', pretrained=None)
         else:

@@ -115,16 +115,24 @@ class MobileNetV2(nn.Module):
         self.mc_dropout = mc_dropout
 
     def _load_pretrained_model(self):
+        """mobilenet_v2.py:139-147: the reference downloads `mobilenet_v2-6a65762b.pth` (torchvision key layout: `features.N...`
+        plus the ImageNet head `features.18.*`, `classifier.1.*`) and copies every entry whose key exists in its own
+        state_dict.  There is no network here: PIXELPICK_MNV2_WEIGHTS names a local copy of that file.  Starting from a RANDOM
+        backbone is never silent: it must be asked for (args.weight_type == "random" -> DeepLab passes pretrained=False, or
+        PIXELPICK_MNV2_WEIGHTS=random); a missing file raises."""
         path = os.environ.get("PIXELPICK_MNV2_WEIGHTS", "")
-        if path and not os.path.isfile(path):
-            raise FileNotFoundError(f"PIXELPICK_MNV2_WEIGHTS={path}: no such file (unset it to start from a random backbone)")
-        if path:
-            pretrain_dict = torch.load(path, map_location="cpu", weights_only=True)
-            own = self.state_dict()
-            self.load_state_dict({k: v for k, v in pretrain_dict.items() if k in own}, strict=False)
-        else:
-            warnings.warn("MobileNetV2 ImageNet weights unavailable offline (reference downloads them, "
-                          "mobilenet_v2.py:140); keeping the random initialisation")
+        if path == "random":
+            return
+        if not path:
+            raise FileNotFoundError("MobileNetV2 ImageNet weights: the reference downloads them (mobilenet_v2.py:140), which is "
+                                    "impossible offline - set PIXELPICK_MNV2_WEIGHTS to a local mobilenet_v2-6a65762b.pth, or ask "
+                                    "for a random backbone explicitly (args.weight_type='random' / PIXELPICK_MNV2_WEIGHTS=random)")
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"PIXELPICK_MNV2_WEIGHTS={path}: no such file")
+        pretrain_dict = torch.load(path, map_location="cpu", weights_only=True)
+        state_dict = self.state_dict()
+        state_dict.update({k: v for k, v in pretrain_dict.items() if k in state_dict})      # mobilenet_v2.py:142-146
+        self.load_state_dict(state_dict)
 
     @staticmethod
     def _run_features(tape, seq, x):

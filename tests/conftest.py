@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# DeepLab starts from the ImageNet MobileNetV2 file unless a random backbone is asked for (networks/mobilenet_v2.py); the tests
+# fill every weight themselves (formula / seeds), so they ask for it once here.  tests/test_checkpoint_format_gpu.py overrides it.
+os.environ.setdefault("PIXELPICK_MNV2_WEIGHTS", "random")
 
 
 def pytest_configure(config):

@@ -65,3 +65,14 @@ def formula_labels(B, H, W, n_classes, ignore_index, n_per_image, key="y") -> to
 def summarize(t: torch.Tensor) -> np.ndarray:
     t = t.detach().double().reshape(-1)
     return np.array([t.sum().item(), t.abs().sum().item(), t.abs().max().item()], dtype=np.float64)
+
+
+def tie_aliases(sd: dict) -> dict:
+    """MobileNetV2 registers its layers three times (`features`, `low_level_features` = features[0:4], `high_level_features` =
+    features[4:], mobilenet_v2.py:118-126), so a real state_dict carries every backbone tensor under two names with ONE value:
+    make a per-key formula dict consistent the same way (the `features.N` entry wins)."""
+    for k in list(sd.keys()):
+        for alias in (".low_level_features.", ".high_level_features."):
+            if alias in k:
+                sd[k] = sd[k.replace(alias, ".features.")].clone()
+    return sd

@@ -14,7 +14,7 @@ from pixelpick_amd.utils.utils import get_model
 from bench import synth_train_batch
 warnings.simplefilter("ignore")
 torch.manual_seed(0)
-m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab")).cuda().train()
+m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab", weight_type="random")).cuda().train()
 tr = FlatTrainer(m, ignore_index=19)
 x, y = synth_train_batch(4, 19, 256, 512, 20, torch.device("cuda"), 1)
 orig = E._conv2d_bwd

@@ -31,7 +31,7 @@ def main():
     C = 19
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab"))
+        m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab", weight_type="random"))
     sd = fi.formula_state_dict(m.state_dict())
     m.load_state_dict(sd)
     for mod in m.modules():

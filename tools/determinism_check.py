@@ -15,7 +15,7 @@ x, y = synth_train_batch(4, C, 256, 512, 20, torch.device("cuda"), 1)
 sigs = []
 for r in range(RUNS):
     torch.manual_seed(0)
-    m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).cuda().train()
+    m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab", weight_type="random")).cuda().train()
     tr = FlatTrainer(m, ignore_index=C)
     E.set_dropout_seed(1234)
     losses = []

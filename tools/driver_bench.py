@@ -17,7 +17,7 @@ ds_val = SyntheticDataset(4, H, W, C, C, seed=2)
 mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh, drop_last=True)
 with tempfile.TemporaryDirectory() as td:
     args = Namespace(dataset_name="cs", debug=False, dir_root=td, experim_name="drv", ignore_index=C, mc_n_steps=20, n_classes=C,
-                     n_pixels_by_us=10, network_name="deeplab", query_strategy="entropy", reverse_order=False, stride_total=16,
+                     n_pixels_by_us=10, network_name="deeplab", weight_type="random", query_strategy="entropy", reverse_order=False, stride_total=16,
                      top_n_percent=0.0, use_mc_dropout=False, vote_type="hard", mc_dropout_p=0.2, n_init_pixels=20, max_budget=20,
                      n_epochs=1, lr_scheduler_type="Poly",
                      optimizer_params={"lr": 5e-4, "betas": (0.9, 0.999), "weight_decay": 2e-4, "eps": 1e-7})

@@ -11,7 +11,7 @@ def main():
     C = 19
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).cuda().eval()
+        m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab", weight_type="random")).cuda().eval()
     for B in [int(v) for v in sys.argv[1:]] or [1, 4, 16]:
         x = torch.randn(B, 3, 256, 512, device="cuda")
         with torch.no_grad():

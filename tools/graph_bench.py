@@ -22,7 +22,7 @@ graph = os.environ.get("GRAPH", "0") == "1"
 replay = os.environ.get("REPLAY", "0") == "1"
 E.Tape.overlap_wgrad = os.environ.get("SIDE", "1") == "1"
 torch.manual_seed(0)
-m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab")).cuda().train()
+m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab", weight_type="random")).cuda().train()
 tr = FlatTrainer(m, ignore_index=19)
 x, y = synth_train_batch(4, 19, 256, 512, 20, torch.device("cuda"), 1)
 for _ in range(3):

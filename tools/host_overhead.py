@@ -6,7 +6,7 @@ from pixelpick_amd.utils.utils import get_model
 from pixelpick_amd.trainer import FlatTrainer
 from bench import synth_train_batch
 warnings.simplefilter("ignore")
-m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab")).cuda().train()
+m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab", weight_type="random")).cuda().train()
 tr = FlatTrainer(m, ignore_index=19)
 x, y = synth_train_batch(4, 19, 256, 512, 20, torch.device("cuda"), 1)
 for _ in range(3): tr.train_step(x, y)

@@ -10,7 +10,7 @@ from pixelpick_amd import query as ppq
 from pixelpick_amd.utils.utils import get_model
 warnings.simplefilter("ignore")
 C, h, w, n = 19, 256, 512, 16
-m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).cuda()
+m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab", weight_type="random")).cuda()
 
 
 class DS:
@@ -32,7 +32,7 @@ class DL:
 
 with tempfile.TemporaryDirectory() as td:
     a = Namespace(dataset_name="cs", debug=False, dir_root=td, experim_name="mc", ignore_index=C, mc_n_steps=20, n_classes=C,
-                  n_pixels_by_us=20, network_name="deeplab", query_strategy="entropy", reverse_order=False, stride_total=16,
+                  n_pixels_by_us=20, network_name="deeplab", weight_type="random", query_strategy="entropy", reverse_order=False, stride_total=16,
                   top_n_percent=0.0, use_mc_dropout=True, vote_type="hard")
     for chunk in (32, 1):
         a.mc_chunk = chunk

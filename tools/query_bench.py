@@ -33,13 +33,13 @@ class DL:
 
 
 warnings.simplefilter("ignore")
-model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).cuda()
+model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab", weight_type="random")).cuda()
 ds = DS()
 for mode in ("k=20", "top5%"):
     for bs in (1, 4, 16):
         with tempfile.TemporaryDirectory() as td:
             a = Namespace(dataset_name="cs", debug=False, dir_root=td, experim_name="qb", ignore_index=C, mc_n_steps=20, n_classes=C,
-                          n_pixels_by_us=20 if mode == "k=20" else 10, network_name="deeplab", query_strategy="entropy",
+                          n_pixels_by_us=20 if mode == "k=20" else 10, network_name="deeplab", weight_type="random", query_strategy="entropy",
                           reverse_order=False, stride_total=16, top_n_percent=0.0 if mode == "k=20" else 0.05,
                           use_mc_dropout=False, vote_type="hard", query_batch_size=bs)
             qs = ppq.QuerySelector(a, DL(ds), device=torch.device("cuda"))
