@@ -162,7 +162,23 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the train step as one hipGraph (FlatTrainer.enable_graph).  Measured on ROCm 7.2: 10.3 ms vs "
                          "9.1-10.0 ms eager — the replay serialises the weight-gradient side stream — so eager is the default")
+    ap.add_argument("--replay", default="auto", choices=["auto", "on", "off"],
+                    help="re-issue the train step's recorded launch list (FlatTrainer.enable_replay: same GPU schedule, half the host "
+                         "time per step).  auto: on when this process has fewer than 8 host cores per rank to enqueue from")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the driver's launch line (one rank per GPU over RCCL), same output
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,12 +256,43 @@ def main():
         tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, ignore_index=C)
         E.set_dropout_seed(1234 + rank)
         x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
+        cores_per_rank = (os.cpu_count() or 1) / max(world, 1)
+        replay = (a.replay == "on" or (a.replay == "auto" and cores_per_rank < 8)) and not a.graph
         if a.graph:
             tr.enable_graph(x, y)                    # whole step (fwd, CE, bwd, all-reduce, Adam) = one hipGraph replay
-        el = timed(lambda: tr.train_step(x, y), a.steps, a.warmup)
+        elif replay:
+            tr.enable_replay(x, y, warmup=1)         # recorded launch list, eager two-queue GPU schedule (bit-identical steps)
+        tr.time_collectives = dist is not None
+        host_s = [0.0]
+
+        def one_step():
+            t = time.perf_counter()
+            tr.train_step(x, y)
+            host_s[0] += time.perf_counter() - t
+        for _ in range(a.warmup):
+            one_step()
+        host_s[0] = 0.0
+        tr.__dict__["comm_times"] = []
+        el = timed(one_step, a.steps, 0)
+        host_loop_ms = max_over_ranks(host_s[0]) / a.steps * 1e3
+        # the enqueue cost proper: one step issued into EMPTY queues (in the loop above a host that runs ahead of the GPU is
+        # throttled by the full queue, so the in-loop figure tends to the GPU step time whatever the host costs)
+        solo = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            tr.train_step(x, y)
+            solo.append(time.perf_counter() - t)
+        torch.cuda.synchronize(dev)
+        host_ms = max_over_ranks(sorted(solo)[len(solo) // 2]) * 1e3
         loss = float(tr.last_loss.item())
         train = {"img_per_s": world * TB * a.steps / el, "ms_per_step": el / a.steps * 1e3, "loss_after": loss,
-                 "launch": "hipGraph replay" if a.graph else "eager, weight gradients on a second stream",
+                 "launch": "hipGraph replay" if a.graph else ("launch-plan replay" if replay else "eager") +
+                           ", weight gradients on a second stream",
+                 # host time spent inside train_step() per step (enqueue only, nothing synchronises): a host slower than the
+                 # GPU step shows up HERE, not as an unexplained scaling loss
+                 "host_enqueue_ms_per_step": host_ms, "host_in_loop_ms_per_step": host_loop_ms, "replay": bool(replay),
+                 "host_cores_per_rank": round(cores_per_rank, 1),
                  "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
         if dist is not None:
             # what the communicator really is, and what the gradient exchange costs on its own (both buckets back to back,
@@ -261,7 +308,12 @@ def main():
                 torch.cuda.synchronize(dev)
                 ar.append(e0.elapsed_time(e1))
             ar_ms = max_over_ranks(sorted(ar[1:])[len(ar[1:]) // 2])
+            in_step = {}
+            for tag, e0, e1 in tr.__dict__.get("comm_times", []):
+                in_step.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e3)
+            tr.time_collectives = False
             line["distributed"] = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                                   "allreduce_in_step_us": {k: round(sum(v) / len(v), 1) for k, v in in_step.items()},
                                    "allreduce_bytes_per_step": tr.n * 4, "buckets": [int((tr.n - tr.n_split) * 4), int(tr.n_split * 4)],
                                    "allreduce_alone_ms": round(ar_ms, 4),
                                    "allreduce_alone_GBps_per_rank": round(tr.n * 4 / (ar_ms * 1e-3) / 1e9, 1),

@@ -150,19 +150,37 @@ class FlatTrainer:
         for s in sides:
             comm.wait_stream(s)
         with torch.cuda.stream(comm):
+            t0 = self._comm_mark(comm)
             self._early_work = torch.distributed.all_reduce(self.flat_g[self.n_split:], op=torch.distributed.ReduceOp.SUM,
                                                             group=self.pg, async_op=True)
+            self._comm_mark(comm, "behind_encoder", t0)
         E.refresh_stream()
+
+    def _comm_mark(self, stream, tag=None, start=None):
+        """bench.py: `time_collectives = True` brackets every gradient all-reduce of the step with events on the stream it
+        runs on (`comm_times`: [(bucket, start event, end event)]), so the line can show what each bucket costs INSIDE the
+        step - under the encoder backward / after the join - not only stand-alone."""
+        if not getattr(self, "time_collectives", False):
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        if tag is not None:
+            self.__dict__.setdefault("comm_times", []).append((tag, start, ev))
+        return ev
 
     def all_reduce_grads(self):
         if self.collectives:
+            main = torch.cuda.current_stream()
+            t0 = self._comm_mark(main)
             if self._early_work is not None:
                 torch.distributed.all_reduce(self.flat_g[:self.n_split], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self._comm_mark(main, "encoder", t0)
                 self._early_work.wait()                   # main stream waits for the overlapped part
-                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                main.wait_stream(self._comm_stream)
                 self._early_work = None
             else:
                 torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self._comm_mark(main, "whole_gradient", t0)
 
     def _stage_hyper(self):
         """Host -> pinned -> device copies of the per-step scalars (enqueued on the current stream)."""

@@ -398,3 +398,30 @@ def test_bench_line_from_two_ranks_through_torch_distributed_run():
     dd = d["distributed"]
     assert dd["nranks"] == 2 and dd["backend"] == "gloo" and dd["allreduce_bytes_per_step"] == 4 * 5815539 and sum(dd["buckets"]) == 4 * 5815539
     assert "roofline" in d and d["acquisition"]["value"] > 0
+
+
+@pytest.mark.parametrize("replay", ["off", "on"])
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay):
+    """`python bench.py --gpus 2` typed WITHOUT torch.distributed.run re-launches itself through the driver's line (one wrong
+    launch line used to end in an assertion): same single JSON line, plus the host enqueue time per step, whether the
+    launch-plan replay was on, and what each gradient bucket cost INSIDE the step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PIXELPICK_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--mode", "train", "--replay", replay]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 8
+    t = d["train"]
+    assert t["replay"] == (replay == "on") and 0 < t["host_enqueue_ms_per_step"] < 1e3 and t["host_cores_per_rank"] > 0
+    dd = d["distributed"]
+    assert dd["nranks"] == 2 and set(dd["allreduce_in_step_us"]) == {"behind_encoder", "encoder"}
+    assert all(v > 0 for v in dd["allreduce_in_step_us"].values())
