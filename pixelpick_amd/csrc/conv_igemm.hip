@@ -873,6 +873,240 @@ __global__ __launch_bounds__(kThreads) void conv1x1_direct_kernel(ConvParams p)
     conv_epilogue<1, 1>(p, accs, m0, n0, 0, 0);
 }
 
+// ---- deep-K pointwise convolutions on few rows: in-block split-K over wave-private LDS-DMA pipelines -----------------------------
+// 960 -> 160, 960 -> 320, 1280 -> 256 and the backward-data of 160 -> 960 at 2048 rows (mobilenet_v2.py:56, aspp.py:73-75): the
+// output has 64-192 64x64 tiles for 256 CUs, so the tiled kernel slices K over grid.y and pays a [splits][M][N] round trip plus a
+// second launch (23-29 us per layer, of which ~5 are the reduce and its kernel boundary).  Here a block owns ONE (32*TM) x 32
+// output tile and its four waves split K four ways, like conv1x1_direct_kernel - but each wave streams its K slice through a
+// PRIVATE ring of LDS stages with coalesced 1-KiB LDS-DMA pieces (global_load_lds_dwordx4), NST-1 K steps of loads in flight per
+// wave, no block barrier inside the K loop (a wave only waits for its own pieces with a counted s_waitcnt vmcnt), and the DMA
+// pieces of step k+NST-1 are issued between the MFMA pairs of step k.  The four partial tiles meet in LDS once, every wave adds a
+// quarter of the tile in wave order (deterministic) and stores it: split-K without the workspace and without the second launch.
+//   A operand (activations / dY): MK form [32*TM rows][16 k], quad q of row r at slot r*4 + (q ^ ((r >> 2) & 3))  (as conv_igemm_dma_kernel)
+//   B operand forward  (W[k][n], n contiguous): KN form [16 k][32 n], logical row k stored at physical row k ^ ((k >> 2) & 1) so that
+//                      the two half-waves of a fragment read (k, k + 4) use different halves of the 64 banks
+//   B operand backward (W[n][k], k contiguous): NK form [32 n][16 k], swizzled like A
+// Measured (960 -> 160 at 2048 rows): 15.3-15.8 us whatever the tile / ring depth (23.6 for split-K + reduce, 26.7 for the direct
+// kernel); floor of the design = 6.4 us of MFMA work on the busiest CU + launch, first round trip and the reduce / store tail.
+template <int TM, int TN, int NST, bool BWD>
+__global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvParams p)
+{
+    constexpr int A_FL = TM * 32 * BK, B_FL = BK * TN * 32, ST_FL = A_FL + B_FL;
+    constexpr int PA = TM * 2, PB = TN * 2, NP = PA + PB;    // 1-KiB pieces per wave and K step
+    constexpr int WAVE_FL = NST * ST_FL;
+    constexpr int BN = TN * 32;
+    static_assert(WAVE_FL >= TM * TN * 16 * 64, "the final reduction reuses a wave's ring");
+    static_assert(NP <= 8 && (NST - 2) * NP < 64, "pieces are issued behind the eight MFMA groups; vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) float smem[4 * WAVE_FL];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+    const int64_t m0 = (int64_t)mt * (32 * TM);
+    const int n0 = nt * BN;
+    const float* zero = g_zero16;
+    asm volatile("" : "+v"(zero));
+    float* wsm = smem + wave * WAVE_FL;
+    const uint32_t lds_w = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)wsm);
+
+    // ---- fixed per-lane source addressing --------------------------------------------------------------------------
+    int a_off[PA], a_c[PA];                                  // element offset of this lane's row (< 0: the row reads zeros), channel offset
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = i * 16 + (lane >> 2);
+        a_c[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 4;
+        a_off[i] = -1;
+        const int64_t m = m0 + row;
+        if (m < p.M) {
+            const unsigned mu = (unsigned)m;
+            const unsigned t = mu / (unsigned)p.Wo;
+            const int ow = (int)(mu - t * (unsigned)p.Wo);
+            const unsigned bb = t / (unsigned)p.Ho;
+            const int oh = (int)(t - bb * (unsigned)p.Ho);
+            const int ih = oh + p.taps.dh[0], iw = ow + p.taps.dw[0];
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                a_off[i] = (((int)bb * p.H + ih) * p.W + iw) * (int)p.ldx + a_c[i];
+        }
+    }
+    int b_off[PB], b_k[PB];
+    bool b_ok[PB];
+    const float* wbase = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        if constexpr (!BWD) {
+            // KN form [16 k][BN n]: a piece is 64 lanes x 16 B = (256 / BN) k rows of BN floats
+            constexpr int QN = BN / 4;                       // quads per k row
+            const int P = i * 64 + lane;
+            const int kp = P / QN, k = kp ^ ((kp >> 2) & 1), nq = P % QN;
+            b_k[i] = k;                                      // checked against Cin with the step's channel base
+            b_ok[i] = n0 + nq * 4 < p.Cout;
+            b_off[i] = k * p.Cout + n0 + nq * 4;
+        } else {
+            const int row = i * 16 + (lane >> 2), kq = (lane & 3) ^ ((row >> 2) & 3);
+            b_k[i] = kq * 4;                                 // checked against Cout
+            b_ok[i] = n0 + row < p.Cin;
+            b_off[i] = (n0 + row) * p.Cout + kq * 4;
+        }
+    }
+
+    // K steps of this wave
+    const int nsteps = (p.Ck + BK - 1) / BK;
+    const int per = (nsteps + 3) / 4;
+    const int s_beg = wave * per;
+    const int n = (s_beg + per < nsteps ? s_beg + per : nsteps) - s_beg;      // may be <= 0
+
+    auto a_src = [&](int i, int c0) -> const float* {
+        const bool ok = a_off[i] >= 0 && c0 + a_c[i] < p.Ck;
+        return ok ? p.x + (size_t)(unsigned)(a_off[i] + c0) : zero;
+    };
+    auto b_src = [&](int i, int c0) -> const float* {
+        const bool ok = b_ok[i] && c0 + b_k[i] < (BWD ? p.Cout : p.Cin);
+        return ok ? wbase + (size_t)(unsigned)(b_off[i] + (BWD ? c0 : c0 * p.Cout)) : zero;
+    };
+    int is_stage = 0, is_c0 = s_beg * BK;                    // ring slot / channel base of the next step to issue
+    auto issue_piece = [&](int piece) {                      // piece 0..PA-1: A, PA..NP-1: B
+        const uint32_t st = lds_w + (uint32_t)(is_stage * ST_FL * 4);
+        if (piece < PA) conv_glds16(a_src(piece, is_c0), st + (uint32_t)(piece * 1024));
+        else            conv_glds16(b_src(piece - PA, is_c0), st + (uint32_t)(A_FL * 4 + (piece - PA) * 1024));
+    };
+    auto issue_advance = [&]() {
+        is_stage = is_stage + 1 == NST ? 0 : is_stage + 1;
+        is_c0 += BK;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float fa[2][TM][4], fb[2][TN][4];
+    auto read_frags = [&](int stage) {
+        const float* As = wsm + stage * ST_FL;
+        const float* Bs = As + A_FL;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int r = tm * 32 + l31;
+                const float4 v = reinterpret_cast<const float4*>(As)[r * 4 + ((2 * q + h) ^ ((r >> 2) & 3))];
+                fa[q][tm][0] = v.x; fa[q][tm][1] = v.y; fa[q][tm][2] = v.z; fa[q][tm][3] = v.w;
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int c = tn * 32 + l31;
+                if constexpr (BWD) {
+                    const float4 v = reinterpret_cast<const float4*>(Bs)[c * 4 + ((2 * q + h) ^ ((c >> 2) & 3))];
+                    fb[q][tn][0] = v.x; fb[q][tn][1] = v.y; fb[q][tn][2] = v.z; fb[q][tn][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[q][tn][j] = Bs[((8 * q + 4 * h + j) ^ h) * BN + c];
+                }
+            }
+        }
+    };
+    auto mma = [&](int q, int j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][tm][j], fb[q][tn][j], acc[tm][tn], 0, 0, 0);
+    };
+
+    // ---- the K loop: NST-1 steps of DMA in flight, the pieces of step k+NST-1 issued between the MFMA groups of step k ----------
+    if (n > 0) {
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < n) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) issue_piece(i);
+                issue_advance();
+            }
+        int k = 0, rd = 0;
+        for (; k + NST - 1 < n; ++k) {                      // steady state: steps k .. k+NST-2 are in flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
+            read_frags(rd);
+            rd = rd + 1 == NST ? 0 : rd + 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {                   // 8 MFMA groups (one per (q, j)); the NP pieces go out behind the first ones
+                mma(g >> 2, g & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g < NP) issue_piece(g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_advance();
+        }
+        for (; k < n; ++k) {                                // the last NST-1 steps: nothing left to issue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_frags(rd);
+            rd = rd + 1 == NST ? 0 : rd + 1;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) mma(g >> 2, g & 3);
+        }
+    }
+
+    // ---- the four partial tiles meet in LDS; wave w adds accumulator registers 4w..4w+3 (rows 8w + 4h + 0..3 of every 32-row
+    //      MFMA block) in wave order and stores them.  (A wave writes into ITS ring, which only it has been reading: no barrier
+    //      in front of the stores.)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wsm[((tm * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n_col = n0 + tn * 32 + l31;
+        if (n_col >= p.Cn) continue;
+        const float bv = p.bias ? p.bias[n_col] : 0.0f;
+        const bool affine = p.epi.gamma != nullptr;
+        float sc = 1.0f, sf = 0.0f;
+        if (affine) {
+            const float is = 1.0f / sqrtf(p.epi.var[n_col] + p.epi.eps);
+            sc = p.epi.gamma[n_col] * is;
+            sf = p.epi.beta[n_col] - p.epi.mean[n_col] * sc;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = wave * 4 + rr;
+                const int e = ((tm * TN + tn) * 16 + r) * 64 + lane;
+                float v = smem[0 * WAVE_FL + e];
+                v += smem[1 * WAVE_FL + e];
+                v += smem[2 * WAVE_FL + e];
+                v += smem[3 * WAVE_FL + e];
+                const int64_t m = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M) {
+                    float o = v + bv;
+                    if (affine) o = fmaf(o, sc, sf);
+                    if (p.epi.res) o += p.epi.res[m * p.epi.ldr + n_col];
+                    if (p.accumulate) o += p.y[m * p.ldy + n_col];
+                    p.y[m * p.ldy + n_col] = epi_act(o, p.epi.act);
+                }
+            }
+    }
+}
+
+// Tile / ring choice of conv1x1_ksplit_dma_kernel, from the measured table (profiles/r03_conv1x1_ksplit.txt; all six shapes x six
+// (TM, TN, NST) candidates at 2048 rows): the ring depth does not matter (3 vs 6 stages: +-0.5 us - the K loop is bound by the
+// MFMA chain of ONE wave per SIMD, not by bytes in flight), the tile does through the grid: 64x32 tiles while the grid stays within
+// ~one block per CU (960 -> 160: 160 blocks, 1280 -> 256: 256), 32x64 for the backward-data form (its B tile is row-major like A),
+// 32x32 tiles and two blocks per CU beyond that (960 -> 320: 640 blocks, 22.6 vs 24.5 us).
+struct KsplitCfg { int tm, tn, nst; };
+static KsplitCfg ksplit_choose(int64_t M, int Cn, bool bwd, int force)
+{
+    static const KsplitCfg cand[] = {{1, 1, 5}, {2, 1, 3}, {1, 2, 3}};
+    if (force >= 1 && force <= 3) return cand[force - 1];
+    const KsplitCfg c = bwd ? cand[2] : cand[1];
+    if (cdiv(M, 32 * c.tm) * cdiv(Cn, 32 * c.tn) > 288) return cand[0];
+    return c;
+}
+
 // split-K second stage: y[m][n] = epilogue(bias[n] + sum_z part[z][m][n]), z in fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int splits, int64_t M, int Cn,
                                                             const float* bias, float* y, int64_t ldy, Epilogue epi, int accumulate)
@@ -1773,6 +2007,7 @@ static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep 
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
 static thread_local int g_conv_direct1x1 = 1, g_direct_rows_max = 4096, g_direct_k_max = 640;   // pp_debug_set_conv_variant bit 23 switches the direct 1x1 kernel off (A/B)
+static thread_local int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
 static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
 static thread_local int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
@@ -1817,6 +2052,14 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
     return pl;
 }
 
+// Shape-level test of the in-block split-K pointwise kernel (the launcher adds the pointer / stride alignment checks; when those fail
+// although the workspace query answered 0, the tiled kernel runs as a single pass).
+static bool ksplit_shape_ok(int64_t M, int Cn, int Ck, int ntaps, int stride)
+{
+    return g_conv_ksplit && ntaps == 1 && stride == 1 && M <= g_direct_rows_max && Ck >= g_ksplit_k_min && Cn >= 32 && Cn <= 512 &&
+           Ck % 4 == 0 && Cn % 4 == 0;
+}
+
 // Partial-statistics rows a forward convolution with this plan writes (ConvParams::stats): one per wave row of the tile
 // grid, or one per block of the split-K reduce.  0: this shape cannot deliver statistics (the caller runs the plain BatchNorm).
 static int64_t splitk_stats_rows_per_block(int64_t M) { return M >= 8192 ? 64 : 16; }
@@ -1843,6 +2086,22 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n, vec);
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
+    }
+    // few-row, deep-K pointwise layers: in-block split-K over wave-private LDS-DMA rings (conv1x1_ksplit_dma_kernel)
+    if (ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride) && vec && !p.stats && p.bwd_stride <= 1 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
+        (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) && (int64_t)p.Cin * p.Cout < (1ll << 31) - (1ll << 24)) {
+        const KsplitCfg kc = ksplit_choose(p.M, p.Cn, BWD, g_conv_ksplit - 1);
+        p.splits = 1;
+        p.ks_per_split = 0;
+        p.part = nullptr;
+        p.n_tiles = (int)cdiv(p.Cn, 32 * kc.tn);
+        const dim3 grid((unsigned)(cdiv(p.M, 32 * kc.tm) * p.n_tiles));
+#define PP_KSPLIT(TM_, TN_, NST_) hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<TM_, TN_, NST_, BWD>), grid, dim3(kThreads), 0, st, p)
+        if (kc.tm == 1 && kc.tn == 1) PP_KSPLIT(1, 1, 5);
+        else if (kc.tm == 2)          PP_KSPLIT(2, 1, 3);
+        else                          PP_KSPLIT(1, 2, 3);
+#undef PP_KSPLIT
+        return check_launch("conv1x1_ksplit_dma_kernel");
     }
     // few-row pointwise layers: the direct kernel (no LDS staging, in-block split-K), see conv1x1_direct_kernel
     if (g_conv_direct1x1 && vec && !p.stats && p.taps.n == 1 && p.stride == 1 && p.bwd_stride <= 1 && p.M <= g_direct_rows_max &&
@@ -2100,6 +2359,8 @@ void pp_debug_set_conv_variant(int v)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
     g_conv_direct1x1 = (v & 8388608) ? 0 : 1;   // bit 23: direct (LDS-free) kernel of the few-row 1x1 layers off (A/B)
     g_bwd_phases = (v & 16777216) ? 0 : 1;      // bit 24: strided backward-data as one masked-tap launch instead of s*s phase problems
+    g_conv_ksplit = (v & (1 << 25)) ? 0 : 1 + ((v >> 26) & 7);   // bit 25: in-block split-K LDS-DMA 1x1 kernel off; bits 26-28: force tile candidate 1..3 (0: the rule)
+    { const int kc[4] = {256, 768, 512, 384}; g_ksplit_k_min = kc[(v >> 29) & 3]; }   // bits 29-30: K threshold 256 (default) / 768 / 512 / 384 (A/B)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
 }
@@ -2112,6 +2373,7 @@ size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int
     ConvTaps t;
     build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     const int64_t M = (int64_t)B * Ho * Wo;
+    if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) return 0;             // in-block split-K: no partial sums leave the block
     const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cout * 4, 256) : 0;
 }
@@ -2124,7 +2386,8 @@ int64_t pp_conv2d_fwd_stats_rows(int B, int H, int W, int Cin, int Cout, int kh,
     ConvTaps t;
     build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     const int64_t M = (int64_t)B * Ho * Wo;
-    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+    ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+    if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) pl.splits = 1;      // no workspace is offered for these shapes: single pass (see conv2d_fwd_impl)
     return conv_stats_rows(pl, M, Cout);
 }
 
@@ -2214,6 +2477,7 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
     const int64_t M = (int64_t)B * H * W;
     const ConvPlan pl = plan_conv(M, Cin, Cout, t.n, Cin % 4 == 0 && Cout % 4 == 0);
     size_t need = pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
+    if (ksplit_shape_ok(M, Cin, Cout, t.n, stride)) need = 0;            // in-block split-K (stride 1 only)
     if (bwd_phases_apply(Cin, Cout, stride, 4)) {
         size_t slabs = 0;
         need = std::max(need, bwd_phases_workspace(B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, &slabs));
@@ -2242,9 +2506,12 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
         if (rows <= 0) return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape delivers no BatchNorm statistics");
         if (stats_floats < (size_t)rows * 2 * Cout) return fail(PP_ERR_WORKSPACE, "conv fwd: statistics buffer too small");
         const ConvPlan pl = plan_conv(p.M, Cout, Cin, p.taps.n, Cin % 4 == 0 && Cout % 4 == 0);
+        p.stats = stats;
+        // layers the in-block split-K kernel serves get no workspace (pp_conv2d_fwd_workspace_bytes == 0) and that kernel
+        // writes no statistics: with statistics requested they run the tiled kernel as ONE pass (rows = its wave rows)
+        if (ksplit_shape_ok(p.M, Cout, Cin, p.taps.n, stride)) return launch_conv<false>(p, nullptr, 0, as_stream(stream));
         if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * Cout * 4))
             return fail(PP_ERR_WORKSPACE, "conv fwd: the split-K workspace is required when statistics are requested");
-        p.stats = stats;
     }
     return launch_conv<false>(p, workspace, ws_bytes, as_stream(stream));
 }

@@ -78,6 +78,11 @@ CONV_CASES = [
     (2, 15, 17, 384, 68, 1, 1, 0, 1, False),      # Cout not a multiple of 32
     (2, 23, 30, 320, 256, 3, 1, 12, 12, False),   # atrous d=12 at CamVid size
     (2, 17, 22, 160, 960, 1, 1, 0, 1, False),
+    # deep-K few-row pointwise layers -> conv1x1_ksplit_dma_kernel (K >= 768): ragged K (not a multiple of 16), ragged rows, a
+    # partial 32-column tile, bias; the mirrored shape sends the backward-data through it
+    (2, 9, 13, 776, 68, 1, 1, 0, 1, True),
+    (2, 9, 13, 68, 776, 1, 1, 0, 1, False),
+    (3, 11, 7, 1284, 36, 1, 1, 1, 1, True),       # folded padding: border rows read zeros
     (4, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead conv1 at bench scale: the 128x128 large-tile kernels
     (3, 50, 100, 256, 304, 3, 1, 1, 1, True),     # large tile, ragged M (15000 rows), Cout=304 (partial N tile)
 ]
@@ -227,7 +232,17 @@ def test_conv2d_split_k_matches_single_pass(case):
     from pixelpick_amd import _lib
     L = _lib.lib()
     B, H, W, Cin, Cout, k, stride, pad, dil = case
-    assert L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad, dil) > 0, "case does not split"
+    KSPLIT_OFF = 1 << 25
+    # deep-K pointwise layers split K INSIDE the block (conv1x1_ksplit_dma_kernel: no workspace); switched off, the tiled kernel
+    # slices K over grid.y - both must agree with the single pass
+    in_block = L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad, dil) == 0
+    if in_block:
+        assert k == 1 and Cin >= 256, "case does not split"
+        L.pp_debug_set_conv_variant(KSPLIT_OFF)
+        try:
+            assert L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad, dil) > 0, "case does not split"
+        finally:
+            L.pp_debug_set_conv_variant(0)
     torch.manual_seed(3)
     x = torch.randn(B, H, W, Cin, device=DEV)
     w = torch.randn(k, k, Cin, Cout, device=DEV) / np.sqrt(Cin * k * k)
@@ -251,7 +266,7 @@ def test_conv2d_split_k_matches_single_pass(case):
     y1, dx1 = run()
     y2, dx2 = run()
     assert torch.equal(y1, y2) and (dx1 is None or torch.equal(dx1, dx2))
-    L.pp_debug_set_conv_variant(64)          # split-K off
+    L.pp_debug_set_conv_variant(64 | KSPLIT_OFF)          # split-K off (both forms)
     try:
         y0, dx0 = run()
     finally:
@@ -259,6 +274,16 @@ def test_conv2d_split_k_matches_single_pass(case):
     close(y1, y0, tol=2e-5, what="split-K fwd vs single pass")
     if dx1 is not None:
         close(dx1, dx0, tol=2e-5, what="split-K bwd-data vs single pass")
+    if in_block:
+        L.pp_debug_set_conv_variant(KSPLIT_OFF)           # the grid.y split-K + reduce form of the same layer
+        try:
+            y3, dx3 = run()
+            y4, dx4 = run()
+        finally:
+            L.pp_debug_set_conv_variant(0)
+        assert torch.equal(y3, y4) and torch.equal(dx3, dx4)
+        close(y3, y0, tol=2e-5, what="grid split-K fwd vs single pass")
+        close(dx3, dx0, tol=2e-5, what="grid split-K bwd-data vs single pass")
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.permute(3, 2, 0, 1).cpu(), bias.cpu(), stride, pad, dil)
     close(nchw(y1), ref, what="split-K fwd vs torch")
 
@@ -499,7 +524,12 @@ def test_conv_epilogue_statistics_feed_the_batchnorm(shape, act, with_res, drop,
         outs[mode] = dict(conv=cv.t.clone(), y=yv.t.clone(), rm=rm, rv=rv, dx=xv.grad.clone(), dw=tape.param_grads[id(w)].clone(),
                           dg=tape.param_grads[id(gamma)].clone(), db=tape.param_grads[id(beta)].clone())
     a, b = outs[True], outs[False]
-    assert torch.equal(a["conv"], b["conv"])                               # the epilogue does not change what is stored
+    if k == 1 and Cin >= 256 and B * Ho * Wo <= 4096 and Cout <= 512:
+        # without statistics these layers run the in-block split-K kernel, with them the tiled kernel in one pass: same sums in
+        # another order
+        close(a["conv"], b["conv"], tol=2e-5, what="conv")
+    else:
+        assert torch.equal(a["conv"], b["conv"])                           # the epilogue does not change what is stored
     assert torch.equal(a["y"] == 0, b["y"] == 0) or drop == 0.0            # same dropout mask (same seed stream)
     for key, tol in (("y", 2e-5), ("rm", 2e-6), ("rv", 2e-6), ("dx", 5e-5), ("dw", 5e-5), ("dg", 5e-5), ("db", 5e-5)):
         close(a[key], b[key], tol=tol, what=key)
