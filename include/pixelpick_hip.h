@@ -144,6 +144,35 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
                   int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
                   size_t ws_bytes, pp_stream_t stream);
 
+/* ---- training BatchNorm split over its neighbours (SURVEY.md 7 hard part (b); mobilenet_v2.py:42-56: pw -> BN -> ReLU6 -> dw ->
+ * BN -> ReLU6 -> pw).  The producer's epilogue delivers partial column statistics (pp_conv2d_fwd_stats, pp_dwconv3x3_fwd_fused),
+ * pp_bn_finalize_partials turns them into mean / invstd / running statistics and the folded per-channel scale / shift, and the
+ * CONSUMER applies act(fma(x, scale, shift)) where it loads its input (pp_dwconv3x3_fwd_fused, pp_conv2d_fwd_affine_in,
+ * pp_dwconv3x3_bwd_weight_affine_in): the normalised tensor is never written.  Arithmetic = pp_scale_shift_act's, so a consumer of
+ * the raw tensor + (scale, shift, act) computes what it would compute from the materialised tensor, bit for bit.
+ *   pp_bn_finalize_partials            stats [rows][2][C] (sum, sum of squares) over M rows -> mean, invstd, scale = gamma*invstd,
+ *                                      shift = beta - mean*scale, running-stat update (nn.BatchNorm2d training semantics)
+ *   pp_dwconv3x3_fwd_stats_rows        partial rows pp_dwconv3x3_fwd_fused writes for this shape
+ *   pp_dwconv3x3_fwd_fused             depthwise 3x3 with optional input affine (in_scale may be NULL) and optional output statistics
+ *   pp_dwconv3x3_bwd_weight_affine_in  pp_dwconv3x3_bwd_weight on x = act(fma(x_raw, in_scale, in_shift))
+ *   pp_conv2d_fwd_accepts_affine_in    1 when pp_conv2d_fwd_affine_in has a kernel for this shape (stride-1 pad-0 pointwise layers:
+ *                                      the in-block split-K kernel, or the 128x32-tiled kernel for <= 32 output channels)
+ *   pp_conv2d_fwd_affine_in            pp_conv2d_fwd on x = act(fma(x_raw, in_scale, in_shift)); fails (no fallback) on other shapes */
+int pp_bn_finalize_partials(const float* stats, int64_t rows, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                            float* shift, pp_stream_t stream);
+int64_t pp_dwconv3x3_fwd_stats_rows(int B, int H, int W, int C, int stride, int pad, int dil);
+int pp_dwconv3x3_fwd_fused(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
+                           const float* in_scale, const float* in_shift, int in_act, float* y, int64_t ldy, float* stats,
+                           size_t stats_floats, pp_stream_t stream);
+int pp_dwconv3x3_bwd_weight_affine_in(const float* x_raw, int64_t ldx, int B, int H, int W, int C, const float* in_scale,
+                                      const float* in_shift, int in_act, const float* dy, int64_t lddy, int stride, int pad, int dil,
+                                      float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream);
+int pp_conv2d_fwd_accepts_affine_in(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pp_conv2d_fwd_affine_in(const float* x_raw, int64_t ldx, int B, int H, int W, int Cin, const float* in_scale, const float* in_shift,
+                            int in_act, const float* w, const float* bias, int kh, int kw, int stride, int pad, int dil, float* y,
+                            int64_t ldy, int Cout, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
 /* Inference form of Conv2d -> BatchNorm2d(eval) [-> + residual] -> ReLU/ReLU6 in ONE launch (mobilenet_v2.py:7-12,
  * 36-57; aspp.py:9-20; decoders.py:107-113; resnet_models.py:71-92): the epilogue folds scale = gamma/sqrt(running_var+eps),
  * shift = beta - running_mean*scale with the arithmetic of pp_bn_eval_affine + pp_scale_shift_act (bit-identical results).

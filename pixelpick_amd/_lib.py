@@ -38,6 +38,12 @@ SIGNATURES = {
     "pp_conv2d_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int,
                                     _p, _i64, _int, _p, _sz, _p]),
     "pp_dwconv3x3_fwd_bn_act": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _p, _p, _p, _f, _p, _i64, _int, _p, _i64, _p]),
+    "pp_bn_finalize_partials": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "pp_dwconv3x3_fwd_stats_rows": (_i64, [_int] * 7),
+    "pp_dwconv3x3_fwd_fused": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _p, _int, _p, _i64, _p, _sz, _p]),
+    "pp_dwconv3x3_bwd_weight_affine_in": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p]),
+    "pp_conv2d_fwd_accepts_affine_in": (_int, [_int] * 10),
+    "pp_conv2d_fwd_affine_in": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_weight_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p]),
@@ -143,7 +149,7 @@ _NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_f
 
 
 def _is_launch(name: str) -> bool:
-    return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints")))
+    return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in")))
 
 
 class LaunchPlan:

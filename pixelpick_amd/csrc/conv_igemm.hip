@@ -65,6 +65,9 @@ struct ConvParams {
     Epilogue epi;     // inference only: folded BatchNorm + residual + activation (all NULL / 0 in training)
     int accumulate;   // y += result (backward-data into a gradient that already holds the residual branch's part)
     int tap_inner;    // K loop order (A/B knob)
+    const float* in_scale;   // forward of a 1x1 / pad-0 convolution BEHIND a training BatchNorm whose apply pass was skipped: the A
+    const float* in_shift;   // operand is act(fma(x, in_scale[c], in_shift[c])) (bn_apply_kernel's arithmetic), applied where the
+    int in_act;              // operand is read.  NULL: x as it is.  (conv_igemm_kernel VEC path, conv1x1_ksplit_dma_kernel)
     float* stats;     // training forward in front of a BatchNorm: per-wave column sums / sums of squares of the stored outputs,
                       // [rows_partial][2][Cn], rows_partial = m0 / (TM*32) + wm (see conv_epilogue); NULL: none
     ConvTaps taps;
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
     struct Regs {
         float4 a[A_F4], b[B_F4];
         unsigned ok;       // VEC: bit i = a[i] valid, bit 8+i = b[i] valid
+        int c0;            // channel base of the K step these registers hold
     };
     Regs R0;
 
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         }
         const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
         const int wt = p.taps.widx[ti];
+        R.c0 = c0;
         if constexpr (VEC) {
             okmask = 0;
 #pragma unroll
@@ -391,8 +396,21 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         float4 (&ra)[A_F4] = R.a;
         float4 (&rb)[B_F4] = R.b;
         const unsigned okmask = R.ok;
+        const int st_c0 = R.c0;
         if constexpr (VEC) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!BWD && p.in_scale) {
+                // producer BatchNorm + activation on load (st_c0: the channel base of the step these registers hold)
+                const int c = st_c0 + a_kq * 4;
+                if (c < p.Ck) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + c), sf = *reinterpret_cast<const float4*>(p.in_shift + c);
+#pragma unroll
+                    for (int i = 0; i < A_F4; ++i) {
+                        ra[i].x = epi_act(fmaf(ra[i].x, sc.x, sf.x), p.in_act); ra[i].y = epi_act(fmaf(ra[i].y, sc.y, sf.y), p.in_act);
+                        ra[i].z = epi_act(fmaf(ra[i].z, sc.z, sf.z), p.in_act); ra[i].w = epi_act(fmaf(ra[i].w, sc.w, sf.w), p.in_act);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < A_F4; ++i)
                 if (!((okmask >> i) & 1u)) ra[i] = z;
@@ -888,16 +906,19 @@ __global__ __launch_bounds__(kThreads) void conv1x1_direct_kernel(ConvParams p)
 //   B operand backward (W[n][k], k contiguous): NK form [32 n][16 k], swizzled like A
 // Measured (960 -> 160 at 2048 rows): 15.3-15.8 us whatever the tile / ring depth (23.6 for split-K + reduce, 26.7 for the direct
 // kernel); floor of the design = 6.4 us of MFMA work on the busiest CU + launch, first round trip and the reduce / store tail.
-template <int TM, int TN, int NST, bool BWD>
+template <int TM, int TN, int NST, bool BWD, bool AFF = false>
 __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvParams p)
 {
+    // AFF: p.in_scale / in_shift / in_act (the producer's training BatchNorm + activation) applied to the A fragments as they
+    // are read; the wave keeps the scale / shift entries of ITS K slice in a private LDS table (<= 2 x 512 floats)
+    constexpr int TBL = AFF ? 512 : 0;
     constexpr int A_FL = TM * 32 * BK, B_FL = BK * TN * 32, ST_FL = A_FL + B_FL;
     constexpr int PA = TM * 2, PB = TN * 2, NP = PA + PB;    // 1-KiB pieces per wave and K step
     constexpr int WAVE_FL = NST * ST_FL;
     constexpr int BN = TN * 32;
     static_assert(WAVE_FL >= TM * TN * 16 * 64, "the final reduction reuses a wave's ring");
     static_assert(NP <= 8 && (NST - 2) * NP < 64, "pieces are issued behind the eight MFMA groups; vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(1024))) float smem[4 * WAVE_FL];
+    __shared__ __attribute__((aligned(1024))) float smem[4 * WAVE_FL + 4 * 2 * TBL + 4];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -982,6 +1003,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    float* tbl = smem + 4 * WAVE_FL + wave * 2 * TBL;        // [0, TBL): scale, [TBL, 2 TBL): shift of channels s_beg*16 ...
+    if constexpr (AFF) {
+        for (int i = lane; i < per * BK; i += 64) {
+            const int c = s_beg * BK + i;
+            tbl[i] = c < p.Ck ? p.in_scale[c] : 0.0f;
+            tbl[TBL + i] = c < p.Ck ? p.in_shift[c] : 0.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // before the counted DMA waits start; wave-private: no barrier
+    }
+    int tbl_k = 0;                                           // table offset of the step whose fragments are read next
+
     float fa[2][TM][4], fb[2][TN][4];
     auto read_frags = [&](int stage) {
         const float* As = wsm + stage * ST_FL;
@@ -993,6 +1025,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
                 const int r = tm * 32 + l31;
                 const float4 v = reinterpret_cast<const float4*>(As)[r * 4 + ((2 * q + h) ^ ((r >> 2) & 3))];
                 fa[q][tm][0] = v.x; fa[q][tm][1] = v.y; fa[q][tm][2] = v.z; fa[q][tm][3] = v.w;
+            }
+            if constexpr (AFF) {
+                const float4 sc = *reinterpret_cast<const float4*>(tbl + tbl_k + 8 * q + 4 * h);
+                const float4 sf = *reinterpret_cast<const float4*>(tbl + TBL + tbl_k + 8 * q + 4 * h);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    fa[q][tm][0] = epi_act(fmaf(fa[q][tm][0], sc.x, sf.x), p.in_act);
+                    fa[q][tm][1] = epi_act(fmaf(fa[q][tm][1], sc.y, sf.y), p.in_act);
+                    fa[q][tm][2] = epi_act(fmaf(fa[q][tm][2], sc.z, sf.z), p.in_act);
+                    fa[q][tm][3] = epi_act(fmaf(fa[q][tm][3], sc.w, sf.w), p.in_act);
+                }
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
@@ -1029,6 +1072,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
             read_frags(rd);
             rd = rd + 1 == NST ? 0 : rd + 1;
+            tbl_k += BK;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {                   // 8 MFMA groups (one per (q, j)); the NP pieces go out behind the first ones
@@ -1043,6 +1087,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             read_frags(rd);
             rd = rd + 1 == NST ? 0 : rd + 1;
+            tbl_k += BK;
 #pragma unroll
             for (int g = 0; g < 8; ++g) mma(g >> 2, g & 3);
         }
@@ -2088,8 +2133,16 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         pl.splits = 1;                   // no (or too small a) workspace: single pass
     }
     // few-row, deep-K pointwise layers: in-block split-K over wave-private LDS-DMA rings (conv1x1_ksplit_dma_kernel)
-    if (ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride) && vec && !p.stats && p.bwd_stride <= 1 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
-        (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) && (int64_t)p.Cin * p.Cout < (1ll << 31) - (1ll << 24)) {
+    const bool use_ksplit = ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride) && vec && !p.stats && p.bwd_stride <= 1 && p.Cout % 4 == 0 &&
+                            p.ldx % 4 == 0 && (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) &&
+                            (int64_t)p.Cin * p.Cout < (1ll << 31) - (1ll << 24) && !(p.in_scale && p.Ck > 2048);
+    if (p.in_scale) {
+        // the producer's BatchNorm is applied where the A operand is read: only kernels that do so may run (no silent fallback)
+        const bool pad0 = p.taps.n == 1 && p.taps.dh[0] == 0 && p.taps.dw[0] == 0 && p.stride == 1;
+        if (BWD || !pad0 || !(use_ksplit || (pl.cfg == 0 && vec)))
+            return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape has no input-affine kernel (ask pp_conv2d_fwd_accepts_affine_in first)");
+    }
+    if (use_ksplit) {
         const KsplitCfg kc = ksplit_choose(p.M, p.Cn, BWD, g_conv_ksplit - 1);
         p.splits = 1;
         p.ks_per_split = 0;
@@ -2097,9 +2150,16 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         p.n_tiles = (int)cdiv(p.Cn, 32 * kc.tn);
         const dim3 grid((unsigned)(cdiv(p.M, 32 * kc.tm) * p.n_tiles));
 #define PP_KSPLIT(TM_, TN_, NST_) hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<TM_, TN_, NST_, BWD>), grid, dim3(kThreads), 0, st, p)
+#define PP_KSPLIT_AFF(TM_, TN_, NST_) hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<TM_, TN_, NST_, false, true>), grid, dim3(kThreads), 0, st, p)
+        if (!BWD && p.in_scale) {
+            if (kc.tm == 1 && kc.tn == 1) PP_KSPLIT_AFF(1, 1, 4);          // (one stage less: the tables must fit beside two blocks per CU)
+            else if (kc.tm == 2)          PP_KSPLIT_AFF(2, 1, 3);
+            else                          PP_KSPLIT_AFF(1, 2, 3);
+        } else
         if (kc.tm == 1 && kc.tn == 1) PP_KSPLIT(1, 1, 5);
         else if (kc.tm == 2)          PP_KSPLIT(2, 1, 3);
         else                          PP_KSPLIT(1, 2, 3);
+#undef PP_KSPLIT_AFF
 #undef PP_KSPLIT
         return check_launch("conv1x1_ksplit_dma_kernel");
     }
@@ -2487,7 +2547,8 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
 
 static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                            int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, const Epilogue& epi,
-                           void* workspace, size_t ws_bytes, pp_stream_t stream, float* stats = nullptr, size_t stats_floats = 0)
+                           void* workspace, size_t ws_bytes, pp_stream_t stream, float* stats = nullptr, size_t stats_floats = 0,
+                           const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0)
 {
     if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
@@ -2498,6 +2559,7 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Ck = Cin; p.Cn = Cout; p.Cin = Cin; p.Cout = Cout;
     p.stride = stride; p.M = (int64_t)B * Ho * Wo; p.bwd_stride = 1;
     p.epi = epi;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
@@ -2523,6 +2585,28 @@ int pp_conv2d_fwd_stats(const float* x, int64_t ldx, int B, int H, int W, int Ci
     if (!stats) return fail(PP_ERR_BAD_ARG, "conv fwd: stats is null");
     return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
                            ws_bytes, stream, stats, stats_floats);
+}
+
+int pp_conv2d_fwd_accepts_affine_in(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 4 || Cout < 1 || kh != 1 || kw != 1 || stride != 1 || pad != 0 || dil < 1) return 0;
+    if (Cin % 4 || Cout % 4) return 0;
+    const int64_t M = (int64_t)B * H * W;
+    if (ksplit_shape_ok(M, Cout, Cin, 1, 1) && Cin <= 2048) return 1;
+    return plan_conv(M, Cout, Cin, 1, true).cfg == 0 ? 1 : 0;
+}
+
+int pp_conv2d_fwd_affine_in(const float* x_raw, int64_t ldx, int B, int H, int W, int Cin, const float* in_scale, const float* in_shift,
+                            int in_act, const float* w, const float* bias, int kh, int kw, int stride, int pad, int dil, float* y,
+                            int64_t ldy, int Cout, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!in_scale || !in_shift || in_act < 0 || in_act > 2) return fail(PP_ERR_BAD_ARG, "conv fwd: input affine");
+    if (!pp_conv2d_fwd_accepts_affine_in(B, H, W, Cin, Cout, kh, kw, stride, pad, dil))
+        return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape has no input-affine kernel");
+    if ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 15)
+        return fail(PP_ERR_BAD_ARG, "conv fwd: input affine vectors must be 16-byte aligned");
+    return conv2d_fwd_impl(x_raw, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace, ws_bytes,
+                           stream, nullptr, 0, in_scale, in_shift, in_act);
 }
 
 int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,

@@ -199,6 +199,49 @@ __global__ __launch_bounds__(kT) void bn_finalize_kernel(const float* part, int 
     }
 }
 
+// The same finalize for partial rows written by a convolution's epilogue (hundreds to thousands of rows): one block per channel
+// QUAD, 256 row lanes with 16-byte loads, fp64 lane sums combined by a fixed-order LDS tree.
+__global__ __launch_bounds__(kT) void bn_finalize_quad_kernel(const float* part, int nblk, int C, double count, const float* gamma,
+                                                             const float* beta, float eps, float momentum, float* running_mean,
+                                                             float* running_var, float* mean, float* invstd, float* scale, float* shift)
+{
+    __shared__ double sh[2][4][kT];
+    const int q = blockIdx.x, t = threadIdx.x;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = t; b < nblk; b += kT) {
+        const float4 a = *reinterpret_cast<const float4*>(part + ((int64_t)b * 2 + 0) * C + q * 4);
+        const float4 c = *reinterpret_cast<const float4*>(part + ((int64_t)b * 2 + 1) * C + q * 4);
+        s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
+        ss[0] += (double)c.x; ss[1] += (double)c.y; ss[2] += (double)c.z; ss[3] += (double)c.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[0][j][t] = s[j]; sh[1][j][t] = ss[j]; }
+    __syncthreads();
+    for (int off = kT / 2; off >= 1; off >>= 1) {
+        if (t < off) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sh[0][j][t] += sh[0][j][t + off]; sh[1][j][t] += sh[1][j][t + off]; }
+        }
+        __syncthreads();
+    }
+    if (t >= 4) return;
+    const int c = q * 4 + t;
+    const double mu = sh[0][t][0] / count;
+    double var = sh[1][t][0] / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 // eval-mode BN: scale/shift from running statistics
 __global__ __launch_bounds__(kT) void bn_eval_affine_kernel(int C, const float* gamma, const float* beta,
                                                            const float* running_mean, const float* running_var,
@@ -1054,6 +1097,130 @@ __global__ __launch_bounds__(kT) void dwconv_s1_x4_kernel(const float* x, int64_
     }
 }
 
+// Depthwise forward BETWEEN two training BatchNorms (mobilenet_v2.py:48-56: pw -> BN -> ReLU6 -> dw -> BN -> ReLU6 -> pw):
+//   * in_scale / in_shift / in_act (optional): the producer's BatchNorm + activation applied WHERE THE INPUT IS LOADED,
+//     v = act(fma(x, scale, shift)) - the arithmetic of bn_apply_kernel, so the sums equal those over the materialised tensor
+//     bit for bit; taps that fall into the zero padding stay zero (the padding is applied to the activated tensor);
+//   * stats (optional): column sums / sums of squares of the outputs this block stores -> stats[blockIdx.x][2][C] (the partial
+//     rows bn_finalize_kernel combines), so the BatchNorm BEHIND this convolution needs no statistics pass either.
+// Thread map as col_reduce_kernel (a thread keeps ONE channel quad, its sums stay in registers; consecutive threads walk the
+// channel axis).  X4: one work item = four neighbouring outputs of a row (stride 1, dilation 1; 18 loads per item).
+template <bool X4>
+__global__ __launch_bounds__(kT) void dwconv_fwd_fused_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq, const float* w,
+                                                             int stride, int pad, int dil, const float* in_scale, const float* in_shift,
+                                                             int in_act, float* y, int64_t ldy, int Ho, int Wo, ColReduceGeom g,
+                                                             float* stats)
+{
+    __shared__ float4 sh[2][kT];
+    const int C = cq * 4;
+    const int t = threadIdx.x;
+    const int ql = t % g.cq_blk, ry = t / g.cq_blk;
+    const int q = blockIdx.y * g.cq_blk + ql;
+    const bool active = ry < g.rows_per_pass && q < cq;
+    const int wq = X4 ? (Wo + 3) / 4 : Wo;
+    const int64_t items = (int64_t)B * Ho * wq;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (active) {
+        float4 ww[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ww[k] = *reinterpret_cast<const float4*>(w + k * C + q * 4);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool aff = in_scale != nullptr;
+        if (aff) {
+            sc = *reinterpret_cast<const float4*>(in_scale + q * 4);
+            sf = *reinterpret_cast<const float4*>(in_shift + q * 4);
+        }
+        auto ld = [&](const float* ptr) -> float4 {
+            float4 v = *reinterpret_cast<const float4*>(ptr);
+            if (aff) {
+                v.x = act_fwd(fmaf(v.x, sc.x, sf.x), in_act); v.y = act_fwd(fmaf(v.y, sc.y, sf.y), in_act);
+                v.z = act_fwd(fmaf(v.z, sc.z, sf.z), in_act); v.w = act_fwd(fmaf(v.w, sc.w, sf.w), in_act);
+            }
+            return v;
+        };
+        const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
+        const int64_t r1 = r0 + g.rows_per_block < items ? r0 + g.rows_per_block : items;
+        for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
+            const unsigned ru = (unsigned)r;                         // items < 2^31 (checked on the host)
+            const unsigned tt = ru / (unsigned)wq;
+            const int owq = (int)(ru - tt * (unsigned)wq);
+            const int b = (int)(tt / (unsigned)Ho);
+            const int oh = (int)(tt - (unsigned)b * (unsigned)Ho);
+            if constexpr (X4) {
+                const int ow0 = owq * 4;
+                float4 acc[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int th = 0; th < 3; ++th) {
+                    const int ih = oh - pad + th;
+                    if ((unsigned)ih >= (unsigned)H) continue;
+                    const float* row = x + ((int64_t)b * H + ih) * W * ldx + q * 4;
+                    float4 v[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int iw = ow0 - pad + j;
+                        v[j] = (unsigned)iw < (unsigned)W ? ld(row + (int64_t)iw * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int tw = 0; tw < 3; ++tw) {
+                        const float4 wk = ww[th * 3 + tw];
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            acc[o].x = fmaf(v[o + tw].x, wk.x, acc[o].x); acc[o].y = fmaf(v[o + tw].y, wk.y, acc[o].y);
+                            acc[o].z = fmaf(v[o + tw].z, wk.z, acc[o].z); acc[o].w = fmaf(v[o + tw].w, wk.w, acc[o].w);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    if (ow0 + o >= Wo) break;
+                    const int64_t ro = ((int64_t)b * Ho + oh) * Wo + ow0 + o;
+                    *reinterpret_cast<float4*>(y + ro * ldy + q * 4) = acc[o];
+                    s1.x += acc[o].x; s1.y += acc[o].y; s1.z += acc[o].z; s1.w += acc[o].w;
+                    s2.x = fmaf(acc[o].x, acc[o].x, s2.x); s2.y = fmaf(acc[o].y, acc[o].y, s2.y);
+                    s2.z = fmaf(acc[o].z, acc[o].z, s2.z); s2.w = fmaf(acc[o].w, acc[o].w, s2.w);
+                }
+            } else {
+                const int ow = owq;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int th = 0; th < 3; ++th) {
+                    const int ih = oh * stride - pad + th * dil;
+                    if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+                    for (int tw = 0; tw < 3; ++tw) {
+                        const int iw = ow * stride - pad + tw * dil;
+                        if ((unsigned)iw >= (unsigned)W) continue;
+                        const float4 v = ld(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
+                        const float4 wk = ww[th * 3 + tw];
+                        acc.x = fmaf(v.x, wk.x, acc.x); acc.y = fmaf(v.y, wk.y, acc.y);
+                        acc.z = fmaf(v.z, wk.z, acc.z); acc.w = fmaf(v.w, wk.w, acc.w);
+                    }
+                }
+                const int64_t ro = ((int64_t)b * Ho + oh) * Wo + ow;
+                *reinterpret_cast<float4*>(y + ro * ldy + q * 4) = acc;
+                s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+                s2.x = fmaf(acc.x, acc.x, s2.x); s2.y = fmaf(acc.y, acc.y, s2.y);
+                s2.z = fmaf(acc.z, acc.z, s2.z); s2.w = fmaf(acc.w, acc.w, s2.w);
+            }
+        }
+    }
+    if (!stats) return;
+    sh[0][t] = s1;
+    sh[1][t] = s2;
+    __syncthreads();
+    if (ry == 0 && q < cq) {
+        for (int k = 1; k < g.rows_per_pass; ++k) {            // fixed order over the row lanes
+            const float4 a = sh[0][k * g.cq_blk + ql], b2 = sh[1][k * g.cq_blk + ql];
+            s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+            s2.x += b2.x; s2.y += b2.y; s2.z += b2.z; s2.w += b2.w;
+        }
+        *reinterpret_cast<float4*>(stats + ((int64_t)blockIdx.x * 2 + 0) * C + q * 4) = s1;
+        *reinterpret_cast<float4*>(stats + ((int64_t)blockIdx.x * 2 + 1) * C + q * 4) = s2;
+    }
+}
+
 // dx(ih,iw) = sum_t dy((ih + pad - th*dil)/stride, ...) * w[t]  where divisible
 __global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq,
                                                             const float* w, int stride, int pad, int dil, float* dx,
@@ -1090,7 +1257,8 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, in
 // dw[t][c] = sum_{b,oh,ow} x[..]*dy[..]: per row-block partials [nblk][9][C], then fixed-order finalize
 __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
                                                               const float* dy, int64_t lddy, int Ho, int Wo, int stride,
-                                                              int pad, int dil, ColReduceGeom g, float* part)
+                                                              int pad, int dil, ColReduceGeom g, float* part,
+                                                              const float* in_scale, const float* in_shift, int in_act)
 {
     __shared__ float4 sh[kT];
     const int C = cq * 4;
@@ -1103,6 +1271,9 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, i
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
+        const bool aff = in_scale != nullptr;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aff) { sc = *reinterpret_cast<const float4*>(in_scale + q * 4); sf = *reinterpret_cast<const float4*>(in_shift + q * 4); }
         const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
         const int64_t r1 = r0 + g.rows_per_block < M ? r0 + g.rows_per_block : M;
         for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
@@ -1120,7 +1291,11 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, i
                 for (int tw = 0; tw < 3; ++tw) {
                     const int iw = ow * stride - pad + tw * dil;
                     if ((unsigned)iw >= (unsigned)W) continue;
-                    const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
+                    float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
+                    if (aff) {               // x is act(bn(raw)) of the producer, applied on load (see dwconv_fwd_fused_kernel)
+                        v.x = act_fwd(fmaf(v.x, sc.x, sf.x), in_act); v.y = act_fwd(fmaf(v.y, sc.y, sf.y), in_act);
+                        v.z = act_fwd(fmaf(v.z, sc.z, sf.z), in_act); v.w = act_fwd(fmaf(v.w, sc.w, sf.w), in_act);
+                    }
                     float4& a = acc[th * 3 + tw];
                     a.x = fmaf(v.x, gg.x, a.x); a.y = fmaf(v.y, gg.y, a.y);
                     a.z = fmaf(v.z, gg.z, a.z); a.w = fmaf(v.w, gg.w, a.w);
@@ -1150,7 +1325,8 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, i
 // (the one-pixel kernel needed 512 row blocks on a 2048-pixel map to hide its latency: 17.7 MB of partials for 7.8 MB of x).
 __global__ __launch_bounds__(kT) void dwconv_bwd_weight_x4_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
                                                                  const float* dy, int64_t lddy, int Ho, int Wo, int pad,
-                                                                 ColReduceGeom g, float* part)
+                                                                 ColReduceGeom g, float* part,
+                                                                 const float* in_scale, const float* in_shift, int in_act)
 {
     __shared__ float4 sh[kT];
     const int C = cq * 4;
@@ -1164,6 +1340,9 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_x4_kernel(const float* x
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
+        const bool aff = in_scale != nullptr;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aff) { sc = *reinterpret_cast<const float4*>(in_scale + q * 4); sf = *reinterpret_cast<const float4*>(in_shift + q * 4); }
         const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_block;
         const int64_t r1 = r0 + g.rows_per_block < M4 ? r0 + g.rows_per_block : M4;
         for (int64_t r = r0 + ry; r < r1; r += g.rows_per_pass) {
@@ -1187,6 +1366,10 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_weight_x4_kernel(const float* x
                     const int iw = ow0 - pad + j;
                     v[j] = (unsigned)iw < (unsigned)W ? *reinterpret_cast<const float4*>(row + (int64_t)iw * ldx)
                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (aff && (unsigned)iw < (unsigned)W) {
+                        v[j].x = act_fwd(fmaf(v[j].x, sc.x, sf.x), in_act); v[j].y = act_fwd(fmaf(v[j].y, sc.y, sf.y), in_act);
+                        v[j].z = act_fwd(fmaf(v[j].z, sc.z, sf.z), in_act); v[j].w = act_fwd(fmaf(v[j].w, sc.w, sf.w), in_act);
+                    }
                 }
 #pragma unroll
                 for (int tw = 0; tw < 3; ++tw) {
@@ -2261,8 +2444,9 @@ int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, in
     return check_launch("dwconv_bwd_data_kernel");
 }
 
-int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
-                            int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream)
+static int dwconv_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
+                                  int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream,
+                                  const float* in_scale, const float* in_shift, int in_act)
 {
     if (!x || !dy || !dw) return fail(PP_ERR_BAD_ARG, "dwconv bwd_weight: null");
     if (int rc = need_c4(C, "dwconv bwd_weight")) return rc;
@@ -2278,7 +2462,7 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
         ColReduceGeom g4 = col_geom(M / 4, C, g_dw_wgrad_x4_blocks);
         if (g4.nblk_rows <= g.nblk_rows) {
             hipLaunchKernelGGL(dwconv_bwd_weight_x4_kernel, dim3(g4.nblk_rows, g4.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4,
-                               dy, lddy, Ho, Wo, pad, g4, part);
+                               dy, lddy, Ho, Wo, pad, g4, part, in_scale, in_shift, in_act);
             if (int rc = check_launch("dwconv_bwd_weight_x4_kernel")) return rc;
             hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv((int64_t)9 * C, 8)), dim3(kT), 0, st, part, g4.nblk_rows,
                                (int64_t)9 * C, dw, 1.0f);
@@ -2286,11 +2470,95 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
         }
     }
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4, dy,
-                       lddy, Ho, Wo, stride, pad, dil, g, part);
+                       lddy, Ho, Wo, stride, pad, dil, g, part, in_scale, in_shift, in_act);
     if (int rc = check_launch("dwconv_bwd_weight_kernel")) return rc;
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(9 * C, 8)), dim3(kT), 0, st, part, g.nblk_rows,
                        (int64_t)9 * C, dw, 1.0f);
     return check_launch("sum_partials_kernel");
+}
+
+int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
+                            int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    return dwconv_bwd_weight_impl(x, ldx, B, H, W, C, dy, lddy, stride, pad, dil, dw, workspace, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+int pp_dwconv3x3_bwd_weight_affine_in(const float* x_raw, int64_t ldx, int B, int H, int W, int C, const float* in_scale,
+                                      const float* in_shift, int in_act, const float* dy, int64_t lddy, int stride, int pad, int dil,
+                                      float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!in_scale || !in_shift || in_act < 0 || in_act > 2) return fail(PP_ERR_BAD_ARG, "dwconv bwd_weight: input affine");
+    return dwconv_bwd_weight_impl(x_raw, ldx, B, H, W, C, dy, lddy, stride, pad, dil, dw, workspace, ws_bytes, stream, in_scale, in_shift,
+                                  in_act);
+}
+
+/* Geometry of the fused depthwise forward: work items (outputs, or groups of four along a row) and the column-reduce grid. */
+static ColReduceGeom dw_fused_geom(int B, int Ho, int Wo, int C, int stride, int dil, bool* x4)
+{
+    // These kernels are latency-bound (18 / 9 dependent-free loads per item, then the arithmetic): ONE item per thread as long as
+    // that gives at most ~2048 row blocks (= partial statistics rows), more items per thread only beyond.
+    *x4 = stride == 1 && dil == 1 && g_dw_x4;
+    const int64_t items = (int64_t)B * Ho * (*x4 ? (Wo + 3) / 4 : Wo);
+    ColReduceGeom g;
+    g.cq = C / 4;
+    g.cq_blk = g.cq < kT ? g.cq : kT;
+    g.rows_per_pass = kT / g.cq_blk;
+    g.nblk_cols = (int)cdiv(g.cq, g.cq_blk);
+    const int64_t passes = cdiv(items, g.rows_per_pass);
+    const int64_t u = cdiv(passes, 2048);
+    g.rows_per_block = (int64_t)g.rows_per_pass * u;
+    g.nblk_rows = (int)cdiv(items, g.rows_per_block);
+    return g;
+}
+
+int64_t pp_dwconv3x3_fwd_stats_rows(int B, int H, int W, int C, int stride, int pad, int dil)
+{
+    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 || stride < 1 || dil < 1 || pad < 0) return 0;
+    const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    if (Ho < 1 || Wo < 1) return 0;
+    bool x4;
+    return dw_fused_geom(B, Ho, Wo, C, stride, dil, &x4).nblk_rows;
+}
+
+int pp_dwconv3x3_fwd_fused(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w, int stride, int pad, int dil,
+                           const float* in_scale, const float* in_shift, int in_act, float* y, int64_t ldy, float* stats,
+                           size_t stats_floats, pp_stream_t stream)
+{
+    if (!x || !w || !y) return fail(PP_ERR_BAD_ARG, "dwconv fwd_fused: null");
+    if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < 0 || in_act > 2) return fail(PP_ERR_BAD_ARG, "dwconv fwd_fused: input affine");
+    if (int rc = need_c4(C, "dwconv fwd_fused")) return rc;
+    if (ldx % 4 || ldy % 4) return fail(PP_ERR_BAD_ARG, "dwconv fwd_fused: ld must be multiples of 4");
+    const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
+    if (Ho < 1 || Wo < 1) return fail(PP_ERR_BAD_ARG, "dwconv fwd_fused: empty output");
+    if ((int64_t)B * Ho * Wo > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "dwconv fwd_fused: more than 2^31 output pixels");
+    bool x4;
+    const ColReduceGeom g = dw_fused_geom(B, Ho, Wo, C, stride, dil, &x4);
+    if (stats && stats_floats < (size_t)g.nblk_rows * 2 * C) return fail(PP_ERR_WORKSPACE, "dwconv fwd_fused: statistics buffer too small");
+    const dim3 grid(g.nblk_rows, g.nblk_cols);
+    if (x4) hipLaunchKernelGGL((dwconv_fwd_fused_kernel<true>), grid, dim3(kT), 0, as_stream(stream), x, ldx, B, H, W, C / 4, w, stride, pad,
+                               dil, in_scale, in_shift, in_act, y, ldy, Ho, Wo, g, stats);
+    else    hipLaunchKernelGGL((dwconv_fwd_fused_kernel<false>), grid, dim3(kT), 0, as_stream(stream), x, ldx, B, H, W, C / 4, w, stride,
+                               pad, dil, in_scale, in_shift, in_act, y, ldy, Ho, Wo, g, stats);
+    return check_launch("dwconv_fwd_fused_kernel");
+}
+
+/* Combine partial column statistics ([rows][2][C]: sum, sum of squares - what pp_conv2d_fwd_stats / pp_dwconv3x3_fwd_fused wrote)
+ * into the training BatchNorm's batch mean / invstd, the folded scale / shift its consumers apply on load, and the running
+ * statistics update (nn.BatchNorm2d training semantics; fixed-order fp64 combine). */
+int pp_bn_finalize_partials(const float* stats, int64_t rows, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                            float* shift, pp_stream_t stream)
+{
+    if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift) return fail(PP_ERR_BAD_ARG, "bn_finalize_partials: null");
+    if (rows < 1 || rows > 0x7FFFFFFFll || M < 1 || C < 1) return fail(PP_ERR_BAD_ARG, "bn_finalize_partials: shape");
+    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(stats) & 15) == 0) {
+        hipLaunchKernelGGL(bn_finalize_quad_kernel, dim3((unsigned)(C / 4)), dim3(kT), 0, as_stream(stream), stats, (int)rows, C, (double)M,
+                           gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+        return check_launch("bn_finalize_quad_kernel");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(kT), 0, as_stream(stream), stats, (int)rows, C, (double)M,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    return check_launch("bn_finalize_kernel");
 }
 
 // ---- padding ------------------------------------------------------------------------------------------

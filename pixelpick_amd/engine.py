@@ -10,6 +10,7 @@ Activations are NHWC `torch.Tensor`s [B,H,W,C]; channel slices of a wider buffer
 (pixel stride `ld` = stride(2)).  Weights are HWIO (dense) / [3,3,C] (depthwise).
 """
 import contextlib
+import math
 import os
 from typing import List, Optional, Sequence
 
@@ -27,18 +28,23 @@ class Var:
     tensor does not exist yet.  If the next consumer is an eval-mode BatchNorm, conv + BN (+ residual) + activation go
     out as ONE launch (pp_conv2d_fwd_bn_act / pp_dwconv3x3_fwd_bn_act); any other consumer reads `.t`, which launches
     the plain convolution first."""
-    __slots__ = ("_t", "grad", "needs_grad", "_pending")
+    __slots__ = ("_t", "grad", "needs_grad", "_pending", "_lazy")
 
     def __init__(self, t: Optional[torch.Tensor], needs_grad: bool = True):
         self._t = t
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
         self._pending = None
+        # training BatchNorm whose apply pass was skipped (_BN_ON_LOAD): (raw [B,H,W,C], scale [C], shift [C], act) - the value
+        # is act(raw * scale + shift); consumers that take the pair apply it where they load, `.t` materialises it for the rest
+        self._lazy = None
 
     @property
     def t(self) -> torch.Tensor:
         if self._pending is not None:
             _launch_deferred(self, None)
+        if self._t is None and self._lazy is not None:
+            self._t = _materialise(self._lazy)
         return self._t
 
     @t.setter
@@ -47,8 +53,10 @@ class Var:
 
 
 def shape_of(v: "Var"):
-    """(B, H, W, C) of a Var WITHOUT launching a deferred convolution."""
+    """(B, H, W, C) of a Var WITHOUT launching a deferred convolution or materialising a skipped BatchNorm apply."""
     if v._pending is None:
+        if v._t is None and v._lazy is not None:
+            return tuple(v._lazy[0].shape)
         return tuple(v._t.shape)
     kind, x, w, _, stride, pad, dil = v._pending
     B, H, W, C = shape_of(x)
@@ -87,9 +95,88 @@ def _dw_out_rows(x: "Var", stride, pad, dil):
 _CONV_BN_STATS = os.environ.get("PIXELPICK_CONV_BN_STATS", "0") == "1"
 
 
+# PIXELPICK_BN_ON_LOAD=1: a training BatchNorm whose producer is a convolution and whose only consumer is a depthwise convolution
+# or an eligible pointwise convolution (the two inner BatchNorms of every InvertedResidual, mobilenet_v2.py:42-56, and the stem's:
+# 33 of the 60) is SPLIT over its neighbours - statistics from the producer's epilogue, one small finalize launch, scale / shift /
+# activation applied where the consumer loads its input (SURVEY.md 7 hard part (b)); the normalised tensor is never written.  Only
+# the callers that know the consumer ask for it (`lazy_ok=`, networks/mobilenet_v2.py); tests/layerwise.py switches it off while
+# it overwrites activations.  OFF by default: built, parity-tested (tests/test_bn_on_load_gpu.py) and measured SLOWER -
+# 6.62-6.68 vs 6.46-6.51 ms/step, no map-size threshold wins (profiles/r03_bn_on_load.txt): the finalize launch costs what the
+# single-launch BatchNorm costs on the small maps (a kernel boundary is the price of both), and the one-item-per-thread depthwise
+# kernel that keeps column sums is slower than the four-outputs-per-thread one it replaces.
+_BN_ON_LOAD = os.environ.get("PIXELPICK_BN_ON_LOAD", "0") == "1"
+_BN_ON_LOAD_MIN_BYTES = int(os.environ.get("PIXELPICK_BN_ON_LOAD_MIN_BYTES", "0"))
+_DW_WGRAD_AFFINE = os.environ.get("PIXELPICK_DW_WGRAD_AFFINE", "0") == "1"
+
+
+def _materialise(lazy) -> torch.Tensor:
+    raw, scale, shift, act = lazy
+    B, H, W, C, ldx = _geom(raw)
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=raw.device)
+    rc = _lib.lib().pp_scale_shift_act(raw.data_ptr(), ldx, B * H * W, C, scale.data_ptr(), shift.data_ptr(), None, 0, act, y.data_ptr(), C,
+                                       _stream())
+    _lib.check(rc, "pp_scale_shift_act")
+    return y
+
+
+_ACCEPTS_AFFINE = {}
+
+
+def conv_accepts_lazy_input(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
+    """True when pp_conv2d_fwd_affine_in has a kernel for this dense convolution (memoised)."""
+    key = (B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+    r = _ACCEPTS_AFFINE.get(key)
+    if r is None:
+        r = _ACCEPTS_AFFINE[key] = bool(_lib.lib().pp_conv2d_fwd_accepts_affine_in(*key))
+    return r
+
+
+def _launch_dw_fused(v: "Var", want_stats: bool):
+    """v is a DEFERRED depthwise convolution: launch it through pp_dwconv3x3_fwd_fused - its input's skipped BatchNorm applied on
+    load, its output's column statistics written for the BatchNorm behind it.  -> (stats, rows) | None."""
+    _, x, w, _, stride, pad, dil = v._pending
+    v._pending = None
+    aff = x._lazy if (x._t is None and x._lazy is not None) else None
+    xin = aff[0] if aff is not None else x.t
+    B, H, W, C, ldx = _geom(xin)
+    Ho, Wo = out_size(H, 3, stride, pad, dil), out_size(W, 3, stride, pad, dil)
+    dev = xin.device
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+    stats, rows = None, 0
+    if want_stats:
+        rows = _wsbytes("pp_dwconv3x3_fwd_stats_rows", B, H, W, C, stride, pad, dil)
+        stats = torch.empty((rows, 2, C), dtype=torch.float32, device=dev)
+    rc = _lib.lib().pp_dwconv3x3_fwd_fused(xin.data_ptr(), ldx, B, H, W, C, w.data_ptr(), stride, pad, dil,
+                                           aff[1].data_ptr() if aff is not None else None, aff[2].data_ptr() if aff is not None else None,
+                                           aff[3] if aff is not None else 0, y.data_ptr(), C,
+                                           stats.data_ptr() if stats is not None else None, stats.numel() if stats is not None else 0,
+                                           _stream())
+    _lib.check(rc, "pp_dwconv3x3_fwd_fused")
+    v._t = y
+    return (stats, rows) if want_stats else None
+
+
 def _launch_deferred(v: "Var", bn):
     """Launch the convolution held in v._pending; bn = None (plain) or (gamma, beta, mean, var, eps, act, residual, dst)."""
     kind, x, w, bias, stride, pad, dil = v._pending
+    if bn is None and x._t is None and x._lazy is not None:
+        # the input is a BatchNorm whose apply pass was skipped: consumers that take (raw, scale, shift, act) apply it on load
+        if kind == "dw":
+            _launch_dw_fused(v, False)
+            return
+        raw, scale, shift, act = x._lazy
+        B, H, W, Cin, ldx = _geom(raw)
+        kh, kw, _, Cout = w.shape
+        if conv_accepts_lazy_input(B, H, W, Cin, Cout, kh, kw, stride, pad, dil):
+            v._pending = None
+            y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=raw.device)
+            ws, wsn = _conv_ws(False, raw.device, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+            rc = _lib.lib().pp_conv2d_fwd_affine_in(raw.data_ptr(), ldx, B, H, W, Cin, scale.data_ptr(), shift.data_ptr(), act, w.data_ptr(),
+                                                    bias.data_ptr() if bias is not None else None, kh, kw, stride, pad, dil, y.data_ptr(),
+                                                    Cout, Cout, ws, wsn, _stream())
+            _lib.check(rc, "pp_conv2d_fwd_affine_in")
+            v._t = y
+            return
     v._pending = None
     L = _lib.lib()
     B, H, W, Cin, ldx = _geom(x.t)
@@ -604,14 +691,14 @@ def _conv_ws(bwd: bool, device, *shape):
 def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, dil=1,
            dst: Optional[torch.Tensor] = None) -> Var:
     """nn.Conv2d (groups=1).  w: HWIO [kh,kw,Cin,Cout].  dst: optional NHWC view to write into."""
-    B, H, W, Cin, ldx = _geom(x.t)
+    B, H, W, Cin = shape_of(x)          # (no launch: x may be a deferred convolution or a skipped BatchNorm apply)
     kh, kw, wcin, Cout = w.shape
     assert wcin == Cin, f"conv2d: Cin {Cin} vs weight {tuple(w.shape)}"
     if _FUSE_EVAL and not tape.enabled and dst is None:
         out = Var(None, needs_grad=False)
         out._pending = ("conv", x, w, bias, stride, pad, dil)
         return out
-    if _CONV_BN_STATS and tape.enabled and dst is None:
+    if (_CONV_BN_STATS or _BN_ON_LOAD) and tape.enabled and dst is None:
         # training: deferred as well - a training-mode BatchNorm right behind it launches the convolution with a statistics
         # epilogue (pp_conv2d_fwd_stats) and then only applies (pp_bn_train_fwd_partials); any other consumer's `.t`
         # launches the plain convolution
@@ -619,6 +706,7 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
         out._pending = ("conv", x, w, bias, stride, pad, dil)
         tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil), out)
         return out
+    _, _, _, _, ldx = _geom(x.t)
     Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
     y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.t.device)
     _, _, _, _, ldy = _geom(y)
@@ -633,14 +721,21 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
 
 def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil):
     L = _lib.lib()
-    B, H, W, Cin, ldx = _geom(x.t)
+    lazy_in = x._lazy if (x._t is None and x._lazy is not None) else None
+    B, H, W, Cin, ldx = _geom(lazy_in[0] if lazy_in is not None else x.t)
+    if lazy_in is not None:
+        ldx = Cin                      # the weight gradient reads the materialised (contiguous) activation
     _, Ho, Wo, Cout, lddy = _geom(dy)
     kh, kw = w.shape[0], w.shape[1]
     dev = dy.device
     if w.requires_grad:
         dw = tape.grad_buffer_for(w)
         db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
-        with tape.side_stream_for(x.t, dy, dw, db):
+        with tape.side_stream_for(lazy_in[0] if lazy_in is not None else x.t, dy, dw, db):
+            if lazy_in is not None:
+                # the weight gradient needs act(bn(raw)), which the forward never wrote: one elementwise launch on the
+                # weight-gradient stream (idle between the encoder's small weight gradients), kept alive until the join
+                tape._keepalive.append(x.t)
             ws = _ws(_wsbytes("pp_conv2d_bwd_weight_workspace_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
             rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
                                         dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
@@ -670,7 +765,7 @@ def dwconv3x3(tape: Tape, x: Var, w: torch.Tensor, stride=1, pad=0, dil=1) -> Va
         out = Var(None, needs_grad=False)
         out._pending = ("dw", x, w, None, stride, pad, dil)
         return out
-    if _FUSE_DW_BN and tape.enabled and _dw_bn_fusable(*_dw_out_rows(x, stride, pad, dil)):
+    if tape.enabled and (_BN_ON_LOAD or (_FUSE_DW_BN and _dw_bn_fusable(*_dw_out_rows(x, stride, pad, dil)))):
         # training: defer as well - a training-mode BatchNorm right behind it computes the convolution inside its own
         # single launch (pp_dwconv3x3_bn_train_fwd_fused); any other consumer's `.t` launches the plain convolution
         out = Var(None)
@@ -689,16 +784,32 @@ def dwconv3x3(tape: Tape, x: Var, w: torch.Tensor, stride=1, pad=0, dil=1) -> Va
 
 def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
     L = _lib.lib()
-    B, H, W, C, ldx = _geom(x.t)
+    lazy_in = x._lazy if (x._t is None and x._lazy is not None) else None
+    B, H, W, C, ldx = _geom(lazy_in[0] if lazy_in is not None else x.t)
+    if lazy_in is not None and not _DW_WGRAD_AFFINE:
+        # (measured: applying the affine inside the nine-tap weight-gradient kernels costs 3x their time; one elementwise launch
+        # on the weight-gradient stream is cheaper)
+        with tape.side_stream_for(lazy_in[0], dy):
+            tape._keepalive.append(x.t)
+        lazy_in, ldx = None, C
     _, Ho, Wo, _, lddy = _geom(dy)
     dev = dy.device
     if w.requires_grad:
         dw = tape.grad_buffer_for(w)
-        with tape.side_stream_for(x.t, dy, dw):
-            ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", B * Ho * Wo, C), dev)
-            rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), _stream())
-        _lib.check(rc, "pp_dwconv3x3_bwd_weight")
+        if lazy_in is not None:
+            raw, scale, shift, act = lazy_in
+            with tape.side_stream_for(raw, dy, dw):
+                ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", B * Ho * Wo, C), dev)
+                rc = L.pp_dwconv3x3_bwd_weight_affine_in(raw.data_ptr(), ldx, B, H, W, C, scale.data_ptr(), shift.data_ptr(), act,
+                                                         dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         _stream())
+            _lib.check(rc, "pp_dwconv3x3_bwd_weight_affine_in")
+        else:
+            with tape.side_stream_for(x.t, dy, dw):
+                ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", B * Ho * Wo, C), dev)
+                rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), _stream())
+            _lib.check(rc, "pp_dwconv3x3_bwd_weight")
         tape.set_param_grad(w, dw)
     if x.needs_grad:
         dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
@@ -743,14 +854,14 @@ def _dw_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_va
 _CONV_BN_STATS_MAX_ROWS = int(os.environ.get("PIXELPICK_CONV_BN_STATS_MAX_ROWS", "160"))
 
 
-def _launch_conv_stats(x: Var):
+def _launch_conv_stats(x: Var, max_rows: Optional[int] = None):
     """x is a DEFERRED dense convolution: launch it with the BatchNorm-statistics epilogue.  -> (stats [rows,2,Cout], rows), or
     None when this shape delivers no statistics (x stays deferred)."""
     _, xin, w, bias, stride, pad, dil = x._pending
     B, H, W, Cin, ldx = _geom(xin.t)
     kh, kw, _, Cout = w.shape
     rows = _wsbytes("pp_conv2d_fwd_stats_rows", B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
-    if rows <= 0 or rows > _CONV_BN_STATS_MAX_ROWS or Cout % 4:
+    if rows <= 0 or rows > (_CONV_BN_STATS_MAX_ROWS if max_rows is None else max_rows) or Cout % 4:
         return None                                 # (large maps: thousands of partial rows - the stem BatchNorm took 93 us instead of 22)
     dev = xin.t.device
     Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
@@ -803,11 +914,43 @@ def _conv_bn_train_partials(tape: Tape, x: Var, gamma, beta, running_mean, runni
 
 
 # ------------------------------------------------------------------------------------------------- batch norm (+act, +residual)
+def _bn_on_load(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act, eps, momentum):
+    """Training BatchNorm (+ activation) behind the DEFERRED convolution x, split over its neighbours: x is launched with the
+    statistics epilogue, pp_bn_finalize_partials makes mean / invstd / running statistics / scale / shift, and the result is a
+    LAZY Var (raw, scale, shift, act) whose consumer applies it on load.  None: not applicable (x stays deferred)."""
+    if x._pending[0] == "conv":
+        got = _launch_conv_stats(x, max_rows=1 << 30)
+    else:
+        got = _launch_dw_fused(x, True)
+    if got is None:
+        return None
+    stats, rows = got
+    B, H, W, C, _ = _geom(x._t)
+    dev = x._t.device
+    mean, invstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    rc = _lib.lib().pp_bn_finalize_partials(stats.data_ptr(), rows, B * H * W, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                            running_mean.data_ptr() if running_mean is not None else None,
+                                            running_var.data_ptr() if running_var is not None else None, mean.data_ptr(),
+                                            invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream())
+    _lib.check(rc, "pp_bn_finalize_partials")
+    out = Var(None)
+    out._lazy = (x._t, scale, shift, act)
+    tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, None, out, 1.0), out)
+    return out
+
+
 def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE,
                    residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
-                   dst: Optional[torch.Tensor] = None, dropout_p: float = 0.0) -> Var:
+                   dst: Optional[torch.Tensor] = None, dropout_p: float = 0.0, lazy_ok: bool = False) -> Var:
     """nn.BatchNorm2d -> (+ residual) -> activation [-> nn.Dropout(dropout_p), already known to be active].
-    Training: batch statistics + running-stat update; the dropout rides in the single-launch kernel's apply pass."""
+    Training: batch statistics + running-stat update; the dropout rides in the single-launch kernel's apply pass.
+    lazy_ok: the caller knows that the ONLY consumer is a depthwise convolution or a pointwise convolution that
+    conv_accepts_lazy_input() - the BatchNorm may then be split over its neighbours (_bn_on_load)."""
+    if (lazy_ok and _BN_ON_LOAD and training and tape.enabled and x._pending is not None and residual is None and dropout_p == 0.0
+            and dst is None and shape_of(x)[3] % 4 == 0 and 4 * math.prod(shape_of(x)) >= _BN_ON_LOAD_MIN_BYTES):
+        out = _bn_on_load(tape, x, gamma, beta, running_mean, running_var, act, eps, momentum)
+        if out is not None:
+            return out
     if dropout_p > 0.0 and not (training and _BN_FUSED and act != ACT_RELU6 and dst is None and _bn_exchange_ok(x.t.device)):
         y = batch_norm_act(tape, x, gamma, beta, running_mean, running_var, training, act, residual, eps, momentum, dst)
         return dropout(tape, y, dropout_p, True)
@@ -820,7 +963,7 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         if out is not None:
             return out
     if (training and x._pending is not None and x._pending[0] == "dw" and tape.enabled and dropout_p == 0.0 and _BN_FUSED
-            and _bn_exchange_ok(x._pending[1].t.device)):
+            and _FUSE_DW_BN and _dw_bn_fusable(*_dw_out_rows(x._pending[1], *x._pending[4:7])) and _bn_exchange_ok(x._pending[1].t.device)):
         fused = _dw_bn_train_fused(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst)
         if fused is not None:
             return fused
@@ -891,7 +1034,8 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     B, H, W, C, ldx = _geom(x.t)
     M = B * H * W
     _, _, _, _, lddy = _geom(dy)
-    _, _, _, _, ldya = _geom(out.t)
+    lazy_out = out._t is None and out._lazy is not None          # the activated output was never written (_bn_on_load)
+    ldya = 0 if lazy_out else _geom(out.t)[4]
     dev = dy.device
     dgamma = tape.grad_buffer_for(gamma)
     dbeta = tape.grad_buffer_for(beta)
@@ -900,7 +1044,7 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     if _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536 and _bn_exchange_ok(dev):
         sync, ws = _bn_exchange(dev)
         # ReLU/ReLU6 mask: from the saved output, or - no residual, no fused dropout - recomputed from x (one tensor less)
-        remask = act != ACT_NONE and residual is None and gscale == 1.0
+        remask = (act != ACT_NONE and residual is None and gscale == 1.0) or lazy_out
         rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
                                mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),

@@ -86,6 +86,14 @@ class Conv2d(nn.Module):
         elif bkey in state_dict and strict:
             unexpected_keys.append(bkey)
 
+    def accepts_lazy_input(self, in_shape, extra_pad: int = 0) -> bool:
+        """Can this convolution apply its producer's skipped BatchNorm on load (engine._BN_ON_LOAD)?  in_shape = (B, H, W, C)."""
+        if self.depthwise:
+            return True
+        B, H, W, C = in_shape
+        k = self.kernel_size
+        return E.conv_accepts_lazy_input(B, H, W, C, self.out_channels, k, k, self.stride, self.padding + extra_pad, self.dilation)
+
     def run(self, tape, x, dst=None, extra_pad: int = 0):
         """extra_pad: zero padding applied to x in front of this convolution (F.pad(x, extra_pad) then conv), folded
         into the kernel's own bounds handling instead of materialising the padded tensor."""
@@ -120,9 +128,10 @@ class BatchNorm2d(nn.Module):
             self._nbt_pending = 0
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
-    def run(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None):
+    def run(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None, lazy_ok=False):
         """dropout: the nn.Dropout module that follows BN -> activation in the reference's Sequential (applied here so
-        that it can ride in the BatchNorm kernel when both are in training mode)."""
+        that it can ride in the BatchNorm kernel when both are in training mode).
+        lazy_ok: the caller guarantees that the only consumer takes a skipped BatchNorm apply (engine.batch_norm_act)."""
         training = self.training
         if training:
             B, H, W, _ = E.shape_of(x)          # (does not launch a deferred depthwise convolution)
@@ -132,7 +141,7 @@ class BatchNorm2d(nn.Module):
                                                        # dict write: nn.Module.__setattr__ costs ~2 us x 60 BN layers per step)
         drop_p = dropout.p if (dropout is not None and dropout.training and dropout.p > 0.0) else 0.0
         return E.batch_norm_act(tape, x, self.weight, self.bias, self.running_mean, self.running_var, training, act,
-                                residual, self.eps, self.momentum, dst=dst, dropout_p=drop_p)
+                                residual, self.eps, self.momentum, dst=dst, dropout_p=drop_p, lazy_ok=lazy_ok)
 
     def forward(self, x):
         raise RuntimeError("pixelpick_amd layers execute through run(tape, x)")

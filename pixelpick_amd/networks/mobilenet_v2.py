@@ -41,8 +41,12 @@ def _run_conv_bn_act_chain(tape, seq, x, residual=None, first_pad=0):
         has_act = i + 2 < len(mods) and isinstance(mods[i + 2], ReLU6)
         is_last = (i + (3 if has_act else 2)) >= len(mods)
         x = conv.run(tape, x, extra_pad=first_pad if i == 0 else 0)
-        x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None)
-        i += 3 if has_act else 2
+        # an inner BatchNorm's only consumer is the next convolution of the chain: when that one can apply scale / shift /
+        # activation where it loads its input, the BatchNorm is split over its neighbours (engine._bn_on_load)
+        nxt = i + (3 if has_act else 2)
+        lazy_ok = (not is_last) and tape.enabled and mods[nxt].accepts_lazy_input(E.shape_of(x))
+        x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None, lazy_ok=lazy_ok)
+        i = nxt
     return x
 
 
@@ -136,11 +140,15 @@ class MobileNetV2(nn.Module):
 
     @staticmethod
     def _run_features(tape, seq, x):
-        for m in seq:
+        mods = list(seq)
+        for j, m in enumerate(mods):
             if isinstance(m, (InvertedResidual, Dropout2d)):
                 x = m.run(tape, x)
-            else:  # stem conv_bn
-                x = m[1].run(tape, m[0].run(tape, x), E.ACT_RELU6)
+            else:  # stem conv_bn; its only consumer is the depthwise conv of the t=1 block behind it (no residual there)
+                nxt = mods[j + 1] if j + 1 < len(mods) else None
+                lazy_ok = (tape.enabled and isinstance(nxt, InvertedResidual) and not nxt.use_res_connect and nxt.conv[0].depthwise
+                           and FOLD_FIXED_PADDING)
+                x = m[1].run(tape, m[0].run(tape, x), E.ACT_RELU6, lazy_ok=lazy_ok)
         return x
 
     def run(self, tape, x):

@@ -144,6 +144,10 @@ class LayerwiseParity:
 
     def __enter__(self):
         me = self
+        # forced / branch-forced runs overwrite activations in place: every BatchNorm must write its output (no skipped apply)
+        self._saved_on_load = E._BN_ON_LOAD
+        if self.force:
+            E._BN_ON_LOAD = False
         self._saved = (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd)
         conv_run, bn_run, gn_run, conv_bwd, dw_bwd, bn_bwd, gn_bwd = self._saved
 
@@ -166,8 +170,8 @@ class LayerwiseParity:
             if ent is not None and bn is None:
                 me._fwd_site("conv", ent[0], ent[0], v)
 
-        def launch_stats_p(x):
-            got = launch_stats(x)
+        def launch_stats_p(x, **kw):
+            got = launch_stats(x, **kw)
             if got is not None:
                 ent = me._deferred.pop(id(x), None)
                 if ent is not None:
@@ -175,8 +179,8 @@ class LayerwiseParity:
                     me._fwd_site("conv", ent[0], ent[0], x)
             return got
 
-        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None):
-            out = bn_run(self, tape, x, act, residual, dst, dropout)
+        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None, lazy_ok=False):
+            out = bn_run(self, tape, x, act, residual, dst, dropout, lazy_ok)
             n = me.mod_name[id(self)]
             site = me.tr.site(n, residual is not None)
             me.res_nodes[n] = residual is not None
@@ -226,6 +230,7 @@ class LayerwiseParity:
     def __exit__(self, *exc):
         (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd) = self._saved
         E._launch_deferred, E._launch_conv_stats = self._saved_launch
+        E._BN_ON_LOAD = self._saved_on_load
         return False
 
     # ------------------------------------------------------------------ after the sweep
