@@ -1995,6 +1995,332 @@ __global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* part,
     if (t < 8 && c < C) dbias[c] = (float)sh[t];
 }
 
+// ---- fp32 convolutions on the bf16 matrix pipe: three-way operand split ("bf16x3") -------------------------------------------
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate.  An fp32 value is EXACTLY the sum of three bf16 values
+// (hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid): 8 + 8 + 8 mantissa bits, both subtractions are exact), a product of
+// two bf16 values is exact in fp32, and the matrix pipe accumulates in fp32; so
+//     a*b = hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi) + O(2^-24 |a b|)
+// - six bf16 MFMAs (v_mfma_f32_32x32x16_bf16, 32 cycles for 16 K values) replace eight fp32 MFMAs of 64 cycles: 2.67x the matrix
+// rate at the accuracy of an fp32 GEMM (the dropped terms mid*lo, lo*mid, lo*lo are below the rounding of the fp32 accumulation;
+// tests/test_conv_x3_gpu.py measures both paths against float64).  The operands are split ONCE per tensor by a bandwidth kernel
+// (x3_split_kernel: [rows][C] fp32 -> 3 planes [rows + 1][Kp] bf16, Kp = C rounded up to 16, plus a row of zeros that padding
+// taps / ragged rows read), the weights once per call into [tap][n][Kp] (k contiguous: the layout both MFMA operands want), and
+// the implicit-GEMM kernel is a pure LDS-DMA pipeline: no conversion in its loop.
+//   tile 128 x BN (BN = 128 | 64), 4 waves (2 x 2), K step = 16 bf16 per plane (32-byte rows), three stages of
+//   3 x (128 + BN) x 32 B; a wave DMAs 32 A rows and 32 B rows of each plane per step (1-KiB pieces, lane -> (row, 16-byte half),
+//   half swizzled by bit 3 of the row so that the fragment reads are conflict-free); fragments are ds_read_b128.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct X3Operands {
+    const uint16_t* a;        // A planes [3][Kp/16][rows_a + 1][16] (row rows_a = zeros)
+    const uint16_t* b;        // B planes [3][Kp/16][ntaps * n_rows + 1][16] (last row = zeros); row = tap_w * n_rows + n
+    int64_t a_plane, b_plane; // elements per plane
+    int Kp;                   // reduction channels per tap, padded to a multiple of 16 (pads are zeros in both operands)
+    int n_rows;               // B rows per tap (= output channels of this GEMM)
+    uint32_t a_zero, b_zero;  // byte offset of the zero row inside a plane (chunk 0)
+    uint32_t a_chunk, b_chunk;   // bytes per 16-channel chunk: (rows + 1) * 32
+    int ablate;               // TIMING ONLY (wrong results): bit 0 no DMA after the prologue, bit 1 no fragment reads, bit 2 no barriers, bit 3 no MFMAs
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);       // inf / nan: truncate
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+__device__ __forceinline__ void x3_split1(float v, uint16_t& hi, uint16_t& mid, uint16_t& lo)
+{
+    hi = f32_to_bf16_rne(v);
+    const float r1 = v - bf16_to_f32(hi);
+    mid = f32_to_bf16_rne(r1);
+    const float r2 = r1 - bf16_to_f32(mid);
+    lo = f32_to_bf16_rne(r2);
+}
+
+// x [rows][C] (pixel stride ldx) -> planes [3][Kp/16 chunks][rows + 1][16] bf16: CHUNK-major, so that the 32 consecutive rows x 16
+// channels a wave DMAs per piece are ONE contiguous KiB (eight full cache lines; row-major planes made every piece touch 32 lines
+// for 32 bytes each and the kernel ran at the texture-address rate: 178 us of data movement for 92 us of MFMA work).
+// One thread = (chunk, row, 8-channel half): consecutive threads write consecutive 16-byte pieces.
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* x, int64_t ldx, int64_t rows, int C, uint16_t* out, int Kp, int64_t plane)
+{
+    const int nchunk = Kp / 16;
+    const int64_t per_chunk = (rows + 1) * 2;
+    const int64_t total = per_chunk * nchunk;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e / per_chunk);
+        const int64_t rem = e - (int64_t)ch * per_chunk;
+        const int64_t r = rem >> 1;
+        const int c0 = ch * 16 + (int)(rem & 1) * 8;
+        uint16_t h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[j] = m[j] = l[j] = 0; }
+        if (r < rows) {
+            if (c0 + 8 <= C && (ldx & 3) == 0) {
+                const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c0), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c0 + 4);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x3_split1(v[j], h[j], m[j], l[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < C) x3_split1(x[r * ldx + c0 + j], h[j], m[j], l[j]);
+            }
+        }
+        uint4 ph, pm, pl;
+        ph.x = h[0] | ((uint32_t)h[1] << 16); ph.y = h[2] | ((uint32_t)h[3] << 16); ph.z = h[4] | ((uint32_t)h[5] << 16); ph.w = h[6] | ((uint32_t)h[7] << 16);
+        pm.x = m[0] | ((uint32_t)m[1] << 16); pm.y = m[2] | ((uint32_t)m[3] << 16); pm.z = m[4] | ((uint32_t)m[5] << 16); pm.w = m[6] | ((uint32_t)m[7] << 16);
+        pl.x = l[0] | ((uint32_t)l[1] << 16); pl.y = l[2] | ((uint32_t)l[3] << 16); pl.z = l[4] | ((uint32_t)l[5] << 16); pl.w = l[6] | ((uint32_t)l[7] << 16);
+        const int64_t o = e * 8;                                    // (chunk, row, half) -> 8 bf16 each, in that order
+        *reinterpret_cast<uint4*>(out + o) = ph;
+        *reinterpret_cast<uint4*>(out + plane + o) = pm;
+        *reinterpret_cast<uint4*>(out + 2 * plane + o) = pl;
+    }
+}
+
+// weights HWIO [taps][Cin][Cout] -> B planes [3][Kp/16][taps * n_rows + 1][16].  transpose == true (forward): row = tap*Cout + n,
+// k = c; false (backward-data): row = tap*Cin + c, k = n.  One thread = (chunk, row, half).
+__global__ __launch_bounds__(256) void x3_split_w_kernel(const float* w, int taps, int Cin, int Cout, int transpose, uint16_t* out, int Kp,
+                                                        int64_t plane)
+{
+    const int n_rows = transpose ? Cout : Cin, K = transpose ? Cin : Cout;
+    const int nchunk = Kp / 16;
+    const int64_t rows = (int64_t)taps * n_rows;
+    const int64_t per_chunk = (rows + 1) * 2;
+    const int64_t total = per_chunk * nchunk;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        // (chunk, half, row) with the row fastest: consecutive threads read consecutive n of one k (coalesced when transposing)
+        const int64_t ch2 = e / (rows + 1);
+        const int64_t r = e - ch2 * (rows + 1);
+        const int ch = (int)(ch2 >> 1);
+        const int k0 = ch * 16 + (int)(ch2 & 1) * 8;
+        uint16_t h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = m[j] = l[j] = 0;
+            if (r < rows && k0 + j < K) {
+                const int t = (int)(r / n_rows), n = (int)(r - (int64_t)t * n_rows);
+                const float v = transpose ? w[((int64_t)t * Cin + (k0 + j)) * Cout + n] : w[((int64_t)t * Cin + n) * Cout + k0 + j];
+                x3_split1(v, h[j], m[j], l[j]);
+            }
+        }
+        const int64_t o = ((int64_t)ch * per_chunk + r * 2 + (ch2 & 1)) * 8;
+        uint4 ph, pm, pl;
+        ph.x = h[0] | ((uint32_t)h[1] << 16); ph.y = h[2] | ((uint32_t)h[3] << 16); ph.z = h[4] | ((uint32_t)h[5] << 16); ph.w = h[6] | ((uint32_t)h[7] << 16);
+        pm.x = m[0] | ((uint32_t)m[1] << 16); pm.y = m[2] | ((uint32_t)m[3] << 16); pm.z = m[4] | ((uint32_t)m[5] << 16); pm.w = m[6] | ((uint32_t)m[7] << 16);
+        pl.x = l[0] | ((uint32_t)l[1] << 16); pl.y = l[2] | ((uint32_t)l[3] << 16); pl.z = l[4] | ((uint32_t)l[5] << 16); pl.w = l[6] | ((uint32_t)l[7] << 16);
+        *reinterpret_cast<uint4*>(out + o) = ph;
+        *reinterpret_cast<uint4*>(out + plane + o) = pm;
+        *reinterpret_cast<uint4*>(out + 2 * plane + o) = pl;
+    }
+}
+
+__device__ __forceinline__ void x3_glds16(uint32_t voff, const void* sbase_in, uint32_t lds_dst_in)
+{
+    // (wave-uniform by construction; readfirstlane tells the compiler so)
+    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
+    const uint64_t sb = reinterpret_cast<uint64_t>(sbase_in);
+    const uint64_t sbu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+    const void* sbase = reinterpret_cast<const void*>(sbu);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(ConvParams p, X3Operands o)
+{
+    // waves: (BM / 64) x 2, each a 64 x (BN / 2) tile; 256 x 128 = eight waves = ONE block per CU (108 KiB of LDS), 128 x BN = four
+    // waves, two blocks per CU.  Pipeline as conv_igemm_dma_kernel: the fragments of step k sit in registers (read during step
+    // k-1), so the DMA of step k+3 can overwrite the ring slot of step k right behind the barrier; the 24 (12) MFMAs of a step go
+    // out in six groups (one per product term) with the fragment reads of step k+1 and one DMA piece behind each group.
+    constexpr int TM = 2, TN = BN / 64, WN = 2, NWAVE = BM / 32;
+    constexpr int NSTAGE = (BM == 256 && BN == 128) ? 4 : (BM == 256 ? 5 : 3);      // one block per CU: as much ring as 160 KiB hold
+    constexpr int A_BYTES = BM * 32, B_BYTES = BN * 32;                    // one plane of one stage
+    constexpr int STAGE_BYTES = 3 * (A_BYTES + B_BYTES);
+    constexpr int NBW = BN / 32;                                          // waves that DMA B rows (32 rows each)
+    static_assert(NBW <= NWAVE, "B rows are loaded by the first BN/32 waves");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
+    struct Frags { bf16x8_t a[3][TM], b[3][TN]; };
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    {
+        const int ntn = p.n_tiles, nblk = gridDim.x, bid = blockIdx.x, per_xcd = nblk / 8;
+        if (p.xcd_remap && per_xcd * 8 == nblk) {
+            const int lin = (bid & 7) * per_xcd + (bid >> 3);
+            mt = lin / ntn; nt = lin - mt * ntn;
+        } else {
+            mt = bid / ntn; nt = bid - mt * ntn;
+        }
+    }
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+
+    // ---- per-lane DMA addressing: lane -> (row = lane >> 1 of this wave's 32 rows, 16-byte half swizzled by bit 3 of the row)
+    const int lr = lane >> 1;
+    const int lhalf = (lane & 1) ^ ((lr >> 3) & 1);
+    uint32_t a_e0 = 0;                                   // byte offset of (pixel row, half) inside a plane, tap (0,0), chunk 0
+    unsigned a_vm = 0u;
+    {
+        const int64_t m = m0 + wave * 32 + lr;
+        if (m < p.M) {
+            const unsigned mu = (unsigned)m;
+            const unsigned t = mu / (unsigned)p.Wo;
+            const int ow = (int)(mu - t * (unsigned)p.Wo);
+            const unsigned bb = t / (unsigned)p.Ho;
+            const int oh = (int)(t - bb * (unsigned)p.Ho);
+            const int ih0 = oh * p.stride, iw0 = ow * p.stride;
+            a_e0 = (uint32_t)((((int)bb * p.H + ih0) * p.W + iw0) * 16 + lhalf * 8) * 2u;
+            for (int t2 = 0; t2 < p.taps.n; ++t2) {
+                const int ih = ih0 + p.taps.dh[t2], iw = iw0 + p.taps.dw[t2];
+                a_vm |= ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (1u << t2) : 0u;
+            }
+        }
+    }
+    const bool loads_b = wave < NBW;
+    const int b_row = n0 + wave * 32 + lr;
+    const bool b_ok = loads_b && b_row < p.Cn;
+    const uint32_t b_e0 = (uint32_t)(b_row * 16 + lhalf * 8) * 2u;
+    const uint32_t a_zero = o.a_zero + (uint32_t)(lhalf * 16), b_zero = o.b_zero + (uint32_t)(lhalf * 16);
+    const uint16_t* a0 = o.a; const uint16_t* a1 = o.a + o.a_plane; const uint16_t* a2 = o.a + 2 * o.a_plane;
+    const uint16_t* b0 = o.b; const uint16_t* b1 = o.b + o.b_plane; const uint16_t* b2 = o.b + 2 * o.b_plane;
+
+    __shared__ int s_tap[32][2];
+    if (tid < p.taps.n) {
+        s_tap[tid][0] = (p.taps.dh[tid] * p.W + p.taps.dw[tid]) * 32;               // byte shift of the A row (32-byte rows)
+        s_tap[tid][1] = p.taps.widx[tid] * o.n_rows * 32;                            // byte offset of the tap's B rows
+    }
+    __syncthreads();
+
+    const int nchunk = o.Kp / 16;
+    const int nk = p.taps.n * nchunk;
+    const int ks_beg = p.splits > 1 ? (int)blockIdx.y * p.ks_per_split : 0;
+    const int ks_end = p.splits > 1 ? (ks_beg + p.ks_per_split < nk ? ks_beg + p.ks_per_split : nk) : nk;
+    const int n = ks_end - ks_beg;
+    int is_ch = ks_beg / p.taps.n, is_ti = ks_beg - is_ch * p.taps.n;                // chunk outer, tap inner (L2 reuse of the halo rows)
+
+    // the DMA of one step in (up to) six pieces; begin() computes the two lane offsets, piece(i) issues one load
+    uint32_t st_va = 0, st_vb = 0, st_lds = 0;
+    auto issue_begin = [&](int stage) {
+        const int ta = s_tap[is_ti][0], tb = s_tap[is_ti][1];
+        st_va = ((a_vm >> is_ti) & 1u) ? a_e0 + (uint32_t)ta + (uint32_t)is_ch * o.a_chunk : a_zero;
+        st_vb = b_ok ? b_e0 + (uint32_t)tb + (uint32_t)is_ch * o.b_chunk : b_zero;
+        st_lds = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)(wave * 1024);
+        if (++is_ti == p.taps.n) { is_ti = 0; ++is_ch; }
+    };
+    auto issue_piece = [&](int i) {
+        if (i == 0) x3_glds16(st_va, a0, st_lds);
+        else if (i == 1) x3_glds16(st_va, a1, st_lds + A_BYTES);
+        else if (i == 2) x3_glds16(st_va, a2, st_lds + 2 * A_BYTES);
+        else if (loads_b) {
+            if (i == 3) x3_glds16(st_vb, b0, st_lds + 3 * A_BYTES);
+            else if (i == 4) x3_glds16(st_vb, b1, st_lds + 3 * A_BYTES + B_BYTES);
+            else x3_glds16(st_vb, b2, st_lds + 3 * A_BYTES + 2 * B_BYTES);
+        }
+    };
+    auto issue_all = [&](int stage) {
+        issue_begin(stage);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment slot of (row r, logical half h): 16-byte slot r*2 + (h ^ ((r >> 3) & 1))
+    int a_slot[TM], b_slot[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { const int r = (wm * TM + t) * 32 + l31; a_slot[t] = r * 2 + (h ^ ((r >> 3) & 1)); }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { const int r = (wn * TN + t) * 32 + l31; b_slot[t] = r * 2 + (h ^ ((r >> 3) & 1)); }
+    auto read_a = [&](int stage, Frags& F, int pl) {
+        const bf16x8_t* S = reinterpret_cast<const bf16x8_t*>(smem + stage * STAGE_BYTES);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) F.a[pl][t] = S[pl * (A_BYTES / 16) + a_slot[t]];
+    };
+    auto read_b = [&](int stage, Frags& F, int pl) {
+        const bf16x8_t* S = reinterpret_cast<const bf16x8_t*>(smem + stage * STAGE_BYTES);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) F.b[pl][t] = S[3 * (A_BYTES / 16) + pl * (B_BYTES / 16) + b_slot[t]];
+    };
+    // six product terms, smallest first: (A plane, B plane)
+    auto mma_term = [&](const Frags& F, int term) {
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[TA[term]][tm], F.b[TB[term]][tn], acc[tm][tn], 0, 0, 0);
+    };
+    auto wait_pieces = [&](int steps_in_flight) {           // my own pieces: all but the newest `steps_in_flight` steps have landed
+        if (loads_b) {
+            if (steps_in_flight >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (steps_in_flight == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (steps_in_flight == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (steps_in_flight >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (steps_in_flight == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (steps_in_flight == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
+        const bool rd = k + 1 < n && !(o.ablate & 2), dm = k + NSTAGE < n && !(o.ablate & 1);
+        const int sn = (k + 1) % NSTAGE;
+        if (k + 1 < n && !(o.ablate & 4)) {
+            // step k+1 has landed; steps k+2 .. k+NSTAGE-1 (as far as they exist) may still fly
+            const int fly = n - (k + 2) < NSTAGE - 2 ? n - (k + 2) : NSTAGE - 2;
+            wait_pieces(fly > 0 ? fly : 0);
+            __builtin_amdgcn_s_barrier();                    // everyone's pieces of step k+1; ring slot k%3 is free
+            asm volatile("" ::: "memory");
+        }
+        if (dm) issue_begin(k % NSTAGE);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (!(o.ablate & 8)) mma_term(cur, g);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rd) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
+            if (dm) issue_piece(g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    Frags F0, F1;
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE; ++s0)
+        if (s0 < n) issue_all(s0);
+    if (n > 0) {
+        wait_pieces((n < NSTAGE ? n : NSTAGE) - 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
+    }
+    int k = 0;
+    for (; k + 1 < n; k += 2) {
+        kstep(k, F0, F1);
+        kstep(k + 1, F1, F0);
+    }
+    if (k < n) kstep(k, F0, F1);
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------
 // live taps for forward-style indexing: input row = oh*stride + (th*dil - pad)
 // Forward (flip == false): rows are output pixels, source row = oh*stride + dh, H/W = input size.
@@ -2120,8 +2446,64 @@ static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
     return cdiv(M, 64) * 2;                                          // 64x64 tiles, 2 x 2 waves
 }
 
+// bf16x3 path (conv_x3_kernel): which problems take it, and what the caller's workspace must hold for it
+static thread_local int g_conv_x3 = 1;
+struct X3Plan { bool ok; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes; };
+static X3Plan x3_plan(const ConvPlan& pl, int64_t rows_a, int Ck, int n_rows, int ntaps_w, int ntaps_live, bool vec)
+{
+    X3Plan x{};
+    // (shallow reductions - the 16 -> 96 expand at 130 x 258 - do not pay for the two split launches: 26 + 14 vs 19 us)
+    if (!g_conv_x3 || pl.cfg != 1 || pl.splits > 1 || !vec || ntaps_live > 32 || (int64_t)ntaps_live * Ck < 512) return x;
+    x.Kp = (int)cdiv(Ck, 16) * 16;
+    x.rows_a = rows_a;
+    x.a_plane = (rows_a + 1) * x.Kp;
+    x.b_rows = (int64_t)ntaps_w * n_rows;
+    x.b_plane = (x.b_rows + 1) * x.Kp;
+    if (x.a_plane * 2 >= (1ll << 32) - 4096 || x.b_plane * 2 >= (1ll << 32) - 4096) return x;
+    x.bytes = align_up((size_t)3 * x.a_plane * 2, 256) + align_up((size_t)3 * x.b_plane * 2, 256);
+    x.ok = true;
+    return x;
+}
+
 template <bool BWD>
-static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes, hipStream_t st)
+static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, int kh_kw, void* workspace, hipStream_t st)
+{
+    uint16_t* ap = reinterpret_cast<uint16_t*>(workspace);
+    uint16_t* bp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)3 * x.a_plane * 2, 256));
+    const int64_t ta = (x.rows_a + 1) * (x.Kp / 8);          // (chunk, row, half) items
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ta, 256), 4096)), dim3(256), 0, st, p.x, p.ldx, x.rows_a, p.Ck, ap,
+                       x.Kp, x.a_plane);
+    if (int rc = check_launch("x3_split_kernel")) return rc;
+    const int64_t tb = (x.b_rows + 1) * (x.Kp / 8);
+    hipLaunchKernelGGL(x3_split_w_kernel, dim3((unsigned)std::min<int64_t>(cdiv(tb, 256), 4096)), dim3(256), 0, st, p.w, kh_kw, p.Cin, p.Cout,
+                       BWD ? 0 : 1, bp, x.Kp, x.b_plane);
+    if (int rc = check_launch("x3_split_w_kernel")) return rc;
+    X3Operands o{ap, bp, x.a_plane, x.b_plane, x.Kp, p.Cn, (uint32_t)(x.rows_a * 32), (uint32_t)(x.b_rows * 32),
+                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), (g_conv_x3 >> 4) & 15};
+    p.n_tiles = pl.n_tiles;
+    p.splits = 1;
+    p.ks_per_split = 0;
+    p.part = nullptr;
+    // 256-row tiles (eight waves, one block per CU) when that still gives every CU a block; (g_conv_x3 bit 1: 128 rows always;
+    // bit 2: 128-wide tiles also for ragged widths)
+    // ragged output widths (304): 128-wide tiles while they pad less than 30 % (384 for 304: 350 us, 64-wide 372 us)
+    const bool n128 = !pl.bn64 || (g_conv_x3 & 4) || (cdiv(p.Cn, 128) * 128 - p.Cn) * 100 < 30 * p.Cn;
+    const int n_tiles = (int)cdiv(p.Cn, n128 ? 128 : 64);
+    const bool m256 = !(g_conv_x3 & 2) && cdiv(p.M, 256) * n_tiles >= 200;
+    p.n_tiles = n_tiles;
+    const dim3 grid((unsigned)(cdiv(p.M, m256 ? 256 : 128) * n_tiles));
+    if (m256) {
+        if (n128) hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
+        else      hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
+    } else {
+        if (n128) hipLaunchKernelGGL((conv_x3_kernel<128, 128>), grid, dim3(256), 0, st, p, o);
+        else      hipLaunchKernelGGL((conv_x3_kernel<128, 64>), grid, dim3(256), 0, st, p, o);
+    }
+    return check_launch("conv_x3_kernel");
+}
+
+template <bool BWD>
+static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes, hipStream_t st, int kh_kw = 0)
 {
     EventScope ev(st);
     ConvParams p = p_in;
@@ -2129,6 +2511,12 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     const bool vec = g_conv_novec == 0 && p.Ck % 4 == 0 && p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
     ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n, vec);
+    if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
+        // large-tile layers: six bf16 MFMAs per product instead of the fp32 MFMA (operands split once into the workspace)
+        const X3Plan x = x3_plan(pl, (int64_t)p.B * p.H * p.W, p.Ck, p.Cn, kh_kw, p.taps.n, vec);
+        if (x.ok && workspace && ws_bytes >= x.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0)
+            return launch_conv_x3<BWD>(p, pl, x, kh_kw, workspace, st);
+    }
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
     }
@@ -2384,6 +2772,9 @@ void pp_debug_set_splitk(int v)
     g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
 
+/* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
+void pp_debug_set_x3(int v) { g_conv_x3 = v; }
+
 void pp_debug_set_wgrad_target(int v)
 {
     g_wgrad_target = (v & 0xFFFF) > 0 ? (v & 0xFFFF) : 1024;
@@ -2434,7 +2825,10 @@ size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int
     build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     const int64_t M = (int64_t)B * Ho * Wo;
     if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) return 0;             // in-block split-K: no partial sums leave the block
-    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+    const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
+    const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, vec);
+    const X3Plan x3 = x3_plan(pl, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec);
+    if (x3.ok) return x3.bytes;                                           // bf16x3 operand planes
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cout * 4, 256) : 0;
 }
 
@@ -2538,6 +2932,10 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
     const ConvPlan pl = plan_conv(M, Cin, Cout, t.n, Cin % 4 == 0 && Cout % 4 == 0);
     size_t need = pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
     if (ksplit_shape_ok(M, Cin, Cout, t.n, stride)) need = 0;            // in-block split-K (stride 1 only)
+    if (stride == 1) {
+        const X3Plan x3 = x3_plan(pl, (int64_t)B * Ho * Wo, Cout, Cin, kh * kw, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+        if (x3.ok) need = std::max(need, x3.bytes);
+    }
     if (bwd_phases_apply(Cin, Cout, stride, 4)) {
         size_t slabs = 0;
         need = std::max(need, bwd_phases_workspace(B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, &slabs));
@@ -2575,7 +2973,7 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
         if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * Cout * 4))
             return fail(PP_ERR_WORKSPACE, "conv fwd: the split-K workspace is required when statistics are requested");
     }
-    return launch_conv<false>(p, workspace, ws_bytes, as_stream(stream));
+    return launch_conv<false>(p, workspace, ws_bytes, as_stream(stream), kh * kw);
 }
 
 int pp_conv2d_fwd_stats(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
@@ -2677,7 +3075,7 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
     build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: more than 2^31 pixels");
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv bwd_data: no live tap");
-    return launch_conv<true>(p, workspace, ws_bytes, as_stream(stream));
+    return launch_conv<true>(p, workspace, ws_bytes, as_stream(stream), kh * kw);
 }
 
 size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
