@@ -2019,6 +2019,7 @@ struct X3Operands {
     int n_rows;               // B rows per tap (= output channels of this GEMM)
     uint32_t a_zero, b_zero;  // byte offset of the zero row inside a plane (chunk 0)
     uint32_t a_chunk, b_chunk;   // bytes per 16-channel chunk: (rows + 1) * 32
+    int col_base;             // first output column of this launch (ragged widths run as a 128-wide launch + a 64-wide one)
     int ablate;               // TIMING ONLY (wrong results): bit 0 no DMA after the prologue, bit 1 no fragment reads, bit 2 no barriers, bit 3 no MFMAs
 };
 
@@ -2160,7 +2161,7 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
         }
     }
     const int64_t m0 = (int64_t)mt * BM;
-    const int n0 = nt * BN;
+    const int n0 = o.col_base + nt * BN;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
 
     // ---- per-lane DMA addressing: lane -> (row = lane >> 1 of this wave's 32 rows, 16-byte half swizzled by bit 3 of the row)
@@ -2321,6 +2322,212 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
+// ---- weight gradient on the bf16 matrix pipe (bf16x3 split) --------------------------------------------------------------------
+// dW[t][c][n] = sum_m X[pix(m) + s_t][c] * dY[m][n]: the reduction index is the PIXEL, while both operands are stored with the
+// channel contiguous - and the bf16 MFMA wants eight consecutive k per lane.  The tiles therefore go into LDS as they are
+// ([16 pixels][16 channels] sub-blocks straight from the chunk-major planes x3_split_kernel writes: a DMA piece = two such blocks,
+// each 512 contiguous bytes) and the fragments are read with ds_read_b64_tr_b16, the LDS transpose read of gfx950: within 16 lanes,
+// lane i supplies the address of 4 contiguous channels of pixel row i/4 and lane c receives channel c of the four rows
+// (tools/probe/tr16.hip).  Two such reads = the 8 k values of one MFMA operand.  Piece w of a plane sits at w*1024 + ((w+1)/2)*128
+// bytes, so that the two 16-lane groups a read cycle serves (channel blocks 2B and 2B+1) use different bank halves.
+// Tile BM (64 | 128 input channels) x 128 output channels for ONE tap and one pixel slice; partial sums + wgrad_reduce4_kernel as
+// the fp32 kernels.  Pipeline as conv_x3_kernel.
+struct X3WOperands {
+    const uint16_t* x;        // X planes  [3][Cin_p/16][rows_x + 1][16]
+    const uint16_t* dy;       // dY planes [3][Cout_p/16][M + 1][16]
+    int64_t x_plane, dy_plane;
+    uint32_t x_chunk, dy_chunk;   // bytes per channel chunk
+    uint32_t x_zero, dy_zero;     // byte offset of the zero row (chunk 0)
+};
+
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s16_t lds_v4s16_t;
+
+template <int BM>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams p, X3WOperands o)
+{
+    constexpr int BN = 128, TM = BM / 64, TN = 2, WN = 2, NSTAGE = 3;
+    constexpr int NPA = BM / 32, NPB = BN / 32;                         // pieces per plane: waves [0, NPA) load A, all four load B
+    constexpr int REG_A = NPA * 1024 + (NPA / 2) * 128, REG_B = NPB * 1024 + (NPB / 2) * 128;   // one plane of one stage: piece w at w*1024 + ((w+1)/2)*128
+    constexpr int STAGE_BYTES = 3 * (REG_A + REG_B);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
+    struct Frags { bf16x8_t a[3][TM], b[3][TN]; };
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ctiles = (p.Cin + BM - 1) / BM;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if ((total & 7u) == 0) {
+            const unsigned lin = bx + gx * (by + gy * bz);
+            const unsigned nl = (lin & 7u) * (total >> 3) + (lin >> 3);
+            bx = nl % gx;
+            const unsigned t2 = nl / gx;
+            by = t2 % gy;
+            bz = t2 / gy;
+        }
+    }
+    const int c0 = (int)(bx % (unsigned)ctiles) * BM;
+    const int ti = (int)(bx / (unsigned)ctiles);
+    const int n0 = (int)by * BN;
+    const int split = (int)bz;
+    const int64_t m_beg = (int64_t)split * p.m_per_split;
+    const int64_t m_end = m_beg + p.m_per_split < p.M ? m_beg + p.m_per_split : p.M;
+    const int dh = p.taps.dh[ti], dw = p.taps.dw[ti];
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const int n = m_beg < m_end ? (int)((m_end - m_beg + 15) / 16) : 0;   // K steps (16 pixels) of this slice
+
+    // ---- DMA addressing: lane -> (block select lane >> 5, pixel row (lane >> 1) & 15, 16-byte half lane & 1)
+    const int hs = lane >> 5, pr = (lane >> 1) & 15, half = lane & 1;
+    const bool loads_a = wave < NPA;
+    const int a_chunk = (c0 >> 4) + wave + (NPA)*hs;          // piece w = channel blocks (w, w + NPA) of the tile
+    const int b_chunk = (n0 >> 4) + wave + (NPB)*hs;
+    const bool a_cok = loads_a && a_chunk * 16 < p.Cin, b_cok = b_chunk * 16 < p.Cout;
+    const uint32_t a_base = (uint32_t)a_chunk * o.x_chunk + (uint32_t)(half * 16);
+    const uint32_t b_base = (uint32_t)b_chunk * o.dy_chunk + (uint32_t)(half * 16);
+    const uint32_t a_zero = o.x_zero + (uint32_t)(half * 16), b_zero = o.dy_zero + (uint32_t)(half * 16);
+    RowIter it;
+    it.init(m_beg + pr < p.M ? m_beg + pr : 0, p.Wo, p.Ho);
+    int64_t is_m = m_beg + pr;                                 // pixel of this lane in the next step to issue
+    const uint16_t* x0 = o.x; const uint16_t* x1 = o.x + o.x_plane; const uint16_t* x2 = o.x + 2 * o.x_plane;
+    const uint16_t* d0 = o.dy; const uint16_t* d1 = o.dy + o.dy_plane; const uint16_t* d2 = o.dy + 2 * o.dy_plane;
+    const uint32_t a_piece = (uint32_t)(wave * 1024 + ((wave + 1) >> 1) * 128);
+    const uint32_t b_piece = (uint32_t)(3 * REG_A + wave * 1024 + ((wave + 1) >> 1) * 128);
+
+    uint32_t st_va = 0, st_vb = 0, st_lds = 0;
+    auto issue_begin = [&](int stage) {
+        const bool okm = is_m < m_end;
+        const int ih = it.oh * p.stride + dh, iw = it.ow * p.stride + dw;
+        const bool oka = okm && a_cok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const uint32_t pix = (uint32_t)((it.bb * p.H + ih) * p.W + iw);
+        st_va = oka ? a_base + pix * 32u : a_zero;
+        st_vb = (okm && b_cok) ? b_base + (uint32_t)is_m * 32u : b_zero;
+        st_lds = lds0 + (uint32_t)(stage * STAGE_BYTES);
+        it.advance(16, p.Wo, p.Ho);
+        is_m += 16;
+    };
+    auto issue_piece = [&](int i) {
+        if (i < 3) {
+            if (loads_a) x3_glds16(st_va, i == 0 ? x0 : (i == 1 ? x1 : x2), st_lds + (uint32_t)(i * REG_A) + a_piece);
+        } else {
+            x3_glds16(st_vb, i == 3 ? d0 : (i == 4 ? d1 : d2), st_lds + (uint32_t)((i - 3) * REG_B) + b_piece);
+        }
+    };
+    auto issue_all = [&](int stage) {
+        issue_begin(stage);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i);
+    };
+
+    // ---- transpose-read addressing: MFMA row block B (32 channels) = channel blocks 2B, 2B+1; lane -> (block (lane >> 4) & 1,
+    //      pixel row 8*(lane >> 5) + ((lane & 15) >> 2), 8-byte piece lane & 3); second read: + 4 rows = + 128 bytes
+    auto tr_off = [&](int blk32, int npieces) -> uint32_t {
+        const int ci = 2 * blk32 + ((lane >> 4) & 1);                  // channel block inside the tile
+        const int piece = ci % npieces, second = ci / npieces;         // piece w holds blocks (w, w + npieces)
+        return (uint32_t)(piece * 1024 + ((piece + 1) >> 1) * 128 + second * 512 + (8 * h + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
+    };
+    uint32_t a_tr[TM], b_tr[TN];                              // byte offsets inside a stage
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a_tr[t] = tr_off(wm * TM + t, NPA);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b_tr[t] = (uint32_t)(3 * REG_A) + tr_off(wn * TN + t, NPB);
+    auto read_op = [&](uint32_t off) -> bf16x8_t {
+        const v4s16_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16_t*)(smem + off));
+        const v4s16_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16_t*)(smem + off + 128));
+        typedef short v8s16_t __attribute__((ext_vector_type(8)));
+        v8s16_t u = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return *reinterpret_cast<bf16x8_t*>(&u);
+    };
+    auto read_a = [&](int stage, Frags& F, int pl) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) F.a[pl][t] = read_op(a_tr[t] + (uint32_t)(stage * STAGE_BYTES + pl * REG_A));
+    };
+    auto read_b = [&](int stage, Frags& F, int pl) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) F.b[pl][t] = read_op(b_tr[t] + (uint32_t)(stage * STAGE_BYTES + pl * REG_B));
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto mma_term = [&](const Frags& F, int term) {
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[TA[term]][tm], F.b[TB[term]][tn], acc[tm][tn], 0, 0, 0);
+    };
+    auto wait_pieces = [&](int steps_in_flight) {
+        if (loads_a) {
+            if (steps_in_flight >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (steps_in_flight >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
+        const bool rd = k + 1 < n, dm = k + NSTAGE < n;
+        const int sn = (k + 1) % NSTAGE;
+        if (rd) {
+            wait_pieces(k + 2 < n ? 1 : 0);                  // step k+1 has landed (k+2 may still fly)
+            __builtin_amdgcn_s_barrier();                    // everyone's pieces of step k+1; ring slot k%3 is free
+            asm volatile("" ::: "memory");
+        }
+        if (dm) issue_begin(k % NSTAGE);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            mma_term(cur, g);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rd) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
+            if (dm) issue_piece(g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    Frags F0, F1;
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE; ++s0)
+        if (s0 < n) issue_all(s0);
+    if (n > 0) {
+        wait_pieces((n < NSTAGE ? n : NSTAGE) - 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
+    }
+    int k = 0;
+    for (; k + 1 < n; k += 2) {
+        kstep(k, F0, F1);
+        kstep(k + 1, F1, F0);
+    }
+    if (k < n) kstep(k, F0, F1);
+
+    float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nn = n0 + (wn * TN + tn) * 32 + l31;
+        if (nn >= p.Cout) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (c < p.Cin) out[(int64_t)c * p.Cout + nn] = acc[tm][tn][r];
+            }
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------
 // live taps for forward-style indexing: input row = oh*stride + (th*dil - pad)
 // Forward (flip == false): rows are output pixels, source row = oh*stride + dh, H/W = input size.
@@ -2479,25 +2686,38 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
                        BWD ? 0 : 1, bp, x.Kp, x.b_plane);
     if (int rc = check_launch("x3_split_w_kernel")) return rc;
     X3Operands o{ap, bp, x.a_plane, x.b_plane, x.Kp, p.Cn, (uint32_t)(x.rows_a * 32), (uint32_t)(x.b_rows * 32),
-                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), (g_conv_x3 >> 4) & 15};
+                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), 0, (g_conv_x3 >> 4) & 15};
     p.n_tiles = pl.n_tiles;
     p.splits = 1;
     p.ks_per_split = 0;
     p.part = nullptr;
-    // 256-row tiles (eight waves, one block per CU) when that still gives every CU a block; (g_conv_x3 bit 1: 128 rows always;
-    // bit 2: 128-wide tiles also for ragged widths)
-    // ragged output widths (304): 128-wide tiles while they pad less than 30 % (384 for 304: 350 us, 64-wide 372 us)
-    const bool n128 = !pl.bn64 || (g_conv_x3 & 4) || (cdiv(p.Cn, 128) * 128 - p.Cn) * 100 < 30 * p.Cn;
-    const int n_tiles = (int)cdiv(p.Cn, n128 ? 128 : 64);
-    const bool m256 = !(g_conv_x3 & 2) && cdiv(p.M, 256) * n_tiles >= 200;
-    p.n_tiles = n_tiles;
-    const dim3 grid((unsigned)(cdiv(p.M, m256 ? 256 : 128) * n_tiles));
-    if (m256) {
-        if (n128) hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
-        else      hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
+    // 256-row tiles (eight waves, one block per CU) when that still gives every CU a block (g_conv_x3 bit 1: 128 rows always).
+    // Ragged widths (304 = 2 x 128 + 48): the full 128-wide tile columns in one launch, the remainder (<= 64 columns) in a second
+    // one with 64-wide tiles - 384 blocks of 256 x 128 on 256 CUs were two rounds for 1.19x the work (349 us; bit 2: that form)
+    const int full128 = p.Cn / 128, rem = p.Cn - full128 * 128;
+    const bool two = rem > 0 && rem <= 64 && full128 > 0 && !(g_conv_x3 & 4);
+    const bool n128_only = !two && (rem == 0 || rem > 64 || (g_conv_x3 & 4));
+    const int64_t mt256 = cdiv(p.M, 256);
+    const bool m256 = !(g_conv_x3 & 2) && mt256 * (two ? full128 : cdiv(p.Cn, n128_only ? 128 : 64)) >= 200;
+    const int64_t mtiles = m256 ? mt256 : cdiv(p.M, 128);
+    auto go = [&](bool n128, int ntile, int col_base) {
+        o.col_base = col_base;
+        p.n_tiles = ntile;
+        const dim3 grid((unsigned)(mtiles * ntile));
+        if (m256) {
+            if (n128) hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
+            else      hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
+        } else {
+            if (n128) hipLaunchKernelGGL((conv_x3_kernel<128, 128>), grid, dim3(256), 0, st, p, o);
+            else      hipLaunchKernelGGL((conv_x3_kernel<128, 64>), grid, dim3(256), 0, st, p, o);
+        }
+    };
+    if (two) {
+        go(true, full128, 0);
+        if (int rc = check_launch("conv_x3_kernel")) return rc;
+        go(false, 1, full128 * 128);
     } else {
-        if (n128) hipLaunchKernelGGL((conv_x3_kernel<128, 128>), grid, dim3(256), 0, st, p, o);
-        else      hipLaunchKernelGGL((conv_x3_kernel<128, 64>), grid, dim3(256), 0, st, p, o);
+        go(n128_only, (int)cdiv(p.Cn, n128_only ? 128 : 64), 0);
     }
     return check_launch("conv_x3_kernel");
 }
@@ -3078,6 +3298,23 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
     return launch_conv<true>(p, workspace, ws_bytes, as_stream(stream), kh * kw);
 }
 
+// bf16x3 weight gradient (conv_wgrad_x3_kernel): the MFMA-bound layers (>= 8 GFLOP, both channel counts > 64, 128-wide outputs)
+struct X3WPlan { bool ok; int Cin_p, Cout_p; int64_t x_plane, dy_plane; size_t bytes; };
+static X3WPlan x3w_plan(int B, int H, int W, int Cin, int Cout, int64_t M, int ntaps, bool shape_ok)
+{
+    X3WPlan x{};
+    if (!g_conv_x3 || (g_conv_x3 & 8) || !shape_ok || ntaps > 32 || 2.0 * ntaps * Cin * Cout * (double)M < 8e9) return x;
+    x.Cin_p = (int)cdiv(Cin, 16) * 16;
+    x.Cout_p = (int)cdiv(Cout, 16) * 16;
+    const int64_t rows_x = (int64_t)B * H * W;
+    x.x_plane = (rows_x + 1) * x.Cin_p;
+    x.dy_plane = (M + 1) * x.Cout_p;
+    if (x.x_plane * 2 >= (1ll << 32) - 4096 || x.dy_plane * 2 >= (1ll << 32) - 4096) return x;
+    x.bytes = align_up((size_t)3 * x.x_plane * 2, 256) + align_up((size_t)3 * x.dy_plane * 2, 256);
+    x.ok = true;
+    return x;
+}
+
 size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                             int dil)
 {
@@ -3093,7 +3330,15 @@ size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Co
         if (n > w) w = n;
     }
     w += (size_t)64 * Cout * 4;            // bias-gradient partials ride behind the weight partials
-    return align_up(w > b ? w : b, 256);
+    size_t total = align_up(w > b ? w : b, 256);
+    {
+        const bool big = Cin > 64 && Cout > 64, vec = Cin % 4 == 0 && Cout % 4 == 0;
+        const int remn = Cout % 128;
+        const bool narrow_n = big && remn != 0 && remn <= 64 && (cdiv(Cout, 128) * 128 - Cout) * 100 > 12 * Cout;
+        const X3WPlan xw = x3w_plan(B, H, W, Cin, Cout, M, kh * kw, vec && big && !narrow_n);
+        if (xw.ok) total += 256 + xw.bytes;
+    }
+    return total;
 }
 
 int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
@@ -3153,6 +3398,28 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     // LDS-DMA kernels: vector operands, no fused bias gradient, 32-bit safe row pitch; bits of g_wgrad_dma: 1 = 128-wide tiles, 2 = 64x64
     const bool dma = vec && p.bias_part == nullptr && (int64_t)p.M * std::max(ldx, lddy) < (1ll << 40);
+    // MFMA-bound layers: the bf16x3 kernel (operand planes behind the partial sums in the workspace)
+    {
+        const X3WPlan xw = x3w_plan(B, H, W, Cin, Cout, p.M, p.taps.n, vec && big && p.bias_part == nullptr && !narrow_n);
+        const size_t off = align_up(need + (dbias ? (size_t)64 * Cout * 4 : 0), 256);
+        if (xw.ok && ws_bytes >= off + xw.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) {
+            uint16_t* xp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + off);
+            uint16_t* dp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(xp) + align_up((size_t)3 * xw.x_plane * 2, 256));
+            const int64_t rows_x = (int64_t)B * H * W;
+            hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((rows_x + 1) * (xw.Cin_p / 8), 256), 4096)), dim3(256), 0, st,
+                               x, ldx, rows_x, Cin, xp, xw.Cin_p, xw.x_plane);
+            hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((p.M + 1) * (xw.Cout_p / 8), 256), 4096)), dim3(256), 0, st,
+                               dy, lddy, p.M, Cout, dp, xw.Cout_p, xw.dy_plane);
+            if (int rc = check_launch("x3_split_kernel")) return rc;
+            X3WOperands o{xp, dp, xw.x_plane, xw.dy_plane, (uint32_t)((rows_x + 1) * 32), (uint32_t)((p.M + 1) * 32),
+                          (uint32_t)(rows_x * 32), (uint32_t)(p.M * 32)};
+            const int bmx = narrow_m ? 64 : 128;
+            dim3 gx((unsigned)(cdiv(Cin, bmx) * p.taps.n), (unsigned)cdiv(Cout, 128), (unsigned)splits);
+            if (narrow_m) hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), gx, dim3(kThreads), 0, st, p, o);
+            else          hipLaunchKernelGGL((conv_wgrad_x3_kernel<128>), gx, dim3(kThreads), 0, st, p, o);
+            goto reduce_partials;
+        }
+    }
     if (dma && (g_wgrad_dma & 1) && big && !(narrow_m && narrow_n)) {
         if (narrow_m)      hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), grid, dim3(kThreads), 0, st, p);
         else if (narrow_n) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), grid, dim3(kThreads), 0, st, p);
@@ -3176,6 +3443,7 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
         if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
         else     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(kThreads), g_wgrad_lds_pad, st, p);
     }
+reduce_partials:
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
     const int64_t cn = (int64_t)Cin * Cout;
     if (cn % 4 == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0)

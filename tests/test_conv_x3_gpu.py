@@ -36,10 +36,11 @@ def _run(case, x3):
         dy = torch.randn(B, Ho, Wo, Cout, device=DEV, generator=gen)
         tape = E.Tape()
         xv = E.Var(x)
-        yv = E.conv2d(tape, xv, w.requires_grad_(False), bias, 1, pad, dil)
+        yv = E.conv2d(tape, xv, w.requires_grad_(True), bias, 1, pad, dil)
         y = yv.t.clone()
         tape.backward(yv, dy)
-        return x, w, bias, dy, y, xv.grad.clone()
+        torch.cuda.synchronize()
+        return x, w.detach(), bias, dy, y, xv.grad.clone(), tape.param_grads[id(w)].clone()
     finally:
         L.pp_debug_set_x3(1)
 
@@ -50,10 +51,11 @@ def test_bf16x3_convolution_is_an_fp32_convolution(case):
     L = _lib.lib()
     L.pp_debug_set_x3(1)
     assert L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, k, k, 1, pad, dil) >= 3 * 2 * (B * H * W + 1) * Cin, "case is not a large-tile layer"
-    x, w, bias, dy, y3, dx3 = _run(case, True)
-    _, _, _, _, y1, dx1 = _run(case, False)
+    x, w, bias, dy, y3, dx3, dw3 = _run(case, True)
+    _, _, _, _, y1, dx1, dw1 = _run(case, False)
     xd, wd = x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(3, 2, 0, 1).cpu()
     xd.requires_grad_(True)
+    wd.requires_grad_(True)
     ref = F.conv2d(xd, wd, bias.double().cpu() if has_bias else None, 1, pad, dil)
     ref.backward(dy.double().permute(0, 3, 1, 2).cpu())
     ref_y, ref_dx = ref.detach().permute(0, 2, 3, 1), xd.grad.permute(0, 2, 3, 1)
@@ -63,14 +65,18 @@ def test_bf16x3_convolution_is_an_fp32_convolution(case):
 
     e3, e1 = err(y3, ref_y), err(y1, ref_y)
     d3, d1 = err(dx3, ref_dx), err(dx1, ref_dx)
+    ref_dw = wd.grad.permute(2, 3, 1, 0)                                 # OIHW -> HWIO
+    g3, g1 = err(dw3, ref_dw), err(dw1, ref_dw)
+    print(f"[x3] weight gradient max/l2 rel err vs fp64: bf16x3 {g3[0]:.2e}/{g3[1]:.2e}  fp32-MFMA {g1[0]:.2e}/{g1[1]:.2e}")
+    assert g3[1] <= max(2.0 * g1[1], 3e-7) and g3[0] <= 5e-6
     print(f"\n[x3] fwd max/l2 rel err vs fp64: bf16x3 {e3[0]:.2e}/{e3[1]:.2e}  fp32-MFMA {e1[0]:.2e}/{e1[1]:.2e} | "
           f"bwd-data: bf16x3 {d3[0]:.2e}/{d3[1]:.2e}  fp32-MFMA {d1[0]:.2e}/{d1[1]:.2e}")
     # the same class of error as the fp32 kernels (both are a few 1e-7 in l2), far inside the op-level bar of 1e-4
     assert e3[1] <= max(2.0 * e1[1], 3e-7) and d3[1] <= max(2.0 * d1[1], 3e-7)
     assert e3[0] <= 5e-6 and d3[0] <= 5e-6
     # bit-reproducible
-    _, _, _, _, y3b, dx3b = _run(case, True)
-    assert torch.equal(y3, y3b) and torch.equal(dx3, dx3b)
+    _, _, _, _, y3b, dx3b, dw3b = _run(case, True)
+    assert torch.equal(y3, y3b) and torch.equal(dx3, dx3b) and torch.equal(dw3, dw3b)
 
 
 def test_bf16_split_is_exact():
