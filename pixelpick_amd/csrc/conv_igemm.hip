@@ -2020,7 +2020,6 @@ struct X3Operands {
     uint32_t a_zero, b_zero;  // byte offset of the zero row inside a plane (chunk 0)
     uint32_t a_chunk, b_chunk;   // bytes per 16-channel chunk: (rows + 1) * 32
     int col_base;             // first output column of this launch (ragged widths run as a 128-wide launch + a 64-wide one)
-    int ablate;               // TIMING ONLY (wrong results): bit 0 no DMA after the prologue, bit 1 no fragment reads, bit 2 no barriers, bit 3 no MFMAs
 };
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
@@ -2131,6 +2130,25 @@ __device__ __forceinline__ void x3_glds16(uint32_t voff, const void* sbase_in, u
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+// the three planes of one operand piece behind ONE M0 save / restore: same lane offset, three plane bases, LDS destinations
+// `stride` bytes apart
+__device__ __forceinline__ void x3_glds16x3(uint32_t voff, const void* s0, const void* s1, const void* s2, uint32_t lds_dst_in, uint32_t stride_in)
+{
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(lds_dst_in);
+    const uint32_t st = __builtin_amdgcn_readfirstlane(stride_in);
+    auto uni = [](const void* q) -> const void* {
+        const uint64_t v = reinterpret_cast<uint64_t>(q);
+        return reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v));
+    };
+    const void* b0 = uni(s0); const void* b1 = uni(s1); const void* b2 = uni(s2);
+    unsigned keep, t;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_add_u32 %1, %6, %7\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                 "s_add_u32 %1, %1, %7\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(t) : "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(d0), "s"(st) : "memory", "scc");
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(ConvParams p, X3Operands o)
 {
@@ -2216,15 +2234,9 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
         st_lds = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)(wave * 1024);
         if (++is_ti == p.taps.n) { is_ti = 0; ++is_ch; }
     };
-    auto issue_piece = [&](int i) {
-        if (i == 0) x3_glds16(st_va, a0, st_lds);
-        else if (i == 1) x3_glds16(st_va, a1, st_lds + A_BYTES);
-        else if (i == 2) x3_glds16(st_va, a2, st_lds + 2 * A_BYTES);
-        else if (loads_b) {
-            if (i == 3) x3_glds16(st_vb, b0, st_lds + 3 * A_BYTES);
-            else if (i == 4) x3_glds16(st_vb, b1, st_lds + 3 * A_BYTES + B_BYTES);
-            else x3_glds16(st_vb, b2, st_lds + 3 * A_BYTES + 2 * B_BYTES);
-        }
+    auto issue_piece = [&](int i) {                      // two batches of three planes: A behind MFMA group 0, B behind group 3
+        if (i == 0) x3_glds16x3(st_va, a0, a1, a2, st_lds, A_BYTES);
+        else if (i == 3 && loads_b) x3_glds16x3(st_vb, b0, b1, b2, st_lds + 3 * A_BYTES, B_BYTES);
     };
     auto issue_all = [&](int stage) {
         issue_begin(stage);
@@ -2280,21 +2292,28 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
-    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
-        const bool rd = k + 1 < n && !(o.ablate & 2), dm = k + NSTAGE < n && !(o.ablate & 1);
-        const int sn = (k + 1) % NSTAGE;
-        if (k + 1 < n && !(o.ablate & 4)) {
+    // STEADY (compile time): at least NSTAGE steps remain, so every `if` of the step is taken - the steady-state loop has no branches
+    // besides the wave-uniform "this wave loads B rows" one (runtime-uniform branches cost conv_igemm_dma_kernel ~10 %)
+    auto kstep = [&](auto steady_tag, int k, int stage, Frags& cur, Frags& nxt) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const bool rd = STEADY || k + 1 < n, dm = STEADY || k + NSTAGE < n;
+        const int sn = stage + 1 == NSTAGE ? 0 : stage + 1;
+        if (rd) {
             // step k+1 has landed; steps k+2 .. k+NSTAGE-1 (as far as they exist) may still fly
-            const int fly = n - (k + 2) < NSTAGE - 2 ? n - (k + 2) : NSTAGE - 2;
-            wait_pieces(fly > 0 ? fly : 0);
-            __builtin_amdgcn_s_barrier();                    // everyone's pieces of step k+1; ring slot k%3 is free
+            if (STEADY) {
+                wait_pieces(NSTAGE - 2);
+            } else {
+                const int fly = n - (k + 2) < NSTAGE - 2 ? n - (k + 2) : NSTAGE - 2;
+                wait_pieces(fly > 0 ? fly : 0);
+            }
+            __builtin_amdgcn_s_barrier();                    // everyone's pieces of step k+1; ring slot k%NSTAGE is free
             asm volatile("" ::: "memory");
         }
-        if (dm) issue_begin(k % NSTAGE);
+        if (dm) issue_begin(stage);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            if (!(o.ablate & 8)) mma_term(cur, g);
+            mma_term(cur, g);
             __builtin_amdgcn_sched_barrier(0);
             if (rd) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
             if (dm) issue_piece(g);
@@ -2313,12 +2332,18 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
     }
+    // (unrolling the steady state over lcm(2, NSTAGE) steps so that ring slots become immediates was measured SLOWER: 203 -> 240 us
+    // on the 256 -> 256 layer - the loop body no longer fits the instruction cache)
     int k = 0;
-    for (; k + 1 < n; k += 2) {
-        kstep(k, F0, F1);
-        kstep(k + 1, F1, F0);
+    for (; k + NSTAGE + 1 < n; k += 2) {
+        kstep(std::true_type{}, k, k % NSTAGE, F0, F1);
+        kstep(std::true_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
     }
-    if (k < n) kstep(k, F0, F1);
+    for (; k + 1 < n; k += 2) {
+        kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
+        kstep(std::false_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
+    }
+    if (k < n) kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
@@ -2408,12 +2433,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
         it.advance(16, p.Wo, p.Ho);
         is_m += 16;
     };
-    auto issue_piece = [&](int i) {
-        if (i < 3) {
-            if (loads_a) x3_glds16(st_va, i == 0 ? x0 : (i == 1 ? x1 : x2), st_lds + (uint32_t)(i * REG_A) + a_piece);
-        } else {
-            x3_glds16(st_vb, i == 3 ? d0 : (i == 4 ? d1 : d2), st_lds + (uint32_t)((i - 3) * REG_B) + b_piece);
-        }
+    auto issue_piece = [&](int i) {                      // two batches of three planes
+        if (i == 0) { if (loads_a) x3_glds16x3(st_va, x0, x1, x2, st_lds + a_piece, REG_A); }
+        else if (i == 3) x3_glds16x3(st_vb, d0, d1, d2, st_lds + b_piece, REG_B);
     };
     auto issue_all = [&](int stage) {
         issue_begin(stage);
@@ -2475,15 +2497,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
-    auto kstep = [&](int k, Frags& cur, Frags& nxt) {
-        const bool rd = k + 1 < n, dm = k + NSTAGE < n;
-        const int sn = (k + 1) % NSTAGE;
+    auto kstep = [&](auto steady_tag, int k, int stage, Frags& cur, Frags& nxt) {
+        constexpr bool STEADY = decltype(steady_tag)::value;     // >= NSTAGE steps remain: no branches in the step
+        const bool rd = STEADY || k + 1 < n, dm = STEADY || k + NSTAGE < n;
+        const int sn = stage + 1 == NSTAGE ? 0 : stage + 1;
         if (rd) {
-            wait_pieces(k + 2 < n ? 1 : 0);                  // step k+1 has landed (k+2 may still fly)
+            wait_pieces(STEADY || k + 2 < n ? 1 : 0);        // step k+1 has landed (k+2 may still fly)
             __builtin_amdgcn_s_barrier();                    // everyone's pieces of step k+1; ring slot k%3 is free
             asm volatile("" ::: "memory");
         }
-        if (dm) issue_begin(k % NSTAGE);
+        if (dm) issue_begin(stage);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
@@ -2507,11 +2530,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
         for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
     }
     int k = 0;
-    for (; k + 1 < n; k += 2) {
-        kstep(k, F0, F1);
-        kstep(k + 1, F1, F0);
+    for (; k + NSTAGE + 1 < n; k += 2) {
+        kstep(std::true_type{}, k, k % NSTAGE, F0, F1);
+        kstep(std::true_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
     }
-    if (k < n) kstep(k, F0, F1);
+    for (; k + 1 < n; k += 2) {
+        kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
+        kstep(std::false_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
+    }
+    if (k < n) kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
 
     float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
 #pragma unroll
@@ -2656,11 +2683,18 @@ static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
 // bf16x3 path (conv_x3_kernel): which problems take it, and what the caller's workspace must hold for it
 static thread_local int g_conv_x3 = 1;
 struct X3Plan { bool ok; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes; };
-static X3Plan x3_plan(const ConvPlan& pl, int64_t rows_a, int Ck, int n_rows, int ntaps_w, int ntaps_live, bool vec)
+static thread_local int g_conv_x3_mid = 1;
+static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int n_rows, int ntaps_w, int ntaps_live, bool vec)
 {
     X3Plan x{};
     // (shallow reductions - the 16 -> 96 expand at 130 x 258 - do not pay for the two split launches: 26 + 14 vs 19 us)
-    if (!g_conv_x3 || pl.cfg != 1 || pl.splits > 1 || !vec || ntaps_live > 32 || (int64_t)ntaps_live * Ck < 512) return x;
+    // large-tile plans, and (ResNet50 at 32 x 64: 8192 rows) the 64x64-tiled layers that give 128-row tiles a full wave of blocks
+    // and >= 16 GFLOP (512 -> 512 3x3: 112 TF on the fp32 pipe)
+    const int64_t t128 = cdiv(M, 128) * cdiv(n_rows, 128);
+    // (measured, FPN-ResNet50: with half a wave of blocks / below 16 GFLOP the operand splits and the idle CUs cost more than the
+    // matrix rate gains - 256 -> 256 3x3 at 8192 rows 94 -> 150 us, 2048 -> 256 87 -> 155 us; 512 -> 512 3x3 345 -> 279 us)
+    const bool mid = g_conv_x3_mid && pl.cfg == 2 && t128 >= 256 && 2.0 * (double)M * n_rows * ntaps_live * Ck >= 16e9;
+    if (!g_conv_x3 || !(pl.cfg == 1 || mid) || pl.splits > 1 || !vec || ntaps_live > 32 || (int64_t)ntaps_live * Ck < 512) return x;
     x.Kp = (int)cdiv(Ck, 16) * 16;
     x.rows_a = rows_a;
     x.a_plane = (rows_a + 1) * x.Kp;
@@ -2686,7 +2720,7 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
                        BWD ? 0 : 1, bp, x.Kp, x.b_plane);
     if (int rc = check_launch("x3_split_w_kernel")) return rc;
     X3Operands o{ap, bp, x.a_plane, x.b_plane, x.Kp, p.Cn, (uint32_t)(x.rows_a * 32), (uint32_t)(x.b_rows * 32),
-                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), 0, (g_conv_x3 >> 4) & 15};
+                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), 0};
     p.n_tiles = pl.n_tiles;
     p.splits = 1;
     p.ks_per_split = 0;
@@ -2733,7 +2767,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n, vec);
     if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
         // large-tile layers: six bf16 MFMAs per product instead of the fp32 MFMA (operands split once into the workspace)
-        const X3Plan x = x3_plan(pl, (int64_t)p.B * p.H * p.W, p.Ck, p.Cn, kh_kw, p.taps.n, vec);
+        const X3Plan x = x3_plan(pl, p.M, (int64_t)p.B * p.H * p.W, p.Ck, p.Cn, kh_kw, p.taps.n, vec);
         if (x.ok && workspace && ws_bytes >= x.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0)
             return launch_conv_x3<BWD>(p, pl, x, kh_kw, workspace, st);
     }
@@ -2993,7 +3027,7 @@ void pp_debug_set_splitk(int v)
 }
 
 /* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
-void pp_debug_set_x3(int v) { g_conv_x3 = v; }
+void pp_debug_set_x3(int v) { g_conv_x3 = v & 0xFF; g_conv_x3_mid = (v & 256) ? 0 : 1; }   /* bit 8: large-tile plans only */
 
 void pp_debug_set_wgrad_target(int v)
 {
@@ -3047,7 +3081,7 @@ size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int
     if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) return 0;             // in-block split-K: no partial sums leave the block
     const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
     const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, vec);
-    const X3Plan x3 = x3_plan(pl, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec);
+    const X3Plan x3 = x3_plan(pl, M, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec);
     if (x3.ok) return x3.bytes;                                           // bf16x3 operand planes
     return pl.splits > 1 ? align_up((size_t)pl.splits * M * Cout * 4, 256) : 0;
 }
@@ -3153,7 +3187,7 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
     size_t need = pl.splits > 1 ? align_up((size_t)pl.splits * M * Cin * 4, 256) : 0;
     if (ksplit_shape_ok(M, Cin, Cout, t.n, stride)) need = 0;            // in-block split-K (stride 1 only)
     if (stride == 1) {
-        const X3Plan x3 = x3_plan(pl, (int64_t)B * Ho * Wo, Cout, Cin, kh * kw, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+        const X3Plan x3 = x3_plan(pl, M, (int64_t)B * Ho * Wo, Cout, Cin, kh * kw, t.n, Cin % 4 == 0 && Cout % 4 == 0);
         if (x3.ok) need = std::max(need, x3.bytes);
     }
     if (bwd_phases_apply(Cin, Cout, stride, 4)) {

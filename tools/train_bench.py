@@ -16,6 +16,9 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = get_model(args).cuda().train()
+    if os.environ.get("X3MODE"):                      # pp_debug_set_x3 word (A/B of the bf16x3 kernels)
+        from pixelpick_amd import _lib
+        _lib.lib().pp_debug_set_x3(int(os.environ["X3MODE"]))
     tr = FlatTrainer(m, ignore_index=C)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(B, 3, H, W, device="cuda", generator=g)
