@@ -159,9 +159,6 @@ def main():
     ap.add_argument("--reduce-mode", type=int, default=0)
     ap.add_argument("--exact-formula", type=int, default=0)
     ap.add_argument("--conv-variant", type=int, default=0)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the train step as one hipGraph (FlatTrainer.enable_graph).  Measured on ROCm 7.2: 10.3 ms vs "
-                         "9.1-10.0 ms eager — the replay serialises the weight-gradient side stream — so eager is the default")
     ap.add_argument("--replay", default="auto", choices=["auto", "on", "off"],
                     help="re-issue the train step's recorded launch list (FlatTrainer.enable_replay: same GPU schedule, half the host "
                          "time per step).  auto: on when this process has fewer than 8 host cores per rank to enqueue from")
@@ -257,10 +254,8 @@ def main():
         E.set_dropout_seed(1234 + rank)
         x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
         cores_per_rank = (os.cpu_count() or 1) / max(world, 1)
-        replay = (a.replay == "on" or (a.replay == "auto" and cores_per_rank < 8)) and not a.graph
-        if a.graph:
-            tr.enable_graph(x, y)                    # whole step (fwd, CE, bwd, all-reduce, Adam) = one hipGraph replay
-        elif replay:
+        replay = a.replay == "on" or (a.replay == "auto" and cores_per_rank < 8)
+        if replay:
             tr.enable_replay(x, y, warmup=1)         # recorded launch list, eager two-queue GPU schedule (bit-identical steps)
         tr.time_collectives = dist is not None
         host_s = [0.0]
@@ -287,8 +282,7 @@ def main():
         host_ms = max_over_ranks(sorted(solo)[len(solo) // 2]) * 1e3
         loss = float(tr.last_loss.item())
         train = {"img_per_s": world * TB * a.steps / el, "ms_per_step": el / a.steps * 1e3, "loss_after": loss,
-                 "launch": "hipGraph replay" if a.graph else ("launch-plan replay" if replay else "eager") +
-                           ", weight gradients on a second stream",
+                 "launch": ("launch-plan replay" if replay else "eager") + ", small weight gradients on a second stream",
                  # host time spent inside train_step() per step (enqueue only, nothing synchronises): a host slower than the
                  # GPU step shows up HERE, not as an unexplained scaling loss
                  "host_enqueue_ms_per_step": host_ms, "host_in_loop_ms_per_step": host_loop_ms, "replay": bool(replay),
@@ -325,20 +319,37 @@ def main():
         wa = torch.randn((3, 3, 304, 256), device=dev) * 0.02
         ya = torch.empty((TB, Hq, Wq, 256), device=dev)
         nrep = max(a.steps, 10)
-        evc = HipEvents(nrep)
+        # the op as the train step runs it: operand splits (x3_split_kernel, x3_split_w_kernel) + conv_x3_kernel - the fp32
+        # convolution on the bf16 matrix pipe (every operand = hi + mid + lo bf16, six MFMAs per product, fp32 accumulate;
+        # error against float64 = that of the fp32-MFMA kernel, tests/test_conv_x3_gpu.py) - and, for reference, the fp32-MFMA
+        # kernel it replaced (pp_debug_set_x3(0))
+        wsx = torch.empty(max(int(L.pp_conv2d_fwd_workspace_bytes(TB, Hq, Wq, 304, 256, 3, 3, 1, 1, 1)), 256), dtype=torch.uint8, device=dev)
 
         def conv_once():
-            rc = L.pp_conv2d_fwd(xa.data_ptr(), 304, TB, Hq, Wq, 304, wa.data_ptr(), None, 3, 3, 1, 1, 1, ya.data_ptr(), 256, 256, None, 0, stream)
+            rc = L.pp_conv2d_fwd(xa.data_ptr(), 304, TB, Hq, Wq, 304, wa.data_ptr(), None, 3, 3, 1, 1, 1, ya.data_ptr(), 256, 256,
+                                 wsx.data_ptr(), wsx.numel(), stream)
             _lib.check(rc, "pp_conv2d_fwd")
-        timed(conv_once, nrep, 12, evc)          # warm: the first launches after the train loop read ~10 % low (clock ramp)
-        cms = evc.elapsed_ms()
-        evc.destroy()
         flops = 2.0 * TB * Hq * Wq * 256 * 9 * 304
-        cavg = sum(cms) / len(cms)
-        line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_igemm_dma_kernel<128,128> SegmentHead 3x3 304->256 fwd",
-                                 "achieved": round(flops / (cavg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                 "frac": round(flops / (cavg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                                 "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
+        res = {}
+        for tag, mode in (("bf16x3", 1), ("fp32_mfma", 0)):
+            L.pp_debug_set_x3(mode)
+            evc = HipEvents(nrep)
+            timed(conv_once, nrep, 12, evc)      # warm: the first launches after the train loop read ~10 % low (clock ramp)
+            cms = evc.elapsed_ms()
+            evc.destroy()
+            res[tag] = sum(cms) / len(cms)
+        L.pp_debug_set_x3(1)
+        cavg = res["bf16x3"]
+        X3_PEAK_TF = MFMA_F32_PEAK_TF * 16.0 / 6.0            # bf16 MFMA = 16x the fp32 MFMA rate, six bf16 MFMAs per fp32 product
+        line["roofline_mfma"] = {"bound": "mfma", "kernel": "x3_split_kernel + x3_split_w_kernel + conv_x3_kernel<256,128>, SegmentHead 3x3 304->256 fwd",
+                                 "arithmetic": "fp32 operands split exactly into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate",
+                                 "achieved": round(flops / (cavg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s (fp32-equivalent)",
+                                 "frac": round(flops / (cavg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                 "peak_of_the_split": round(X3_PEAK_TF, 1), "frac_of_the_split_peak": round(flops / (cavg * 1e-3) / 1e12 / X3_PEAK_TF, 4),
+                                 "fp32_mfma_kernel": {"kernel": "conv_igemm_dma_kernel<128,128>", "kernel_ms_avg": round(res["fp32_mfma"], 4),
+                                                      "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2),
+                                                      "frac": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
+                                 "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
         # SURVEY 8(d) graded 1x1 shapes at the BASELINE batch: op time (split-K launch + its reduce where the plan
         # splits) from HIP events; ceiling = min(MFMA peak, arithmetic intensity x HBM peak) for ONE pass over x, w, y.
         graded = [("ASPP fuse 1280->256 @16x32 (aspp.py:73-75)", 16, 32, 1280, 256),
@@ -477,7 +488,10 @@ def main():
 
     if rank == 0:
         head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "dtype_note": "fp32 tensors and fp32 accumulation throughout; the MFMA-bound 3x3 / large 1x1 convolutions split each fp32 operand "
+                              "exactly into three bf16 terms and run six bf16 MFMAs per product (error vs float64 equal to the fp32-MFMA "
+                              "kernels', tests/test_conv_x3_gpu.py; pp_debug_set_x3(0) selects the fp32-MFMA kernels)"}
         net_desc = {"deeplab": "BASELINE configs[1]: Cityscapes {}x{}, C={}, DeepLabv3+-MobileNetV2",
                     "FPN": "BASELINE configs[2] (per GPU): Cityscapes {}x{}, C={}, ResNet50 model of the reference (FPNSeg)",
                     "deeplab_r50": "BASELINE configs[2] as named (per GPU): Cityscapes {}x{}, C={}, DeepLabv3+-ResNet50 assembled from "

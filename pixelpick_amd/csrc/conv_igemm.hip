@@ -791,111 +791,12 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
-// ---- pointwise (1x1, stride 1) convolutions on few rows: operands straight from L1/L2 into MFMA fragments ---------------------
-// The 1/16-resolution layers of MobileNetV2 / ASPP are 1x1 convolutions over 2048-2448 rows (mobilenet_v2.py:42,56,
-// aspp.py:49,73-75).  With 256-640 reduction channels and a narrow output (384 -> 64, 576 -> 96/160, 320 -> 256 and the
-// backward-data of 64 -> 384, 96 -> 576) the LDS-staged kernels are dominated by fixed costs: pipeline fill, one barrier per
-// K step, and a split-K pass through global memory plus a second launch.  Here a block owns ONE 32x32 output tile, wave w
-// reduces channels [w*K/4, (w+1)*K/4) reading its A rows (float4 per lane: 4 consecutive channels of one pixel) and B columns
-// directly in fragment order (the permuted K order of mma_step: lane half h consumes k = 8q + 4h + j), CH K steps ahead, and
-// the four partial tiles are added through LDS in wave order (deterministic) - split-K without a second launch.
-// Measured (profiles/r02_train_ablation.txt): 3-5 us per call faster than split-K + reduce in that K range; slower above it
-// (the per-lane row reads are uncoalesced, 32 cache lines per instruction, and a 32x32 tile re-reads both operands too often),
-// and a whole-K-per-wave variant for wide outputs (160 -> 960) lost 2x to the staged kernel - so neither is dispatched.
-// BWD: backward-data of the same convolution (A = dY, B = W transposed: float4 along Cout).  Padding of a 1x1 convolution
-// (the folded fixed_padding of mobilenet_v2.py:15-21) only shifts / blanks rows: handled by the row decode.
-template <bool BWD>
-__global__ __launch_bounds__(kThreads) void conv1x1_direct_kernel(ConvParams p)
-{
-    constexpr int CH = 8;                                   // K steps (of 8 channels) per register chunk
-    __shared__ float red[3][16][64];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
-    const int64_t m0 = (int64_t)mt * 32;
-    const int n0 = nt * 32;
-    // A row of this lane
-    const int64_t m = m0 + l31;
-    const float* arow = nullptr;
-    if (m < p.M) {
-        const unsigned mu = (unsigned)m;
-        const unsigned t = mu / (unsigned)p.Wo;
-        const int ow = (int)(mu - t * (unsigned)p.Wo);
-        const unsigned bb = t / (unsigned)p.Ho;
-        const int oh = (int)(t - bb * (unsigned)p.Ho);
-        const int ih = oh + p.taps.dh[0], iw = ow + p.taps.dw[0];
-        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) arow = p.x + (((int64_t)bb * p.H + ih) * p.W + iw) * p.ldx;
-    }
-    const int col = n0 + l31;
-    const bool col_ok = col < p.Cn;
-    const float* wbase = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout;
-    // K range of this wave, in steps of 8 channels
-    const int nsteps = (p.Ck + 7) / 8;
-    const int per = (nsteps + 3) / 4;
-    const int s_beg = wave * per;
-    const int s_end = s_beg + per < nsteps ? s_beg + per : nsteps;
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    float4 a[2][CH];
-    float b[2][CH][4];
-    auto load_chunk = [&](int buf, int s0) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int k = (s0 + u) * 8 + 4 * h;
-            const bool kin = (s0 + u) < s_end && k < p.Ck;
-            a[buf][u] = (kin && arow) ? *reinterpret_cast<const float4*>(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (BWD) {
-                const float4 v = (kin && col_ok) ? *reinterpret_cast<const float4*>(wbase + (int64_t)col * p.Cout + k)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                b[buf][u][0] = v.x; b[buf][u][1] = v.y; b[buf][u][2] = v.z; b[buf][u][3] = v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[buf][u][j] = (kin && col_ok) ? wbase[(int64_t)(k + j) * p.Cout + col] : 0.0f;
-            }
-        }
-    };
-    auto mma_chunk = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].x, b[buf][u][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].y, b[buf][u][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].z, b[buf][u][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u].w, b[buf][u][3], acc, 0, 0, 0);
-        }
-    };
-    if (s_beg < s_end) {
-        load_chunk(0, s_beg);
-        for (int s0 = s_beg; s0 < s_end; s0 += 2 * CH) {
-            if (s0 + CH < s_end) load_chunk(1, s0 + CH);
-            mma_chunk(0);
-            if (s0 + CH < s_end) {
-                if (s0 + 2 * CH < s_end) load_chunk(0, s0 + 2 * CH);
-                mma_chunk(1);
-            }
-        }
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
-    f32x16 accs[1][1];
-    accs[0][0] = acc;
-    conv_epilogue<1, 1>(p, accs, m0, n0, 0, 0);
-}
-
 // ---- deep-K pointwise convolutions on few rows: in-block split-K over wave-private LDS-DMA pipelines -----------------------------
 // 960 -> 160, 960 -> 320, 1280 -> 256 and the backward-data of 160 -> 960 at 2048 rows (mobilenet_v2.py:56, aspp.py:73-75): the
 // output has 64-192 64x64 tiles for 256 CUs, so the tiled kernel slices K over grid.y and pays a [splits][M][N] round trip plus a
 // second launch (23-29 us per layer, of which ~5 are the reduce and its kernel boundary).  Here a block owns ONE (32*TM) x 32
-// output tile and its four waves split K four ways, like conv1x1_direct_kernel - but each wave streams its K slice through a
+// output tile and its four waves split K four ways (round 2's conv1x1_direct_kernel did that with per-lane row loads straight into
+// fragment registers and lost above K = 640; this kernel supersedes it for every K >= 256) - each wave streams its K slice through a
 // PRIVATE ring of LDS stages with coalesced 1-KiB LDS-DMA pieces (global_load_lds_dwordx4), NST-1 K steps of loads in flight per
 // wave, no block barrier inside the K loop (a wave only waits for its own pieces with a counted s_waitcnt vmcnt), and the DMA
 // pieces of step k+NST-1 are issued between the MFMA pairs of step k.  The four partial tiles meet in LDS once, every wave adds a
@@ -2611,7 +2512,7 @@ static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-D
 static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
-static thread_local int g_conv_direct1x1 = 1, g_direct_rows_max = 4096, g_direct_k_max = 640;   // pp_debug_set_conv_variant bit 23 switches the direct 1x1 kernel off (A/B)
+static thread_local int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
 static thread_local int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
 static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
 static thread_local int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
@@ -2804,20 +2705,6 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
 #undef PP_KSPLIT_AFF
 #undef PP_KSPLIT
         return check_launch("conv1x1_ksplit_dma_kernel");
-    }
-    // few-row pointwise layers: the direct kernel (no LDS staging, in-block split-K), see conv1x1_direct_kernel
-    if (g_conv_direct1x1 && vec && !p.stats && p.taps.n == 1 && p.stride == 1 && p.bwd_stride <= 1 && p.M <= g_direct_rows_max &&
-        p.Ck >= 32 && p.Cn >= 32 && p.Ck % 4 == 0 && (BWD ? p.Cout % 4 == 0 : true) && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) {
-        const int64_t t64 = cdiv(p.M, 64) * cdiv(p.Cn, 64);
-        if (t64 < 256 && p.Ck >= 256 && p.Ck <= g_direct_k_max) {   // too few 64x64 tiles for 256 CUs, a reduction worth splitting four ways
-            p.splits = 1;
-            p.ks_per_split = 0;
-            p.part = nullptr;
-            p.n_tiles = (int)cdiv(p.Cn, 32);
-            const int64_t blocks = cdiv(p.M, 32) * p.n_tiles;
-            hipLaunchKernelGGL((conv1x1_direct_kernel<BWD>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p);
-            return check_launch("conv1x1_direct_kernel");
-        }
     }
     p.tap_inner = g_conv_tap_inner;
     p.n_tiles = pl.n_tiles;
@@ -3062,7 +2949,6 @@ void pp_debug_set_conv_variant(int v)
     g_conv_dma64 = (v & 262144) ? 0 : ((v & 524288) ? 2 : 1);   // bit 18: LDS-DMA kernel of the 64x64 tiles off; bit 19: forward only
     g_conv_big_bk32 = (v & 4096) ? 1 : 0;    // bit 12: 32-deep K step for the 128x128 tiles (A/B)
     g_conv_deepk = (v & 128) ? 0 : 1;        // bit 7 switches the 64-deep K step of the 64x64 kernel off (A/B)
-    g_conv_direct1x1 = (v & 8388608) ? 0 : 1;   // bit 23: direct (LDS-free) kernel of the few-row 1x1 layers off (A/B)
     g_bwd_phases = (v & 16777216) ? 0 : 1;      // bit 24: strided backward-data as one masked-tap launch instead of s*s phase problems
     g_conv_ksplit = (v & (1 << 25)) ? 0 : 1 + ((v >> 26) & 7);   // bit 25: in-block split-K LDS-DMA 1x1 kernel off; bits 26-28: force tile candidate 1..3 (0: the rule)
     { const int kc[4] = {256, 768, 512, 384}; g_ksplit_k_min = kc[(v >> 29) & 3]; }   // bits 29-30: K threshold 256 (default) / 768 / 512 / 384 (A/B)
@@ -3421,23 +3307,25 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     const size_t need = (size_t)splits * p.taps.n * Cin * Cout * 4;
     if (!workspace || ws_bytes < need) return fail(PP_ERR_WORKSPACE, "conv bwd_weight: workspace %zu < %zu", ws_bytes, need);
     p.part = reinterpret_cast<float*>(workspace);
+    const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    // MFMA-bound layers run the bf16x3 kernel (operand planes behind the partial sums in the workspace); a bias gradient then takes
+    // the separate column-sum pass at the end
+    const X3WPlan xw = x3w_plan(B, H, W, Cin, Cout, p.M, p.taps.n, vec && big && !narrow_n);
+    const size_t x3_off = align_up(need + (size_t)64 * Cout * 4, 256);
+    const bool use_x3 = xw.ok && ws_bytes >= x3_off + xw.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0;
     // bias gradient = column sums of dy: the blocks of tile column 0 read every dy tile anyway (no second pass over dy)
-    const bool fuse_bias = dbias != nullptr && ws_bytes >= need + (size_t)splits * Cout * 4;
+    const bool fuse_bias = !use_x3 && dbias != nullptr && ws_bytes >= need + (size_t)splits * Cout * 4;
     p.bias_part = fuse_bias ? p.part + (size_t)splits * p.taps.n * Cin * Cout : nullptr;
     if (p.taps.n != kh * kw)
         if (hipMemsetAsync(dw, 0, (size_t)kh * kw * Cin * Cout * 4, st) != hipSuccess)
             return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
     dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
-    const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
-                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     // LDS-DMA kernels: vector operands, no fused bias gradient, 32-bit safe row pitch; bits of g_wgrad_dma: 1 = 128-wide tiles, 2 = 64x64
     const bool dma = vec && p.bias_part == nullptr && (int64_t)p.M * std::max(ldx, lddy) < (1ll << 40);
-    // MFMA-bound layers: the bf16x3 kernel (operand planes behind the partial sums in the workspace)
     {
-        const X3WPlan xw = x3w_plan(B, H, W, Cin, Cout, p.M, p.taps.n, vec && big && p.bias_part == nullptr && !narrow_n);
-        const size_t off = align_up(need + (dbias ? (size_t)64 * Cout * 4 : 0), 256);
-        if (xw.ok && ws_bytes >= off + xw.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) {
-            uint16_t* xp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + off);
+        if (use_x3) {
+            uint16_t* xp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + x3_off);
             uint16_t* dp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(xp) + align_up((size_t)3 * xw.x_plane * 2, 256));
             const int64_t rows_x = (int64_t)B * H * W;
             hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((rows_x + 1) * (xw.Cin_p / 8), 256), 4096)), dim3(256), 0, st,

@@ -85,7 +85,7 @@ class FlatTrainer:
         self.lr_factor = 1.0
         self.last_loss: Optional[torch.Tensor] = None
         self.last_logits: Optional[torch.Tensor] = None
-        # run-time hyper-parameters live in device memory so that the whole step can be a replayed hipGraph:
+        # run-time hyper-parameters live in device memory so that the whole step can be replayed from a recorded launch list:
         # hyper = [lr_backbone, lr_head, 1-beta1^t, sqrt(1-beta2^t)], seed = per-step dropout base seed
         # (a ring of pinned staging slots: the host runs ahead of graph replays, so a slot is only rewritten once the copy
         # that read it has executed - its event is waited for first)
@@ -94,8 +94,6 @@ class FlatTrainer:
         self._stage_used = [False] * len(self._stage)
         self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
         self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        self._graph = None
-        self._graph_bn = []
         self._plan = self._plan_pool = self._plan_stream = None
         self._gx = self._gy = None
 
@@ -115,7 +113,7 @@ class FlatTrainer:
         tape = E.Tape(enabled=True)
         tape.param_grad_dst = lambda p: self._grad_view.get(id(p))
         self._early_work = None
-        if self.collectives and OVERLAP_ALLREDUCE and self.n_split < self.n and not torch.cuda.is_current_stream_capturing():
+        if self.collectives and OVERLAP_ALLREDUCE and self.n_split < self.n:
             tape.hooks["encoder_done"] = self._early_all_reduce
         if SPARSE_LOWRES_CE and getattr(self.model, "LOWRES_LOGITS", False):
             # deeplab.py:55-56 + model.py:116 without the [B,C,H,W] logits: the loss kernels interpolate the classifier output
@@ -224,24 +222,19 @@ class FlatTrainer:
         return loss
 
     def train_step(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
-        """One optimisation step (model.py:101-122).  After enable_graph() the step is a hipGraph replay."""
+        """One optimisation step (model.py:101-122).  After enable_replay() the recorded launch list is re-issued."""
         self._ensure_train_mode()
         self.step_count += 1
-        if self._graph is not None or self._plan is not None:
+        if self._plan is not None:
             if tuple(x.shape) != tuple(self._gx.shape) or tuple(y.shape) != tuple(self._gy.shape):
                 raise ValueError(f"replayed train_step needs the recorded shapes {tuple(self._gx.shape)} / {tuple(self._gy.shape)}, "
                                  f"got {tuple(x.shape)} / {tuple(y.shape)} (disable_replay() first)")
             self._gx.copy_(x, non_blocking=True)              # copy_ converts strides / dtype into the recorded layout
             self._gy.copy_(y, non_blocking=True)
             self._stage_hyper()
-            if self._plan is not None:
-                if torch.cuda.current_stream().cuda_stream != self._plan_stream:
-                    raise RuntimeError("train_step after enable_replay() must run on the stream the plan was recorded on")
-                self._plan.replay()
-            else:
-                for d in self._graph_bn:                  # host-side num_batches_tracked bookkeeping the graph cannot hold
-                    d["_nbt_pending"] += 1
-                self._graph.replay()
+            if torch.cuda.current_stream().cuda_stream != self._plan_stream:
+                raise RuntimeError("train_step after enable_replay() must run on the stream the plan was recorded on")
+            self._plan.replay()
             return self.last_loss
         return self._step_body(x, y, keep_logits, False)
 
@@ -250,11 +243,12 @@ class FlatTrainer:
         all-reduces at N > 1) as a _lib.LaunchPlan and re-issue them from a tight loop in every later train_step(): the
         Python around each launch (5.4 ms per 6.85 ms step) is paid once.  The GPU schedule is the eager one - main stream,
         weight-gradient stream, all-reduce under the encoder backward - which a captured hipGraph does not keep
-        (profiles/r02_graph_replay.txt).  As for enable_graph(): the step runs on private copies of x / y, per-step scalars
+        (profiles/r02_graph_replay.txt; the hipGraph variant measured there - 7.8-8.0 vs 6.8 ms eager - was removed in round 3).
+        The step runs on private copies of x / y, per-step scalars
         (learning rates, Adam bias corrections, dropout seed) are read from device memory, and the recorded step allocates
         from a private memory pool that is kept, so every address in the plan stays valid and is never handed to another
         tensor.  `warmup` eager steps (real optimisation steps, as is the recorded one) first grow the scratch buffers."""
-        assert self._graph is None and self._plan is None
+        assert self._plan is None
         self.model.train()
         E.set_dropout_device_seed(self._seed_dev)
         # the private copies have the layout the recorded launches read: torch-side conversions inside the step
@@ -272,31 +266,6 @@ class FlatTrainer:
                 self._step_body(self._gx, self._gy, True, True)
         self._plan, self._plan_pool = plan, pool
         self._plan_stream = torch.cuda.current_stream(x.device).cuda_stream
-        return self
-
-    def enable_graph(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 2):
-        """Capture forward + loss + backward (+ all-reduce) + Adam for this input shape into ONE hipGraph (~700 kernel
-        launches per step otherwise go through Python/ctypes one by one and the step becomes host-bound below ~9 ms).
-        Per-step scalars (learning rates, Adam bias corrections, dropout seed) are read from device memory at run time.
-        `warmup` eager steps run first (they are real optimisation steps)."""
-        assert self._graph is None
-        self.model.train()
-        E.set_dropout_device_seed(self._seed_dev)
-        self._gx, self._gy = x.contiguous().clone(), y.to(torch.int64).contiguous().clone()
-        side = torch.cuda.Stream(device=x.device)
-        side.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(side):                      # warm-up on a side stream, as torch's capture recipe asks
-            for _ in range(warmup):
-                self.step_count += 1
-                self._stage_hyper()
-                self._step_body(self._gx, self._gy, True, True)
-        torch.cuda.current_stream(x.device).wait_stream(side)
-        torch.cuda.synchronize(x.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_body(self._gx, self._gy, True, True)
-        self._graph = g
-        self._graph_bn = [m.__dict__ for m in self.model.modules() if "_nbt_pending" in m.__dict__ and m.training]
         return self
 
     def sync_buffers(self, src: int = 0):
@@ -317,21 +286,18 @@ class FlatTrainer:
             b.copy_(flat[off:off + b.numel()].view_as(b))
             off += b.numel()
 
-    def disable_graph(self):
-        """Back to eager steps; also removes the process-wide device seed word enable_graph() installed, so that later
+    def disable_replay(self):
+        """Back to eager steps; also removes the process-wide device seed word enable_replay() installed, so that later
         eager trainers / MC-dropout forwards draw their masks from the host counter again."""
-        if self._graph is not None or self._plan is not None:
-            if self._plan is not None:
-                self.last_loss = self.last_logits = None  # they live in the plan's memory pool
-                # the plan holds bound methods of this trainer (all_reduce_grads, _early_all_reduce_on): clear it so that no
-                # trainer <-> plan reference cycle keeps the memory pool (a full step of activations) alive until a GC pass
-                self._plan.calls.clear()
-            self._graph = self._plan = self._plan_pool = None
+        if self._plan is not None:
+            self.last_loss = self.last_logits = None      # they live in the plan's memory pool
+            # the plan holds bound methods of this trainer (all_reduce_grads, _early_all_reduce_on): clear it so that no
+            # trainer <-> plan reference cycle keeps the memory pool (a full step of activations) alive until a GC pass
+            self._plan.calls.clear()
+            self._plan = self._plan_pool = None
             self._gx = self._gy = None
         if E._dropout_seed_dev[0] is self._seed_dev:
             E.set_dropout_device_seed(None)
-
-    disable_replay = disable_graph
 
     def __del__(self):
         try:

@@ -122,7 +122,7 @@ def test_active_learning_round_with_replayed_train_steps(tmp_path, monkeypatch):
     mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
     args = _args(str(tmp_path), replay_train_step=True, max_budget=10)
     seen = {"replayed": 0, "recorded": 0, "dropped": 0}
-    orig_enable, orig_disable = FlatTrainer.enable_replay, FlatTrainer.disable_graph
+    orig_enable, orig_disable = FlatTrainer.enable_replay, FlatTrainer.disable_replay
 
     def enable(self, *a, **k):
         seen["recorded"] += 1
@@ -133,7 +133,6 @@ def test_active_learning_round_with_replayed_train_steps(tmp_path, monkeypatch):
         return orig_disable(self)
 
     monkeypatch.setattr(FlatTrainer, "enable_replay", enable)
-    monkeypatch.setattr(FlatTrainer, "disable_graph", disable)
     monkeypatch.setattr(FlatTrainer, "disable_replay", disable)
     m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device(DEV))
     m()

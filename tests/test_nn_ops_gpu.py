@@ -67,8 +67,8 @@ CONV_CASES = [
     (3, 96, 128, 256, 19, 1, 1, 0, 1, True),      # classifier (bias), 36864 pixels
     (1, 64, 128, 304, 256, 3, 1, 1, 1, False),    # SegmentHead at Cityscapes-quarter size (128x128 tiles)
     (2, 23, 30, 1280, 256, 1, 1, 0, 1, False),    # ASPP fuse at CamVid size (M = 1380)
-    # few-row pointwise layers: 256 <= K <= 640 with a narrow output -> conv1x1_direct_kernel (forward, and the backward-data
-    # of the mirrored shape), the others -> the staged kernels; ragged rows / channels, the folded padding, bias
+    # few-row pointwise layers: K >= 256 -> conv1x1_ksplit_dma_kernel (forward, and the backward-data of the mirrored shape), the
+    # others -> the tiled kernels; ragged rows / channels, the folded padding, bias
     (4, 16, 32, 160, 960, 1, 1, 1, 1, False),     # MNv2 expand 160->960 on the padded 18x34 map
     (4, 16, 32, 960, 160, 1, 1, 0, 1, False),     # MNv2 project 960->160
     (4, 16, 32, 960, 320, 1, 1, 0, 1, False),

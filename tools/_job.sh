@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_conv_x3_gpu.py -q 2>&1 | tail -2
-ONLY=64x128x3 python tools/conv_layer_table.py 2>/dev/null | tail -3
-for i in 1 2 3; do python tools/train_bench.py 2>/dev/null | tail -1; done
+O=gpurun_out/r3h; mkdir -p $O
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -3 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
