@@ -452,10 +452,13 @@ void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise
 void pp_debug_set_splitk(int v);       /* tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 */
 void pp_debug_set_wgrad_target(int blocks);   /* split-M target of the weight-gradient kernels (default 1024) */
 void pp_debug_set_bn_target(int blocks);   /* strips x row chunks of the single-launch BatchNorm (default 384, <= 1024) */
-void pp_debug_set_bn_bytes_per_block(int bytes);   /* large maps: one block per this many bytes (default 0 = off: measured neutral) */
+void pp_debug_set_bn_bytes_per_block(int bytes);   /* large maps: one block per this many bytes (default 0 = off: measured neutral); -1: register-cached variants off */
 /* Blocks of the single-launch BatchNorm kernels that fit on the device at once (occupancy x CUs; 0 = no device).  A launch
  * uses at most half of it, so that two spin-waiting launches (second stream / second process) are always co-resident. */
 int pp_bn_fused_capacity(void);
+/* Debug: pp_bn_train_fwd_fused writes per-block wall-clock stamps (100 MHz; [blocks][8]: entry, statistics pass done, block
+ * reduction done, partial published, strip combined, rows written) into this device buffer; NULL (default) = off. */
+void pp_debug_set_bn_probe(void* device_buffer);
 void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 12 (defaults 384 / 128) */
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */

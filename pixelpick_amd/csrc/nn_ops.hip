@@ -498,6 +498,21 @@ __device__ __forceinline__ void strip_combine(const xword* part, int strip, int 
     if (sub < nsub) {
         const xword* p = part + (int64_t)strip * R * nout + o;
         int c = sub;
+        // narrow strips of long maps (C <= 64: one or two strips x 128-256 row chunks): sixteen words in flight per thread, or the
+        // combine is R / (4 nsub) dependent round trips to fine-grained memory (8.7 us of a 23 us launch on the 32-channel stem map)
+        for (; c + 15 * nsub < R; c += 16 * nsub) {
+            xword w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = __hip_atomic_load(p + (int64_t)(c + j * nsub) * nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = (unsigned)(w[j + i] >> 32) == tag ? __uint_as_float((unsigned)w[j + i]) : xchg_get(p + (int64_t)(c + (j + i) * nsub) * nout, tag);
+                s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);      // the four-at-a-time loop's association
+            }
+        }
         for (; c + 3 * nsub < R; c += 4 * nsub) {
             // four words in flight; a word whose tag is not this launch's yet is re-read by xchg_get
             const xword* p0 = p + (int64_t)c * nout;
@@ -547,7 +562,9 @@ struct BnFwdArgs {
     int dw_H, dw_W, dw_Ho, dw_Wo, dw_stride, dw_pad, dw_dil;
     // PARTIALS variant: the statistics were accumulated by the producer (convolution epilogue / split-K reduce):
     const float* stats; int stat_rows;      // [stat_rows][2][C] column sums and sums of squares
+    unsigned long long* probe;              // pp_debug_set_bn_probe: [blocks][8] wall-clock stamps (100 MHz) of the kernel's phases, or NULL
 };
+#define BN_STAMP(i) do { if (a.probe && threadIdx.x == 0) a.probe[(int64_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
 // one output quad of the depthwise 3x3 convolution, same tap order / fma chain as dwconv_fwd_kernel (bit-identical)
 __device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int q)
@@ -594,6 +611,7 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
     __shared__ float aff[2][32];
     const BnFusedGeom g = a.g;
     unsigned tag = 0, tag0 = 0;
+    BN_STAMP(0);
     if constexpr (MODE != 2) tag0 = tag_issue(a.sync);
     const int t = threadIdx.x;
     const int strip = blockIdx.x % g.nstrips, chunk = blockIdx.x / g.nstrips;
@@ -685,13 +703,17 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
             }
         }
     }
+    BN_STAMP(1);
     tag_share(tag0, &sh_tag);
     rowlane_tree(s0, s1, sh, rl, g.nrl, g.bq);
     tag = sh_tag;
+    BN_STAMP(2);
     if (rl == 0) {
         publish_partial(a.part + ((int64_t)strip * g.R + chunk) * nout + ql * 4, nch, s0, s1, tag);
     }
+    BN_STAMP(3);
     strip_combine(a.part, strip, g.R, nout, tag, shd, tot);
+    BN_STAMP(4);
     launch_done(a.sync);
     }
     if (t < nch) {
@@ -742,6 +764,7 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
             if (drop) drop4(oa, (uint64_t)(r * g.cq + q) * 4, dseed, a.drop_p, a.drop_inv_keep);
             *reinterpret_cast<float4*>(yq + r * a.ldy) = oa;
         }
+        BN_STAMP(5);
         return;
     }
     for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
@@ -765,6 +788,7 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
             *reinterpret_cast<float4*>(yq + rr * a.ldy) = o;
         }
     }
+    BN_STAMP(5);
 }
 
 // dx of one element; no fma contraction, so that every kernel variant (and the mask / dropout scaling in front of it, which
@@ -2201,6 +2225,8 @@ void pp_debug_set_bn_bytes_per_block(int bytes)
     g_bn_bytes_per_block = bytes > 0 ? bytes : 0;
     g_bn_row_cache = bytes == -1 ? 0 : 1;          // -1: the register-cached variants off (A/B)
 }
+static thread_local unsigned long long* g_bn_probe = nullptr;
+void pp_debug_set_bn_probe(void* device_buffer) { g_bn_probe = reinterpret_cast<unsigned long long*>(device_buffer); }
 int pp_bn_fused_capacity(void) { return bn_fused_capacity(); }
 
 // ---- batch norm -----------------------------------------------------------------------------------
@@ -2275,7 +2301,7 @@ int pp_bn_train_fwd_fused(const float* x, int64_t ldx, int64_t M, int C, const f
     if (int rc = bn_fused_check("bn_train_fwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnFwdArgs a{x, ldx, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
                 reinterpret_cast<xword*>(workspace), sync, g, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev,
-                nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
+                nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, g_bn_probe};
     if (g_bn_row_cache && g.rows_per_chunk <= (int64_t)g.nrl * kBnRowCache)
         hipLaunchKernelGGL((bn_fused_fwd_kernel<0, kBnRowCache>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     else

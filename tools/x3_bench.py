@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-level timing of conv_x3_kernel variants (pp_debug_set_x3 modes) on the SegmentHead shapes: rocprofv3 gives the per-kernel
-durations; this script just runs forward + backward-data of the two layers N times per mode."""
+durations; this script runs forward, backward-data and the weight gradient of the two layers N times per mode."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -15,10 +15,12 @@ for mode in modes:
         x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(3, 3, Cin, Cout, device="cuda") * 0.02
         y = torch.empty(B, H, W, Cout, device="cuda"); dy = torch.randn(B, H, W, Cout, device="cuda"); dx = torch.empty_like(x)
         wf = int(L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, 1, 1)); wb = int(L.pp_conv2d_bwd_data_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, 1, 1))
-        ws = torch.empty(max(wf, wb, 256), dtype=torch.uint8, device="cuda")
+        ww = int(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, 1, 1)); dw = torch.empty_like(w)
+        ws = torch.empty(max(wf, wb, ww, 256), dtype=torch.uint8, device="cuda")
         def fwd(): _lib.check(L.pp_conv2d_fwd(x.data_ptr(), Cin, B, H, W, Cin, w.data_ptr(), None, 3, 3, 1, 1, 1, y.data_ptr(), Cout, Cout, ws.data_ptr(), ws.numel(), st), "f")
         def bwd(): _lib.check(L.pp_conv2d_bwd_data(dy.data_ptr(), Cout, B, H, W, Cout, w.data_ptr(), 3, 3, 1, 1, 1, dx.data_ptr(), Cin, H, W, Cin, 0, ws.data_ptr(), ws.numel(), st), "b")
-        for name, fn in (("fwd", fwd), ("bwdD", bwd)):
+        def wgr(): _lib.check(L.pp_conv2d_bwd_weight(x.data_ptr(), Cin, B, H, W, Cin, dy.data_ptr(), Cout, Cout, 3, 3, 1, 1, 1, dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "w")
+        for name, fn in (("fwd", fwd), ("bwdD", bwd), ("wgrad", wgr)):
             for _ in range(3): fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
