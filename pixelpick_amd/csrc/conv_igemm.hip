@@ -2633,9 +2633,11 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
     const bool two = rem > 0 && rem <= 64 && full128 > 0 && !(g_conv_x3 & 4);
     const bool n128_only = !two && (rem == 0 || rem > 64 || (g_conv_x3 & 4));
     const int64_t mt256 = cdiv(p.M, 256);
-    const bool m256 = !(g_conv_x3 & 2) && mt256 * (two ? full128 : cdiv(p.Cn, n128_only ? 128 : 64)) >= 200;
-    const int64_t mtiles = m256 ? mt256 : cdiv(p.M, 128);
     auto go = [&](bool n128, int ntile, int col_base) {
+        // (the 64-wide remainder launch of a ragged width decides for itself: 128 blocks of 256 x 64 leave half of the CUs idle for
+        // as long as a full tile column takes - 96 us for 16 % of the layer; 256 blocks of 128 x 64 do it in one short round)
+        const bool m256 = !(g_conv_x3 & 2) && mt256 * ntile >= 200;
+        const int64_t mtiles = m256 ? mt256 : cdiv(p.M, 128);
         o.col_base = col_base;
         p.n_tiles = ntile;
         const dim3 grid((unsigned)(mtiles * ntile));
