@@ -66,6 +66,16 @@ def main():
     print("-- per kernel (this step)")
     for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
         print(f"  {k:46s} n={n:3d} {t / 1e3:8.1f} us")
+    if "--by-queue" in sys.argv:
+        for q, rs in sorted(byq.items()):
+            aq = defaultdict(lambda: [0, 0])
+            for r in rs:
+                k = short(r["Kernel_Name"])
+                aq[k][0] += 1
+                aq[k][1] += r["e"] - r["s"]
+            print(f"-- queue {q}: every kernel")
+            for k, (n, t) in sorted(aq.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {k:46s} n={n:3d} {t / 1e3:8.1f} us  ({t / n / 1e3:6.1f} each)")
     if "--list" in sys.argv:
         print("-- launch order: start offset us | dur us | queue | grid | kernel")
         for r in step:

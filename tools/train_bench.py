@@ -19,6 +19,10 @@ def main():
     if os.environ.get("X3MODE"):                      # pp_debug_set_x3 word (A/B of the bf16x3 kernels)
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_x3(int(os.environ["X3MODE"]))
+    if os.environ.get("NO_WGRAD"):                    # TIMING ONLY: no convolution weight gradients at all (what the second queue costs the step)
+        for p_ in m.parameters():
+            if p_.dim() == 4:
+                p_.requires_grad_(False)
     tr = FlatTrainer(m, ignore_index=C)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(B, 3, H, W, device="cuda", generator=g)
