@@ -448,7 +448,8 @@ void pp_debug_set_acq_tuning(int occ, int ppt);
  * bit 18 LDS-DMA kernel of the 64x64 tiles off (bit 19: forward only); bit 20 LDS-DMA weight-gradient kernel of the
  * 128-wide tiles off; bit 21 LDS-DMA weight-gradient kernel for the 64x64 tiles on.
  * Findings: profiles/r01_conv_ablation.txt. */
-void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B); bit 8: separable bilinear backward off */
+void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B); bit 8: separable bilinear backward off;
+                                        * bits 13-15 / 16-17: column-block width / least rows per thread of the depthwise weight gradient (0 = by map size) */
 void pp_debug_set_splitk(int v);       /* tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 */
 void pp_debug_set_wgrad_target(int blocks);   /* split-M target of the weight-gradient kernels (default 1024) */
 void pp_debug_set_bn_target(int blocks);   /* strips x row chunks of the single-launch BatchNorm (default 384, <= 1024) */

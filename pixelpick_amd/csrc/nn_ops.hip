@@ -71,11 +71,14 @@ struct ColReduceGeom {
 
 static thread_local int g_dw_wgrad_blocks = 1024;    // row blocks aimed at by the depthwise weight gradient (pp_debug_set_dw_variant bits 1..)
 
-static ColReduceGeom col_geom(int64_t M, int C, int target_blocks = 1024)
+// cq_blk_max < 256: NARROW column blocks (wide maps get several block columns and 256 / cq_blk row lanes each: the 1/16-resolution
+// depthwise weight gradients - 2048 pixels x 384..960 channels - otherwise run one row lane per block and walk their rows in sequence);
+// min_passes: rows a thread walks at least (fewer, fatter blocks keep the partial traffic down)
+static ColReduceGeom col_geom(int64_t M, int C, int target_blocks = 1024, int cq_blk_max = kT, int min_passes = 4)
 {
     ColReduceGeom g;
     g.cq = C / 4;
-    g.cq_blk = g.cq < kT ? g.cq : kT;
+    g.cq_blk = g.cq < cq_blk_max ? g.cq : cq_blk_max;
     g.rows_per_pass = kT / g.cq_blk;
     g.nblk_cols = (int)cdiv(g.cq, g.cq_blk);
     // measured (profiles/r01_train_step_*): these reductions are latency-bound, more row blocks win even
@@ -83,7 +86,7 @@ static ColReduceGeom col_geom(int64_t M, int C, int target_blocks = 1024)
     int64_t want_blocks = target_blocks / g.nblk_cols;
     if (want_blocks < 1) want_blocks = 1;
     int64_t rpb = cdiv(cdiv(M, want_blocks), g.rows_per_pass) * g.rows_per_pass;
-    if (rpb < g.rows_per_pass * 4) rpb = g.rows_per_pass * 4;
+    if (rpb < g.rows_per_pass * min_passes) rpb = g.rows_per_pass * min_passes;
     g.rows_per_block = rpb;
     g.nblk_rows = (int)cdiv(M, rpb);
     return g;
@@ -142,33 +145,6 @@ __global__ __launch_bounds__(kT) void col_reduce_kernel(const float* x, const fl
         *reinterpret_cast<float4*>(p0) = s0;
         *reinterpret_cast<float4*>(p1) = s1;
     }
-}
-
-// Fixed-order fp64 sum of `nblk` partial values per output, 32 lanes per output (8 outputs per 256-thread
-// block): lane l adds blocks l, l+32, ... then an LDS tree combines the lanes.  Deterministic.
-__device__ __forceinline__ double lanes32_sum(const float* part, int nblk, int64_t stride_b, int64_t idx, bool valid,
-                                              double* sh /*[256]*/)
-{
-    const int t = threadIdx.x, lane = t >> 3;
-    double s = 0.0;
-    if (valid) {
-        int b = lane;
-        for (; b + 96 < nblk; b += 128) {      // 4 independent loads in flight per lane
-            const float v0 = part[(int64_t)b * stride_b + idx], v1 = part[(int64_t)(b + 32) * stride_b + idx];
-            const float v2 = part[(int64_t)(b + 64) * stride_b + idx], v3 = part[(int64_t)(b + 96) * stride_b + idx];
-            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-        }
-        for (; b < nblk; b += 32) s += (double)part[(int64_t)b * stride_b + idx];
-    }
-    sh[t] = s;
-    __syncthreads();
-    for (int off = 128; off >= 8; off >>= 1) {
-        if (t < off) sh[t] += sh[t + off];
-        __syncthreads();
-    }
-    const double r = sh[t & 7];
-    __syncthreads();
-    return r;
 }
 
 // BN forward finalize: batch mean / biased var (fp64 combine), running-stat update (momentum, unbiased var),
@@ -2188,6 +2164,7 @@ __global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_
 
 static thread_local int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
 static thread_local int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
+static thread_local int g_dw_wgrad_cq_blk = 0, g_dw_wgrad_passes = 0;      // column-block width / least rows per thread (pp_debug_set_dw_variant bits 13-17); 0 = by map size
 static thread_local int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
 
 static inline unsigned grid_for(int64_t total)
@@ -2216,6 +2193,8 @@ void pp_debug_set_dw_variant(int v)
     g_bil_sep = (v & 256) ? 0 : 1;
     g_dw_wgrad_x4 = (v & 512) ? 0 : 1;                      // bit 9: four-pixel depthwise weight-gradient kernel off
     { const int s4 = (v >> 10) & 7; g_dw_wgrad_x4_blocks = s4 == 1 ? 128 : s4 == 2 ? 512 : s4 == 3 ? 1024 : s4 == 4 ? 64 : 256; }
+    { const int cb = (v >> 13) & 7; g_dw_wgrad_cq_blk = cb == 1 ? 8 : cb == 2 ? 16 : cb == 3 ? 32 : cb == 4 ? 64 : cb == 5 ? 128 : cb == 6 ? kT : 0; }
+    { const int mp = (v >> 16) & 3; g_dw_wgrad_passes = mp == 1 ? 1 : mp == 2 ? 2 : mp == 3 ? 4 : 0; }
     const int sel = (v >> 1) & 7;                 // 0: default, 1: 512, 2: 256, 3: 128, 4: 2048 row blocks for the weight gradient
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
@@ -2481,12 +2460,17 @@ static int dwconv_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
     if (M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "dwconv bwd_weight: more than 2^31 output pixels");
     ColReduceGeom g = col_geom(M, C, g_dw_wgrad_blocks);
     if (!workspace || ws_bytes < (size_t)g.nblk_rows * 9 * C * 4) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
+    const size_t ws_rows = ws_bytes / ((size_t)9 * C * 4);
+    // maps of <= 8192 pixels (1/8 and 1/16 resolution, 192..960 channels): 32-quad column blocks x 8 row lanes, one item per
+    // thread - 13.0-17.6 -> 10.1-12.1 us per call (tools/dw_wgrad_bench.py); the large maps keep full-width blocks (b3: 23 vs 27 us)
+    const int cq_blk = g_dw_wgrad_cq_blk ? g_dw_wgrad_cq_blk : (M <= 8192 ? 32 : kT);
+    const int passes = g_dw_wgrad_passes ? g_dw_wgrad_passes : (M <= 8192 ? 1 : 4);
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
     if (stride == 1 && dil == 1 && Wo % 4 == 0 && g_dw_wgrad_x4) {
         // items of four pixels; the same workspace bound holds (never more row blocks than the one-pixel geometry)
-        ColReduceGeom g4 = col_geom(M / 4, C, g_dw_wgrad_x4_blocks);
-        if (g4.nblk_rows <= g.nblk_rows) {
+        ColReduceGeom g4 = col_geom(M / 4, C, g_dw_wgrad_x4_blocks, cq_blk, passes);
+        if ((size_t)g4.nblk_rows <= ws_rows) {
             hipLaunchKernelGGL(dwconv_bwd_weight_x4_kernel, dim3(g4.nblk_rows, g4.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4,
                                dy, lddy, Ho, Wo, pad, g4, part, in_scale, in_shift, in_act);
             if (int rc = check_launch("dwconv_bwd_weight_x4_kernel")) return rc;
@@ -2494,6 +2478,10 @@ static int dwconv_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
                                (int64_t)9 * C, dw, 1.0f);
             return check_launch("sum_partials_kernel");
         }
+    }
+    if (cq_blk != kT || passes != 4) {
+        const ColReduceGeom gn = col_geom(M, C, g_dw_wgrad_blocks, cq_blk, passes);
+        if ((size_t)gn.nblk_rows <= ws_rows) g = gn;
     }
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4, dy,
                        lddy, Ho, Wo, stride, pad, dil, g, part, in_scale, in_shift, in_act);

@@ -156,6 +156,34 @@ __device__ __forceinline__ float key_to_float(uint32_t key, bool largest)
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
     return __uint_as_float(u);
 }
+
+// Fixed-order fp64 sum of `nblk` partial values per output, 32 lanes per output (8 outputs per 256-thread
+// block): lane l adds blocks l, l+32, ... then an LDS tree combines the lanes.  Deterministic.
+__device__ __forceinline__ double lanes32_sum(const float* part, int nblk, int64_t stride_b, int64_t idx, bool valid,
+                                              double* sh /*[256]*/)
+{
+    const int t = threadIdx.x, lane = t >> 3;
+    double s = 0.0;
+    if (valid) {
+        int b = lane;
+        for (; b + 96 < nblk; b += 128) {      // 4 independent loads in flight per lane
+            const float v0 = part[(int64_t)b * stride_b + idx], v1 = part[(int64_t)(b + 32) * stride_b + idx];
+            const float v2 = part[(int64_t)(b + 64) * stride_b + idx], v3 = part[(int64_t)(b + 96) * stride_b + idx];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nblk; b += 32) s += (double)part[(int64_t)b * stride_b + idx];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (t < off) sh[t] += sh[t + off];
+        __syncthreads();
+    }
+    const double r = sh[t & 7];
+    __syncthreads();
+    return r;
+}
+
 #endif  // __HIPCC__
 
 }  // namespace pp
