@@ -198,6 +198,29 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
                          int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
                          void* workspace, size_t ws_bytes, pp_stream_t stream);
 
+/* Deferred reduces.  A weight gradient is a partial-sum kernel ([slices][...] in the workspace) followed by a small
+ * fixed-order reduce; a backward pass has ~60 of them (model.py:121 loss.backward()).  The *_partials forms run only the
+ * first kernel and describe the reduce in *job (kind 0: nothing left to do - the call completed the gradient itself, e.g.
+ * when a bias gradient is asked for); pp_wgrad_reduce_batch then runs any number of jobs in one launch per 64 jobs, with
+ * the arithmetic of the single-layer kernels (bit-identical).  The caller keeps every job's workspace untouched until
+ * the batch has been enqueued on the same stream. */
+typedef struct pp_reduce_job {
+    const float* part;   /* partial sums */
+    float* dst;          /* the gradient tensor */
+    int64_t cn;          /* elements per tap (kinds 1, 2) / outputs (kind 3) */
+    int32_t splits;      /* partial slices */
+    int32_t ntaps;       /* live taps (kinds 1, 2) */
+    int32_t kind;        /* 0 none, 1 float4 sequential, 2 32-lane tree, 3 32-lane fp64 (depthwise) */
+    uint8_t widx[12];    /* weight-tensor tap index of every live tap */
+} pp_reduce_job;
+int pp_conv2d_bwd_weight_partials(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                                  int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                                  void* workspace, size_t ws_bytes, pp_reduce_job* job, pp_stream_t stream);
+int pp_dwconv3x3_bwd_weight_partials(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
+                                     int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_reduce_job* job,
+                                     pp_stream_t stream);
+int pp_wgrad_reduce_batch(const pp_reduce_job* jobs, int n, pp_stream_t stream);
+
 /* Column-reduction workspace shared by pp_bn_train_fwd, pp_bn_bwd and pp_dwconv3x3_bwd_weight. */
 size_t pp_colreduce_workspace_bytes(int64_t M, int C);
 

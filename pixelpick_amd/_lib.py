@@ -47,6 +47,8 @@ SIGNATURES = {
     "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_weight_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p]),
+    "pp_conv2d_bwd_weight_partials": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p, _p]),
+    "pp_wgrad_reduce_batch": (_int, [_p, _int, _p]),
     "pp_colreduce_workspace_bytes": (_sz, [_i64, _int]),
     "pp_bn_train_fwd": (_int, [_p, _i64, _i64, _int, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pp_bn_eval_affine": (_int, [_int, _p, _p, _p, _p, _f, _p, _p, _p]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p]),
+    "pp_dwconv3x3_bwd_weight_partials": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p, _p]),
     "pp_groupnorm_workspace_bytes": (_sz, [_int, _i64, _int]),
     "pp_groupnorm_relu_fwd": (_int, [_p, _i64, _int, _i64, _int, _int, _p, _p, _f, _int, _p, _i64, _p, _p, _p, _sz, _p]),
     "pp_groupnorm_relu_bwd": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _sz, _p]),
@@ -152,6 +155,12 @@ _NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_f
 
 def _is_launch(name: str) -> bool:
     return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in")))
+
+
+class ReduceJob(ctypes.Structure):
+    """pp_reduce_job (include/pixelpick_hip.h): a deferred weight-gradient reduce."""
+    _fields_ = [("part", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("cn", ctypes.c_int64), ("splits", ctypes.c_int32),
+                ("ntaps", ctypes.c_int32), ("kind", ctypes.c_int32), ("widx", ctypes.c_uint8 * 12)]
 
 
 class LaunchPlan:

@@ -1684,11 +1684,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
 // float4 form (Cin*Cout % 4 == 0, 16-byte aligned buffers): four outputs per thread, the partials of four splits in flight
 // at once, summed in split order (fixed order: deterministic).  The scalar form walks `splits` dependent 4-byte loads per
 // thread: 66 us for the SegmentHead gradient (31 MB of partials) where the bytes need ~10.
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, int splits, int ntaps, int64_t cn,
-                                                           ConvTaps taps, float* dw)
+template <typename WIdx>
+__device__ __forceinline__ void wgrad_reduce4_body(int64_t blk, const float* part, int splits, int ntaps, int64_t cn, WIdx widx, float* dw)
 {
     const int64_t cn4 = cn >> 2;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blk * 256 + threadIdx.x;
     if (i >= (int64_t)ntaps * cn4) return;
     const int ti = (int)(i / cn4);
     const int64_t e = (i - (int64_t)ti * cn4) * 4;
@@ -1710,7 +1710,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, i
         const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)k * stride);
         s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
-    *reinterpret_cast<float4*>(dw + (int64_t)taps.widx[ti] * cn + e) = s;
+    *reinterpret_cast<float4*>(dw + (int64_t)widx(ti) * cn + e) = s;
+}
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, int splits, int ntaps, int64_t cn,
+                                                           ConvTaps taps, float* dw)
+{
+    wgrad_reduce4_body((int64_t)blockIdx.x, part, splits, ntaps, cn, [&](int ti) { return taps.widx[ti]; }, dw);
 }
 
 // ---- weight gradient of the narrow layers ----------------------------------------------------------------------
@@ -1834,12 +1839,12 @@ __global__ __launch_bounds__(256) void wgrad_narrow_out_kernel(WgradParams p, in
 }
 
 // Many-split reduce: 32 lanes per output add splits l, l+32, .. then a fixed LDS tree (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* part, int splits, int ntaps, int64_t cn,
-                                                               ConvTaps taps, float* dw)
+template <typename WIdx>
+__device__ __forceinline__ void wgrad_reduce_wide_body(int64_t blk, const float* part, int splits, int ntaps, int64_t cn, WIdx widx, float* dw,
+                                                       float* sh /*[256]*/)
 {
-    __shared__ float sh[256];
     const int t = threadIdx.x, lane = t >> 3;
-    const int64_t i = (int64_t)blockIdx.x * 8 + (t & 7);
+    const int64_t i = blk * 8 + (t & 7);
     const int64_t total = (int64_t)ntaps * cn;
     float s = 0.0f;
     if (i < total) {
@@ -1857,7 +1862,50 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* par
     }
     if (t < 8 && i < total) {
         const int ti = (int)(i / cn);
-        dw[(int64_t)taps.widx[ti] * cn + (i - (int64_t)ti * cn)] = sh[t];
+        dw[(int64_t)widx(ti) * cn + (i - (int64_t)ti * cn)] = sh[t];
+    }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* part, int splits, int ntaps, int64_t cn,
+                                                               ConvTaps taps, float* dw)
+{
+    __shared__ float sh[256];
+    wgrad_reduce_wide_body((int64_t)blockIdx.x, part, splits, ntaps, cn, [&](int ti) { return taps.widx[ti]; }, dw, sh);
+}
+
+// ---- every partial-sum reduce of a backward pass in ONE launch ---------------------------------------------------------------
+// The weight-gradient kernels leave [splits][...] partial sums; each layer's reduce is a 5-20 us launch of a few hundred
+// blocks (~60 per DeepLab step, 0.41 ms of the weight-gradient queue).  pp_*_bwd_weight_partials stop after the partial kernel
+// and describe the reduce as a pp_reduce_job; pp_wgrad_reduce_batch runs up to 64 jobs per launch - block -> (job, block of the
+// job) through a prefix table in the kernel arguments, then the SAME code the single-layer kernels run (bit-identical results).
+constexpr int kBatchJobs = 64;
+struct ReduceBatch {
+    const float* part[kBatchJobs];
+    float* dst[kBatchJobs];
+    int cn[kBatchJobs];            // elements per tap (kinds 1, 2) / outputs (kind 3)
+    int splits[kBatchJobs];
+    int start[kBatchJobs + 1];     // first block of every job
+    uint8_t ntaps[kBatchJobs], kind[kBatchJobs];
+    uint8_t widx[kBatchJobs][12];
+    int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceBatch b)
+{
+    __shared__ double shd[256];
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;      // uniform: scalar loads from the kernel arguments
+    const int64_t blk = (int)blockIdx.x - b.start[j];
+    const float* part = b.part[j];
+    float* dst = b.dst[j];
+    const int cn = b.cn[j], splits = b.splits[j], ntaps = b.ntaps[j];
+    const uint8_t* wi = b.widx[j];
+    if (b.kind[j] == 1) {
+        wgrad_reduce4_body(blk, part, splits, ntaps, (int64_t)cn, [&](int ti) { return (int)wi[ti]; }, dst);
+    } else if (b.kind[j] == 2) {
+        wgrad_reduce_wide_body(blk, part, splits, ntaps, (int64_t)cn, [&](int ti) { return (int)wi[ti]; }, dst, reinterpret_cast<float*>(shd));
+    } else {                                                            // 3: sum_partials_kernel (nn_ops.hip), mul = 1
+        const int64_t i = blk * 8 + (threadIdx.x & 7);
+        const double s = lanes32_sum(part, splits, (int64_t)cn, i, i < cn, shd);
+        if (i < cn && threadIdx.x < 8) dst[i] = (float)(s * 1.0);
     }
 }
 
@@ -2823,8 +2871,24 @@ static int64_t wgrad_balanced_splits(int64_t tiles, int64_t M, int bm, int bn, i
 }
 
 // returns 0 when the layer was handled, 1 when it is not a narrow layer, < 0 on error
+static void fill_reduce_job(pp_reduce_job* job, int kind, const float* part, float* dst, int64_t cn, int64_t splits, const ConvTaps& taps)
+{
+    job->part = part;
+    job->dst = dst;
+    job->cn = cn;
+    job->splits = (int32_t)splits;
+    job->ntaps = taps.n;
+    job->kind = kind;
+    for (int i = 0; i < 12; ++i) job->widx[i] = (uint8_t)(i < taps.n ? taps.widx[i] : 0);
+}
+// a reduce may be left to pp_wgrad_reduce_batch when the caller asked for it and the batch kernel's table can describe it
+static bool reduce_deferrable(const pp_reduce_job* job, const ConvTaps& taps, int64_t cn, int64_t splits, const float* dbias)
+{
+    return job != nullptr && dbias == nullptr && taps.n <= 12 && (int64_t)taps.n * cn < (1ll << 31) && splits < (1 << 20);
+}
+
 static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* dbias, bool* bias_done, void* workspace,
-                               size_t ws_bytes, hipStream_t st)
+                               size_t ws_bytes, hipStream_t st, pp_reduce_job* job)
 {
     *bias_done = false;
     const int nt = p.taps.n;
@@ -2868,6 +2932,11 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
         else                    hipLaunchKernelGGL((wgrad_narrow_out_kernel<32, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
     }
     if (int rc = check_launch("wgrad_narrow_kernel")) return rc;
+    if (reduce_deferrable(job, p.taps, cn, splits, dbias)) {
+        fill_reduce_job(job, 2, p.part, dw, cn, splits, p.taps);
+        *bias_done = true;                   // (no bias gradient asked for)
+        return PP_OK;
+    }
     hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)cdiv((int64_t)nt * cn, 8)), dim3(256), 0, st, p.part, (int)splits,
                        nt, cn, p.taps, dw);
     if (int rc = check_launch("wgrad_reduce_wide_kernel")) return rc;
@@ -3263,10 +3332,11 @@ size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Co
     return total;
 }
 
-int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
-                         int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
-                         void* workspace, size_t ws_bytes, pp_stream_t stream)
+static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                                  int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                                  void* workspace, size_t ws_bytes, pp_stream_t stream, pp_reduce_job* job)
 {
+    if (job) job->kind = 0;
     if (int rc = conv_common_check(x, dy, dw, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     hipStream_t st = as_stream(stream);
@@ -3280,7 +3350,7 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
     p.xcd_remap = g_wgrad_xcd;
     if (g_wgrad_narrow) {
         bool bias_done = false;
-        const int rc = launch_wgrad_narrow(p, kh, kw, dw, dbias, &bias_done, workspace, ws_bytes, st);
+        const int rc = launch_wgrad_narrow(p, kh, kw, dw, dbias, &bias_done, workspace, ws_bytes, st, job);
         if (rc != 1) {                       // 0: handled, < 0: error, 1: not a narrow layer
             if (rc < 0) return rc;
             if (bias_done) return PP_OK;
@@ -3370,6 +3440,11 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
 reduce_partials:
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
     const int64_t cn = (int64_t)Cin * Cout;
+    if (cn % 4 == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 &&
+        reduce_deferrable(job, p.taps, cn, splits, dbias)) {
+        fill_reduce_job(job, 1, p.part, dw, cn, splits, p.taps);
+        return PP_OK;
+    }
     if (cn % 4 == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0)
         hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)cdiv(p.taps.n * (cn / 4), 256)), dim3(256), 0, st, p.part,
                            (int)splits, p.taps.n, cn, p.taps, dw);
@@ -3397,6 +3472,56 @@ bias_part:
         if (int rc = check_launch("bias_grad_partial_kernel")) return rc;
         hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)cdiv(Cout, 8)), dim3(256), 0, st, bpart, nblk, Cout, dbias);
         if (int rc = check_launch("bias_grad_final_kernel")) return rc;
+    }
+    return PP_OK;
+}
+
+int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                         int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                         void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    return conv2d_bwd_weight_impl(x, ldx, B, H, W, Cin, dy, lddy, Cout, kh, kw, stride, pad, dil, dw, dbias, workspace, ws_bytes, stream, nullptr);
+}
+
+int pp_conv2d_bwd_weight_partials(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                                  int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                                  void* workspace, size_t ws_bytes, pp_reduce_job* job, pp_stream_t stream)
+{
+    if (!job) return fail(PP_ERR_BAD_ARG, "conv bwd_weight_partials: job is NULL");
+    return conv2d_bwd_weight_impl(x, ldx, B, H, W, Cin, dy, lddy, Cout, kh, kw, stride, pad, dil, dw, dbias, workspace, ws_bytes, stream, job);
+}
+
+int pp_wgrad_reduce_batch(const pp_reduce_job* jobs, int n, pp_stream_t stream)
+{
+    if (n < 0 || (n > 0 && !jobs)) return fail(PP_ERR_BAD_ARG, "wgrad_reduce_batch: jobs");
+    hipStream_t st = as_stream(stream);
+    int i = 0;
+    while (i < n) {
+        ReduceBatch b{};
+        int m = 0;
+        int64_t blocks = 0;
+        for (; i < n && m < kBatchJobs; ++i) {
+            const pp_reduce_job& j = jobs[i];
+            if (j.kind == 0) continue;                       // nothing was deferred for this layer
+            if (j.kind < 1 || j.kind > 3 || !j.part || !j.dst || j.cn < 1 || j.splits < 1 || (j.kind != 3 && (j.ntaps < 1 || j.ntaps > 12)))
+                return fail(PP_ERR_BAD_ARG, "wgrad_reduce_batch: job %d is malformed", i);
+            const int64_t total = j.kind == 3 ? j.cn : (int64_t)j.ntaps * j.cn;
+            if (total >= (1ll << 31) || (j.kind == 1 && (j.cn % 4 != 0 || ((reinterpret_cast<uintptr_t>(j.part) | reinterpret_cast<uintptr_t>(j.dst)) & 15))))
+                return fail(PP_ERR_BAD_ARG, "wgrad_reduce_batch: job %d: size / alignment", i);
+            const int64_t nb = j.kind == 1 ? cdiv(total / 4, 256) : cdiv(total, 8);
+            if (blocks + nb >= (1ll << 31)) break;
+            b.part[m] = j.part; b.dst[m] = j.dst; b.cn[m] = (int)j.cn; b.splits[m] = j.splits;
+            b.ntaps[m] = (uint8_t)(j.kind == 3 ? 1 : j.ntaps); b.kind[m] = (uint8_t)j.kind;
+            for (int k = 0; k < 12; ++k) b.widx[m][k] = j.widx[k];
+            b.start[m] = (int)blocks;
+            blocks += nb;
+            ++m;
+        }
+        if (m == 0) continue;
+        b.start[m] = (int)blocks;
+        b.n = m;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+        if (int rc = check_launch("wgrad_reduce_batch_kernel")) return rc;
     }
     return PP_OK;
 }

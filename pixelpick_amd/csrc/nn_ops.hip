@@ -2214,7 +2214,7 @@ size_t pp_colreduce_workspace_bytes(int64_t M, int C)
     if (M < 1 || C < 4) return 256;
     ColReduceGeom g = col_geom(M, C);
     size_t a = (size_t)g.nblk_rows * 2 * C * 4;
-    size_t b = (size_t)col_geom(M, C, 2048).nblk_rows * 9 * C * 4;  // depthwise weight-gradient partials (largest geometry it may pick)
+    size_t b = (size_t)(M < 2048 ? M : 2048) * 9 * C * 4;           // depthwise weight-gradient partials: no geometry has more than 2048 row blocks
     return align_up(a > b ? a : b, 256);
 }
 
@@ -2451,16 +2451,16 @@ int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, in
 
 static int dwconv_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
                                   int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream,
-                                  const float* in_scale, const float* in_shift, int in_act)
+                                  const float* in_scale, const float* in_shift, int in_act, pp_reduce_job* job = nullptr)
 {
+    if (job) job->kind = 0;
     if (!x || !dy || !dw) return fail(PP_ERR_BAD_ARG, "dwconv bwd_weight: null");
     if (int rc = need_c4(C, "dwconv bwd_weight")) return rc;
     const int Ho = (H + 2 * pad - 2 * dil - 1) / stride + 1, Wo = (W + 2 * pad - 2 * dil - 1) / stride + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
     if (M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "dwconv bwd_weight: more than 2^31 output pixels");
-    ColReduceGeom g = col_geom(M, C, g_dw_wgrad_blocks);
-    if (!workspace || ws_bytes < (size_t)g.nblk_rows * 9 * C * 4) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
-    const size_t ws_rows = ws_bytes / ((size_t)9 * C * 4);
+    // (the geometry must not depend on how large the caller's workspace happens to be: the summation order would)
+    if (!workspace || ws_bytes < pp_colreduce_workspace_bytes(M, C)) return fail(PP_ERR_WORKSPACE, "dwconv bwd_weight: workspace");
     // maps of <= 8192 pixels (1/8 and 1/16 resolution, 192..960 channels): 32-quad column blocks x 8 row lanes, one item per
     // thread - 13.0-17.6 -> 10.1-12.1 us per call (tools/dw_wgrad_bench.py); the large maps keep full-width blocks (b3: 23 vs 27 us)
     const int cq_blk = g_dw_wgrad_cq_blk ? g_dw_wgrad_cq_blk : (M <= 8192 ? 32 : kT);
@@ -2470,22 +2470,22 @@ static int dwconv_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
     if (stride == 1 && dil == 1 && Wo % 4 == 0 && g_dw_wgrad_x4) {
         // items of four pixels; the same workspace bound holds (never more row blocks than the one-pixel geometry)
         ColReduceGeom g4 = col_geom(M / 4, C, g_dw_wgrad_x4_blocks, cq_blk, passes);
-        if ((size_t)g4.nblk_rows <= ws_rows) {
+        if (g4.nblk_rows <= 2048) {
             hipLaunchKernelGGL(dwconv_bwd_weight_x4_kernel, dim3(g4.nblk_rows, g4.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4,
                                dy, lddy, Ho, Wo, pad, g4, part, in_scale, in_shift, in_act);
             if (int rc = check_launch("dwconv_bwd_weight_x4_kernel")) return rc;
+            if (job) { job->part = part; job->dst = dw; job->cn = (int64_t)9 * C; job->splits = g4.nblk_rows; job->ntaps = 1; job->kind = 3; return PP_OK; }
             hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv((int64_t)9 * C, 8)), dim3(kT), 0, st, part, g4.nblk_rows,
                                (int64_t)9 * C, dw, 1.0f);
             return check_launch("sum_partials_kernel");
         }
     }
-    if (cq_blk != kT || passes != 4) {
-        const ColReduceGeom gn = col_geom(M, C, g_dw_wgrad_blocks, cq_blk, passes);
-        if ((size_t)gn.nblk_rows <= ws_rows) g = gn;
-    }
+    ColReduceGeom g = col_geom(M, C, g_dw_wgrad_blocks, cq_blk, passes);
+    if (g.nblk_rows > 2048) return fail(PP_ERR_UNSUPPORTED, "dwconv bwd_weight: geometry");
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g.nblk_rows, g.nblk_cols), dim3(kT), 0, st, x, ldx, B, H, W, C / 4, dy,
                        lddy, Ho, Wo, stride, pad, dil, g, part, in_scale, in_shift, in_act);
     if (int rc = check_launch("dwconv_bwd_weight_kernel")) return rc;
+    if (job) { job->part = part; job->dst = dw; job->cn = (int64_t)9 * C; job->splits = g.nblk_rows; job->ntaps = 1; job->kind = 3; return PP_OK; }
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(9 * C, 8)), dim3(kT), 0, st, part, g.nblk_rows,
                        (int64_t)9 * C, dw, 1.0f);
     return check_launch("sum_partials_kernel");
@@ -2495,6 +2495,14 @@ int pp_dwconv3x3_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, in
                             int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_stream_t stream)
 {
     return dwconv_bwd_weight_impl(x, ldx, B, H, W, C, dy, lddy, stride, pad, dil, dw, workspace, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+int pp_dwconv3x3_bwd_weight_partials(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy, int64_t lddy,
+                                     int stride, int pad, int dil, float* dw, void* workspace, size_t ws_bytes, pp_reduce_job* job,
+                                     pp_stream_t stream)
+{
+    if (!job) return fail(PP_ERR_BAD_ARG, "dwconv bwd_weight_partials: job is NULL");
+    return dwconv_bwd_weight_impl(x, ldx, B, H, W, C, dy, lddy, stride, pad, dil, dw, workspace, ws_bytes, stream, nullptr, nullptr, 0, job);
 }
 
 int pp_dwconv3x3_bwd_weight_affine_in(const float* x_raw, int64_t ldx, int B, int H, int W, int C, const float* in_scale,

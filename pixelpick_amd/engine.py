@@ -11,6 +11,7 @@ Activations are NHWC `torch.Tensor`s [B,H,W,C]; channel slices of a wider buffer
 """
 import contextlib
 import math
+import ctypes
 import os
 from typing import List, Optional, Sequence
 
@@ -245,6 +246,9 @@ class Tape:
         self._side_rr = 0
         self._keepalive = []
         self.hooks = {}                # name -> callable run when backward() gets back to Tape.mark(name)
+        self._jobs_first = 0           # deferred weight-gradient reduces: slots [_jobs_first, _jobs_next) of _JOB_POOL are pending
+        self._jobs_next = 0
+        self._arena_off = 0
 
     def mark(self, name: str):
         """Forward: remember this point.  backward() calls hooks[name] (if set) when every node recorded AFTER this point
@@ -270,8 +274,10 @@ class Tape:
     def set_param_grad(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
         if key in self.param_grads:   # parameter used twice on the tape: accumulate
+            self.flush_reduces(g.device)          # (a deferred reduce may still owe either summand)
             prev = self.param_grads[key]
-            add2d_(prev.view(1, -1), g.view(1, -1), prev.view(1, -1))
+            with (self.side_stream_for(prev, g) if _role[0] == 0 else _NULL_CTX):     # both summands were written on the side stream
+                add2d_(prev.view(1, -1), g.view(1, -1), prev.view(1, -1))
         else:
             self.param_grads[key] = g
 
@@ -298,6 +304,48 @@ class Tape:
         _SIDE_CTX.role = 1 + i
         return _SIDE_CTX
 
+    # ---- deferred reduces (pp_*_bwd_weight_partials + pp_wgrad_reduce_batch) ------------------------------------------------
+    # A weight gradient is a partial-sum kernel followed by a small reduce launch; ~60 of those reduces per step are 0.41 ms of
+    # launches of a few hundred blocks on the weight-gradient queue.  With PIXELPICK_BATCH_REDUCE=1 the layers on the side
+    # stream run only their partial kernel - partials in a slice of an arena that stays untouched until the flush - and ONE
+    # launch per <= 64 layers reduces them: at every Tape.mark (the gradients behind a mark must be final before its hook
+    # starts their all-reduce), every PIXELPICK_REDUCE_FLUSH_MB of pending partials, and at the join.  Bit-identical to the
+    # per-layer reduces (tested).  OFF by default - measured (profiles/r03_side_queue.txt): the second queue loses 57 launches and
+    # 0.35 ms of kernel time and the step gets SLOWER (5.77-5.78 -> 5.80-5.93 ms): the per-layer reduces ran in the shadow of
+    # the main queue on partials that were still in L2, the batch reads them back cold and its last launch (110 us when
+    # everything is flushed at the join) sits between the last weight gradient and the optimiser.
+    def defer_slot(self, nbytes: int, device):
+        """(job struct, arena pointer, arena bytes) for one deferred layer, or None: not deferrable right now."""
+        if not (_BATCH_REDUCE and Tape.overlap_wgrad and N_SIDE_STREAMS == 1) or nbytes > _ARENA_BYTES:
+            return None
+        if (self._jobs_next >= len(_JOB_POOL) or self._arena_off + nbytes > _ARENA_BYTES or self._jobs_next - self._jobs_first >= 64
+                or self._arena_off >= _FLUSH_BYTES):
+            self.flush_reduces(device)
+            if self._jobs_next >= len(_JOB_POOL):
+                return None
+        return _JOB_POOL[self._jobs_next], _arena(device).data_ptr() + self._arena_off, nbytes
+
+    def defer_commit(self, job):
+        """The partial kernel of `job` is enqueued: keep the slot and the bytes its partials occupy (the workspace query is an
+        upper bound over every slice count; the job says how many slices there are) if something was left to reduce."""
+        if job.kind != 0:
+            used = job.splits * job.cn * 4 * (1 if job.kind == 3 else job.ntaps)
+            self._arena_off = (self._arena_off + used + 255) & ~255
+            self._jobs_next += 1
+
+    def flush_reduces(self, device):
+        n = self._jobs_next - self._jobs_first
+        if n > 0:
+            args = (ctypes.addressof(_JOB_POOL[self._jobs_first]), n)
+            if _role[0] != 0:              # called from inside a side-stream context (the single _SIDE_CTX does not nest)
+                rc = _lib.lib().pp_wgrad_reduce_batch(*args, _stream())
+            else:
+                with self.side_stream_for(_arena(device)):
+                    rc = _lib.lib().pp_wgrad_reduce_batch(*args, _stream())
+            _lib.check(rc, "pp_wgrad_reduce_batch")
+        self._jobs_first = self._jobs_next
+        self._arena_off = 0
+
     def backward(self, out: Var, dout: torch.Tensor):
         refresh_stream()               # autograd may call this from its own thread / stream
         if Tape.trace is not None:
@@ -307,6 +355,7 @@ class Tape:
             if fn is _MARK:
                 hook = self.hooks.get(ctx)
                 if hook is not None:
+                    self.flush_reduces(dout.device)
                     hook(self)
                 continue
             if o.grad is None:
@@ -314,6 +363,7 @@ class Tape:
             fn(self, o.grad, *ctx)
             o.grad = None             # free as we go
         self.nodes = []
+        self.flush_reduces(dout.device)
         if Tape.trace is not None:
             Tape.trace.append(("bwd_main_end", _mark()))
         if self._side is not None:    # join: the optimiser / all-reduce must see every weight gradient
@@ -415,6 +465,22 @@ def _geom(t: torch.Tensor):
 _SCRATCH = {}
 _SCRATCH_RETIRED = []
 _WS_BYTES = {}
+
+
+_BATCH_REDUCE = os.environ.get("PIXELPICK_BATCH_REDUCE", "0") != "0"
+_ARENA_BYTES = int(os.environ.get("PIXELPICK_REDUCE_ARENA_MB", "768")) << 20
+_FLUSH_BYTES = int(os.environ.get("PIXELPICK_REDUCE_FLUSH_MB", "768")) << 20      # flush once this many bytes of partials are pending
+_ARENAS = {}
+_JOB_POOL = (_lib.ReduceJob * 512)()      # fixed addresses: a recorded launch plan replays calls that point into it
+
+
+def _arena(device) -> torch.Tensor:
+    """Partial sums of the deferred weight gradients of one flush interval (side stream only; allocated once per device)."""
+    key = (device.type, device.index)
+    a = _ARENAS.get(key)
+    if a is None:
+        a = _ARENAS[key] = torch.empty(_ARENA_BYTES, dtype=torch.uint8, device=device)
+    return a
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -742,10 +808,18 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
                 # the weight gradient needs act(bn(raw)), which the forward never wrote: one elementwise launch on the
                 # weight-gradient stream (idle between the encoder's small weight gradients), kept alive until the join
                 tape._keepalive.append(x.t)
-            ws = _ws(_wsbytes("pp_conv2d_bwd_weight_workspace_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil), dev)
-            rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
-                                        dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
-                                        _stream())
+            nws = _wsbytes("pp_conv2d_bwd_weight_workspace_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+            slot = tape.defer_slot(nws, dev) if (not big and db is None) else None
+            if slot is not None:
+                job, wptr, _ = slot
+                rc = L.pp_conv2d_bwd_weight_partials(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
+                                                     dw.data_ptr(), None, wptr, nws, ctypes.addressof(job), _stream())
+                tape.defer_commit(job)
+            else:
+                ws = _ws(nws, dev)
+                rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
+                                            dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+                                            _stream())
         _lib.check(rc, "pp_conv2d_bwd_weight")
         tape.set_param_grad(w, dw)
         if db is not None:
@@ -812,9 +886,17 @@ def _dwconv_bwd(tape: Tape, dy, x: Var, w, stride, pad, dil):
             _lib.check(rc, "pp_dwconv3x3_bwd_weight_affine_in")
         else:
             with tape.side_stream_for(x.t, dy, dw):
-                ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", B * Ho * Wo, C), dev)
-                rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), _stream())
+                nws = _wsbytes("pp_colreduce_workspace_bytes", B * Ho * Wo, C)
+                slot = tape.defer_slot(nws, dev)
+                if slot is not None:
+                    job, wptr, _ = slot
+                    rc = L.pp_dwconv3x3_bwd_weight_partials(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil,
+                                                            dw.data_ptr(), wptr, nws, ctypes.addressof(job), _stream())
+                    tape.defer_commit(job)
+                else:
+                    ws = _ws(nws, dev)
+                    rc = L.pp_dwconv3x3_bwd_weight(x.t.data_ptr(), ldx, B, H, W, C, dy.data_ptr(), lddy, stride, pad, dil, dw.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _stream())
             _lib.check(rc, "pp_dwconv3x3_bwd_weight")
         tape.set_param_grad(w, dw)
     if x.needs_grad:

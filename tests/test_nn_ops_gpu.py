@@ -326,6 +326,55 @@ def test_dwconv_fwd_bwd(case):
     close(tape.param_grads[id(wg)].permute(2, 0, 1).cpu()[:, None], w.grad, what="dw dW")
 
 
+def test_batched_weight_gradient_reduces_are_bit_identical(monkeypatch):
+    """PIXELPICK_BATCH_REDUCE: the layers on the weight-gradient stream run pp_*_bwd_weight_partials and ONE
+    pp_wgrad_reduce_batch launch reduces them all (table in the kernel arguments) - the arithmetic of the per-layer reduce
+    kernels, so every gradient is bit-equal to the undeferred path.  One tape with every job kind: 3x3 with dead taps (kind 1, tap
+    map), pointwise, narrow-input / narrow-output layers (kind 2), depthwise stride 1 / 2 (kind 3), a bias layer (not
+    deferrable: completed in place), a parameter used twice (forces an early flush) and > 64 layers (several launches)."""
+    convs = [(2, 16, 32, 320, 256, 3, 1, 6, 6, False), (2, 16, 32, 64, 96, 3, 1, 18, 18, False), (2, 10, 12, 960, 160, 1, 1, 0, 1, False),
+             (2, 128, 160, 32, 16, 1, 1, 0, 1, False), (2, 128, 136, 96, 24, 1, 1, 0, 1, False), (2, 256, 264, 3, 32, 3, 2, 1, 1, False),
+             (2, 12, 12, 128, 128, 3, 1, 1, 1, True), (2, 9, 11, 24, 144, 1, 1, 0, 1, False), (1, 24, 20, 304, 256, 3, 1, 1, 1, False)]
+    convs = convs + [(2, 9, 11, 24 + 8 * i, 40, 1, 1, 0, 1, False) for i in range(60)]
+    dws = [(2, 18, 34, 32, 1, 0, 1), (2, 19, 35, 96, 2, 0, 1), (2, 20, 36, 960, 1, 0, 2), (4, 16, 32, 384, 1, 1, 1)]
+    gen = torch.Generator().manual_seed(9)
+    data = []
+    for (B, H, W, Cin, Cout, k, st, pad, dil, hb) in convs:
+        data.append(("c", nhwc(torch.randn(B, Cin, H, W, generator=gen)), (torch.randn(k, k, Cin, Cout, generator=gen) / np.sqrt(Cin * k * k)).to(DEV),
+                     torch.randn(Cout, generator=gen).to(DEV) if hb else None, st, pad, dil))
+    for (B, H, W, C, st, pad, dil) in dws:
+        data.append(("d", nhwc(torch.randn(B, C, H, W, generator=gen)), (torch.randn(3, 3, C, generator=gen) / 3).to(DEV), None, st, pad, dil))
+
+    def run(batch):
+        monkeypatch.setattr(E, "_BATCH_REDUCE", batch)
+        tape = E.Tape()
+        params, outs = [], []
+        shared = None
+        for i, (kind, x, w, b, st, pad, dil) in enumerate(data):
+            w = w.clone().requires_grad_(True)
+            b = b.clone().requires_grad_(True) if b is not None else None
+            params += [w] + ([b] if b is not None else [])
+            y = E.conv2d(tape, E.Var(x), w, b, st, pad, dil) if kind == "c" else E.dwconv3x3(tape, E.Var(x), w, st, pad, dil)
+            outs.append(y)
+            if i == 2:                    # the same weight on a second input: its two gradients are accumulated on the tape
+                shared = (w, E.conv2d(tape, E.Var(x * 0.5), w, None, st, pad, dil))
+                outs.append(shared[1])
+        g = torch.Generator(device=DEV).manual_seed(4)
+        # one backward per output on the same tape is not how the tape works: chain them through a sum of means instead
+        for y in outs:
+            y.grad = torch.randn(y.t.shape, device=DEV, generator=g)
+        last = outs[-1]
+        tape.backward(last, last.grad)
+        torch.cuda.synchronize()
+        return [tape.param_grads[id(p)].clone() for p in params]
+
+    a = run(True)
+    b = run(False)
+    assert len(a) == len(b) and len(a) >= 70
+    bad = [i for i, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
+    assert not bad, f"gradients {bad} differ"
+
+
 @pytest.fixture(params=[True, False], ids=["bn-1launch", "bn-3launch"])
 def bn_fused(request):
     old = E._BN_FUSED
