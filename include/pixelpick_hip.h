@@ -198,6 +198,26 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
                          int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
                          void* workspace, size_t ws_bytes, pp_stream_t stream);
 
+/* bf16x3 operand planes shared between the calls of one layer.  The MFMA-bound convolutions (see pp_debug_set_x3) read their
+ * activation operand as three chunk-major bf16 planes; by default every call splits its operand into its workspace.  The
+ * forward's operand x is also the weight gradient's, and the backward-data's operand dy is the weight gradient's other one:
+ * a caller may split a tensor ONCE with pp_x3_split and pass the planes to every *_pre call that reads it (NULL = split
+ * inside, as the plain entry points do; planes are ignored by calls that do not run a bf16x3 kernel).
+ * pp_conv2d_x3_planes_bytes(which, ...): 0 if the call (which = 0 forward, 1 backward-data, 2 weight gradient) would not use
+ * planes, else the size of its activation planes (forward / weight gradient: of x; backward-data: of dy). */
+size_t pp_x3_planes_bytes(int64_t rows, int C);
+int pp_x3_split(const float* x, int64_t ldx, int64_t rows, int C, void* planes, size_t planes_bytes, pp_stream_t stream);
+size_t pp_conv2d_x3_planes_bytes(int which, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pp_conv2d_fwd_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                      int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                      size_t ws_bytes, const void* x_planes, pp_stream_t stream);
+int pp_conv2d_bwd_data_pre(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                           int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                           void* workspace, size_t ws_bytes, const void* dy_planes, pp_stream_t stream);
+int pp_conv2d_bwd_weight_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                             int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                             void* workspace, size_t ws_bytes, const void* x_planes, const void* dy_planes, pp_stream_t stream);
+
 /* Deferred reduces.  A weight gradient is a partial-sum kernel ([slices][...] in the workspace) followed by a small
  * fixed-order reduce; a backward pass has ~60 of them (model.py:121 loss.backward()).  The *_partials forms run only the
  * first kernel and describe the reduce in *job (kind 0: nothing left to do - the call completed the gradient itself, e.g.

@@ -44,6 +44,7 @@ struct ConvTaps {
 };
 
 struct ConvParams {
+    const uint16_t* a_pre;   // bf16x3 planes of the A operand the CALLER already holds (pp_x3_split), or NULL: split here
     const float* x;   // A-side activations (X for fwd/wgrad, dY for bwd-data)
     const float* w;   // HWIO weights
     const float* bias;
@@ -2658,12 +2659,14 @@ static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int
 template <bool BWD>
 static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, int kh_kw, void* workspace, hipStream_t st)
 {
-    uint16_t* ap = reinterpret_cast<uint16_t*>(workspace);
+    const uint16_t* ap = p.a_pre ? p.a_pre : reinterpret_cast<uint16_t*>(workspace);
     uint16_t* bp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)3 * x.a_plane * 2, 256));
-    const int64_t ta = (x.rows_a + 1) * (x.Kp / 8);          // (chunk, row, half) items
-    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ta, 256), 4096)), dim3(256), 0, st, p.x, p.ldx, x.rows_a, p.Ck, ap,
-                       x.Kp, x.a_plane);
-    if (int rc = check_launch("x3_split_kernel")) return rc;
+    if (!p.a_pre) {
+        const int64_t ta = (x.rows_a + 1) * (x.Kp / 8);          // (chunk, row, half) items
+        hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ta, 256), 4096)), dim3(256), 0, st, p.x, p.ldx, x.rows_a, p.Ck,
+                           reinterpret_cast<uint16_t*>(workspace), x.Kp, x.a_plane);
+        if (int rc = check_launch("x3_split_kernel")) return rc;
+    }
     const int64_t tb = (x.b_rows + 1) * (x.Kp / 8);
     hipLaunchKernelGGL(x3_split_w_kernel, dim3((unsigned)std::min<int64_t>(cdiv(tb, 256), 4096)), dim3(256), 0, st, p.w, kh_kw, p.Cin, p.Cout,
                        BWD ? 0 : 1, bp, x.Kp, x.b_plane);
@@ -3157,7 +3160,7 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
 static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                            int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, const Epilogue& epi,
                            void* workspace, size_t ws_bytes, pp_stream_t stream, float* stats = nullptr, size_t stats_floats = 0,
-                           const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0)
+                           const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, const void* x_planes = nullptr)
 {
     if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
@@ -3169,6 +3172,7 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
     p.stride = stride; p.M = (int64_t)B * Ho * Wo; p.bwd_stride = 1;
     p.epi = epi;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
+    p.a_pre = reinterpret_cast<const uint16_t*>(x_planes);
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
@@ -3226,6 +3230,14 @@ int pp_conv2d_fwd(const float* x, int64_t ldx, int B, int H, int W, int Cin, con
                            ws_bytes, stream);
 }
 
+int pp_conv2d_fwd_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                      int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                      size_t ws_bytes, const void* x_planes, pp_stream_t stream)
+{
+    return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
+                           ws_bytes, stream, nullptr, 0, nullptr, nullptr, 0, x_planes);
+}
+
 int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                          int kh, int kw, int stride, int pad, int dil, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, float eps, const float* residual,
@@ -3238,9 +3250,9 @@ int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int C
     return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, e, workspace, ws_bytes, stream);
 }
 
-int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
-                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
-                       void* workspace, size_t ws_bytes, pp_stream_t stream)
+static int conv2d_bwd_data_impl(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                                int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                                void* workspace, size_t ws_bytes, pp_stream_t stream, const void* dy_planes)
 {
     if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
@@ -3286,7 +3298,49 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
     build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: more than 2^31 pixels");
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv bwd_data: no live tap");
+    p.a_pre = stride == 1 ? reinterpret_cast<const uint16_t*>(dy_planes) : nullptr;
     return launch_conv<true>(p, workspace, ws_bytes, as_stream(stream), kh * kw);
+}
+
+int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                       int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                       void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    return conv2d_bwd_data_impl(dy, lddy, B, Ho, Wo, Cout, w, kh, kw, stride, pad, dil, dx, lddx, H, W, Cin, accumulate, workspace, ws_bytes,
+                                stream, nullptr);
+}
+
+// ---- bf16x3 operand planes shared between the calls of a layer ---------------------------------------------------------------------
+// The forward's A operand (X) is also the weight gradient's, the backward-data's (dY) is the weight gradient's other one: the
+// caller may split an activation ONCE (pp_x3_split: three chunk-major bf16 planes, the layout conv_x3_kernel / conv_wgrad_x3_kernel
+// DMA from) and hand the planes to every call that reads it.  pp_conv2d_x3_planes_bytes tells whether a call would use them.
+size_t pp_x3_planes_bytes(int64_t rows, int C)
+{
+    if (rows < 1 || C < 1) return 0;
+    return align_up((size_t)3 * (size_t)(rows + 1) * (size_t)(cdiv(C, 16) * 16) * 2, 256);
+}
+
+int pp_x3_split(const float* x, int64_t ldx, int64_t rows, int C, void* planes, size_t planes_bytes, pp_stream_t stream)
+{
+    if (!x || !planes || rows < 1 || C < 1) return fail(PP_ERR_BAD_ARG, "x3_split: null / empty");
+    if (C % 4 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 255))
+        return fail(PP_ERR_BAD_ARG, "x3_split: C and ld must be multiples of 4, x 16-byte and planes 256-byte aligned");
+    const int Kp = (int)cdiv(C, 16) * 16;
+    const int64_t plane = (rows + 1) * Kp;
+    if (plane * 2 >= (1ll << 32) - 4096) return fail(PP_ERR_UNSUPPORTED, "x3_split: plane of %lld bytes", (long long)(plane * 2));
+    if (planes_bytes < pp_x3_planes_bytes(rows, C)) return fail(PP_ERR_WORKSPACE, "x3_split: planes buffer");
+    const int64_t ta = (rows + 1) * (Kp / 8);
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ta, 256), 4096)), dim3(256), 0, as_stream(stream), x, ldx, rows, C,
+                       reinterpret_cast<uint16_t*>(planes), Kp, plane);
+    return check_launch("x3_split_kernel");
+}
+
+int pp_conv2d_bwd_data_pre(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                           int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                           void* workspace, size_t ws_bytes, const void* dy_planes, pp_stream_t stream)
+{
+    return conv2d_bwd_data_impl(dy, lddy, B, Ho, Wo, Cout, w, kh, kw, stride, pad, dil, dx, lddx, H, W, Cin, accumulate, workspace, ws_bytes,
+                                stream, dy_planes);
 }
 
 // bf16x3 weight gradient (conv_wgrad_x3_kernel): the MFMA-bound layers (>= 8 GFLOP, both channel counts > 64, 128-wide outputs)
@@ -3334,7 +3388,8 @@ size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Co
 
 static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
                                   int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
-                                  void* workspace, size_t ws_bytes, pp_stream_t stream, pp_reduce_job* job)
+                                  void* workspace, size_t ws_bytes, pp_stream_t stream, pp_reduce_job* job,
+                                  const void* x_planes = nullptr, const void* dy_planes = nullptr)
 {
     if (job) job->kind = 0;
     if (int rc = conv_common_check(x, dy, dw, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
@@ -3397,13 +3452,17 @@ static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
     const bool dma = vec && p.bias_part == nullptr && (int64_t)p.M * std::max(ldx, lddy) < (1ll << 40);
     {
         if (use_x3) {
-            uint16_t* xp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + x3_off);
-            uint16_t* dp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(xp) + align_up((size_t)3 * xw.x_plane * 2, 256));
+            uint16_t* xw_ = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + x3_off);
+            uint16_t* dw_ = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(xw_) + align_up((size_t)3 * xw.x_plane * 2, 256));
+            const uint16_t* xp = x_planes ? reinterpret_cast<const uint16_t*>(x_planes) : xw_;
+            const uint16_t* dp = dy_planes ? reinterpret_cast<const uint16_t*>(dy_planes) : dw_;
             const int64_t rows_x = (int64_t)B * H * W;
-            hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((rows_x + 1) * (xw.Cin_p / 8), 256), 4096)), dim3(256), 0, st,
-                               x, ldx, rows_x, Cin, xp, xw.Cin_p, xw.x_plane);
-            hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((p.M + 1) * (xw.Cout_p / 8), 256), 4096)), dim3(256), 0, st,
-                               dy, lddy, p.M, Cout, dp, xw.Cout_p, xw.dy_plane);
+            if (!x_planes)
+                hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((rows_x + 1) * (xw.Cin_p / 8), 256), 4096)), dim3(256), 0, st,
+                                   x, ldx, rows_x, Cin, xw_, xw.Cin_p, xw.x_plane);
+            if (!dy_planes)
+                hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv((p.M + 1) * (xw.Cout_p / 8), 256), 4096)), dim3(256), 0, st,
+                                   dy, lddy, p.M, Cout, dw_, xw.Cout_p, xw.dy_plane);
             if (int rc = check_launch("x3_split_kernel")) return rc;
             X3WOperands o{xp, dp, xw.x_plane, xw.dy_plane, (uint32_t)((rows_x + 1) * 32), (uint32_t)((p.M + 1) * 32),
                           (uint32_t)(rows_x * 32), (uint32_t)(p.M * 32)};
@@ -3481,6 +3540,49 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
                          void* workspace, size_t ws_bytes, pp_stream_t stream)
 {
     return conv2d_bwd_weight_impl(x, ldx, B, H, W, Cin, dy, lddy, Cout, kh, kw, stride, pad, dil, dw, dbias, workspace, ws_bytes, stream, nullptr);
+}
+
+int pp_conv2d_bwd_weight_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
+                             int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
+                             void* workspace, size_t ws_bytes, const void* x_planes, const void* dy_planes, pp_stream_t stream)
+{
+    return conv2d_bwd_weight_impl(x, ldx, B, H, W, Cin, dy, lddy, Cout, kh, kw, stride, pad, dil, dw, dbias, workspace, ws_bytes, stream, nullptr,
+                                  x_planes, dy_planes);
+}
+
+// 0: the call would not run a bf16x3 kernel (planes would be ignored); else the bytes of the A-operand planes it reads
+// (which: 0 forward -> planes of x, 1 backward-data -> planes of dy, 2 weight gradient -> planes of x AND of dy are used)
+size_t pp_conv2d_x3_planes_bytes(int which, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return 0;
+    const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
+    ConvTaps t;
+    if (which == 0) {
+        build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+        const int64_t M = (int64_t)B * Ho * Wo;
+        if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) return 0;
+        const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, vec);
+        return x3_plan(pl, M, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec).ok ? pp_x3_planes_bytes((int64_t)B * H * W, Cin) : 0;
+    }
+    if (which == 1) {
+        if (stride != 1) return 0;
+        build_taps(t, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
+        const int64_t M = (int64_t)B * H * W;
+        if (ksplit_shape_ok(M, Cin, Cout, t.n, stride)) return 0;
+        const ConvPlan pl = plan_conv(M, Cin, Cout, t.n, vec);
+        return x3_plan(pl, M, (int64_t)B * Ho * Wo, Cout, Cin, kh * kw, t.n, vec).ok ? pp_x3_planes_bytes((int64_t)B * Ho * Wo, Cout) : 0;
+    }
+    if (which == 2) {
+        build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+        const int64_t M = (int64_t)B * Ho * Wo;
+        const bool big = Cin > 64 && Cout > 64;
+        const int remn = Cout % 128;
+        const bool narrow_n = big && remn != 0 && remn <= 64 && (cdiv(Cout, 128) * 128 - Cout) * 100 > 12 * Cout;
+        return x3w_plan(B, H, W, Cin, Cout, M, t.n, vec && big && !narrow_n).ok ? pp_x3_planes_bytes((int64_t)B * H * W, Cin) : 0;
+    }
+    return 0;
 }
 
 int pp_conv2d_bwd_weight_partials(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,

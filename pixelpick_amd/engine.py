@@ -467,6 +467,24 @@ _SCRATCH_RETIRED = []
 _WS_BYTES = {}
 
 
+# bf16x3 operand planes shared inside a layer (pp_x3_split + the *_pre entry points): the forward's split of x is kept for the
+# weight gradient, the backward splits dy once for backward-data AND the weight gradient - 2 instead of 4 activation splits per
+# MFMA-bound layer (DeepLab-MNv2: 8 -> 4 launches of 17.7 us; DeepLabv3+-R50: 73 -> ~37 of 15.5 us).  Costs 1.5x the activation in
+# bf16 planes kept from forward to backward.  PIXELPICK_X3_SHARE=0: every call splits for itself.
+_X3_SHARE = os.environ.get("PIXELPICK_X3_SHARE", "1") != "0"
+
+
+def _x3_planes(which: int, B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> int:
+    return _wsbytes("pp_conv2d_x3_planes_bytes", which, B, H, W, Cin, Cout, kh, kw, stride, pad, dil) if _X3_SHARE else 0
+
+
+def _x3_split(t: torch.Tensor, ld: int, rows: int, C: int) -> torch.Tensor:
+    nb = _wsbytes("pp_x3_planes_bytes", rows, C)
+    planes = torch.empty(nb, dtype=torch.uint8, device=t.device)
+    _lib.check(_lib.lib().pp_x3_split(t.data_ptr(), ld, rows, C, planes.data_ptr(), nb, _stream()), "pp_x3_split")
+    return planes
+
+
 _BATCH_REDUCE = os.environ.get("PIXELPICK_BATCH_REDUCE", "0") != "0"
 _ARENA_BYTES = int(os.environ.get("PIXELPICK_REDUCE_ARENA_MB", "768")) << 20
 _FLUSH_BYTES = int(os.environ.get("PIXELPICK_REDUCE_FLUSH_MB", "768")) << 20      # flush once this many bytes of partials are pending
@@ -778,15 +796,23 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
     y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.t.device)
     _, _, _, _, ldy = _geom(y)
     ws, wsn = _conv_ws(False, x.t.device, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
-    rc = _lib.lib().pp_conv2d_fwd(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                  kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, _stream())
+    xp = None
+    if (tape.enabled and w.requires_grad and _x3_planes(0, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+            and _x3_planes(2, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
+        xp = _x3_split(x.t, ldx, B * H * W, Cin)          # read by this forward and, in backward(), by the weight gradient
+    if xp is not None:
+        rc = _lib.lib().pp_conv2d_fwd_pre(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, xp.data_ptr(), _stream())
+    else:
+        rc = _lib.lib().pp_conv2d_fwd(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, _stream())
     _lib.check(rc, "pp_conv2d_fwd")
     out = Var(y)
-    tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil), out)
+    tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil, xp), out)
     return out
 
 
-def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil):
+def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil, xp=None):
     L = _lib.lib()
     lazy_in = x._lazy if (x._t is None and x._lazy is not None) else None
     B, H, W, Cin, ldx = _geom(lazy_in[0] if lazy_in is not None else x.t)
@@ -795,6 +821,10 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
     _, Ho, Wo, Cout, lddy = _geom(dy)
     kh, kw = w.shape[0], w.shape[1]
     dev = dy.device
+    dyp = None
+    if (w.requires_grad and x.needs_grad and lazy_in is None and _x3_planes(1, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+            and _x3_planes(2, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
+        dyp = _x3_split(dy, lddy, B * Ho * Wo, Cout)       # one split of dy for backward-data and the weight gradient (main stream, before the fork)
     if w.requires_grad:
         dw = tape.grad_buffer_for(w)
         db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
@@ -815,6 +845,12 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
                 rc = L.pp_conv2d_bwd_weight_partials(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
                                                      dw.data_ptr(), None, wptr, nws, ctypes.addressof(job), _stream())
                 tape.defer_commit(job)
+            elif xp is not None or dyp is not None:
+                ws = _ws(nws, dev)
+                tape._keepalive.extend(t for t in (xp, dyp) if t is not None)
+                rc = L.pp_conv2d_bwd_weight_pre(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
+                                                dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+                                                xp.data_ptr() if xp is not None else None, dyp.data_ptr() if dyp is not None else None, _stream())
             else:
                 ws = _ws(nws, dev)
                 rc = L.pp_conv2d_bwd_weight(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
@@ -830,8 +866,12 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil)
                               and tuple(x.grad.shape) == (B, H, W, Cin)) else None
         dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
-        rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                  dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
+        if dyp is not None:
+            rc = L.pp_conv2d_bwd_data_pre(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
+                                          dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, dyp.data_ptr(), _stream())
+        else:
+            rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
+                                      dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
         _lib.check(rc, "pp_conv2d_bwd_data")
         if acc_into is None:
             dx._pp_owned = True              # fresh tensor referenced by x.grad only: later consumers may add in place
