@@ -2634,6 +2634,8 @@ static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
 static thread_local int g_conv_x3 = 1;
 struct X3Plan { bool ok; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes; };
 static thread_local int g_conv_x3_mid = 1;
+static thread_local double g_x3_mid_flop = 16e9, g_x3w_flop = 8e9;     // least work of a mid-size layer / a weight gradient (pp_debug_set_x3 bits 9-11 / 14-16)
+static thread_local int g_x3_mid_tiles = 256;                          // least 128 x 128 tiles of a mid-size layer (bits 12-13)
 static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int n_rows, int ntaps_w, int ntaps_live, bool vec)
 {
     X3Plan x{};
@@ -2643,7 +2645,7 @@ static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int
     const int64_t t128 = cdiv(M, 128) * cdiv(n_rows, 128);
     // (measured, FPN-ResNet50: with half a wave of blocks / below 16 GFLOP the operand splits and the idle CUs cost more than the
     // matrix rate gains - 256 -> 256 3x3 at 8192 rows 94 -> 150 us, 2048 -> 256 87 -> 155 us; 512 -> 512 3x3 345 -> 279 us)
-    const bool mid = g_conv_x3_mid && pl.cfg == 2 && t128 >= 256 && 2.0 * (double)M * n_rows * ntaps_live * Ck >= 16e9;
+    const bool mid = g_conv_x3_mid && pl.cfg == 2 && t128 >= g_x3_mid_tiles && 2.0 * (double)M * n_rows * ntaps_live * Ck >= g_x3_mid_flop;
     if (!g_conv_x3 || !(pl.cfg == 1 || mid) || pl.splits > 1 || !vec || ntaps_live > 32 || (int64_t)ntaps_live * Ck < 512) return x;
     x.Kp = (int)cdiv(Ck, 16) * 16;
     x.rows_a = rows_a;
@@ -2988,7 +2990,17 @@ void pp_debug_set_splitk(int v)
 }
 
 /* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
-void pp_debug_set_x3(int v) { g_conv_x3 = v & 0xFF; g_conv_x3_mid = (v & 256) ? 0 : 1; }   /* bit 8: large-tile plans only */
+void pp_debug_set_x3(int v)
+{
+    g_conv_x3 = v & 0xFF;
+    g_conv_x3_mid = (v & 256) ? 0 : 1;                     /* bit 8: large-tile plans only */
+    static const double gf[8] = {16e9, 12e9, 8e9, 6e9, 4e9, 3e9, 2e9, 1e9};
+    g_x3_mid_flop = gf[(v >> 9) & 7];                      /* bits 9-11: least work of a mid-size layer */
+    static const int tl[4] = {256, 128, 64, 32};
+    g_x3_mid_tiles = tl[(v >> 12) & 3];                    /* bits 12-13: least 128 x 128 tiles of a mid-size layer */
+    static const double wf[8] = {8e9, 6e9, 4e9, 3e9, 2e9, 1.5e9, 1e9, 0.5e9};
+    g_x3w_flop = wf[(v >> 14) & 7];                        /* bits 14-16: least work of a bf16x3 weight gradient */
+}
 
 void pp_debug_set_wgrad_target(int v)
 {
@@ -3348,7 +3360,7 @@ struct X3WPlan { bool ok; int Cin_p, Cout_p; int64_t x_plane, dy_plane; size_t b
 static X3WPlan x3w_plan(int B, int H, int W, int Cin, int Cout, int64_t M, int ntaps, bool shape_ok)
 {
     X3WPlan x{};
-    if (!g_conv_x3 || (g_conv_x3 & 8) || !shape_ok || ntaps > 32 || 2.0 * ntaps * Cin * Cout * (double)M < 8e9) return x;
+    if (!g_conv_x3 || (g_conv_x3 & 8) || !shape_ok || ntaps > 32 || 2.0 * ntaps * Cin * Cout * (double)M < g_x3w_flop) return x;
     x.Cin_p = (int)cdiv(Cin, 16) * 16;
     x.Cout_p = (int)cdiv(Cout, 16) * 16;
     const int64_t rows_x = (int64_t)B * H * W;

@@ -211,6 +211,7 @@ def _launch_deferred(v: "Var", bn):
 
 
 _BIG_WGRAD_MAIN = os.environ.get("PIXELPICK_BIG_WGRAD_MAIN", "1") != "0"
+_BIG_WGRAD_FLOP = float(os.environ.get("PIXELPICK_BIG_WGRAD_FLOP", "8e9"))      # (the bf16x3 weight-gradient threshold of the library)
 _side_streams = {}
 N_SIDE_STREAMS = int(os.environ.get("PIXELPICK_SIDE_STREAMS", "1"))
 SIDE_PRIORITY = int(os.environ.get("PIXELPICK_SIDE_PRIORITY", "0"))      # HIP stream priority of the weight-gradient stream(s)
@@ -832,7 +833,7 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
         # 512-thread block and 108-144 KiB of LDS per CU, which cannot become resident beside the weight-gradient blocks (647 / 751 us
         # in the trace instead of 210 / 350 alone) - and two MFMA-bound kernels gain nothing from sharing the matrix pipes anyway:
         # the weight gradient of such a layer goes out on the MAIN stream, behind nothing it could overlap with
-        big = _BIG_WGRAD_MAIN and 2.0 * B * Ho * Wo * Cin * Cout * kh * kw >= 8e9
+        big = _BIG_WGRAD_MAIN and 2.0 * B * Ho * Wo * Cin * Cout * kh * kw >= _BIG_WGRAD_FLOP
         with (_NULL_CTX if big else tape.side_stream_for(lazy_in[0] if lazy_in is not None else x.t, dy, dw, db)):
             if lazy_in is not None:
                 # the weight gradient needs act(bn(raw)), which the forward never wrote: one elementwise launch on the

@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_conv_x3_gpu.py tests/test_nn_ops_gpu.py -q -x -m gpu -k "x3 or conv2d_fwd_bwd or batched or split" 2>&1 | tail -3
-for s in 0 1 0 1; do PIXELPICK_X3_SHARE=$s timeout 300 python tools/train_bench.py 2>&1 | tail -1; done
-for net in FPN deeplab_r50; do for s in 0 1; do PIXELPICK_X3_SHARE=$s NET=$net timeout 300 python tools/train_bench.py 2>&1 | tail -1; done; done
+O=gpurun_out/r3k; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/tr
+NET=FPN STEPS=5 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -o t -- python $GRAFT_REPO_ROOT/tools/train_bench.py > $GRAFT_REPO_ROOT/$O/trace_FPN2.log 2>&1
+cd $GRAFT_REPO_ROOT
+cp $(find /tmp/tr -name "*kernel_stats.csv" | head -1) $O/fpn_kernel_stats.csv
+head -30 $O/fpn_kernel_stats.csv | cut -c1-150
