@@ -23,6 +23,9 @@ def main():
         for p_ in m.parameters():
             if p_.dim() == 4:
                 p_.requires_grad_(False)
+    if os.environ.get("CONVVAR"):                     # pp_debug_set_conv_variant word
+        from pixelpick_amd import _lib
+        _lib.lib().pp_debug_set_conv_variant(int(os.environ["CONVVAR"]))
     tr = FlatTrainer(m, ignore_index=C)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(B, 3, H, W, device="cuda", generator=g)
