@@ -79,6 +79,39 @@ def test_bf16x3_convolution_is_an_fp32_convolution(case):
     assert torch.equal(y3, y3b) and torch.equal(dx3, dx3b) and torch.equal(dw3, dw3b)
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[3]], ids=[str(CASES[0]), str(CASES[2]), str(CASES[3])])
+def test_shared_operand_planes_are_bit_identical(case, monkeypatch):
+    """PIXELPICK_X3_SHARE: the forward's bf16 planes of x are kept for the weight gradient and dy is split once for backward-data
+    and the weight gradient (pp_x3_split + the *_pre entry points) - the same planes the calls would have made themselves, so
+    forward, both gradients and the bias gradient are bit-equal to the every-call-splits path; and pp_x3_split + pp_conv2d_fwd_pre
+    called by hand equal pp_conv2d_fwd."""
+    monkeypatch.setattr(E, "_X3_SHARE", True)
+    E._WS_BYTES.clear()
+    _, _, _, _, y1, dx1, dw1 = _run(case, True)
+    monkeypatch.setattr(E, "_X3_SHARE", False)
+    _, _, _, _, y0, dx0, dw0 = _run(case, True)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and torch.equal(dw1, dw0)
+    B, H, W, Cin, Cout, k, pad, dil, has_bias = case
+    L = _lib.lib()
+    nb = L.pp_conv2d_x3_planes_bytes(0, B, H, W, Cin, Cout, k, k, 1, pad, dil)
+    if nb:
+        assert nb == L.pp_x3_planes_bytes(B * H * W, Cin)
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        x = torch.randn(B, H, W, Cin, device=DEV, generator=gen)
+        w = torch.randn(k, k, Cin, Cout, device=DEV, generator=gen) / np.sqrt(Cin * k * k)
+        st = torch.cuda.current_stream().cuda_stream
+        planes = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _lib.check(L.pp_x3_split(x.data_ptr(), Cin, B * H * W, Cin, planes.data_ptr(), nb, st), "split")
+        ws = torch.empty(L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, k, k, 1, pad, dil), dtype=torch.uint8, device=DEV)
+        Ho, Wo = E.out_size(H, k, 1, pad, dil), E.out_size(W, k, 1, pad, dil)
+        ya, yb = torch.empty(B, Ho, Wo, Cout, device=DEV), torch.empty(B, Ho, Wo, Cout, device=DEV)
+        _lib.check(L.pp_conv2d_fwd(x.data_ptr(), Cin, B, H, W, Cin, w.data_ptr(), None, k, k, 1, pad, dil, ya.data_ptr(), Cout, Cout,
+                                   ws.data_ptr(), ws.numel(), st), "fwd")
+        _lib.check(L.pp_conv2d_fwd_pre(x.data_ptr(), Cin, B, H, W, Cin, w.data_ptr(), None, k, k, 1, pad, dil, yb.data_ptr(), Cout, Cout,
+                                       ws.data_ptr(), ws.numel(), planes.data_ptr(), st), "fwd_pre")
+        assert torch.equal(ya, yb)
+
+
 def test_bf16_split_is_exact():
     """hi + mid + lo == a exactly for normal fp32 values (the property the path rests on) - checked through a 1x1 convolution with an
     identity-like weight: y = x * 1.0 must reproduce x bit for bit in the split path."""
