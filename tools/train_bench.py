@@ -26,6 +26,9 @@ def main():
     if os.environ.get("CONVVAR"):                     # pp_debug_set_conv_variant word
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_conv_variant(int(os.environ["CONVVAR"]))
+    if os.environ.get("WGRAD_TARGET"):                # pp_debug_set_wgrad_target word (blocks the weight-gradient kernels aim at)
+        from pixelpick_amd import _lib
+        _lib.lib().pp_debug_set_wgrad_target(int(os.environ["WGRAD_TARGET"]))
     tr = FlatTrainer(m, ignore_index=C)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(B, 3, H, W, device="cuda", generator=g)
