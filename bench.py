@@ -463,11 +463,32 @@ def main():
                 traffic_src = f"profiles/acq_traffic.json ({rec['kernel'].split('(')[0]}, measured {rec['measured_unix']})"
             elif same_cfg:
                 traffic_src = "profiles/acq_traffic.json is for another build of csrc/acq.hip: re-run tools/measure_acq_traffic.py"
+        # yardstick, measurement only: a kernel that does nothing but read the same logits buffer (one wave per SIMD, eight 16-byte
+        # loads in flight per lane - the fastest form tools/probe/hbm_rw.hip found): what "bandwidth-bound" can reach on this box
+        yard = None
+        if a.layout == "nchw":
+            sink = torch.zeros(4, device=dev)
+            nbytes = logits.numel() * 4
+            for _ in range(3):
+                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, 256, sink.data_ptr(), stream), "pp_debug_stream_read")
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            torch.cuda.synchronize(dev)
+            for e0, e1 in evs:
+                e0.record()
+                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, 256, sink.data_ptr(), stream), "pp_debug_stream_read")
+                e1.record()
+            torch.cuda.synchronize(dev)
+            yms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
+            yard = nbytes / (yms * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                             "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
-                            "kernel_ms_min": round(min(kms), 4)}
+                            "kernel_ms_min": round(min(kms), 4),
+                            "read_only_yardstick": ({"GB/s": round(yard, 1), "frac_of_peak": round(yard / HBM_PEAK_GBS, 4),
+                                                     "acq_kernel_vs_yardstick": round(achieved / yard, 4),
+                                                     "what": "pp_debug_stream_read: a kernel that only reads the same logits buffer"}
+                                                    if yard else None)}
 
         # the same selection straight from the classifier output at 1/4 resolution (what DeepLab's
         # head writes before deeplab.py:55-56), interpolated on the fly - the production path of QuerySelector for DeepLab

@@ -503,6 +503,9 @@ int pp_bn_fused_capacity(void);
 /* Debug: pp_bn_train_fwd_fused writes per-block wall-clock stamps (100 MHz; [blocks][8]: entry, statistics pass done, block
  * reduction done, partial published, strip combined, rows written) into this device buffer; NULL (default) = off. */
 void pp_debug_set_bn_probe(void* device_buffer);
+/* Yardstick, measurement only: a kernel that only reads `bytes` of x (float4 per lane, `blocks` blocks of 256 threads, 0 = 256).
+ * bench.py reports acq_kernel's bandwidth against what this reaches on the same buffer. */
+int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);
 void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 12 (defaults 384 / 128) */
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */

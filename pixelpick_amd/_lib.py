@@ -111,6 +111,7 @@ SIGNATURES = {
     "pp_debug_set_bn_bytes_per_block": (None, [_int]),
     "pp_bn_fused_capacity": (_int, []),
     "pp_debug_set_bn_probe": (None, [_p]),
+    "pp_debug_stream_read": (_int, [_p, _sz, _int, _p, _p]),
     "pp_debug_set_conv_thresholds": (None, [_int]),
     "pp_debug_conv_plan": (None, [_i64, _int, _int, _int, _p]),
     "pp_debug_set_conv_variant": (None, [_int]),

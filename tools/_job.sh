@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for c in 1024 512 256 128 2048 1024; do echo "wgrad target $c: $(WGRAD_TARGET=$c timeout 300 python tools/train_bench.py 2>&1 | tail -1 | cut -c1-80)"; done
+python bench.py --mode acq --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(d['roofline'], indent=1))"
