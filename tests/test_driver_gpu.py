@@ -144,6 +144,36 @@ def test_active_learning_round_with_replayed_train_steps(tmp_path, monkeypatch):
     assert (tmp_path / "checkpoints" / "synthetic" / "1_query" / "best_miou_model.pt").exists()
 
 
+def test_replayed_rounds_do_not_grow_device_memory(tmp_path):
+    """Every active-learning round builds a new trainer with its own private memory pool for the recorded step; _train() drops the
+    plan (FlatTrainer.disable_replay in a finally) so that the pool is released with the trainer: reserved device memory after
+    round r + 1 is not above round r's (it grew by a full step of activations per round before the teardown existed)."""
+    import gc
+    import warnings
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ds = SyntheticDataset(8, 64, 96, 5, 5, n_init_pixels=10, seed=1)
+    ds_val = SyntheticDataset(4, 64, 96, 5, 5, seed=2)
+    mk = lambda d, b, sh: torch.utils.data.DataLoader(d, batch_size=b, shuffle=sh)
+    args = _args(str(tmp_path), replay_train_step=True, max_budget=40)          # four rounds of 10 pixels per image
+    m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=torch.device(DEV))
+    reserved = []
+    orig = m._train
+
+    def train_and_measure(*a, **k):
+        out = orig(*a, **k)
+        gc.collect()
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved())
+        return out
+
+    m._train = train_and_measure
+    m()
+    assert len(reserved) >= 3
+    assert max(reserved[2:]) <= reserved[1] + (8 << 20), [r >> 20 for r in reserved]
+
+
 def test_active_learning_round_on_the_device_data_path(tmp_path):
     """SURVEY.md 8f-4 wired end to end: the train loader yields RAW uint8 batches (RawSyntheticDataset), Model._train_epoch
     augments them on the GPU (DeviceAugmenter: random scale / pad / crop / flip of image + label map + query mask, colour
