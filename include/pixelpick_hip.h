@@ -218,6 +218,20 @@ int pp_conv2d_bwd_weight_pre(const float* x, int64_t ldx, int B, int H, int W, i
                              int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
                              void* workspace, size_t ws_bytes, const void* x_planes, const void* dy_planes, pp_stream_t stream);
 
+/* Convolution + training BatchNorm (+ residual, activation) in ONE launch (mobilenet_v2.py:42-43,48-49,56-57: conv -> BatchNorm2d
+ * [-> ReLU6]): the blocks of the convolution exchange their column sums the way the blocks of pp_bn_train_fwd_fused do (same
+ * fine-grained `xchg` / `sync` areas, same epoch protocol) and normalise the tile they still hold in registers.  conv_out
+ * receives the raw convolution (the BatchNorm backward's input), y the normalised output; mean / invstd / running statistics as
+ * pp_bn_train_fwd_fused.  Only for shapes whose whole grid is co-resident: ask pp_conv2d_fwd_bn_train_ok (1 / 0) first - the call
+ * refuses other shapes instead of falling back. */
+int pp_conv2d_fwd_bn_train_ok(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+size_t pp_conv2d_fwd_bn_train_xchg_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pp_conv2d_fwd_bn_train(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, int kh, int kw, int stride, int pad,
+                           int dil, float* conv_out, int64_t ldc, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* invstd, const float* residual, int64_t ldr,
+                           int act, float* y, int64_t ldy, int Cout, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints,
+                           pp_stream_t stream);
+
 /* Deferred reduces.  A weight gradient is a partial-sum kernel ([slices][...] in the workspace) followed by a small
  * fixed-order reduce; a backward pass has ~60 of them (model.py:121 loss.backward()).  The *_partials forms run only the
  * first kernel and describe the reduce in *job (kind 0: nothing left to do - the call completed the gradient itself, e.g.

@@ -47,6 +47,10 @@ SIGNATURES = {
     "pp_conv2d_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_weight_workspace_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p]),
+    "pp_conv2d_fwd_bn_train_ok": (_int, [_int] * 10),
+    "pp_conv2d_fwd_bn_train_xchg_bytes": (_sz, [_int] * 10),
+    "pp_conv2d_fwd_bn_train": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _p, _p, _f, _f, _p, _p, _p, _p,
+                                      _p, _i64, _int, _p, _i64, _int, _p, _sz, _p, _sz, _p]),
     "pp_x3_planes_bytes": (_sz, [_i64, _int]),
     "pp_x3_split": (_int, [_p, _i64, _i64, _int, _p, _sz, _p]),
     "pp_conv2d_x3_planes_bytes": (_sz, [_int] * 11),
@@ -161,7 +165,7 @@ _NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_f
 
 
 def _is_launch(name: str) -> bool:
-    return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in")))
+    return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in", "_ok")))
 
 
 class ReduceJob(ctypes.Structure):

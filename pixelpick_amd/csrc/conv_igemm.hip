@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "pp_common.h"
+#include "bn_xchg.h"
 
 namespace pp {
 
@@ -41,6 +42,17 @@ struct ConvTaps {
     int dh[kMaxTaps];       // input row offset of tap (already includes -pad / flip); int: wave-uniform s_load
     int dw[kMaxTaps];
     int widx[kMaxTaps];     // index of the tap in the weight tensor (kh*KW + kw)
+};
+
+// Training BatchNorm finished in the convolution's own epilogue (conv_epilogue_bn): the blocks of a column strip exchange their
+// column sums exactly as the blocks of the single-launch BatchNorm kernel do (bn_xchg.h), then every block normalises the tile it
+// still holds in registers.  part == NULL: off.
+struct BnTrain {
+    const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* mean; float* invstd;
+    const float* res; int64_t ldr; int act;
+    float* y; int64_t ldy;              // the normalised (+ residual, activation) output; ConvParams::y receives the raw convolution
+    xword* part; int* sync; int R;      // exchange area [strips][R][64] words, launch epoch, M tiles of the grid
 };
 
 struct ConvParams {
@@ -69,6 +81,7 @@ struct ConvParams {
     const float* in_scale;   // forward of a 1x1 / pad-0 convolution BEHIND a training BatchNorm whose apply pass was skipped: the A
     const float* in_shift;   // operand is act(fma(x, in_scale[c], in_shift[c])) (bn_apply_kernel's arithmetic), applied where the
     int in_act;              // operand is read.  NULL: x as it is.  (conv_igemm_kernel VEC path, conv1x1_ksplit_dma_kernel)
+    BnTrain bn;
     float* stats;     // training forward in front of a BatchNorm: per-wave column sums / sums of squares of the stored outputs,
                       // [rows_partial][2][Cn], rows_partial = m0 / (TM*32) + wm (see conv_epilogue); NULL: none
     ConvTaps taps;
@@ -180,6 +193,154 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 p.stats[(pr * 2 + 1) * p.Cn + n] = s2;
             }
         }
+    }
+}
+
+// ---- epilogue that also finishes a training BatchNorm (+ residual, activation) --------------------------------------------------
+// conv -> BatchNorm as ONE launch for the layers whose whole grid is co-resident (<= half of the kernel's occupancy x CUs, host-
+// checked): a 1/16-resolution pointwise convolution is 12-20 us and its BatchNorm launch another 11.5, of which 4.5 are dispatch and
+// 2.3 the two passes over a tensor the convolution had in registers a moment earlier (profiles/r03_bn_phases.txt).  Here the block
+//   1. sums its tile's columns (lane -> 32-lane halves -> the WM wave rows through LDS, fixed order),
+//   2. publishes the 32-channel strips' partial sums as tagged words and combines the strip's R partial rows (bn_xchg.h: the
+//      exchange of bn_fused_fwd_kernel - same memory, same epoch protocol, fp64 combine in a fixed order),
+//   3. computes mean / invstd / scale / shift with bn_fused_fwd_kernel's expressions (the backward recomputes the activation mask
+//      from them), block row 0 writes them and the running statistics,
+//   4. stores the raw convolution (the BatchNorm backward's input) AND the normalised, activated output.
+// scratch: >= (2 * WM * BN + 64) floats + (256 + 2 * BN) doubles of LDS nobody reads any more (the caller put a barrier in front).
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_bn(const ConvParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn, int mt,
+                                                 float* scratch, unsigned tag0)
+{
+    constexpr int BNT = WN * TN * 32;                      // columns of the block tile
+    constexpr int NSTRIP = BNT / 32;
+    const BnTrain& bn = p.bn;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    double* shd = reinterpret_cast<double*>(scratch);                       // [256]
+    double* tot = shd + 256;                                                // [NSTRIP][64]
+    float* colsum = reinterpret_cast<float*>(tot + NSTRIP * 64);            // [2][WM][BNT]
+    float* aff = colsum + 2 * WM * BNT;                                     // [2][BNT]
+    unsigned* sh_tag = reinterpret_cast<unsigned*>(aff + 2 * BNT);
+    // 1. column sums of what this lane holds (rows < M)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = m < p.M ? acc[tm][tn][r] : 0.0f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (hh == 0) {
+            const int c = (wn * TN + tn) * 32 + l31;
+            colsum[(0 * WM + wm) * BNT + c] = s1;
+            colsum[(1 * WM + wm) * BNT + c] = s2;
+        }
+    }
+    if (tid == 0) *sh_tag = tag0;
+    __syncthreads();
+    const unsigned tag = *sh_tag;
+    // 2. publish: thread (stat, column)
+    if (tid < 2 * BNT) {
+        const int stat = tid / BNT, c = tid - stat * BNT;
+        const int n = n0 + c;
+        if (n < p.Cn) {
+            float v = colsum[(stat * WM + 0) * BNT + c];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) v += colsum[(stat * WM + w) * BNT + c];
+            const int strip = n >> 5, cl = n & 31;
+            xchg_put(bn.part + ((int64_t)strip * bn.R + mt) * 64 + stat * 32 + cl, v, tag);
+        }
+    }
+    // combine: all strips of the tile at once - thread (sub, strip, output) adds partial rows sub, sub + NSUB, ... in that order,
+    // sixteen words in flight (a strip after the other with four in flight was ~6 dependent round trips to fine-grained memory:
+    // the fused launch ran 10 us longer than the plain convolution, i.e. as long as the BatchNorm launch it replaces)
+    {
+        constexpr int NSUB = 256 / (64 * NSTRIP);
+        const int o = tid & 63, sl = (tid >> 6) % NSTRIP, sub = tid / (64 * NSTRIP);
+        const int strip = (n0 >> 5) + sl;
+        double sacc = 0.0;
+        if (strip * 32 < p.Cn) {
+            const xword* pp_ = bn.part + (int64_t)strip * bn.R * 64 + o;
+            int c = sub;
+            for (; c + 15 * NSUB < bn.R; c += 16 * NSUB) {
+                xword wv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) wv[j] = __hip_atomic_load(pp_ + (int64_t)(c + j * NSUB) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    sacc += (double)((unsigned)(wv[j] >> 32) == tag ? __uint_as_float((unsigned)wv[j]) : xchg_get(pp_ + (int64_t)(c + j * NSUB) * 64, tag));
+            }
+            for (; c + 3 * NSUB < bn.R; c += 4 * NSUB) {
+                xword wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[j] = __hip_atomic_load(pp_ + (int64_t)(c + j * NSUB) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sacc += (double)((unsigned)(wv[j] >> 32) == tag ? __uint_as_float((unsigned)wv[j]) : xchg_get(pp_ + (int64_t)(c + j * NSUB) * 64, tag));
+            }
+            for (; c < bn.R; c += NSUB) sacc += (double)xchg_get(pp_ + (int64_t)c * 64, tag);
+        }
+        shd[tid] = sacc;
+        __syncthreads();
+        if (tid < 64 * NSTRIP) {
+            double a = shd[tid];
+#pragma unroll
+            for (int k = 1; k < NSUB; ++k) a += shd[k * 64 * NSTRIP + tid];
+            tot[tid] = a;                                   // tot[sl * 64 + o]: tid = sl * 64 + o for tid < 64 * NSTRIP
+        }
+        __syncthreads();
+    }
+    launch_done(bn.sync);
+    // 3. per-column affine
+    if (tid < BNT) {
+        const int n = n0 + tid;
+        if (n < p.Cn) {
+            const int sl = tid >> 5, cl = tid & 31;
+            const double count = (double)p.M;
+            const double mu = tot[sl * 64 + cl] / count;
+            double var = tot[sl * 64 + 32 + cl] / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)bn.eps));
+            const float sc = bn.gamma[n] * is;
+            aff[tid] = sc;
+            aff[BNT + tid] = bn.beta[n] - (float)mu * sc;
+            if (mt == 0) {
+                bn.mean[n] = (float)mu;
+                bn.invstd[n] = is;
+                if (bn.running_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    bn.running_mean[n] = (1.0f - bn.momentum) * bn.running_mean[n] + bn.momentum * (float)mu;
+                    bn.running_var[n] = (1.0f - bn.momentum) * bn.running_var[n] + bn.momentum * (float)unbiased;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 4. stores
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int c = (wn * TN + tn) * 32 + l31;
+        const int n = n0 + c;
+        if (n >= p.Cn) continue;
+        const float sc = aff[c], sf = aff[BNT + c];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m < p.M) {
+                    const float v = acc[tm][tn][r];
+                    p.y[m * p.ldy + n] = v;
+                    float o = fmaf(v, sc, sf);
+                    if (bn.res) o += bn.res[m * bn.ldr + n];
+                    bn.y[m * bn.ldy + n] = epi_act(o, bn.act);
+                }
+            }
     }
 }
 
@@ -534,6 +695,8 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     }
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
+    unsigned tag0 = 0;                       // conv -> BatchNorm in one launch: this launch's exchange tag, requested now, used in the epilogue
+    if constexpr (BM == 64 && BN == 64 && !BWD) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
     const float* zero = g_zero16;
     asm volatile("" : "+v"(zero));          // keep the pointer in registers (hipcc re-derives it from the PC in every K step otherwise)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
@@ -788,6 +951,13 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     for (; k < n; k += 2) {                                       // the last (up to four) steps
         kstep(std::false_type{}, SR{}, k, F0, F1);
         if (k + 1 < n) kstep(std::false_type{}, SR{}, k + 1, F1, F0);
+    }
+    if constexpr (BM == 64 && BN == 64 && !BWD) {
+        if (p.bn.part) {                                           // wave-uniform: conv -> training BatchNorm in this launch
+            __syncthreads();                                       // the ring is scratch from here on
+            conv_epilogue_bn<TM, TN, (BM / 32 / TM), WN>(p, acc, m0, n0, wm, wn, mt, smem, tag0);
+            return;
+        }
     }
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
@@ -2712,6 +2882,32 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
     return check_launch("conv_x3_kernel");
 }
 
+// Blocks of conv_igemm_dma_kernel<64, 64, false> that can be resident at once (occupancy x CUs); a fused conv + BatchNorm launch
+// (spin-waiting blocks, see conv_epilogue_bn) uses at most HALF of it - the rule of the single-launch BatchNorm kernels.
+static int device_cus();
+static int conv_bn_capacity()
+{
+    static const int cap = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, false>, kThreads, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        return n * device_cus();
+    }();
+    return cap;
+}
+static thread_local int g_conv_bn_fuse = 1;      // pp_debug_set_conv_variant2 bit 0 switches the fused conv + BatchNorm epilogue off
+static bool bn_fuse_ok(const ConvParams& p, const ConvPlan& pl, bool vec)
+{
+    const bool dma_ok = vec && g_conv_dma64 && p.taps.n <= 32 && (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) &&
+                        (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
+    const bool ksplit = ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride);
+    return g_conv_bn_fuse && pl.cfg == 2 && pl.splits == 1 && dma_ok && !ksplit && !p.stats && !p.in_scale && !p.bias && p.epi.gamma == nullptr &&
+           p.epi.res == nullptr && p.epi.act == 0 && !p.accumulate && p.bwd_stride <= 1 && p.Cn % 32 == 0 && pl.tiles <= conv_bn_capacity() / 2 &&
+           pl.tiles * 64 >= 1;
+}
+
 template <bool BWD>
 static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes, hipStream_t st, int kh_kw = 0)
 {
@@ -2721,6 +2917,16 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     const bool vec = g_conv_novec == 0 && p.Ck % 4 == 0 && p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.ldx % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
     ConvPlan pl = plan_conv(p.M, p.Cn, p.Ck, p.taps.n, vec);
+    if (p.bn.part) {
+        // conv -> training BatchNorm in one launch: only the kernel that implements it may run (the caller asked
+        // pp_conv2d_fwd_bn_train_ok first; no silent fallback that would drop the BatchNorm)
+        if (BWD || !bn_fuse_ok(p, pl, vec)) return fail(PP_ERR_UNSUPPORTED, "conv fwd + BatchNorm: this shape has no fused kernel");
+        p.bn.R = (int)cdiv(p.M, 64);
+        p.tap_inner = g_conv_tap_inner;
+        p.n_tiles = pl.n_tiles; p.splits = 1; p.ks_per_split = 0; p.part = nullptr;
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+        return check_launch("conv_igemm_dma_kernel<bn>");
+    }
     if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
         // large-tile layers: six bf16 MFMAs per product instead of the fp32 MFMA (operands split once into the workspace)
         const X3Plan x = x3_plan(pl, p.M, (int64_t)p.B * p.H * p.W, p.Ck, p.Cn, kh_kw, p.taps.n, vec);
@@ -3248,6 +3454,57 @@ int pp_conv2d_fwd_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin,
 {
     return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
                            ws_bytes, stream, nullptr, 0, nullptr, nullptr, 0, x_planes);
+}
+
+// ---- convolution + training BatchNorm (+ residual, activation) in one launch -----------------------------------------------------
+static bool conv_bn_shape(ConvParams& p, ConvPlan& pl, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil,
+                          int64_t ldx)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return false;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return false;
+    p = ConvParams{};
+    p.ldx = ldx; p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Ck = Cin; p.Cn = Cout; p.Cin = Cin; p.Cout = Cout;
+    p.stride = stride; p.M = (int64_t)B * Ho * Wo; p.bwd_stride = 1;
+    build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
+    if (p.M > 0x7FFFFFFFll || p.taps.n == 0) return false;
+    const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0;
+    pl = plan_conv(p.M, Cout, Cin, p.taps.n, vec);
+    return bn_fuse_ok(p, pl, vec);
+}
+
+int pp_conv2d_fwd_bn_train_ok(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    ConvParams p; ConvPlan pl;
+    return conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Cin) ? 1 : 0;
+}
+
+size_t pp_conv2d_fwd_bn_train_xchg_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    ConvParams p; ConvPlan pl;
+    if (!conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Cin)) return 0;
+    return align_up((size_t)cdiv(Cout, 32) * (size_t)cdiv(p.M, 64) * 64 * 8, 256);
+}
+
+int pp_conv2d_fwd_bn_train(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, int kh, int kw, int stride, int pad,
+                           int dil, float* conv_out, int64_t ldc, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* invstd, const float* residual, int64_t ldr,
+                           int act, float* y, int64_t ldy, int Cout, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints,
+                           pp_stream_t stream)
+{
+    if (int rc = conv_common_check(x, w, conv_out, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
+    if (!gamma || !beta || !mean || !invstd || !y || !xchg || !sync) return fail(PP_ERR_BAD_ARG, "conv fwd + BatchNorm: null");
+    if (act < 0 || act > 2) return fail(PP_ERR_BAD_ARG, "conv fwd + BatchNorm: act %d", act);
+    if ((reinterpret_cast<uintptr_t>(xchg) & 7) != 0 || sync_ints < 2) return fail(PP_ERR_BAD_ARG, "conv fwd + BatchNorm: exchange area");
+    ConvParams p; ConvPlan pl;
+    if (!conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, ldx))
+        return fail(PP_ERR_UNSUPPORTED, "conv fwd + BatchNorm: this shape has no fused kernel (ask pp_conv2d_fwd_bn_train_ok first)");
+    const size_t need = (size_t)cdiv(Cout, 32) * (size_t)cdiv(p.M, 64) * 64 * 8;
+    if (xchg_bytes < need) return fail(PP_ERR_WORKSPACE, "conv fwd + BatchNorm: exchange area %zu < %zu", xchg_bytes, need);
+    p.x = x; p.w = w; p.bias = nullptr; p.y = conv_out; p.ldy = ldc;
+    p.bn = BnTrain{gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
+                   reinterpret_cast<xword*>(xchg), sync, 0};
+    return launch_conv<false>(p, nullptr, 0, as_stream(stream), kh * kw);
 }
 
 int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,

@@ -784,7 +784,8 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
         out = Var(None, needs_grad=False)
         out._pending = ("conv", x, w, bias, stride, pad, dil)
         return out
-    if (_CONV_BN_STATS or _BN_ON_LOAD) and tape.enabled and dst is None:
+    if (tape.enabled and dst is None and (_CONV_BN_STATS or _BN_ON_LOAD or
+                                           (_CONV_BN_FUSE and bias is None and _conv_bn_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil)))):
         # training: deferred as well - a training-mode BatchNorm right behind it launches the convolution with a statistics
         # epilogue (pp_conv2d_fwd_stats) and then only applies (pp_bn_train_fwd_partials); any other consumer's `.t`
         # launches the plain convolution
@@ -983,6 +984,59 @@ def _dw_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_va
 _CONV_BN_STATS_MAX_ROWS = int(os.environ.get("PIXELPICK_CONV_BN_STATS_MAX_ROWS", "160"))
 
 
+# PIXELPICK_CONV_BN_FUSE (default on): a training BatchNorm right behind a dense convolution whose whole grid is co-resident (the
+# 1/16- and 1/8-resolution pointwise layers) is finished in the convolution's own epilogue - pp_conv2d_fwd_bn_train: one launch
+# instead of two, no statistics pass, no second read of the convolution's output.  The convolution is DEFERRED until its consumer is
+# known; any other consumer's `.t` launches it plain.
+_CONV_BN_FUSE = os.environ.get("PIXELPICK_CONV_BN_FUSE", "1") != "0"
+
+
+def _conv_bn_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
+    if not (_BN_FUSED and Cout % 32 == 0):
+        return False
+    if not _wsbytes("pp_conv2d_fwd_bn_train_ok", B, H, W, Cin, Cout, kh, kw, stride, pad, dil):
+        return False
+    return _wsbytes("pp_conv2d_fwd_bn_train_xchg_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil) <= _BN_XCHG_PART_BYTES
+
+
+def _conv_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst):
+    """x is a DEFERRED dense convolution followed by this training BatchNorm: one launch (pp_conv2d_fwd_bn_train).  None: not
+    applicable (x stays deferred, the caller takes the ordinary path)."""
+    _, xin, w, bias, stride, pad, dil = x._pending
+    if bias is not None:
+        return None
+    B, H, W, Cin, ldx = _geom(xin.t)
+    kh, kw, _, Cout = w.shape
+    if not _conv_bn_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) or ldx % 4:
+        return None
+    dev = xin.t.device
+    if not _bn_exchange_ok(dev):
+        return None
+    Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
+    raw = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+    y = dst if dst is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+    _, _, _, _, ldy = _geom(y)
+    mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+    invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+    rptr, ldr = (None, 0)
+    if residual is not None:
+        _, _, _, _, ldr = _geom(residual.t)
+        rptr = residual.t.data_ptr()
+    sync, ws = _bn_exchange(dev)
+    rc = _lib.lib().pp_conv2d_fwd_bn_train(xin.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), kh, kw, stride, pad, dil, raw.data_ptr(), Cout,
+                                           gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                           running_mean.data_ptr() if running_mean is not None else None,
+                                           running_var.data_ptr() if running_var is not None else None, mean.data_ptr(), invstd.data_ptr(),
+                                           rptr, ldr, act, y.data_ptr(), ldy, Cout, ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(),
+                                           _stream())
+    _lib.check(rc, "pp_conv2d_fwd_bn_train")
+    x._pending = None
+    x._t = raw
+    out = Var(y)
+    tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0), out)
+    return out
+
+
 def _launch_conv_stats(x: Var, max_rows: Optional[int] = None):
     """x is a DEFERRED dense convolution: launch it with the BatchNorm-statistics epilogue.  -> (stats [rows,2,Cout], rows), or
     None when this shape delivers no statistics (x stays deferred)."""
@@ -1087,6 +1141,10 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         _launch_deferred(x, (gamma, beta, running_mean, running_var, eps, act, residual, dst))
         return Var(x._t, needs_grad=False)
     L = _lib.lib()
+    if training and x._pending is not None and x._pending[0] == "conv" and tape.enabled and _CONV_BN_FUSE and dropout_p == 0.0:
+        out = _conv_bn_train_fused(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst)
+        if out is not None:
+            return out
     if training and x._pending is not None and x._pending[0] == "conv" and tape.enabled and _CONV_BN_STATS:
         out = _conv_bn_train_partials(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst, dropout_p)
         if out is not None:

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_driver_gpu.py -q -x -m gpu 2>&1 | tail -6
+for s in 0 1 0 1 0 1; do echo "fuse $s: $(PIXELPICK_CONV_BN_FUSE=$s timeout 120 python tools/train_bench.py 2>&1 | tail -1 | cut -c1-100)"; done
