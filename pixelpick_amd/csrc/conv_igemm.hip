@@ -207,51 +207,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 //      from them), block row 0 writes them and the running statistics,
 //   4. stores the raw convolution (the BatchNorm backward's input) AND the normalised, activated output.
 // scratch: >= (2 * WM * BN + 64) floats + (256 + 2 * BN) doubles of LDS nobody reads any more (the caller put a barrier in front).
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue_bn(const ConvParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn, int mt,
-                                                 float* scratch, unsigned tag0)
+// scratch layout shared by the two fused epilogues (LDS nobody reads any more): doubles shd[256], tot[NSTRIP][64]; floats
+// colsum[2][WM][BNT], aff[2][BNT]; one unsigned
+template <int BNT, int WM>
+struct BnScratch {
+    static constexpr int NSTRIP = BNT / 32;
+    double* shd; double* tot; float* colsum; float* aff; unsigned* sh_tag;
+    __device__ __forceinline__ explicit BnScratch(float* scratch)
+    {
+        shd = reinterpret_cast<double*>(scratch);
+        tot = shd + 256;
+        colsum = reinterpret_cast<float*>(tot + NSTRIP * 64);
+        aff = colsum + 2 * WM * BNT;
+        sh_tag = reinterpret_cast<unsigned*>(aff + 2 * BNT);
+    }
+    static constexpr int kFloats = (256 + NSTRIP * 64) * 2 + 2 * WM * BNT + 2 * BNT + 4;
+};
+
+// colsum[stat][wave row][column] is filled (no barrier yet) -> aff[0][c] = scale, aff[1][c] = shift of the tile's columns; block row 0
+// writes mean / invstd / running statistics.  Ends with a barrier.
+template <int BNT, int WM>
+__device__ __forceinline__ void bn_block_finish(const ConvParams& p, const BnScratch<BNT, WM>& S, int n0, int mt, unsigned tag0)
 {
-    constexpr int BNT = WN * TN * 32;                      // columns of the block tile
     constexpr int NSTRIP = BNT / 32;
     const BnTrain& bn = p.bn;
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-    double* shd = reinterpret_cast<double*>(scratch);                       // [256]
-    double* tot = shd + 256;                                                // [NSTRIP][64]
-    float* colsum = reinterpret_cast<float*>(tot + NSTRIP * 64);            // [2][WM][BNT]
-    float* aff = colsum + 2 * WM * BNT;                                     // [2][BNT]
-    unsigned* sh_tag = reinterpret_cast<unsigned*>(aff + 2 * BNT);
-    // 1. column sums of what this lane holds (rows < M)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float v = m < p.M ? acc[tm][tn][r] : 0.0f;
-                s1 += v;
-                s2 = fmaf(v, v, s2);
-            }
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (hh == 0) {
-            const int c = (wn * TN + tn) * 32 + l31;
-            colsum[(0 * WM + wm) * BNT + c] = s1;
-            colsum[(1 * WM + wm) * BNT + c] = s2;
-        }
-    }
-    if (tid == 0) *sh_tag = tag0;
+    const int tid = threadIdx.x;
+    if (tid == 0) *S.sh_tag = tag0;
     __syncthreads();
-    const unsigned tag = *sh_tag;
-    // 2. publish: thread (stat, column)
+    const unsigned tag = *S.sh_tag;
+    // publish: thread (stat, column) adds the wave rows in order
     if (tid < 2 * BNT) {
         const int stat = tid / BNT, c = tid - stat * BNT;
         const int n = n0 + c;
         if (n < p.Cn) {
-            float v = colsum[(stat * WM + 0) * BNT + c];
+            float v = S.colsum[(stat * WM + 0) * BNT + c];
 #pragma unroll
-            for (int w = 1; w < WM; ++w) v += colsum[(stat * WM + w) * BNT + c];
+            for (int w = 1; w < WM; ++w) v += S.colsum[(stat * WM + w) * BNT + c];
             const int strip = n >> 5, cl = n & 31;
             xchg_put(bn.part + ((int64_t)strip * bn.R + mt) * 64 + stat * 32 + cl, v, tag);
         }
@@ -285,30 +276,30 @@ __device__ __forceinline__ void conv_epilogue_bn(const ConvParams& p, f32x16 (&a
             }
             for (; c < bn.R; c += NSUB) sacc += (double)xchg_get(pp_ + (int64_t)c * 64, tag);
         }
-        shd[tid] = sacc;
+        S.shd[tid] = sacc;
         __syncthreads();
         if (tid < 64 * NSTRIP) {
-            double a = shd[tid];
+            double a = S.shd[tid];
 #pragma unroll
-            for (int k = 1; k < NSUB; ++k) a += shd[k * 64 * NSTRIP + tid];
-            tot[tid] = a;                                   // tot[sl * 64 + o]: tid = sl * 64 + o for tid < 64 * NSTRIP
+            for (int k = 1; k < NSUB; ++k) a += S.shd[k * 64 * NSTRIP + tid];
+            S.tot[tid] = a;                                 // tot[sl * 64 + o]: tid = sl * 64 + o for tid < 64 * NSTRIP
         }
         __syncthreads();
     }
     launch_done(bn.sync);
-    // 3. per-column affine
+    // per-column affine (bn_fused_fwd_kernel's expressions: the backward recomputes the activation mask from them)
     if (tid < BNT) {
         const int n = n0 + tid;
         if (n < p.Cn) {
             const int sl = tid >> 5, cl = tid & 31;
             const double count = (double)p.M;
-            const double mu = tot[sl * 64 + cl] / count;
-            double var = tot[sl * 64 + 32 + cl] / count - mu * mu;
+            const double mu = S.tot[sl * 64 + cl] / count;
+            double var = S.tot[sl * 64 + 32 + cl] / count - mu * mu;
             if (var < 0.0) var = 0.0;
             const float is = (float)(1.0 / sqrt(var + (double)bn.eps));
             const float sc = bn.gamma[n] * is;
-            aff[tid] = sc;
-            aff[BNT + tid] = bn.beta[n] - (float)mu * sc;
+            S.aff[tid] = sc;
+            S.aff[BNT + tid] = bn.beta[n] - (float)mu * sc;
             if (mt == 0) {
                 bn.mean[n] = (float)mu;
                 bn.invstd[n] = is;
@@ -321,13 +312,45 @@ __device__ __forceinline__ void conv_epilogue_bn(const ConvParams& p, f32x16 (&a
         }
     }
     __syncthreads();
-    // 4. stores
+}
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_bn(const ConvParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn, int mt,
+                                                 float* scratch, unsigned tag0)
+{
+    constexpr int BNT = WN * TN * 32;                      // columns of the block tile
+    const BnTrain& bn = p.bn;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const BnScratch<BNT, WM> S(scratch);
+    // column sums of what this lane holds (rows < M)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = m < p.M ? acc[tm][tn][r] : 0.0f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (hh == 0) {
+            const int c = (wn * TN + tn) * 32 + l31;
+            S.colsum[(0 * WM + wm) * BNT + c] = s1;
+            S.colsum[(1 * WM + wm) * BNT + c] = s2;
+        }
+    }
+    bn_block_finish<BNT, WM>(p, S, n0, mt, tag0);
+    // stores: the raw convolution (the BatchNorm backward's input) and the normalised, activated output
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int c = (wn * TN + tn) * 32 + l31;
         const int n = n0 + c;
         if (n >= p.Cn) continue;
-        const float sc = aff[c], sf = aff[BNT + c];
+        const float sc = S.aff[c], sf = S.aff[BNT + c];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -997,6 +1020,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
     const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
     const int64_t m0 = (int64_t)mt * (32 * TM);
     const int n0 = nt * BN;
+    unsigned tag0 = 0;                                       // conv -> BatchNorm in one launch: the exchange tag, requested now
+    if constexpr (!BWD && !AFF) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
     const float* zero = g_zero16;
     asm volatile("" : "+v"(zero));
     float* wsm = smem + wave * WAVE_FL;
@@ -1175,6 +1200,70 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) wsm[((tm * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
     __syncthreads();
+    if constexpr (!BWD && !AFF) {
+        if (p.bn.part) {
+            // conv -> training BatchNorm in this launch (see conv_epilogue_bn): this lane's 4 * TM rows of every column tile, summed over
+            // the four K slices in wave order, stay in registers across the exchange
+            constexpr int BNT = TN * 32;
+            float vv[TM][TN][4];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int e = ((tm * TN + tn) * 16 + wave * 4 + rr) * 64 + lane;
+                        float v = smem[0 * WAVE_FL + e];
+                        v += smem[1 * WAVE_FL + e];
+                        v += smem[2 * WAVE_FL + e];
+                        v += smem[3 * WAVE_FL + e];
+                        vv[tm][tn][rr] = v;
+                    }
+            __syncthreads();                                 // every partial tile has been read: the rings are scratch now
+            const BnScratch<BNT, 4> S(smem);
+            static_assert(4 * WAVE_FL >= BnScratch<BNT, 4>::kFloats, "the exchange scratch fits the rings");
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int64_t m = m0 + tm * 32 + rr + 8 * wave + 4 * h;
+                        const float v = m < p.M ? vv[tm][tn][rr] : 0.0f;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    S.colsum[(0 * 4 + wave) * BNT + tn * 32 + l31] = s1;
+                    S.colsum[(1 * 4 + wave) * BNT + tn * 32 + l31] = s2;
+                }
+            }
+            bn_block_finish<BNT, 4>(p, S, n0, mt, tag0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int c = tn * 32 + l31, n_col = n0 + c;
+                if (n_col >= p.Cn) continue;
+                const float sc = S.aff[c], sf = S.aff[BNT + c];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int64_t m = m0 + tm * 32 + rr + 8 * wave + 4 * h;
+                        if (m < p.M) {
+                            const float v = vv[tm][tn][rr];
+                            p.y[m * p.ldy + n_col] = v;
+                            float o = fmaf(v, sc, sf);
+                            if (p.bn.res) o += p.bn.res[m * p.bn.ldr + n_col];
+                            p.bn.y[m * p.bn.ldy + n_col] = epi_act(o, p.bn.act);
+                        }
+                    }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n_col = n0 + tn * 32 + l31;
@@ -2897,15 +2986,38 @@ static int conv_bn_capacity()
     }();
     return cap;
 }
-static thread_local int g_conv_bn_fuse = 1;      // pp_debug_set_conv_variant2 bit 0 switches the fused conv + BatchNorm epilogue off
-static bool bn_fuse_ok(const ConvParams& p, const ConvPlan& pl, bool vec)
+static thread_local int g_conv_bn_fuse = 3;      // bit 0: fused conv + BatchNorm epilogue of the 64x64-tiled layers, bit 1: of the in-block split-K kernel
+static int ksplit_bn_capacity(int which)         // 0: <1,1,5>, 1: <2,1,3> (the forward candidates)
 {
-    const bool dma_ok = vec && g_conv_dma64 && p.taps.n <= 32 && (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31) - (1ll << 24) &&
-                        (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
-    const bool ksplit = ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride);
-    return g_conv_bn_fuse && pl.cfg == 2 && pl.splits == 1 && dma_ok && !ksplit && !p.stats && !p.in_scale && !p.bias && p.epi.gamma == nullptr &&
-           p.epi.res == nullptr && p.epi.act == 0 && !p.accumulate && p.bwd_stride <= 1 && p.Cn % 32 == 0 && pl.tiles <= conv_bn_capacity() / 2 &&
-           pl.tiles * 64 >= 1;
+    static const int cap[2] = {
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<1, 1, 5, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<2, 1, 3, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
+    return cap[which];
+}
+// How a convolution that is to finish a training BatchNorm in its own epilogue would run: kind 0 = no fused kernel for this shape,
+// 1 = conv_igemm_dma_kernel<64, 64>, 2 = conv1x1_ksplit_dma_kernel (forward candidates).  R = partial rows per strip = M tiles.
+struct BnFusePlan { int kind; int R; int64_t blocks; KsplitCfg kc; };
+static BnFusePlan bn_fuse_plan(const ConvParams& p, const ConvPlan& pl, bool vec)
+{
+    BnFusePlan f{0, 0, 0, {0, 0, 0}};
+    if (!g_conv_bn_fuse || !vec || p.stats || p.in_scale || p.bias || p.epi.gamma || p.epi.res || p.epi.act != 0 || p.accumulate || p.bwd_stride > 1 ||
+        p.Cn % 32 != 0 || (int64_t)p.B * p.H * p.W * p.ldx >= (1ll << 31) - (1ll << 24))
+        return f;
+    const bool ksplit = ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride) && p.Cout % 4 == 0 && (int64_t)p.Cin * p.Cout < (1ll << 31) - (1ll << 24);
+    if (ksplit) {
+        if (!(g_conv_bn_fuse & 2)) return f;
+        const KsplitCfg kc = ksplit_choose(p.M, p.Cn, false, g_conv_ksplit - 1);
+        if (kc.tn != 1) return f;                            // (a forced backward candidate)
+        const int64_t blocks = cdiv(p.M, 32 * kc.tm) * cdiv(p.Cn, 32);
+        if (blocks > ksplit_bn_capacity(kc.tm == 2 ? 1 : 0) / 2) return f;
+        f.kind = 2; f.R = (int)cdiv(p.M, 32 * kc.tm); f.blocks = blocks; f.kc = kc;
+        return f;
+    }
+    const bool dma_ok = g_conv_dma64 && p.taps.n <= 32 && (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
+    if ((g_conv_bn_fuse & 1) && pl.cfg == 2 && pl.splits == 1 && dma_ok && pl.tiles <= conv_bn_capacity() / 2) {
+        f.kind = 1; f.R = (int)cdiv(p.M, 64); f.blocks = pl.tiles;
+    }
+    return f;
 }
 
 template <bool BWD>
@@ -2920,11 +3032,21 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     if (p.bn.part) {
         // conv -> training BatchNorm in one launch: only the kernel that implements it may run (the caller asked
         // pp_conv2d_fwd_bn_train_ok first; no silent fallback that would drop the BatchNorm)
-        if (BWD || !bn_fuse_ok(p, pl, vec)) return fail(PP_ERR_UNSUPPORTED, "conv fwd + BatchNorm: this shape has no fused kernel");
-        p.bn.R = (int)cdiv(p.M, 64);
-        p.tap_inner = g_conv_tap_inner;
-        p.n_tiles = pl.n_tiles; p.splits = 1; p.ks_per_split = 0; p.part = nullptr;
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+        const BnFusePlan f = BWD ? BnFusePlan{0, 0, 0, {0, 0, 0}} : bn_fuse_plan(p, pl, vec);
+        if (f.kind == 0) return fail(PP_ERR_UNSUPPORTED, "conv fwd + BatchNorm: this shape has no fused kernel");
+        p.bn.R = f.R;
+        p.splits = 1; p.ks_per_split = 0; p.part = nullptr;
+        if constexpr (!BWD) {
+            if (f.kind == 2) {
+                p.n_tiles = (int)cdiv(p.Cn, 32);
+                if (f.kc.tm == 2) hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<2, 1, 3, false>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
+                else              hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<1, 1, 5, false>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
+                return check_launch("conv1x1_ksplit_dma_kernel<bn>");
+            }
+            p.tap_inner = g_conv_tap_inner;
+            p.n_tiles = pl.n_tiles;
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+        }
         return check_launch("conv_igemm_dma_kernel<bn>");
     }
     if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
@@ -3458,7 +3580,7 @@ int pp_conv2d_fwd_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin,
 
 // ---- convolution + training BatchNorm (+ residual, activation) in one launch -----------------------------------------------------
 static bool conv_bn_shape(ConvParams& p, ConvPlan& pl, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil,
-                          int64_t ldx)
+                          int64_t ldx, int* R_out = nullptr)
 {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return false;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
@@ -3470,7 +3592,9 @@ static bool conv_bn_shape(ConvParams& p, ConvPlan& pl, int B, int H, int W, int 
     if (p.M > 0x7FFFFFFFll || p.taps.n == 0) return false;
     const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0;
     pl = plan_conv(p.M, Cout, Cin, p.taps.n, vec);
-    return bn_fuse_ok(p, pl, vec);
+    const BnFusePlan f = bn_fuse_plan(p, pl, vec);
+    if (R_out) *R_out = f.R;
+    return f.kind != 0;
 }
 
 int pp_conv2d_fwd_bn_train_ok(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
@@ -3482,8 +3606,9 @@ int pp_conv2d_fwd_bn_train_ok(int B, int H, int W, int Cin, int Cout, int kh, in
 size_t pp_conv2d_fwd_bn_train_xchg_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
     ConvParams p; ConvPlan pl;
-    if (!conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Cin)) return 0;
-    return align_up((size_t)cdiv(Cout, 32) * (size_t)cdiv(p.M, 64) * 64 * 8, 256);
+    int R = 0;
+    if (!conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Cin, &R)) return 0;
+    return align_up((size_t)cdiv(Cout, 32) * (size_t)R * 64 * 8, 256);
 }
 
 int pp_conv2d_fwd_bn_train(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, int kh, int kw, int stride, int pad,
@@ -3497,9 +3622,10 @@ int pp_conv2d_fwd_bn_train(const float* x, int64_t ldx, int B, int H, int W, int
     if (act < 0 || act > 2) return fail(PP_ERR_BAD_ARG, "conv fwd + BatchNorm: act %d", act);
     if ((reinterpret_cast<uintptr_t>(xchg) & 7) != 0 || sync_ints < 2) return fail(PP_ERR_BAD_ARG, "conv fwd + BatchNorm: exchange area");
     ConvParams p; ConvPlan pl;
-    if (!conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, ldx))
+    int R = 0;
+    if (!conv_bn_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, ldx, &R))
         return fail(PP_ERR_UNSUPPORTED, "conv fwd + BatchNorm: this shape has no fused kernel (ask pp_conv2d_fwd_bn_train_ok first)");
-    const size_t need = (size_t)cdiv(Cout, 32) * (size_t)cdiv(p.M, 64) * 64 * 8;
+    const size_t need = (size_t)cdiv(Cout, 32) * (size_t)R * 64 * 8;
     if (xchg_bytes < need) return fail(PP_ERR_WORKSPACE, "conv fwd + BatchNorm: exchange area %zu < %zu", xchg_bytes, need);
     p.x = x; p.w = w; p.bias = nullptr; p.y = conv_out; p.ldy = ldc;
     p.bn = BnTrain{gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, residual, ldr, act, y, ldy,
