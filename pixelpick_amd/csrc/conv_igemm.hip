@@ -652,6 +652,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         __syncthreads();
     }
 
+    if constexpr (BM == 128 && BN == 32 && WM == 4 && WN == 1 && !BWD && VEC && BKT == BK) {
+        if (p.bn.part) {                                           // conv -> training BatchNorm in this launch (conv_epilogue_bn)
+            __syncthreads();                                       // the tiles are scratch from here on
+            static_assert(BM * PITCH_A >= BnScratch<32, 4>::kFloats, "the exchange scratch fits the A tile");
+            conv_epilogue_bn<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, mt, As, p.bn.part ? tag_issue(p.bn.sync) : 0u);
+            return;
+        }
+    }
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
     unsigned tag0 = 0;                       // conv -> BatchNorm in one launch: this launch's exchange tag, requested now, used in the epilogue
-    if constexpr (BM == 64 && BN == 64 && !BWD) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
+    if constexpr (BN == 64 && !BWD) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
     const float* zero = g_zero16;
     asm volatile("" : "+v"(zero));          // keep the pointer in registers (hipcc re-derives it from the PC in every K step otherwise)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
@@ -975,7 +983,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         kstep(std::false_type{}, SR{}, k, F0, F1);
         if (k + 1 < n) kstep(std::false_type{}, SR{}, k + 1, F1, F0);
     }
-    if constexpr (BM == 64 && BN == 64 && !BWD) {
+    if constexpr (BN == 64 && !BWD) {
         if (p.bn.part) {                                           // wave-uniform: conv -> training BatchNorm in this launch
             __syncthreads();                                       // the ring is scratch from here on
             conv_epilogue_bn<TM, TN, (BM / 32 / TM), WN>(p, acc, m0, n0, wm, wn, mt, smem, tag0);
@@ -2974,17 +2982,13 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
 // Blocks of conv_igemm_dma_kernel<64, 64, false> that can be resident at once (occupancy x CUs); a fused conv + BatchNorm launch
 // (spin-waiting blocks, see conv_epilogue_bn) uses at most HALF of it - the rule of the single-launch BatchNorm kernels.
 static int device_cus();
-static int conv_bn_capacity()
+static int conv_bn_capacity(int which = 0)        // 0: conv_igemm_dma_kernel<64, 64>, 1: <128, 64>, 2: conv_igemm_kernel<128, 32, 4, 1>
 {
-    static const int cap = [] {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, false>, kThreads, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0;
-        }
-        return n * device_cus();
-    }();
-    return cap;
+    static const int cap[3] = {
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<128, 64, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 32, 4, 1, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
+    return cap[which];
 }
 static thread_local int g_conv_bn_fuse = 3;      // bit 0: fused conv + BatchNorm epilogue of the 64x64-tiled layers, bit 1: of the in-block split-K kernel
 static int ksplit_bn_capacity(int which)         // 0: <1,1,5>, 1: <2,1,3> (the forward candidates)
@@ -3014,8 +3018,13 @@ static BnFusePlan bn_fuse_plan(const ConvParams& p, const ConvPlan& pl, bool vec
         return f;
     }
     const bool dma_ok = g_conv_dma64 && p.taps.n <= 32 && (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
-    if ((g_conv_bn_fuse & 1) && pl.cfg == 2 && pl.splits == 1 && dma_ok && pl.tiles <= conv_bn_capacity() / 2) {
+    if (!(g_conv_bn_fuse & 1) || pl.splits != 1) return f;
+    if (pl.cfg == 2 && dma_ok && pl.tiles <= conv_bn_capacity() / 2) {
         f.kind = 1; f.R = (int)cdiv(p.M, 64); f.blocks = pl.tiles;
+    } else if (pl.cfg == 2 && dma_ok && g_conv_dma && cdiv(p.M, 128) * cdiv(p.Cn, 64) <= conv_bn_capacity(1) / 2) {
+        f.kind = 3; f.R = (int)cdiv(p.M, 128); f.blocks = cdiv(p.M, 128) * cdiv(p.Cn, 64);       // 128 x 64 tiles: half the blocks
+    } else if (pl.cfg == 0 && p.Cn == 32 && pl.tiles <= conv_bn_capacity(2) / 2) {
+        f.kind = 4; f.R = (int)cdiv(p.M, 128); f.blocks = pl.tiles;                               // 128 x 32 register-staged kernel
     }
     return f;
 }
@@ -3044,10 +3053,18 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
                 return check_launch("conv1x1_ksplit_dma_kernel<bn>");
             }
             p.tap_inner = g_conv_tap_inner;
-            p.n_tiles = pl.n_tiles;
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+            if (f.kind == 3) {
+                p.n_tiles = (int)cdiv(p.Cn, 64);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, false>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
+            } else if (f.kind == 4) {
+                p.n_tiles = pl.n_tiles;
+                hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, false, true>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+            } else {
+                p.n_tiles = pl.n_tiles;
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+            }
         }
-        return check_launch("conv_igemm_dma_kernel<bn>");
+        return check_launch("conv_igemm_kernel<bn>");
     }
     if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
         // large-tile layers: six bf16 MFMAs per product instead of the fp32 MFMA (operands split once into the workspace)
@@ -3394,9 +3411,14 @@ int64_t pp_conv2d_fwd_stats_rows(int B, int H, int W, int Cin, int Cout, int kh,
     ConvTaps t;
     build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     const int64_t M = (int64_t)B * Ho * Wo;
-    ConvPlan pl = plan_conv(M, Cout, Cin, t.n, Cin % 4 == 0 && Cout % 4 == 0);
+    const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
+    ConvPlan pl = plan_conv(M, Cout, Cin, t.n, vec);
     if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) pl.splits = 1;      // no workspace is offered for these shapes: single pass (see conv2d_fwd_impl)
-    return conv_stats_rows(pl, M, Cout);
+    int64_t rows = conv_stats_rows(pl, M, Cout);
+    // a layer the bf16x3 kernels may serve (they do when the caller passes the workspace): their wave rows are 64 rows of a 128- or
+    // 256-row tile, whatever tile the fp32 plan has - room for both row sets; conv2d_fwd_impl zero-fills the buffer for such a layer
+    if (rows > 0 && x3_plan(pl, M, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec).ok) rows = std::max<int64_t>(rows, cdiv(M, 256) * 4);
+    return rows;
 }
 
 // ---- backward-data of a STRIDED convolution by phases -------------------------------------------------------------------------
@@ -3522,6 +3544,9 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
         if (stats_floats < (size_t)rows * 2 * Cout) return fail(PP_ERR_WORKSPACE, "conv fwd: statistics buffer too small");
         const ConvPlan pl = plan_conv(p.M, Cout, Cin, p.taps.n, Cin % 4 == 0 && Cout % 4 == 0);
         p.stats = stats;
+        if (x3_plan(pl, p.M, (int64_t)B * H * W, Cin, Cout, kh * kw, p.taps.n, Cin % 4 == 0 && Cout % 4 == 0).ok &&
+            hipMemsetAsync(stats, 0, (size_t)rows * 2 * Cout * 4, as_stream(stream)) != hipSuccess)
+            return fail(PP_ERR_LAUNCH, "conv fwd: clearing the statistics buffer failed");     // (the kernel that runs writes ITS rows)
         // layers the in-block split-K kernel serves get no workspace (pp_conv2d_fwd_workspace_bytes == 0) and that kernel
         // writes no statistics: with statistics requested they run the tiled kernel as ONE pass (rows = its wave rows)
         if (ksplit_shape_ok(p.M, Cout, Cin, p.taps.n, stride)) return launch_conv<false>(p, nullptr, 0, as_stream(stream));

@@ -375,6 +375,68 @@ def test_batched_weight_gradient_reduces_are_bit_identical(monkeypatch):
     assert not bad, f"gradients {bad} differ"
 
 
+FUSED_CONV_BN = [
+    # B, H, W, Cin, Cout, act, residual   (pointwise, stride 1)
+    (4, 16, 32, 64, 384, 2, False),      # 64x64-tiled LDS-DMA kernel, 234 blocks
+    (4, 16, 32, 96, 576, 2, False),
+    (4, 32, 64, 32, 192, 2, False),      # 1/8 resolution, 8192 rows
+    (4, 18, 34, 160, 960, 2, False),     # 585 blocks of 64x64 are too many: 128x64 tiles
+    (4, 34, 66, 144, 32, 0, False),      # 128x32 register-staged kernel
+    (4, 16, 32, 960, 160, 0, True),      # in-block split-K kernel, BatchNorm + residual (InvertedResidual project)
+    (4, 16, 32, 384, 64, 0, False),
+    (4, 16, 32, 320, 256, 1, False),     # ASPP 1x1 branch
+    (3, 23, 30, 576, 96, 0, True),       # ragged rows (2070)
+    (2, 9, 11, 64, 96, 2, False),        # 198 rows: a handful of blocks
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CONV_BN, ids=[str(c) for c in FUSED_CONV_BN])
+def test_conv_batchnorm_in_one_launch(case, monkeypatch):
+    """PIXELPICK_CONV_BN_FUSE: a training BatchNorm (+ residual, activation) right behind a dense convolution whose grid is co-resident is
+    finished in the convolution's epilogue (pp_conv2d_fwd_bn_train: the BatchNorm kernels' cross-block exchange inside the convolution).
+    Output, batch / running statistics and every gradient equal the two-launch path to fp32 rounding (the column sums are taken over
+    other partitions of the rows), the result equals torch, repeated launches are bit-identical, and the convolution really was deferred."""
+    B, H, W, Cin, Cout, act, with_res = case
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / np.sqrt(Cin)
+    gamma, beta = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, W, generator=gen) if with_res else None
+    dy = torch.randn(B, Cout, H, W, generator=gen)
+
+    def run(fuse):
+        monkeypatch.setattr(E, "_CONV_BN_FUSE", fuse)
+        tape = E.Tape()
+        xv = E.Var(nhwc(x))
+        wg, gg, bg = gparam(hwio(w)), gparam(gamma), gparam(beta)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        c = E.conv2d(tape, xv, wg, None, 1, 0, 1)
+        deferred = c._pending is not None
+        rvv = E.Var(nhwc(res)) if with_res else None
+        y = E.batch_norm_act(tape, c, gg, bg, rm, rv, True, act, rvv)
+        yt = y.t.clone()
+        tape.backward(y, nhwc(dy))
+        torch.cuda.synchronize()
+        return deferred, [yt, rm, rv, xv.grad.clone(), tape.param_grads[id(wg)].clone(), tape.param_grads[id(gg)].clone(),
+                          tape.param_grads[id(bg)].clone()] + ([rvv.grad.clone()] if with_res else [])
+
+    d1, a = run(True)
+    d1b, a2 = run(True)
+    d0, b = run(False)
+    assert d1 and d1b and not d0, "the fused path was not taken"
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)                                      # bit-reproducible
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= 2e-5 * (v.abs().max().item() + 1e-6)
+    # torch reference of the forward
+    xr = x.clone()
+    yr = F.batch_norm(F.conv2d(xr, w), None, None, gamma, beta, True, 0.1, 1e-5)
+    if with_res:
+        yr = yr + res
+    yr = F.relu(yr) if act == 1 else (F.relu6(yr) if act == 2 else yr)
+    close(nchw(a[0]), yr, what="conv + BatchNorm fused forward")
+
+
 @pytest.fixture(params=[True, False], ids=["bn-1launch", "bn-3launch"])
 def bn_fused(request):
     old = E._BN_FUSED
@@ -557,6 +619,7 @@ def test_conv_epilogue_statistics_feed_the_batchnorm(shape, act, with_res, drop,
     res = torch.randn(B, Ho, Wo, Cout, device=DEV, generator=gen) if with_res else None
     dy = torch.randn(B, Ho, Wo, Cout, device=DEV, generator=gen)
     outs = {}
+    monkeypatch.setattr(E, "_CONV_BN_FUSE", False)            # (the one-launch conv + BatchNorm path has its own test)
     for mode in (True, False):
         monkeypatch.setattr(E, "_CONV_BN_STATS", mode)
         monkeypatch.setattr(E, "_CONV_BN_STATS_MAX_ROWS", 1 << 30)
