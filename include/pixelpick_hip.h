@@ -232,6 +232,19 @@ int pp_conv2d_fwd_bn_train(const float* x, int64_t ldx, int B, int H, int W, int
                            int act, float* y, int64_t ldy, int Cout, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints,
                            pp_stream_t stream);
 
+/* Backward-data convolution + the BatchNorm backward of the layer in FRONT of it, in one launch (the mirror of
+ * pp_conv2d_fwd_bn_train; conv -> BatchNorm -> activation -> THIS convolution, the activated tensor having no other consumer:
+ * mobilenet_v2.py:52-56, depthwise BatchNorm / ReLU6 -> project convolution).  dy is the gradient of this convolution's output;
+ * bn_x / mean / invstd / gamma / beta / act describe the BatchNorm whose output this convolution read; dx_bn receives the gradient of
+ * the BatchNorm's INPUT (what pp_bn_bwd_fused would have written), dgamma / dbeta its parameter gradients.  The gradient of the
+ * BatchNorm's output is never written.  Same xchg / sync areas as the single-launch BatchNorm; ask *_ok first. */
+int pp_conv2d_bwd_data_bn_bwd_ok(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+size_t pp_conv2d_bwd_data_bn_bwd_xchg_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pp_conv2d_bwd_data_bn_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw, int stride,
+                              int pad, int dil, int H, int W, int Cin, const float* bn_x, int64_t ldbx, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, int act, float* dgamma, float* dbeta,
+                              float* dx_bn, int64_t lddx, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
+
 /* Deferred reduces.  A weight gradient is a partial-sum kernel ([slices][...] in the workspace) followed by a small
  * fixed-order reduce; a backward pass has ~60 of them (model.py:121 loss.backward()).  The *_partials forms run only the
  * first kernel and describe the reduce in *job (kind 0: nothing left to do - the call completed the gradient itself, e.g.

@@ -51,6 +51,10 @@ SIGNATURES = {
     "pp_conv2d_fwd_bn_train_xchg_bytes": (_sz, [_int] * 10),
     "pp_conv2d_fwd_bn_train": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _p, _p, _f, _f, _p, _p, _p, _p,
                                       _p, _i64, _int, _p, _i64, _int, _p, _sz, _p, _sz, _p]),
+    "pp_conv2d_bwd_data_bn_bwd_ok": (_int, [_int] * 10),
+    "pp_conv2d_bwd_data_bn_bwd_xchg_bytes": (_sz, [_int] * 10),
+    "pp_conv2d_bwd_data_bn_bwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p, _p, _p, _p,
+                                         _int, _p, _p, _p, _i64, _p, _sz, _p, _sz, _p]),
     "pp_x3_planes_bytes": (_sz, [_i64, _int]),
     "pp_x3_split": (_int, [_p, _i64, _i64, _int, _p, _sz, _p]),
     "pp_conv2d_x3_planes_bytes": (_sz, [_int] * 11),

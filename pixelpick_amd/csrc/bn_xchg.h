@@ -115,4 +115,22 @@ __device__ __forceinline__ void strip_combine(const xword* part, int strip, int 
 }
 
 
+// derivative mask from the activation OUTPUT y (relu: y>0, relu6: 0<y<6)
+__device__ __forceinline__ float act_mask(float y, int act)
+{
+    if (act == 1) return y > 0.0f ? 1.0f : 0.0f;
+    if (act == 2) return (y > 0.0f && y < 6.0f) ? 1.0f : 0.0f;
+    return 1.0f;
+}
+
+
+// dx of one element; no fma contraction, so that every kernel variant (and the mask / dropout scaling in front of it, which
+// the row-cached variant applies in the reduction pass) rounds identically
+__device__ __forceinline__ float bn_dx(float u, float v, float mu, float is, float ga, float db, float dg, float inv_count)
+{
+#pragma clang fp contract(off)
+    return ga * is * (u - db * inv_count - (v - mu) * is * dg * inv_count);
+}
+
+
 }  // namespace pp

@@ -53,6 +53,9 @@ struct BnTrain {
     const float* res; int64_t ldr; int act;
     float* y; int64_t ldy;              // the normalised (+ residual, activation) output; ConvParams::y receives the raw convolution
     xword* part; int* sync; int R;      // exchange area [strips][R][64] words, launch epoch, M tiles of the grid
+    // backward form (a backward-data convolution that also runs the BatchNorm backward of the layer in FRONT of it, conv_epilogue_bn_bwd):
+    // bx = the BatchNorm's input, mean / invstd are inputs, y receives the gradient of that input, dgamma / dbeta the parameter gradients
+    const float* bx; int64_t ldbx; float* dgamma; float* dbeta;
 };
 
 struct ConvParams {
@@ -226,7 +229,7 @@ struct BnScratch {
 
 // colsum[stat][wave row][column] is filled (no barrier yet) -> aff[0][c] = scale, aff[1][c] = shift of the tile's columns; block row 0
 // writes mean / invstd / running statistics.  Ends with a barrier.
-template <int BNT, int WM>
+template <int BNT, int WM, bool BWDF = false>
 __device__ __forceinline__ void bn_block_finish(const ConvParams& p, const BnScratch<BNT, WM>& S, int n0, int mt, unsigned tag0)
 {
     constexpr int NSTRIP = BNT / 32;
@@ -287,6 +290,21 @@ __device__ __forceinline__ void bn_block_finish(const ConvParams& p, const BnScr
         __syncthreads();
     }
     launch_done(bn.sync);
+    if constexpr (BWDF) {
+        // backward: aff[0][c] = sum of the masked gradient, aff[1][c] = sum of masked gradient x normalised input (bn_fused_bwd_kernel)
+        if (tid < BNT) {
+            const int n = n0 + tid;
+            if (n < p.Cn) {
+                const int sl = tid >> 5, cl = tid & 31;
+                const float db = (float)S.tot[sl * 64 + cl], dg = (float)S.tot[sl * 64 + 32 + cl];
+                S.aff[tid] = db;
+                S.aff[BNT + tid] = dg;
+                if (mt == 0) { bn.dbeta[n] = db; bn.dgamma[n] = dg; }
+            }
+        }
+        __syncthreads();
+        return;
+    }
     // per-column affine (bn_fused_fwd_kernel's expressions: the backward recomputes the activation mask from them)
     if (tid < BNT) {
         const int n = n0 + tid;
@@ -363,6 +381,69 @@ __device__ __forceinline__ void conv_epilogue_bn(const ConvParams& p, f32x16 (&a
                     if (bn.res) o += bn.res[m * bn.ldr + n];
                     bn.y[m * bn.ldy + n] = epi_act(o, bn.act);
                 }
+            }
+    }
+}
+
+// Backward-data convolution + the BatchNorm backward of the layer in FRONT of it (conv -> BatchNorm -> act -> THIS conv, the
+// activated output having no other consumer): the tile in registers is the gradient of the BatchNorm's output; with the BatchNorm's
+// input (one more tile read) the lane forms the masked gradient u and the two column sums of bn_fused_bwd_kernel, the blocks
+// exchange them as in the forward form, and the lane writes the gradient of the BatchNorm's INPUT (bn_dx, the BatchNorm kernels'
+// own expression).  The gradient of the BatchNorm's output is never written.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_bn_bwd(const ConvParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn, int mt,
+                                                     float* scratch, unsigned tag0)
+{
+    constexpr int BNT = WN * TN * 32;
+    const BnTrain& bn = p.bn;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const BnScratch<BNT, WM> S(scratch);
+    float xs[TM][TN][16];                                  // the BatchNorm's input at this lane's elements
+    float mu_[TN], is_[TN], ga_[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + l31;
+        const bool ok = n < p.Cn;
+        const float mu = ok ? bn.mean[n] : 0.0f, is = ok ? bn.invstd[n] : 0.0f, ga = ok ? bn.gamma[n] : 0.0f, be = ok ? bn.beta[n] : 0.0f;
+        mu_[tn] = mu; is_[tn] = is; ga_[tn] = ga;
+        const float zsc = ga * is, zsf = be - mu * zsc;    // the forward's scale / shift: z = fma(x, zsc, zsf) is what the activation saw
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const bool in = ok && m < p.M;
+                const float x = in ? bn.bx[m * bn.ldbx + n] : 0.0f;
+                xs[tm][tn][r] = x;
+                float u = in ? acc[tm][tn][r] : 0.0f;
+                if (bn.act != 0) u *= act_mask(fmaf(x, zsc, zsf), bn.act);
+                acc[tm][tn][r] = u;
+                s1 += u;
+                s2 = fmaf(u, (x - mu) * is, s2);
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (hh == 0) {
+            const int c = (wn * TN + tn) * 32 + l31;
+            S.colsum[(0 * WM + wm) * BNT + c] = s1;
+            S.colsum[(1 * WM + wm) * BNT + c] = s2;
+        }
+    }
+    bn_block_finish<BNT, WM, true>(p, S, n0, mt, tag0);
+    const float inv_count = 1.0f / (float)p.M;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int c = (wn * TN + tn) * 32 + l31;
+        const int n = n0 + c;
+        if (n >= p.Cn) continue;
+        const float db = S.aff[c], dg = S.aff[BNT + c];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m < p.M) bn.y[m * bn.ldy + n] = bn_dx(acc[tm][tn][r], xs[tm][tn][r], mu_[tn], is_[tn], ga_[tn], db, dg, inv_count);
             }
     }
 }
@@ -697,8 +778,11 @@ __device__ __forceinline__ void conv_glds16x2(const float* g0, const float* g1, 
 
 template <int TM, int TN> struct DmaFrags { float a[2][TM][4], b[2][TN][4]; };
 
-template <int BM, int BN, bool BWD>
-__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv_igemm_dma_kernel(ConvParams p)
+// BNF: the instantiation whose epilogue also finishes (forward) / runs the backward of (backward-data) a training BatchNorm -
+// conv_epilogue_bn / conv_epilogue_bn_bwd.  A separate instantiation with a looser register budget: inside the plain kernel the extra
+// epilogue pushed the 128-register kernels into scratch (124-176 bytes per lane) for every launch, fused or not.
+template <int BM, int BN, bool BWD, bool BNF = false>
+__global__ __launch_bounds__(kThreads, (BNF ? 3 : (BM * BN >= 128 * 128 ? 3 : 4))) void conv_igemm_dma_kernel(ConvParams p)
 {
     constexpr int TM = BM / 64, TN = BN / 64, WN = 2, NSTAGE = 3;
     constexpr int PA = BM / 64, PB = BN / 64;                     // 1-KiB DMA pieces per wave and K step
@@ -727,7 +811,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
     unsigned tag0 = 0;                       // conv -> BatchNorm in one launch: this launch's exchange tag, requested now, used in the epilogue
-    if constexpr (BN == 64 && !BWD) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
+    if constexpr (BNF) tag0 = tag_issue(p.bn.sync);
     const float* zero = g_zero16;
     asm volatile("" : "+v"(zero));          // keep the pointer in registers (hipcc re-derives it from the PC in every K step otherwise)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
@@ -983,12 +1067,11 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
         kstep(std::false_type{}, SR{}, k, F0, F1);
         if (k + 1 < n) kstep(std::false_type{}, SR{}, k + 1, F1, F0);
     }
-    if constexpr (BN == 64 && !BWD) {
-        if (p.bn.part) {                                           // wave-uniform: conv -> training BatchNorm in this launch
-            __syncthreads();                                       // the ring is scratch from here on
-            conv_epilogue_bn<TM, TN, (BM / 32 / TM), WN>(p, acc, m0, n0, wm, wn, mt, smem, tag0);
-            return;
-        }
+    if constexpr (BNF) {
+        __syncthreads();                                           // the ring is scratch from here on
+        if constexpr (BWD) conv_epilogue_bn_bwd<TM, TN, (BM / 32 / TM), WN>(p, acc, m0, n0, wm, wn, mt, smem, tag0);
+        else               conv_epilogue_bn<TM, TN, (BM / 32 / TM), WN>(p, acc, m0, n0, wm, wn, mt, smem, tag0);
+        return;
     }
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
@@ -2985,12 +3068,12 @@ static int device_cus();
 static int conv_bn_capacity(int which = 0)        // 0: conv_igemm_dma_kernel<64, 64>, 1: <128, 64>, 2: conv_igemm_kernel<128, 32, 4, 1>
 {
     static const int cap[3] = {
-        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
-        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<128, 64, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<128, 64, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 32, 4, 1, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
     return cap[which];
 }
-static thread_local int g_conv_bn_fuse = 3;      // bit 0: fused conv + BatchNorm epilogue of the 64x64-tiled layers, bit 1: of the in-block split-K kernel
+static thread_local int g_conv_bn_fuse = 7;      // bit 0: fused conv + BatchNorm epilogue of the tiled kernels, bit 1: of the in-block split-K kernel, bit 2: backward form
 static int ksplit_bn_capacity(int which)         // 0: <1,1,5>, 1: <2,1,3> (the forward candidates)
 {
     static const int cap[2] = {
@@ -3029,6 +3112,26 @@ static BnFusePlan bn_fuse_plan(const ConvParams& p, const ConvPlan& pl, bool vec
     return f;
 }
 
+// backward-data convolution + BatchNorm backward (conv_epilogue_bn_bwd): the 64x64-tiled LDS-DMA kernel, whole grid co-resident
+static int conv_bn_bwd_capacity()
+{
+    static const int cap = [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, true, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }();
+    return cap;
+}
+static BnFusePlan bn_fuse_plan_bwd(const ConvParams& p, const ConvPlan& pl, bool vec)
+{
+    BnFusePlan f{0, 0, 0, {0, 0, 0}};
+    if (!(g_conv_bn_fuse & 4) || !vec || p.stats || p.in_scale || p.bias || p.epi.gamma || p.epi.res || p.epi.act != 0 || p.accumulate || p.bwd_stride > 1 ||
+        p.stride != 1 || p.Cn % 32 != 0 || (int64_t)p.B * p.H * p.W * p.ldx >= (1ll << 31) - (1ll << 24))
+        return f;
+    if (ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride)) return f;
+    const bool dma_ok = g_conv_dma64 == 1 && p.taps.n <= 32 && (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
+    if (pl.cfg == 2 && pl.splits == 1 && dma_ok && pl.tiles <= conv_bn_bwd_capacity() / 2) {
+        f.kind = 1; f.R = (int)cdiv(p.M, 64); f.blocks = pl.tiles;
+    }
+    return f;
+}
+
 template <bool BWD>
 static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes, hipStream_t st, int kh_kw = 0)
 {
@@ -3041,10 +3144,16 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     if (p.bn.part) {
         // conv -> training BatchNorm in one launch: only the kernel that implements it may run (the caller asked
         // pp_conv2d_fwd_bn_train_ok first; no silent fallback that would drop the BatchNorm)
-        const BnFusePlan f = BWD ? BnFusePlan{0, 0, 0, {0, 0, 0}} : bn_fuse_plan(p, pl, vec);
-        if (f.kind == 0) return fail(PP_ERR_UNSUPPORTED, "conv fwd + BatchNorm: this shape has no fused kernel");
+        const BnFusePlan f = BWD ? bn_fuse_plan_bwd(p, pl, vec) : bn_fuse_plan(p, pl, vec);
+        if (f.kind == 0) return fail(PP_ERR_UNSUPPORTED, "conv + BatchNorm: this shape has no fused kernel");
         p.bn.R = f.R;
         p.splits = 1; p.ks_per_split = 0; p.part = nullptr;
+        if constexpr (BWD) {
+            p.tap_inner = g_conv_tap_inner;
+            p.n_tiles = pl.n_tiles;
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, true, true>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+            return check_launch("conv_igemm_dma_kernel<bn bwd>");
+        }
         if constexpr (!BWD) {
             if (f.kind == 2) {
                 p.n_tiles = (int)cdiv(p.Cn, 32);
@@ -3055,13 +3164,13 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
             p.tap_inner = g_conv_tap_inner;
             if (f.kind == 3) {
                 p.n_tiles = (int)cdiv(p.Cn, 64);
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, false>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, false, true>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
             } else if (f.kind == 4) {
                 p.n_tiles = pl.n_tiles;
                 hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, false, true>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
             } else {
                 p.n_tiles = pl.n_tiles;
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, false, true>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
             }
         }
         return check_launch("conv_igemm_kernel<bn>");
@@ -3753,6 +3862,62 @@ int pp_x3_split(const float* x, int64_t ldx, int64_t rows, int C, void* planes, 
     hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ta, 256), 4096)), dim3(256), 0, as_stream(stream), x, ldx, rows, C,
                        reinterpret_cast<uint16_t*>(planes), Kp, plane);
     return check_launch("x3_split_kernel");
+}
+
+// backward-data + the BatchNorm backward of the layer in front (see conv_epilogue_bn_bwd)
+static bool conv_bn_bwd_shape(ConvParams& p, ConvPlan& pl, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil,
+                              int64_t lddy, int* R_out)
+{
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride != 1 || dil < 1) return false;
+    const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
+    if (Ho < 1 || Wo < 1) return false;
+    p = ConvParams{};
+    p.ldx = lddy; p.B = B; p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.Ck = Cout; p.Cn = Cin; p.Cin = Cin; p.Cout = Cout;
+    p.stride = 1; p.M = (int64_t)B * H * W; p.bwd_stride = 1;
+    build_taps(p.taps, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, 1);
+    if (p.M > 0x7FFFFFFFll || p.taps.n == 0) return false;
+    const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && lddy % 4 == 0;
+    pl = plan_conv(p.M, Cin, Cout, p.taps.n, vec);
+    const BnFusePlan f = bn_fuse_plan_bwd(p, pl, vec);
+    if (R_out) *R_out = f.R;
+    return f.kind != 0;
+}
+
+int pp_conv2d_bwd_data_bn_bwd_ok(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    ConvParams p; ConvPlan pl;
+    return conv_bn_bwd_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Cout, nullptr) ? 1 : 0;
+}
+
+size_t pp_conv2d_bwd_data_bn_bwd_xchg_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
+{
+    ConvParams p; ConvPlan pl;
+    int R = 0;
+    if (!conv_bn_bwd_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, Cout, &R)) return 0;
+    return align_up((size_t)cdiv(Cin, 32) * (size_t)R * 64 * 8, 256);
+}
+
+int pp_conv2d_bwd_data_bn_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw, int stride,
+                              int pad, int dil, int H, int W, int Cin, const float* bn_x, int64_t ldbx, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, int act, float* dgamma, float* dbeta,
+                              float* dx_bn, int64_t lddx, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
+{
+    if (int rc = conv_common_check(dy, w, dx_bn, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
+    if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
+        return fail(PP_ERR_BAD_ARG, "conv bwd_data + BatchNorm bwd: inconsistent sizes");
+    if (!bn_x || !mean || !invstd || !gamma || !beta || !dgamma || !dbeta || !xchg || !sync) return fail(PP_ERR_BAD_ARG, "conv bwd_data + BatchNorm bwd: null");
+    if (act < 0 || act > 2) return fail(PP_ERR_BAD_ARG, "conv bwd_data + BatchNorm bwd: act %d", act);
+    if ((reinterpret_cast<uintptr_t>(xchg) & 7) != 0 || sync_ints < 2) return fail(PP_ERR_BAD_ARG, "conv bwd_data + BatchNorm bwd: exchange area");
+    ConvParams p; ConvPlan pl;
+    int R = 0;
+    if (!conv_bn_bwd_shape(p, pl, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, lddy, &R))
+        return fail(PP_ERR_UNSUPPORTED, "conv bwd_data + BatchNorm bwd: this shape has no fused kernel (ask pp_conv2d_bwd_data_bn_bwd_ok first)");
+    const size_t need = (size_t)cdiv(Cin, 32) * (size_t)R * 64 * 8;
+    if (xchg_bytes < need) return fail(PP_ERR_WORKSPACE, "conv bwd_data + BatchNorm bwd: exchange area %zu < %zu", xchg_bytes, need);
+    p.x = dy; p.w = w; p.bias = nullptr; p.y = dx_bn; p.ldy = lddx;
+    p.bn = BnTrain{gamma, beta, 0.0f, 0.0f, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(invstd), nullptr, 0, act, dx_bn, lddx,
+                   reinterpret_cast<xword*>(xchg), sync, 0, bn_x, ldbx, dgamma, dbeta};
+    return launch_conv<true>(p, nullptr, 0, as_stream(stream), kh * kw);
 }
 
 int pp_conv2d_bwd_data_pre(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,

@@ -26,14 +26,6 @@ __device__ __forceinline__ float act_fwd(float z, int act)
     if (act == 2) return fminf(fmaxf(z, 0.0f), 6.0f);
     return z;
 }
-// derivative mask from the activation OUTPUT y (relu: y>0, relu6: 0<y<6)
-__device__ __forceinline__ float act_mask(float y, int act)
-{
-    if (act == 1) return y > 0.0f ? 1.0f : 0.0f;
-    if (act == 2) return (y > 0.0f && y < 6.0f) ? 1.0f : 0.0f;
-    return 1.0f;
-}
-
 // flat element index -> (q, w, h, b) for an array [B][H][W][cq]; 32-bit unsigned divisions whenever the index fits
 // (64-bit integer division is emulated in ~100 instructions on this ISA and was most of the depthwise kernels' work)
 __device__ __forceinline__ void decode_bhwq(int64_t e, int cq, int Wd, int Hd, int& q, int& w, int& h, int& b)
@@ -659,14 +651,6 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
         }
     }
     BN_STAMP(5);
-}
-
-// dx of one element; no fma contraction, so that every kernel variant (and the mask / dropout scaling in front of it, which
-// the row-cached variant applies in the reduction pass) rounds identically
-__device__ __forceinline__ float bn_dx(float u, float v, float mu, float is, float ga, float db, float dg, float inv_count)
-{
-#pragma clang fp contract(off)
-    return ga * is * (u - db * inv_count - (v - mu) * is * dg * inv_count);
 }
 
 struct BnBwdArgs {

@@ -45,7 +45,8 @@ def _run_conv_bn_act_chain(tape, seq, x, residual=None, first_pad=0):
         # activation where it loads its input, the BatchNorm is split over its neighbours (engine._bn_on_load)
         nxt = i + (3 if has_act else 2)
         lazy_ok = (not is_last) and tape.enabled and mods[nxt].accepts_lazy_input(E.shape_of(x))
-        x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None, lazy_ok=lazy_ok)
+        x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None, lazy_ok=lazy_ok,
+                   single_consumer=not is_last)
         i = nxt
     return x
 

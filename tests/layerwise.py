@@ -146,6 +146,10 @@ class LayerwiseParity:
         me = self
         # forced / branch-forced runs overwrite activations in place: every BatchNorm must write its output (no skipped apply)
         self._saved_on_load = E._BN_ON_LOAD
+        # every BatchNorm node's arriving gradient is compared / forced here: the BatchNorm backward must stay a node of its own
+        # (the form that runs it inside the consumer convolution's backward-data launch has its own op-level and network-level tests)
+        self._saved_fuse_bwd = E._CONV_BN_FUSE_BWD
+        E._CONV_BN_FUSE_BWD = False
         if self.force:
             E._BN_ON_LOAD = False
         self._saved = (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd)
@@ -179,8 +183,8 @@ class LayerwiseParity:
                     me._fwd_site("conv", ent[0], ent[0], x)
             return got
 
-        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None, lazy_ok=False):
-            out = bn_run(self, tape, x, act, residual, dst, dropout, lazy_ok)
+        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None, lazy_ok=False, single_consumer=False):
+            out = bn_run(self, tape, x, act, residual, dst, dropout, lazy_ok, single_consumer)
             n = me.mod_name[id(self)]
             site = me.tr.site(n, residual is not None)
             me.res_nodes[n] = residual is not None
@@ -231,6 +235,7 @@ class LayerwiseParity:
         (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd) = self._saved
         E._launch_deferred, E._launch_conv_stats = self._saved_launch
         E._BN_ON_LOAD = self._saved_on_load
+        E._CONV_BN_FUSE_BWD = self._saved_fuse_bwd
         return False
 
     # ------------------------------------------------------------------ after the sweep

@@ -437,6 +437,60 @@ def test_conv_batchnorm_in_one_launch(case, monkeypatch):
     close(nchw(a[0]), yr, what="conv + BatchNorm fused forward")
 
 
+FUSED_BN_BWD = [(4, 16, 32, 384, 64, 2), (4, 16, 32, 576, 96, 2), (4, 32, 64, 192, 32, 2), (3, 23, 30, 384, 64, 2), (4, 16, 32, 384, 64, 0),
+                (4, 16, 32, 384, 64, 1), (2, 9, 11, 96, 32, 2)]
+
+
+@pytest.mark.parametrize("case", FUSED_BN_BWD, ids=[str(c) for c in FUSED_BN_BWD])
+def test_batchnorm_backward_inside_the_consumer_convolutions_backward_data(case, monkeypatch):
+    """PIXELPICK_CONV_BN_FUSE_BWD: depthwise -> BatchNorm -> activation -> pointwise convolution, the activated tensor read by that
+    convolution only (single_consumer): the convolution's backward-data launch also runs the BatchNorm backward
+    (pp_conv2d_bwd_data_bn_bwd) - the gradient of the BatchNorm's output is never written and the BatchNorm node is skipped.
+    Every gradient equals the two-launch path to fp32 rounding and torch autograd; repeated runs are bit-identical."""
+    B, H, W, C, Cout, act = case
+    gen = torch.Generator().manual_seed(C + Cout + act)
+    x = torch.randn(B, C, H, W, generator=gen)
+    wd = torch.randn(C, 1, 3, 3, generator=gen) / 3
+    w = torch.randn(Cout, C, 1, 1, generator=gen) / np.sqrt(C)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    dy = torch.randn(B, Cout, H, W, generator=gen)
+    def run(fuse):
+        monkeypatch.setattr(E, "_CONV_BN_FUSE_BWD", fuse)
+        tape = E.Tape()
+        xv = E.Var(nhwc(x))
+        wdg, wg, gg, bg = gparam(wd[:, 0].permute(1, 2, 0).contiguous()), gparam(hwio(w)), gparam(gamma), gparam(beta)
+        d = E.dwconv3x3(tape, xv, wdg, 1, 1, 1)
+        y = E.batch_norm_act(tape, d, gg, bg, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, act, single_consumer=True)
+        fused_ctx = y._bn_bwd_ctx is not None
+        c = E.conv2d(tape, y, wg, None, 1, 0, 1)
+        tape.backward(c, nhwc(dy))
+        torch.cuda.synchronize()
+        return fused_ctx, [xv.grad.clone()] + [tape.param_grads[id(t)].clone() for t in (wdg, wg, gg, bg)]
+
+    c1, a = run(True)
+    _, a2 = run(True)
+    _, b = run(False)
+    assert c1
+    assert E._conv_bn_bwd_fusable(B, H, W, C, Cout, 1, 1, 1, 0, 1), "the fused path was not available for this case"
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= 2e-5 * (v.abs().max().item() + 1e-6)
+    xr, wdr, wr = x.clone().requires_grad_(True), wd.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(F.conv2d(xr, wdr, padding=1, groups=C), None, None, gr, br, True, 0.1, 1e-5)
+    z = F.relu(z) if act == 1 else (F.relu6(z) if act == 2 else z)
+    F.conv2d(z, wr).backward(dy)
+    close(nchw(a[0]), xr.grad, what="dx through the fused BatchNorm backward")
+    close(a[3].cpu(), gr.grad, what="dgamma")
+    close(a[4].cpu(), br.grad, what="dbeta")
+
+
+def _lib_mod():
+    from pixelpick_amd import _lib
+    return _lib
+
+
 @pytest.fixture(params=[True, False], ids=["bn-1launch", "bn-3launch"])
 def bn_fused(request):
     old = E._BN_FUSED
