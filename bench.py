@@ -255,6 +255,28 @@ def main():
         x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
         cores_per_rank = (os.cpu_count() or 1) / max(world, 1)
         replay = a.replay == "on" or (a.replay == "auto" and cores_per_rank < 8)
+        replay_why = "forced" if a.replay == "on" else ("fewer than 8 host cores per rank" if replay else None)
+        if a.replay == "auto" and not replay:
+            # probe (untimed, before the warmup): what a step costs the HOST when issued into empty queues against what it costs the
+            # GPU.  A host that needs more than 0.8 of the GPU step to enqueue it would bound the run on a busier or slower box than
+            # this one: take the recorded launch list then (about half the host cost, same GPU schedule, bit-identical steps).
+            for _ in range(3):
+                tr.train_step(x, y)
+            probe = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                tr.train_step(x, y)
+                probe.append(time.perf_counter() - t)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(5):
+                tr.train_step(x, y)
+            torch.cuda.synchronize(dev)
+            gpu_step = max_over_ranks((time.perf_counter() - t) / 5)
+            host_step = max_over_ranks(sorted(probe)[1])
+            if host_step > 0.8 * gpu_step:
+                replay, replay_why = True, f"host enqueue {host_step * 1e3:.2f} ms > 0.8 x step {gpu_step * 1e3:.2f} ms in the probe"
         if replay:
             tr.enable_replay(x, y, warmup=1)         # recorded launch list, eager two-queue GPU schedule (bit-identical steps)
         tr.time_collectives = dist is not None
@@ -286,6 +308,7 @@ def main():
                  # host time spent inside train_step() per step (enqueue only, nothing synchronises): a host slower than the
                  # GPU step shows up HERE, not as an unexplained scaling loss
                  "host_enqueue_ms_per_step": host_ms, "host_in_loop_ms_per_step": host_loop_ms, "replay": bool(replay),
+                 "replay_reason": replay_why,
                  "host_cores_per_rank": round(cores_per_rank, 1),
                  "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
         if dist is not None:
