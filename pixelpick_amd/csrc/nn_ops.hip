@@ -429,7 +429,7 @@ struct BnFwdArgs {
 #define BN_STAMP(i) do { if (a.probe && threadIdx.x == 0) a.probe[(int64_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
 // one output quad of the depthwise 3x3 convolution, same tap order / fma chain as dwconv_fwd_kernel (bit-identical)
-__device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int q)
+__device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int q, const float4* wreg)
 {
     const unsigned ru = (unsigned)row;
     const unsigned t = ru / (unsigned)a.dw_Wo;
@@ -446,8 +446,8 @@ __device__ __forceinline__ float4 dw_point(const BnFwdArgs& a, int64_t row, int 
             const int iw = ow * a.dw_stride - a.dw_pad + tw * a.dw_dil;
             if ((unsigned)iw >= (unsigned)a.dw_W) continue;
             const float4 v = *reinterpret_cast<const float4*>(a.dw_in + (((int64_t)b * a.dw_H + ih) * a.dw_W + iw) * a.dw_ld + q * 4);
-            const float4 ww = *reinterpret_cast<const float4*>(a.dw_w + (th * 3 + tw) * a.C + q * 4);
-            acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
+            const float4 ww = wreg[th * 3 + tw];           // the thread's nine weight quads, loaded once (the stores to x_out kept the
+            acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);   // compiler from hoisting them: nine more loads per row)
             acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
         }
     }
@@ -511,6 +511,13 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
         __syncthreads();
     } else {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float4 wreg[DW ? 9 : 1];
+    if constexpr (DW) {
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wreg[k] = *reinterpret_cast<const float4*>(a.dw_w + k * a.C + q * 4);
+        }
+    }
     // four rows r, r + nrl, ...: loads, then the accumulation in the order every variant uses
     auto stat_load = [&](int64_t r, float4* v, float* w) {
 #pragma unroll
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(kT) void bn_fused_fwd_kernel(BnFwdArgs a)
             const int64_t rr = r + (int64_t)j * g.nrl;
             w[j] = rr < r1 ? 1.0f : 0.0f;
             if constexpr (DW) {
-                v[j] = dw_point(a, rr < r1 ? rr : r1 - 1, q);
+                v[j] = dw_point(a, rr < r1 ? rr : r1 - 1, q, wreg);
                 if (rr < r1) *reinterpret_cast<float4*>(a.x_out + rr * a.ldx + q * 4) = v[j];   // BN's input, kept for backward
             } else {
                 v[j] = *reinterpret_cast<const float4*>(xq + (rr < r1 ? rr : r1 - 1) * a.ldx);

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for r in auto on off; do python bench.py --mode train --no-cpu-baseline --replay $r 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t=d['train']; print('$r', d['value'], d['ms_per_step'], t['replay'], t.get('replay_reason'), round(t['host_enqueue_ms_per_step'],2))"; done
+O=gpurun_out/r3o; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -3 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
