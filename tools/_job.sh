@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3o; mkdir -p $O
-timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -3 $O/tall.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+cp pixelpick_amd/libpixelpick_hip.so /tmp/new.so
+for i in 1 2 3; do
+cp tools/probe/lib_old.so pixelpick_amd/libpixelpick_hip.so; echo "old: $(STEPS=40 timeout 120 python tools/train_bench.py 2>&1 | tail -1 | cut -c1-60)"
+cp /tmp/new.so pixelpick_amd/libpixelpick_hip.so; echo "new: $(STEPS=40 timeout 120 python tools/train_bench.py 2>&1 | tail -1 | cut -c1-60)"
+done
