@@ -331,7 +331,9 @@ def main():
             tr.time_collectives = False
             line["distributed"] = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
                                    "allreduce_in_step_us": {k: round(sum(v) / len(v), 1) for k, v in in_step.items()},
-                                   "allreduce_bytes_per_step": tr.n * 4, "buckets": [int((tr.n - tr.n_split) * 4), int(tr.n_split * 4)],
+                                   "allreduce_bytes_per_step": tr.n * 4,
+                                   "buckets": ([int((tr.n - tr.n_split) * 4), int((tr.n_split - tr.n_mid) * 4), int(tr.n_mid * 4)] if tr.n_mid
+                                               else [int((tr.n - tr.n_split) * 4), int(tr.n_split * 4)]),
                                    "allreduce_alone_ms": round(ar_ms, 4),
                                    "allreduce_alone_GBps_per_rank": round(tr.n * 4 / (ar_ms * 1e-3) / 1e9, 1),
                                    "overlapped": bool(__import__("pixelpick_amd.trainer", fromlist=["x"]).OVERLAP_ALLREDUCE)}

@@ -118,10 +118,18 @@ class DilatedResnetBackbone(nn.Module):
         x = self.prefix.bn1.run(tape, self.prefix.conv1.run(tape, x), E.ACT_RELU)
         x = E.max_pool2d(tape, x, 3, 2, 1)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            if layer is self.layer3:
+                # layer3 + layer4 hold 22 of ResNet50's 23.5 M parameters; when backward() is back here, layer2 / layer1 / the stem are
+                # still ahead: data-parallel training starts the all-reduce of their gradients now (trainer.FlatTrainer)
+                tape.mark("encoder_late_done")
             for blk in layer:
                 x = blk.run(tape, x)
             feats.append(x)
         return feats
+
+    def late_modules(self):
+        """The modules whose parameter gradients are complete when backward() reaches Tape.mark("encoder_late_done")."""
+        return [self.layer3, self.layer4]
 
 
 def ResNetBackbone(backbone=None, width_multiplier=1.0, pretrained=None, multi_grid=None, norm_type='batchnorm'):

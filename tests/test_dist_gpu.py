@@ -33,14 +33,15 @@ def _batch(seed, B=2, H=64, W=96, C=7):
     return x.cuda(), y.cuda()
 
 
-def _trainer(C=7):
+def _trainer(network="deeplab", C=7):
     from pixelpick_amd.networks.layers import Dropout
     from pixelpick_amd.trainer import FlatTrainer
     from pixelpick_amd.utils.utils import get_model
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="deeplab")).cuda().train()
+        m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=network, weight_type="random", n_layers=50,
+                                use_softmax=True, use_dilated_resnet=True, width_multiplier=1.0)).cuda().train()
     for mod in m.modules():
         if isinstance(mod, Dropout):
             mod.p = 0.0
@@ -70,8 +71,15 @@ def _worker(rank, world, port, q):
         same_as_single = torch.equal(pa, ref.flat_p)
         # (B) disjoint shards: the replicas must stay identical to each other
         tr2 = _trainer()
+        # three buckets for MobileNetV2: behind the encoder / its late blocks (both under the backward pass) / the first 0.9 MB
+        assert 0 < tr2.n_mid < tr2.n_split < tr2.n and (tr2.n_split - tr2.n_mid) > 4 * tr2.n_mid
+        tr2.time_collectives = True
         xs, ys = _batch(100 + rank)
         losses = [float(tr2.train_step(xs, ys)) for _ in range(2)]
+        torch.cuda.synchronize()
+        tags = [t for t, _, _ in tr2.comm_times]
+        assert tags[:3] == ["behind_encoder", "encoder_late", "encoder_early"], tags
+        tr2.time_collectives = False
         others = [torch.empty_like(tr2.flat_p) for _ in range(world)]
         dist.all_gather(others, tr2.flat_p)
         replicas_equal = all(torch.equal(others[0], o) for o in others[1:])
@@ -97,7 +105,19 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         replay_equals_eager = torch.equal(tr4.flat_p, tr5.flat_p) and len(tr4._plan) > 100
         tr4.disable_replay()
-        q.put((rank, same_as_single, replicas_equal, differs_from_a and overlap_equals_plain and replay_equals_eager, losses))
+        # (E) the ResNet50 encoder (FPNSeg): its late bucket is layer3 + layer4; three overlapped buckets == one all-reduce
+        trf = _trainer("FPN")
+        assert 0 < trf.n_mid < trf.n_split < trf.n and (trf.n_split - trf.n_mid) > 8 * trf.n_mid
+        for _ in range(2):
+            trf.train_step(xs, ys)
+        T.OVERLAP_ALLREDUCE = False
+        trg = _trainer("FPN")
+        for _ in range(2):
+            trg.train_step(xs, ys)
+        T.OVERLAP_ALLREDUCE = True
+        torch.cuda.synchronize()
+        fpn_ok = torch.equal(trf.flat_p, trg.flat_p)
+        q.put((rank, same_as_single, replicas_equal, differs_from_a and overlap_equals_plain and replay_equals_eager and fpn_ok, losses))
     finally:
         dist.destroy_process_group()
 
@@ -423,5 +443,6 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay):
     t = d["train"]
     assert t["replay"] == (replay == "on") and 0 < t["host_enqueue_ms_per_step"] < 1e3 and t["host_cores_per_rank"] > 0
     dd = d["distributed"]
-    assert dd["nranks"] == 2 and set(dd["allreduce_in_step_us"]) == {"behind_encoder", "encoder"}
+    assert dd["nranks"] == 2 and set(dd["allreduce_in_step_us"]) == {"behind_encoder", "encoder_late", "encoder_early"}
+    assert len(dd["buckets"]) == 3 and sum(dd["buckets"]) == dd["allreduce_bytes_per_step"] and dd["buckets"][2] < dd["buckets"][1]
     assert all(v > 0 for v in dd["allreduce_in_step_us"].values())
