@@ -2797,8 +2797,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
-    auto kstep = [&](auto steady_tag, int k, int stage, Frags& cur, Frags& nxt) {
+    // a wave whose 64 channel rows lie entirely past Cin (the ragged last tile: 304 channels = 2.4 tiles of 128) keeps loading its
+    // pieces and meeting the barriers but issues no fragment reads and no MFMA: the tile costs the MFMA pipe what its live rows cost
+    auto kstep = [&](auto steady_tag, auto live_tag, int k, int stage, Frags& cur, Frags& nxt) {
         constexpr bool STEADY = decltype(steady_tag)::value;     // >= NSTAGE steps remain: no branches in the step
+        constexpr bool LIVE = decltype(live_tag)::value;
         const bool rd = STEADY || k + 1 < n, dm = STEADY || k + NSTAGE < n;
         const int sn = stage + 1 == NSTAGE ? 0 : stage + 1;
         if (rd) {
@@ -2810,9 +2813,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            mma_term(cur, g);
+            if constexpr (LIVE) mma_term(cur, g);
             __builtin_amdgcn_sched_barrier(0);
-            if (rd) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
+            if (LIVE && rd) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
             if (dm) issue_piece(g);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -2822,23 +2825,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE; ++s0)
         if (s0 < n) issue_all(s0);
-    if (n > 0) {
-        wait_pieces((n < NSTAGE ? n : NSTAGE) - 1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    auto run = [&](auto live_tag) {
+        constexpr bool LIVE = decltype(live_tag)::value;
+        if (n > 0) {
+            wait_pieces((n < NSTAGE ? n : NSTAGE) - 1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (LIVE) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
+                for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
+            }
+        }
+        int k = 0;
+        for (; k + NSTAGE + 1 < n; k += 2) {
+            kstep(std::true_type{}, live_tag, k, k % NSTAGE, F0, F1);
+            kstep(std::true_type{}, live_tag, k + 1, (k + 1) % NSTAGE, F1, F0);
+        }
+        for (; k + 1 < n; k += 2) {
+            kstep(std::false_type{}, live_tag, k, k % NSTAGE, F0, F1);
+            kstep(std::false_type{}, live_tag, k + 1, (k + 1) % NSTAGE, F1, F0);
+        }
+        if (k < n) kstep(std::false_type{}, live_tag, k, k % NSTAGE, F0, F1);
+    };
+    if (__builtin_amdgcn_readfirstlane(c0 + wm * (TM * 32) < p.Cin ? 1 : 0)) run(std::true_type{});
+    else {
+        run(std::false_type{});
+        return;                                              // nothing of this wave's rows exists
     }
-    int k = 0;
-    for (; k + NSTAGE + 1 < n; k += 2) {
-        kstep(std::true_type{}, k, k % NSTAGE, F0, F1);
-        kstep(std::true_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
-    }
-    for (; k + 1 < n; k += 2) {
-        kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
-        kstep(std::false_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
-    }
-    if (k < n) kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
 
     float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
 #pragma unroll
@@ -4002,9 +4015,15 @@ static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
     // 128-row tiles waste (128 - Cin % 128) rows of the last tile: 304 input channels (SegmentHead, decoders.py:107) fill
     // 2.4 of 3 tiles; 64-row tiles waste 5 % instead of 21 %
     const int rem = Cin % 128;
-    const bool narrow_m = big && g_wgrad_m64 && rem != 0 && rem <= 64 && (cdiv(Cin, 128) * 128 - Cin) * 100 > 12 * Cin;
     const int remn = Cout % 128;
     const bool narrow_n = big && g_wgrad_m64 && remn != 0 && remn <= 64 && (cdiv(Cout, 128) * 128 - Cout) * 100 > 12 * Cout;
+    const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    // MFMA-bound layers run the bf16x3 kernel (operand planes behind the partial sums in the workspace); a bias gradient then takes
+    // the separate column-sum pass at the end.  Its 128-row tiles skip the waves whose rows lie past Cin, so it keeps them for a
+    // ragged Cin (measured on 304 -> 256: 300 us against 312 us with 64-row tiles, profiles/r03_conv_x3.txt)
+    const X3WPlan xw = x3w_plan(B, H, W, Cin, Cout, p.M, p.taps.n, vec && big && !narrow_n);
+    const bool narrow_m = big && !xw.ok && g_wgrad_m64 && rem != 0 && rem <= 64 && (cdiv(Cin, 128) * 128 - Cin) * 100 > 12 * Cin;
     const int bm = big ? (narrow_m ? 64 : 128) : 64, bn = big ? (narrow_n ? 64 : 128) : 64;
     const int64_t tiles = cdiv(Cin, bm) * cdiv(Cout, bn) * p.taps.n;
     int64_t splits = cdiv(g_wgrad_target, tiles);
@@ -4019,11 +4038,6 @@ static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
     const size_t need = (size_t)splits * p.taps.n * Cin * Cout * 4;
     if (!workspace || ws_bytes < need) return fail(PP_ERR_WORKSPACE, "conv bwd_weight: workspace %zu < %zu", ws_bytes, need);
     p.part = reinterpret_cast<float*>(workspace);
-    const bool vec = g_conv_novec == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
-                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-    // MFMA-bound layers run the bf16x3 kernel (operand planes behind the partial sums in the workspace); a bias gradient then takes
-    // the separate column-sum pass at the end
-    const X3WPlan xw = x3w_plan(B, H, W, Cin, Cout, p.M, p.taps.n, vec && big && !narrow_n);
     const size_t x3_off = align_up(need + (size_t)64 * Cout * 4, 256);
     const bool use_x3 = xw.ok && ws_bytes >= x3_off + xw.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0;
     // bias gradient = column sums of dy: the blocks of tile column 0 read every dy tile anyway (no second pass over dy)
@@ -4051,10 +4065,8 @@ static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
             if (int rc = check_launch("x3_split_kernel")) return rc;
             X3WOperands o{xp, dp, xw.x_plane, xw.dy_plane, (uint32_t)((rows_x + 1) * 32), (uint32_t)((p.M + 1) * 32),
                           (uint32_t)(rows_x * 32), (uint32_t)(p.M * 32)};
-            const int bmx = narrow_m ? 64 : 128;
-            dim3 gx((unsigned)(cdiv(Cin, bmx) * p.taps.n), (unsigned)cdiv(Cout, 128), (unsigned)splits);
-            if (narrow_m) hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), gx, dim3(kThreads), 0, st, p, o);
-            else          hipLaunchKernelGGL((conv_wgrad_x3_kernel<128>), gx, dim3(kThreads), 0, st, p, o);
+            dim3 gx((unsigned)(cdiv(Cin, 128) * p.taps.n), (unsigned)cdiv(Cout, 128), (unsigned)splits);
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<128>), gx, dim3(kThreads), 0, st, p, o);
             goto reduce_partials;
         }
     }
