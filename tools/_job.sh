@@ -1,2 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_conv_x3_gpu.py tests/test_nn_ops_gpu.py -q -m gpu -x 2>&1 | tail -3
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r3s; mkdir -p $O
+for v in 0 -2; do
+  rm -rf /tmp/p$v; 
+  BNBYTES=$v STEPS=20 rocprofv3 --kernel-trace --stats -d /tmp/p$v -o t --output-format csv -- python tools/train_bench.py > /dev/null 2>&1
+  f=$(find /tmp/p$v -name "*kernel_stats.csv" | head -1)
+  echo "BNBYTES=$v"; grep "bn_fused" $f | cut -d, -f1-4 | head -8
+  cp $f $O/stats_$v.csv
+done
