@@ -45,6 +45,16 @@ def main():
         for _ in range(warm):
             loss = tr.train_step(x, y)
         torch.cuda.synchronize()
+        if os.environ.get("HOSTPROF"):                # cProfile of the host side of HOSTPROF steps, each issued into empty queues
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            for _ in range(int(os.environ["HOSTPROF"])):
+                torch.cuda.synchronize()
+                pr.enable()
+                tr.train_step(x, y)
+                pr.disable()
+            torch.cuda.synchronize()
+            pstats.Stats(pr).sort_stats("tottime").print_stats(45)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = tr.train_step(x, y)
