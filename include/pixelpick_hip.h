@@ -237,13 +237,18 @@ int pp_conv2d_fwd_bn_train(const float* x, int64_t ldx, int B, int H, int W, int
  * mobilenet_v2.py:52-56, depthwise BatchNorm / ReLU6 -> project convolution).  dy is the gradient of this convolution's output;
  * bn_x / mean / invstd / gamma / beta / act describe the BatchNorm whose output this convolution read; dx_bn receives the gradient of
  * the BatchNorm's INPUT (what pp_bn_bwd_fused would have written), dgamma / dbeta its parameter gradients.  The gradient of the
- * BatchNorm's output is never written.  Same xchg / sync areas as the single-launch BatchNorm; ask *_ok first. */
+ * BatchNorm's output is never written.  Same xchg / sync areas as the single-launch BatchNorm; ask *_ok first.
+ * A BatchNorm output with more consumers (mobilenet_v2.py:63-66: the block output feeds the next block's expand convolution AND
+ * its residual add) is handled when THIS convolution's backward is the last of them to run: grad_in (or NULL) = the gradient the
+ * output already holds from the others, added to the tile first (the `accumulate` of a plain backward-data); dres (or NULL) receives
+ * the gradient of the BatchNorm's own residual input (the masked total gradient, what pp_bn_bwd_fused writes to its dres). */
 int pp_conv2d_bwd_data_bn_bwd_ok(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 size_t pp_conv2d_bwd_data_bn_bwd_xchg_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 int pp_conv2d_bwd_data_bn_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw, int stride,
                               int pad, int dil, int H, int W, int Cin, const float* bn_x, int64_t ldbx, const float* mean,
                               const float* invstd, const float* gamma, const float* beta, int act, float* dgamma, float* dbeta,
-                              float* dx_bn, int64_t lddx, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
+                              float* dx_bn, int64_t lddx, const float* grad_in, int64_t ldgi, float* dres, int64_t lddr,
+                              void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
 
 /* Deferred reduces.  A weight gradient is a partial-sum kernel ([slices][...] in the workspace) followed by a small
  * fixed-order reduce; a backward pass has ~60 of them (model.py:121 loss.backward()).  The *_partials forms run only the
@@ -535,6 +540,7 @@ void pp_debug_set_bn_probe(void* device_buffer);
 int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);
 void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 12 (defaults 384 / 128) */
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
+void pp_debug_set_conv_bn_fuse(int bits);   /* fused conv + BatchNorm launches offered: bit 0 tiled fwd, 1 split-K fwd, 2 bwd 64x64, 3 bwd split-K / 128x32 (default 15; A/B) */
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */
 void pp_debug_set_conv_variant(int v);
 

@@ -54,7 +54,7 @@ SIGNATURES = {
     "pp_conv2d_bwd_data_bn_bwd_ok": (_int, [_int] * 10),
     "pp_conv2d_bwd_data_bn_bwd_xchg_bytes": (_sz, [_int] * 10),
     "pp_conv2d_bwd_data_bn_bwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _int, _int, _int, _p, _i64, _p, _p, _p, _p,
-                                         _int, _p, _p, _p, _i64, _p, _sz, _p, _sz, _p]),
+                                         _int, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _sz, _p, _sz, _p]),
     "pp_x3_planes_bytes": (_sz, [_i64, _int]),
     "pp_x3_split": (_int, [_p, _i64, _i64, _int, _p, _sz, _p]),
     "pp_conv2d_x3_planes_bytes": (_sz, [_int] * 11),
@@ -123,6 +123,7 @@ SIGNATURES = {
     "pp_debug_set_conv_thresholds": (None, [_int]),
     "pp_debug_conv_plan": (None, [_i64, _int, _int, _int, _p]),
     "pp_debug_set_conv_variant": (None, [_int]),
+    "pp_debug_set_conv_bn_fuse": (None, [_int]),
     "pp_debug_set_x3": (None, [_int]),
     "pp_debug_set_kernel_events": (None, [_p, _p, _int]),
 }

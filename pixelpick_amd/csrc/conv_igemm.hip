@@ -56,6 +56,10 @@ struct BnTrain {
     // backward form (a backward-data convolution that also runs the BatchNorm backward of the layer in FRONT of it, conv_epilogue_bn_bwd):
     // bx = the BatchNorm's input, mean / invstd are inputs, y receives the gradient of that input, dgamma / dbeta the parameter gradients
     const float* bx; int64_t ldbx; float* dgamma; float* dbeta;
+    // backward form, a BatchNorm output with MORE consumers / a residual input: gin = the gradient the output already holds from the
+    // consumers whose backward ran earlier (added to the tile before anything else, the `accumulate` of a plain backward-data), dres =
+    // where the gradient of the BatchNorm's residual input goes (the masked gradient itself).  NULL: none.
+    const float* gin; int64_t ldgin; float* dres; int64_t lddr;
 };
 
 struct ConvParams {
@@ -417,6 +421,7 @@ __device__ __forceinline__ void conv_epilogue_bn_bwd(const ConvParams& p, f32x16
                 const float x = in ? bn.bx[m * bn.ldbx + n] : 0.0f;
                 xs[tm][tn][r] = x;
                 float u = in ? acc[tm][tn][r] : 0.0f;
+                if (in && bn.gin) u += bn.gin[m * bn.ldgin + n];
                 if (bn.act != 0) u *= act_mask(fmaf(x, zsc, zsf), bn.act);
                 acc[tm][tn][r] = u;
                 s1 += u;
@@ -443,7 +448,10 @@ __device__ __forceinline__ void conv_epilogue_bn_bwd(const ConvParams& p, f32x16
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m < p.M) bn.y[m * bn.ldy + n] = bn_dx(acc[tm][tn][r], xs[tm][tn][r], mu_[tn], is_[tn], ga_[tn], db, dg, inv_count);
+                if (m < p.M) {
+                    if (bn.dres) bn.dres[m * bn.lddr + n] = acc[tm][tn][r];
+                    bn.y[m * bn.ldy + n] = bn_dx(acc[tm][tn][r], xs[tm][tn][r], mu_[tn], is_[tn], ga_[tn], db, dg, inv_count);
+                }
             }
     }
 }
@@ -733,11 +741,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvParams p)
         __syncthreads();
     }
 
-    if constexpr (BM == 128 && BN == 32 && WM == 4 && WN == 1 && !BWD && VEC && BKT == BK) {
-        if (p.bn.part) {                                           // conv -> training BatchNorm in this launch (conv_epilogue_bn)
+    if constexpr (BM == 128 && BN == 32 && WM == 4 && WN == 1 && VEC && BKT == BK) {
+        if (p.bn.part) {                                           // conv -> training BatchNorm in this launch (conv_epilogue_bn / _bwd)
             __syncthreads();                                       // the tiles are scratch from here on
             static_assert(BM * PITCH_A >= BnScratch<32, 4>::kFloats, "the exchange scratch fits the A tile");
-            conv_epilogue_bn<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, mt, As, p.bn.part ? tag_issue(p.bn.sync) : 0u);
+            if constexpr (BWD) conv_epilogue_bn_bwd<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, mt, As, tag_issue(p.bn.sync));
+            else               conv_epilogue_bn<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, mt, As, tag_issue(p.bn.sync));
             return;
         }
     }
@@ -1112,7 +1121,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
     const int64_t m0 = (int64_t)mt * (32 * TM);
     const int n0 = nt * BN;
     unsigned tag0 = 0;                                       // conv -> BatchNorm in one launch: the exchange tag, requested now
-    if constexpr (!BWD && !AFF) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
+    if constexpr (!AFF) { if (p.bn.part) tag0 = tag_issue(p.bn.sync); }
     const float* zero = g_zero16;
     asm volatile("" : "+v"(zero));
     float* wsm = smem + wave * WAVE_FL;
@@ -1349,6 +1358,83 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
                             float o = fmaf(v, sc, sf);
                             if (p.bn.res) o += p.bn.res[m * p.bn.ldr + n_col];
                             p.bn.y[m * p.bn.ldy + n_col] = epi_act(o, p.bn.act);
+                        }
+                    }
+            }
+            return;
+        }
+    }
+    if constexpr (BWD && !AFF) {
+        if (p.bn.part) {
+            // backward-data + the BatchNorm backward of the layer in front, in this launch (see conv_epilogue_bn_bwd): the lane's rows of
+            // the gradient tile, summed over the four K slices in wave order, and the BatchNorm's input at the same elements stay in
+            // registers across the exchange
+            constexpr int BNT = TN * 32;
+            const BnTrain& bn = p.bn;
+            float vv[TM][TN][4], xs[TM][TN][4];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int e = ((tm * TN + tn) * 16 + wave * 4 + rr) * 64 + lane;
+                        float v = smem[0 * WAVE_FL + e];
+                        v += smem[1 * WAVE_FL + e];
+                        v += smem[2 * WAVE_FL + e];
+                        v += smem[3 * WAVE_FL + e];
+                        vv[tm][tn][rr] = v;
+                    }
+            __syncthreads();                                 // every partial tile has been read: the rings are scratch now
+            const BnScratch<BNT, 4> S(smem);
+            static_assert(4 * WAVE_FL >= BnScratch<BNT, 4>::kFloats, "the exchange scratch fits the rings");
+            float mu_[TN], is_[TN], ga_[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n_col = n0 + tn * 32 + l31;
+                const bool ok = n_col < p.Cn;
+                const float mu = ok ? bn.mean[n_col] : 0.0f, is = ok ? bn.invstd[n_col] : 0.0f, ga = ok ? bn.gamma[n_col] : 0.0f,
+                            be = ok ? bn.beta[n_col] : 0.0f;
+                mu_[tn] = mu; is_[tn] = is; ga_[tn] = ga;
+                const float zsc = ga * is, zsf = be - mu * zsc;
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int64_t m = m0 + tm * 32 + rr + 8 * wave + 4 * h;
+                        const bool in = ok && m < p.M;
+                        const float x = in ? bn.bx[m * bn.ldbx + n_col] : 0.0f;
+                        xs[tm][tn][rr] = x;
+                        float u = in ? vv[tm][tn][rr] : 0.0f;
+                        if (in && bn.gin) u += bn.gin[m * bn.ldgin + n_col];
+                        if (bn.act != 0) u *= act_mask(fmaf(x, zsc, zsf), bn.act);
+                        vv[tm][tn][rr] = u;
+                        s1 += u;
+                        s2 = fmaf(u, (x - mu) * is, s2);
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    S.colsum[(0 * 4 + wave) * BNT + tn * 32 + l31] = s1;
+                    S.colsum[(1 * 4 + wave) * BNT + tn * 32 + l31] = s2;
+                }
+            }
+            bn_block_finish<BNT, 4, true>(p, S, n0, mt, tag0);
+            const float inv_count = 1.0f / (float)p.M;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int c = tn * 32 + l31, n_col = n0 + c;
+                if (n_col >= p.Cn) continue;
+                const float db = S.aff[c], dg = S.aff[BNT + c];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int64_t m = m0 + tm * 32 + rr + 8 * wave + 4 * h;
+                        if (m < p.M) {
+                            if (bn.dres) bn.dres[m * bn.lddr + n_col] = vv[tm][tn][rr];
+                            bn.y[m * bn.ldy + n_col] = bn_dx(vv[tm][tn][rr], xs[tm][tn][rr], mu_[tn], is_[tn], ga_[tn], db, dg, inv_count);
                         }
                     }
             }
@@ -3086,7 +3172,8 @@ static int conv_bn_capacity(int which = 0)        // 0: conv_igemm_dma_kernel<64
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 32, 4, 1, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
     return cap[which];
 }
-static thread_local int g_conv_bn_fuse = 7;      // bit 0: fused conv + BatchNorm epilogue of the tiled kernels, bit 1: of the in-block split-K kernel, bit 2: backward form
+static thread_local int g_conv_bn_fuse = 15;     // bit 0: fused conv + BatchNorm epilogue of the tiled kernels, bit 1: of the in-block split-K kernel, bit 2: backward form,
+                                                 // bit 3: backward form of the in-block split-K kernel
 static int ksplit_bn_capacity(int which)         // 0: <1,1,5>, 1: <2,1,3> (the forward candidates)
 {
     static const int cap[2] = {
@@ -3126,10 +3213,19 @@ static BnFusePlan bn_fuse_plan(const ConvParams& p, const ConvPlan& pl, bool vec
 }
 
 // backward-data convolution + BatchNorm backward (conv_epilogue_bn_bwd): the 64x64-tiled LDS-DMA kernel, whole grid co-resident
-static int conv_bn_bwd_capacity()
+static int conv_bn_bwd_capacity(int which = 0)   // 0: conv_igemm_dma_kernel<64, 64, true, true>, 1: conv_igemm_kernel<128, 32, 4, 1, true, true>
 {
-    static const int cap = [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, true, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }();
-    return cap;
+    static const int cap[2] = {
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, true, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 32, 4, 1, true, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
+    return cap[which];
+}
+static int ksplit_bn_bwd_capacity(int which)     // 0: <1,1,5>, 1: <1,2,3> (the backward candidates)
+{
+    static const int cap[2] = {
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<1, 1, 5, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
+        [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<1, 2, 3, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
+    return cap[which];
 }
 static BnFusePlan bn_fuse_plan_bwd(const ConvParams& p, const ConvPlan& pl, bool vec)
 {
@@ -3137,10 +3233,22 @@ static BnFusePlan bn_fuse_plan_bwd(const ConvParams& p, const ConvPlan& pl, bool
     if (!(g_conv_bn_fuse & 4) || !vec || p.stats || p.in_scale || p.bias || p.epi.gamma || p.epi.res || p.epi.act != 0 || p.accumulate || p.bwd_stride > 1 ||
         p.stride != 1 || p.Cn % 32 != 0 || (int64_t)p.B * p.H * p.W * p.ldx >= (1ll << 31) - (1ll << 24))
         return f;
-    if (ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride)) return f;
+    if (ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride)) {
+        // few-row, deep-K pointwise layers (the expand convolutions' backward-data at 1/16 resolution): the in-block split-K kernel
+        if (!(g_conv_bn_fuse & 8) || p.Cout % 4 != 0 || (int64_t)p.Cin * p.Cout >= (1ll << 31) - (1ll << 24)) return f;
+        const KsplitCfg kc = ksplit_choose(p.M, p.Cn, true, g_conv_ksplit - 1);
+        if (kc.tm != 1) return f;                            // (a forced forward candidate)
+        const int64_t blocks = cdiv(p.M, 32) * cdiv(p.Cn, 32 * kc.tn);
+        if (blocks > ksplit_bn_bwd_capacity(kc.tn == 2 ? 1 : 0) / 2) return f;
+        f.kind = 2; f.R = (int)cdiv(p.M, 32); f.blocks = blocks; f.kc = kc;
+        return f;
+    }
     const bool dma_ok = g_conv_dma64 == 1 && p.taps.n <= 32 && (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
-    if (pl.cfg == 2 && pl.splits == 1 && dma_ok && pl.tiles <= conv_bn_bwd_capacity() / 2) {
+    // (a plan with grid split-K - few tiles, deep K - runs as ONE pass here: the split's second launch is what the fusion removes)
+    if (pl.cfg == 2 && (pl.splits == 1 || (g_conv_bn_fuse & 8)) && dma_ok && pl.tiles <= conv_bn_bwd_capacity() / 2) {
         f.kind = 1; f.R = (int)cdiv(p.M, 64); f.blocks = pl.tiles;
+    } else if (pl.cfg == 0 && p.Cn == 32 && (g_conv_bn_fuse & 8) && pl.tiles <= conv_bn_bwd_capacity(1) / 2) {
+        f.kind = 4; f.R = (int)cdiv(p.M, 128); f.blocks = pl.tiles;                               // 128 x 32 register-staged kernel
     }
     return f;
 }
@@ -3162,8 +3270,18 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         p.bn.R = f.R;
         p.splits = 1; p.ks_per_split = 0; p.part = nullptr;
         if constexpr (BWD) {
+            if (f.kind == 2) {
+                p.n_tiles = (int)cdiv(p.Cn, 32 * f.kc.tn);
+                if (f.kc.tn == 2) hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<1, 2, 3, true>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
+                else              hipLaunchKernelGGL((conv1x1_ksplit_dma_kernel<1, 1, 5, true>), dim3((unsigned)f.blocks), dim3(kThreads), 0, st, p);
+                return check_launch("conv1x1_ksplit_dma_kernel<bn bwd>");
+            }
             p.tap_inner = g_conv_tap_inner;
             p.n_tiles = pl.n_tiles;
+            if (f.kind == 4) {
+                hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, true, true>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
+                return check_launch("conv_igemm_kernel<bn bwd>");
+            }
             hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, true, true>), dim3((unsigned)pl.tiles), dim3(kThreads), 0, st, p);
             return check_launch("conv_igemm_dma_kernel<bn bwd>");
         }
@@ -3455,6 +3573,10 @@ void pp_debug_set_splitk(int v)
     g_splitk_min_nk = ((v >> 20) & 63) ? ((v >> 20) & 63) : 12;
     g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
+
+/* which shapes pp_conv2d_fwd_bn_train_ok / pp_conv2d_bwd_data_bn_bwd_ok accept (A/B): bit 0 tiled forward kernels, 1 in-block split-K
+ * forward, 2 backward form (64x64 tiles), 3 backward form of the in-block split-K and the 128x32 kernels; default 15 */
+void pp_debug_set_conv_bn_fuse(int bits) { g_conv_bn_fuse = bits & 15; }
 
 /* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
 void pp_debug_set_x3(int v)
@@ -3913,7 +4035,8 @@ size_t pp_conv2d_bwd_data_bn_bwd_xchg_bytes(int B, int H, int W, int Cin, int Co
 int pp_conv2d_bwd_data_bn_bwd(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw, int stride,
                               int pad, int dil, int H, int W, int Cin, const float* bn_x, int64_t ldbx, const float* mean,
                               const float* invstd, const float* gamma, const float* beta, int act, float* dgamma, float* dbeta,
-                              float* dx_bn, int64_t lddx, void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
+                              float* dx_bn, int64_t lddx, const float* grad_in, int64_t ldgi, float* dres, int64_t lddr,
+                              void* xchg, size_t xchg_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
 {
     if (int rc = conv_common_check(dy, w, dx_bn, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
@@ -3929,7 +4052,7 @@ int pp_conv2d_bwd_data_bn_bwd(const float* dy, int64_t lddy, int B, int Ho, int 
     if (xchg_bytes < need) return fail(PP_ERR_WORKSPACE, "conv bwd_data + BatchNorm bwd: exchange area %zu < %zu", xchg_bytes, need);
     p.x = dy; p.w = w; p.bias = nullptr; p.y = dx_bn; p.ldy = lddx;
     p.bn = BnTrain{gamma, beta, 0.0f, 0.0f, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(invstd), nullptr, 0, act, dx_bn, lddx,
-                   reinterpret_cast<xword*>(xchg), sync, 0, bn_x, ldbx, dgamma, dbeta};
+                   reinterpret_cast<xword*>(xchg), sync, 0, bn_x, ldbx, dgamma, dbeta, grad_in, ldgi, dres, lddr};
     return launch_conv<true>(p, nullptr, 0, as_stream(stream), kh * kw);
 }
 

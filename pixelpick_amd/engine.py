@@ -29,7 +29,7 @@ class Var:
     tensor does not exist yet.  If the next consumer is an eval-mode BatchNorm, conv + BN (+ residual) + activation go
     out as ONE launch (pp_conv2d_fwd_bn_act / pp_dwconv3x3_fwd_bn_act); any other consumer reads `.t`, which launches
     the plain convolution first."""
-    __slots__ = ("_t", "grad", "needs_grad", "_pending", "_lazy", "_bn_bwd_ctx")
+    __slots__ = ("_t", "grad", "needs_grad", "_pending", "_lazy", "_bn_bwd_ctx", "_closed")
 
     def __init__(self, t: Optional[torch.Tensor], needs_grad: bool = True):
         self._t = t
@@ -39,9 +39,12 @@ class Var:
         # training BatchNorm whose apply pass was skipped (_BN_ON_LOAD): (raw [B,H,W,C], scale [C], shift [C], act) - the value
         # is act(raw * scale + shift); consumers that take the pair apply it where they load, `.t` materialises it for the rest
         self._lazy = None
-        # output of a training BatchNorm (+ activation) with ONE consumer (the caller said so): (input Var, gamma, beta, mean, invstd,
-        # act) - a dense convolution consuming it may run this BatchNorm's backward inside its own backward-data launch
+        # output of a training BatchNorm (+ residual, activation) whose consumers the caller named: (input Var, gamma, beta, mean,
+        # invstd, act, residual Var or None, consumers) - the dense convolution that reads it FIRST (so whose backward runs last) may
+        # run this BatchNorm's backward inside its own backward-data launch.  _closed: that has happened - a gradient arriving
+        # afterwards means the consumer count was wrong, and raises
         self._bn_bwd_ctx = None
+        self._closed = False
 
     @property
     def t(self) -> torch.Tensor:
@@ -614,6 +617,9 @@ def _acc(v: Var, g: torch.Tensor):
     """Accumulate gradient g into v (pp_add2d when v already holds one)."""
     if not v.needs_grad:
         return
+    if v._closed:
+        raise RuntimeError("a gradient arrived at a BatchNorm output whose backward already ran inside its consumer's backward-data "
+                           "launch: the `consumers` hint given to batch_norm_act was too small")
     if v.grad is None:
         v.grad = g
         return
@@ -865,24 +871,43 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
         tape.set_param_grad(w, dw)
         if db is not None:
             tape.set_param_grad(bias, db)
-    bctx = x._bn_bwd_ctx if (x.needs_grad and x.grad is None and _CONV_BN_FUSE_BWD and lazy_in is None) else None
+    if x._closed:
+        raise RuntimeError("a second convolution's backward reached a BatchNorm output whose backward already ran (wrong `consumers` hint)")
+    bctx = x._bn_bwd_ctx if (x.needs_grad and _CONV_BN_FUSE_BWD and lazy_in is None) else None
+    if bctx is not None:
+        # every OTHER consumer's gradient must be here already (their backward ran earlier: they read x later in the forward);
+        # one other consumer = the residual add of the block behind, whose gradient is a contiguous tensor of x's shape
+        have = x.grad is not None
+        if bctx[7] != (2 if have else 1) or (have and not (x.grad.is_contiguous() and tuple(x.grad.shape) == (B, H, W, Cin))):
+            bctx = None
     if bctx is not None and bctx[0].needs_grad and _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) and _bn_exchange_ok(dev):
-        # x is the output of a training BatchNorm (+ activation) that only this convolution reads: its backward runs inside this
-        # backward-data launch (pp_conv2d_bwd_data_bn_bwd) - the BatchNorm node then finds no gradient on its output and is skipped
-        bin_, g_, b_, mean_, invstd_, act_ = bctx
+        # x is the output of a training BatchNorm (+ residual, activation) and this convolution's backward is the last of its
+        # consumers' to run: the BatchNorm's backward runs inside this backward-data launch (pp_conv2d_bwd_data_bn_bwd) - the BatchNorm
+        # node then finds no gradient on its output and is skipped
+        bin_, g_, b_, mean_, invstd_, act_, res_, _ = bctx
         _, _, _, _, ldb = _geom(bin_.t)
         dxbn = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        dres = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev) if (res_ is not None and res_.needs_grad) else None
+        gin = x.grad
         dg_, db_ = tape.grad_buffer_for(g_), tape.grad_buffer_for(b_)
         sync, xws = _bn_exchange(dev)
         rc = L.pp_conv2d_bwd_data_bn_bwd(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil, H, W, Cin,
                                          bin_.t.data_ptr(), ldb, mean_.data_ptr(), invstd_.data_ptr(), g_.data_ptr(), b_.data_ptr(), act_,
-                                         dg_.data_ptr(), db_.data_ptr(), dxbn.data_ptr(), Cin, xws.data_ptr(), xws.numel(),
-                                         sync.data_ptr(), sync.numel(), _stream())
+                                         dg_.data_ptr(), db_.data_ptr(), dxbn.data_ptr(), Cin,
+                                         gin.data_ptr() if gin is not None else None, Cin, dres.data_ptr() if dres is not None else None, Cin,
+                                         xws.data_ptr(), xws.numel(), sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_conv2d_bwd_data_bn_bwd")
         tape.set_param_grad(g_, dg_)
         tape.set_param_grad(b_, db_)
+        if gin is not None:
+            tape._keepalive.append(gin)
+        x.grad = None                    # consumed here: the BatchNorm node is skipped
+        x._closed = True
         dxbn._pp_owned = True
         _acc(bin_, dxbn)
+        if dres is not None:
+            dres._pp_owned = True
+            _acc(res_, dres)
     elif x.needs_grad:
         # x already has a gradient from another consumer (the residual branch): add into it in the kernel's epilogue
         acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
@@ -1032,7 +1057,7 @@ def _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
     return _wsbytes("pp_conv2d_bwd_data_bn_bwd_xchg_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil) <= _BN_XCHG_PART_BYTES
 
 
-def _conv_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst):
+def _conv_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst, ncons=0):
     """x is a DEFERRED dense convolution followed by this training BatchNorm: one launch (pp_conv2d_fwd_bn_train).  None: not
     applicable (x stays deferred, the caller takes the ordinary path)."""
     _, xin, w, bias, stride, pad, dil = x._pending
@@ -1067,6 +1092,8 @@ def _conv_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_
     x._t = raw
     out = Var(y)
     tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0), out)
+    if ncons:
+        out._bn_bwd_ctx = (x, gamma, beta, mean, invstd, act, residual, ncons)
     return out
 
 
@@ -1157,7 +1184,8 @@ def _bn_on_load(tape: Tape, x: Var, gamma, beta, running_mean, running_var, act,
 
 def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE,
                    residual: Optional[Var] = None, eps: float = 1e-5, momentum: float = 0.1,
-                   dst: Optional[torch.Tensor] = None, dropout_p: float = 0.0, lazy_ok: bool = False, single_consumer: bool = False) -> Var:
+                   dst: Optional[torch.Tensor] = None, dropout_p: float = 0.0, lazy_ok: bool = False, single_consumer: bool = False,
+                   consumers: int = 0) -> Var:
     """nn.BatchNorm2d -> (+ residual) -> activation [-> nn.Dropout(dropout_p), already known to be active].
     Training: batch statistics + running-stat update; the dropout rides in the single-launch kernel's apply pass.
     lazy_ok: the caller knows that the ONLY consumer is a depthwise convolution or a pointwise convolution that
@@ -1175,7 +1203,9 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         return Var(x._t, needs_grad=False)
     L = _lib.lib()
     if training and x._pending is not None and x._pending[0] == "conv" and tape.enabled and _CONV_BN_FUSE and dropout_p == 0.0:
-        out = _conv_bn_train_fused(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst)
+        ncons = consumers if consumers > 0 else (1 if (lazy_ok or single_consumer) else 0)
+        out = _conv_bn_train_fused(tape, x, gamma, beta, running_mean, running_var, act, residual, eps, momentum, dst,
+                                   ncons if (dst is None and (residual is None or act == ACT_NONE)) else 0)
         if out is not None:
             return out
     if training and x._pending is not None and x._pending[0] == "conv" and tape.enabled and _CONV_BN_STATS:
@@ -1215,8 +1245,9 @@ def batch_norm_act(tape: Tape, x: Var, gamma, beta, running_mean, running_var, t
         _lib.check(rc, "pp_bn_train_fwd_fused")
         out = Var(y)
         tape.record(_bn_bwd, (x, gamma, beta, mean, invstd, act, residual, out, 1.0 / (1.0 - dropout_p)), out)
-        if (lazy_ok or single_consumer) and residual is None and dropout_p == 0.0 and dst is None:
-            out._bn_bwd_ctx = (x, gamma, beta, mean, invstd, act)
+        ncons = consumers if consumers > 0 else (1 if (lazy_ok or single_consumer) else 0)
+        if ncons and dropout_p == 0.0 and dst is None and (residual is None or act == ACT_NONE):
+            out._bn_bwd_ctx = (x, gamma, beta, mean, invstd, act, residual, ncons)
         return out
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     shift = torch.empty(C, dtype=torch.float32, device=dev)

@@ -31,9 +31,10 @@ def fixed_padding_amounts(kernel_size, dilation):
     return pad_beg, pad_total - pad_beg
 
 
-def _run_conv_bn_act_chain(tape, seq, x, residual=None, first_pad=0):
+def _run_conv_bn_act_chain(tape, seq, x, residual=None, first_pad=0, out_consumers=0):
     """Execute an nn.Sequential of [Conv2d, BatchNorm2d, (ReLU6)] groups; the last BN may take a residual.
-    first_pad: zero padding of x folded into the first convolution."""
+    first_pad: zero padding of x folded into the first convolution.  out_consumers: how many ops read the chain's output, the first
+    of them a dense convolution (BatchNorm2d.run `consumers`); 0: unknown."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -46,7 +47,7 @@ def _run_conv_bn_act_chain(tape, seq, x, residual=None, first_pad=0):
         nxt = i + (3 if has_act else 2)
         lazy_ok = (not is_last) and tape.enabled and mods[nxt].accepts_lazy_input(E.shape_of(x))
         x = bn.run(tape, x, E.ACT_RELU6 if has_act else E.ACT_NONE, residual if is_last else None, lazy_ok=lazy_ok,
-                   single_consumer=not is_last)
+                   single_consumer=not is_last, consumers=out_consumers if is_last else 0)
         i = nxt
     return x
 
@@ -70,16 +71,22 @@ class InvertedResidual(nn.Module):
                    Conv2d(hidden_dim, oup, 1, 1, 0, 1, bias=False), BatchNorm(oup)]
         self.conv = nn.Sequential(*layers)
 
-    def run(self, tape, x):
+    def takes_input_through_a_dense_conv(self):
+        """The block's input is read by its expand convolution first (with the fixed padding folded into it), then - in a residual
+        block - by the add behind the project BatchNorm: the producer of that input may be told so (`out_consumers`)."""
+        pad_beg, pad_end = fixed_padding_amounts(self.kernel_size, self.dilation)
+        return FOLD_FIXED_PADDING and pad_beg == pad_end and not self.conv[0].depthwise
+
+    def run(self, tape, x, out_consumers=0):
         pad_beg, pad_end = fixed_padding_amounts(self.kernel_size, self.dilation)
         res = x if self.use_res_connect else None
         if FOLD_FIXED_PADDING and pad_beg == pad_end:
             # F.pad(x) followed by a bias-free 1x1 conv (or the depthwise 3x3 of the t=1 block) is that convolution
             # with padding=pad: the border outputs are the same zeros, the BN statistics over the padded map too,
             # and neither the padded copy (forward) nor its cropped gradient (backward) is materialised.
-            return _run_conv_bn_act_chain(tape, self.conv, x, residual=res, first_pad=pad_beg)
+            return _run_conv_bn_act_chain(tape, self.conv, x, residual=res, first_pad=pad_beg, out_consumers=out_consumers)
         x_pad = E.pad2d(tape, x, pad_beg, pad_end)
-        return _run_conv_bn_act_chain(tape, self.conv, x_pad, residual=res)
+        return _run_conv_bn_act_chain(tape, self.conv, x_pad, residual=res, out_consumers=out_consumers)
 
 
 class MobileNetV2(nn.Module):
@@ -154,7 +161,16 @@ class MobileNetV2(nn.Module):
         for j, m in enumerate(mods):
             if mark_before is not None and j == mark_before:
                 tape.mark("encoder_late_done")
-            if isinstance(m, (InvertedResidual, Dropout2d)):
+            if isinstance(m, InvertedResidual):
+                # the block behind (inside THIS Sequential: the last block's output leaves it) reads the output through its expand
+                # convolution first, then - a residual block - through its add: its backward-data takes this block's project
+                # BatchNorm backward along (engine._conv2d_bwd)
+                nxt = mods[j + 1] if j + 1 < len(mods) else None
+                nc = 0
+                if tape.enabled and isinstance(nxt, InvertedResidual) and nxt.takes_input_through_a_dense_conv():
+                    nc = 2 if nxt.use_res_connect else 1
+                x = m.run(tape, x, out_consumers=nc)
+            elif isinstance(m, Dropout2d):
                 x = m.run(tape, x)
             else:  # stem conv_bn; its only consumer is the depthwise conv of the t=1 block behind it (no residual there)
                 nxt = mods[j + 1] if j + 1 < len(mods) else None

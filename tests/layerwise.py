@@ -183,8 +183,8 @@ class LayerwiseParity:
                     me._fwd_site("conv", ent[0], ent[0], x)
             return got
 
-        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None, lazy_ok=False, single_consumer=False):
-            out = bn_run(self, tape, x, act, residual, dst, dropout, lazy_ok, single_consumer)
+        def bn_run_p(self, tape, x, act=E.ACT_NONE, residual=None, dst=None, dropout=None, lazy_ok=False, single_consumer=False, consumers=0):
+            out = bn_run(self, tape, x, act, residual, dst, dropout, lazy_ok, single_consumer, consumers)
             n = me.mod_name[id(self)]
             site = me.tr.site(n, residual is not None)
             me.res_nodes[n] = residual is not None

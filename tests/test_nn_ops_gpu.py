@@ -486,6 +486,101 @@ def test_batchnorm_backward_inside_the_consumer_convolutions_backward_data(case,
     close(a[4].cpu(), br.grad, what="dbeta")
 
 
+LAST_CONSUMER_BN_BWD = [
+    # B, H, W, Cexp (project conv input), C (BatchNorm channels), pad of the consuming 1x1 convolution, BatchNorm residual, consumers
+    (4, 16, 32, 384, 64, 0, True, 2),      # 1/16 resolution, in-block split-K backward-data, one 64-wide tile
+    (4, 16, 32, 384, 96, 1, True, 1),      # ragged second column tile; the fixed padding folded into the convolution
+    (4, 16, 32, 576, 160, 0, False, 2),    # three column tiles, no residual into the BatchNorm, residual add behind
+    (4, 16, 32, 192, 64, 1, False, 1),
+    (4, 32, 64, 144, 32, 0, True, 2),      # 1/8 resolution, 32 channels: the 128x32 register-staged kernel (its grid split-K plan as one pass)
+    (4, 32, 64, 144, 32, 1, False, 1),
+    (4, 32, 64, 192, 64, 0, True, 2),      # 64x64 LDS-DMA tiles with a gradient already there and a residual gradient to write
+    (2, 9, 11, 96, 32, 0, True, 2),        # ragged rows
+    (2, 9, 11, 96, 32, 1, True, 1),
+]
+
+
+@pytest.mark.parametrize("case", LAST_CONSUMER_BN_BWD, ids=[str(c) for c in LAST_CONSUMER_BN_BWD])
+def test_batchnorm_backward_inside_the_last_consumers_backward_data(case, monkeypatch):
+    """mobilenet_v2.py:63-66 across two InvertedResiduals: project convolution -> BatchNorm (+ the block's residual) = the block
+    output, read FIRST by the next block's expand convolution (fixed padding folded in) and then by that block's residual add
+    (`consumers=2`).  The expand convolution's backward runs last: its backward-data launch adds the gradient that is already
+    there, runs the BatchNorm backward and writes the gradient of the BatchNorm's residual input (pp_conv2d_bwd_data_bn_bwd with
+    grad_in / dres).  Every gradient equals the separate-launch path to fp32 rounding and torch autograd; repeated runs are
+    bit-identical; the BatchNorm output is closed afterwards."""
+    B, H, W, Cexp, C, pad, with_res, ncons = case
+    gen = torch.Generator().manual_seed(Cexp + C + pad)
+    x = torch.randn(B, Cexp, H, W, generator=gen)
+    wp = torch.randn(C, Cexp, 1, 1, generator=gen) / np.sqrt(Cexp)
+    we = torch.randn(6 * C, C, 1, 1, generator=gen) / np.sqrt(C)
+    wf = torch.randn(C, 6 * C, 1, 1, generator=gen) / np.sqrt(6 * C)
+    res = torch.randn(B, C, H, W, generator=gen)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    Ho, Wo = H + 2 * pad, W + 2 * pad
+    dy = torch.randn(B, C, Ho, Wo, generator=gen)
+    if ncons == 2:
+        assert pad == 0
+    def run(fuse):
+        monkeypatch.setattr(E, "_CONV_BN_FUSE_BWD", fuse)
+        tape = E.Tape()
+        xv, rv = E.Var(nhwc(x)), (E.Var(nhwc(res)) if with_res else None)
+        wpg, weg, wfg, gg, bg = gparam(hwio(wp)), gparam(hwio(we)), gparam(hwio(wf)), gparam(gamma), gparam(beta)
+        pr = E.conv2d(tape, xv, wpg, None, 1, 0, 1)
+        y = E.batch_norm_act(tape, pr, gg, bg, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, E.ACT_NONE, rv, consumers=ncons)
+        assert y._bn_bwd_ctx is not None
+        e = E.conv2d(tape, y, weg, None, 1, pad, 1)
+        f = E.conv2d(tape, e, wfg, None, 1, 0, 1)
+        out = E.add(tape, f, y) if ncons == 2 else f
+        tape.backward(out, nhwc(dy))
+        torch.cuda.synchronize()
+        return y._closed, [xv.grad.clone()] + ([rv.grad.clone()] if with_res else []) + [tape.param_grads[id(t)].clone() for t in (wpg, weg, wfg, gg, bg)]
+
+    c1, a = run(True)
+    _, a2 = run(True)
+    c0, b = run(False)
+    assert E._conv_bn_bwd_fusable(B, H, W, C, 6 * C, 1, 1, 1, pad, 1), "the fused path is not available for this case"
+    assert c1 and not c0, "the fused path was not taken"
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= 2e-5 * (v.abs().max().item() + 1e-6)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    wpr, wer, wfr = wp.clone().requires_grad_(True), we.clone().requires_grad_(True), wf.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.batch_norm(F.conv2d(xr, wpr), None, None, gr, br, True, 0.1, 1e-5)
+    if with_res:
+        yr = yr + rr
+    fr = F.conv2d(F.conv2d(yr, wer, padding=pad), wfr)
+    (fr + yr if ncons == 2 else fr).backward(dy)
+    i = 0
+    close(nchw(a[i]), xr.grad, what="dx through the fused BatchNorm backward"); i += 1
+    if with_res:
+        close(nchw(a[i]), rr.grad, what="gradient of the BatchNorm's residual input"); i += 1
+    close(a[i + 3].cpu(), gr.grad, what="dgamma")
+    close(a[i + 4].cpu(), br.grad, what="dbeta")
+
+
+def test_a_late_gradient_at_a_closed_batchnorm_output_raises(monkeypatch):
+    """A `consumers` hint that is too small must not lose a gradient silently: the BatchNorm output is closed once its backward ran
+    inside the convolution's launch, and a gradient arriving afterwards raises."""
+    monkeypatch.setattr(E, "_CONV_BN_FUSE_BWD", True)
+    B, H, W, Cexp, C = 4, 16, 32, 384, 64
+    gen = torch.Generator().manual_seed(5)
+    tape = E.Tape()
+    xv = E.Var(nhwc(torch.randn(B, Cexp, H, W, generator=gen)))
+    wpg = gparam(hwio(torch.randn(C, Cexp, 1, 1, generator=gen)))
+    gg, bg = gparam(torch.ones(C)), gparam(torch.zeros(C))
+    y = E.batch_norm_act(tape, E.conv2d(tape, xv, wpg, None, 1, 0, 1), gg, bg, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True,
+                         E.ACT_NONE, None, consumers=1)                  # wrong: two ops read y
+    first = E.add(tape, y, y)                                            # recorded first, so its backward runs LAST
+    e = E.conv2d(tape, y, gparam(hwio(torch.randn(384, C, 1, 1, generator=gen))), None, 1, 0, 1)
+    e2 = E.conv2d(tape, e, gparam(hwio(torch.randn(C, 384, 1, 1, generator=gen))), None, 1, 0, 1)
+    out = E.add(tape, e2, first)
+    with pytest.raises(RuntimeError, match="consumers"):
+        tape.backward(out, torch.randn(B, H, W, C, device=DEV))
+    torch.cuda.synchronize()
+
+
 def _lib_mod():
     from pixelpick_amd import _lib
     return _lib

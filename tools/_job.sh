@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r3u; mkdir -p $O
-HOSTPROF=20 STEPS=20 python tools/train_bench.py > $O/hostprof.txt 2>&1
+O=gpurun_out/r3w; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -5 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

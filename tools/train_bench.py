@@ -29,6 +29,9 @@ def main():
     if os.environ.get("BNBYTES"):                     # pp_debug_set_bn_bytes_per_block word (-1: no row cache, -2: no reversed second pass)
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_bn_bytes_per_block(int(os.environ["BNBYTES"]))
+    if os.environ.get("BNFUSE"):                      # pp_debug_set_conv_bn_fuse bits (which fused conv + BatchNorm launches are offered)
+        from pixelpick_amd import _lib
+        _lib.lib().pp_debug_set_conv_bn_fuse(int(os.environ["BNFUSE"]))
     if os.environ.get("WGRAD_TARGET"):                # pp_debug_set_wgrad_target word (blocks the weight-gradient kernels aim at)
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_wgrad_target(int(os.environ["WGRAD_TARGET"]))
