@@ -2218,6 +2218,73 @@ __global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int
     }
 }
 
+// The MobileNetV2 stem (mobilenet_v2.py:7-12: Conv2d(3, 32, 3, stride 2, padding 1)) is the LAST weight gradient of the backward pass:
+// the optimiser waits for it and its reduce.  Its three input channels are contiguous, so the 3 x 3 taps of an output pixel are three
+// runs of NINE contiguous floats (input row ih, pixels iw0-1 .. iw0+1): three wide loads per tap row (global loads need dword alignment
+// only) instead of nine scalar ones - the generic kernel is bound by its 28 load instructions per output pixel - and the eight row lanes
+// of a block meet in LDS before the partial sums leave it (one slice of partials per BLOCK: 1/8 of the reduce's input).
+// W even, Wo = W / 2, pad 1: the right neighbour always exists, only iw0 - 1 (ow = 0) and ih (oh = 0) can fall outside.
+struct __attribute__((packed, aligned(4))) StemF4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) StemF3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) StemF2 { float x, y; };
+template <int U>
+__global__ __launch_bounds__(256) void wgrad_stem3x3s2_kernel(WgradParams p, int64_t rows_per_split)
+{
+    __shared__ float sh[8][27][33];
+    const int t = threadIdx.x;
+    const int n = t & 31, rl = t >> 5;
+    const int64_t split = (int64_t)blockIdx.x * 8 + rl;
+    const int64_t m0 = split * rows_per_split;
+    const int64_t m1 = m0 + rows_per_split < p.M ? m0 + rows_per_split : p.M;
+    float acc[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) acc[j] = 0.0f;
+    const bool live = n < p.Cout;
+    const float* __restrict__ xg = p.x;
+    const float* __restrict__ dyg = p.dy;
+    RowIter it;
+    it.init(m0 < p.M ? m0 : 0, p.Wo, p.Ho);
+    for (int64_t m = m0; m < m1; m += U) {
+        float g[U];
+        float xv[U][27];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rv = m + u < m1;
+            g[u] = (live && rv) ? dyg[(m + u) * p.lddy + n] : 0.0f;
+            const bool left = it.ow > 0;
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                const int ih = it.oh * 2 - 1 + th;
+                const bool ok = rv && (unsigned)ih < (unsigned)p.H;
+                const float* px = xg + (ok ? (((int64_t)it.bb * p.H + ih) * p.W + it.ow * 2) * 3 : 3);   // pixel iw0 = 2 ow of row ih
+                const StemF3 a = *reinterpret_cast<const StemF3*>(px - ((ok && left) ? 3 : 0));
+                const StemF4 b = *reinterpret_cast<const StemF4*>(px);
+                const StemF2 c = *reinterpret_cast<const StemF2*>(px + 4);
+                const bool oka = ok && left;
+                xv[u][th * 9 + 0] = oka ? a.x : 0.0f; xv[u][th * 9 + 1] = oka ? a.y : 0.0f; xv[u][th * 9 + 2] = oka ? a.z : 0.0f;
+                xv[u][th * 9 + 3] = ok ? b.x : 0.0f; xv[u][th * 9 + 4] = ok ? b.y : 0.0f; xv[u][th * 9 + 5] = ok ? b.z : 0.0f;
+                xv[u][th * 9 + 6] = ok ? b.w : 0.0f; xv[u][th * 9 + 7] = ok ? c.x : 0.0f; xv[u][th * 9 + 8] = ok ? c.y : 0.0f;
+            }
+            it.next(p.Wo, p.Ho);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 27; ++j) acc[j] = fmaf(xv[u][j], g[u], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 27; ++j) sh[rl][j][n] = acc[j];
+    __syncthreads();
+    float* out = p.part + (int64_t)blockIdx.x * 27 * p.Cout;           // [block][tap][c][n]
+    for (int e = t; e < 27 * 32; e += 256) {
+        const int j = e >> 5, nn = e & 31;
+        float v = sh[0][j][nn];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v += sh[r][j][nn];                  // row lanes in order
+        if (nn < p.Cout) out[(int64_t)j * p.Cout + nn] = v;
+    }
+}
+
 //   lanes-over-Cin form (1x1 convolutions with a narrow OUTPUT): thread = input channel c, registers = the COUT
 //   outputs (dy values are wave-uniform loads).
 template <int COUT, int U>
@@ -3414,6 +3481,7 @@ static int64_t narrow_splits_max(int64_t floats_per_split)
     return s;
 }
 static thread_local int g_wgrad_narrow = 1;
+static thread_local int g_wgrad_stem = 1;          // pp_debug_set_conv_variant bit 23 switches the specialised stem weight gradient off (A/B)
 static thread_local int g_wgrad_m64 = 1;
 static thread_local int g_wgrad_xcd = 1;
 static thread_local int g_wgrad_dma = 1;          // LDS-DMA weight-gradient kernels: bit 0 = the 128-wide tiles (default on: DeepLab 7.17 -> 7.12 ms/step,
@@ -3504,12 +3572,19 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
     const size_t need = (size_t)splits * nt * cn * 4;
     if (!workspace || ws_bytes < need) return 1;           // caller sized the workspace for the MFMA path: use that
     p.part = reinterpret_cast<float*>(workspace);
+    // the 3 -> <= 32 channel 3x3 / stride 2 / pad 1 stem on an even-width image with packed pixels: wide loads, one slice per block
+    const bool stem = g_wgrad_stem && form == 1 && p.Cin == 3 && nt == 9 && kh == 3 && kw == 3 && p.stride == 2 && p.taps.dh[0] == -1 &&
+                      p.taps.dw[0] == -1 && p.W % 2 == 0 && p.Wo * 2 == p.W && p.Ho * 2 == p.H && p.ldx == 3 && p.Cout <= 32 && RL == 8 &&
+                      (int64_t)p.B * p.H * p.W * 3 < (1ll << 31);
     const bool fuse_bias = form == 2 && dbias != nullptr && ws_bytes >= need + (size_t)splits * p.Cout * 4;
     p.bias_part = fuse_bias ? p.part + (size_t)splits * nt * cn : nullptr;
     if (nt != kh * kw)
         if (hipMemsetAsync(dw, 0, (size_t)kh * kw * cn * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
     dim3 grid((unsigned)nblk), blk(256);
-    if (form == 1) {
+    if (stem) {
+        hipLaunchKernelGGL((wgrad_stem3x3s2_kernel<4>), grid, blk, 0, st, p, rows_per_split);
+        splits = nblk;                                    // one slice of partial sums per block from here on
+    } else if (form == 1) {
         if (p.Cin == 3 && nt == 9)        hipLaunchKernelGGL((wgrad_narrow_in_kernel<3, 9, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
         else if (p.Cin == 3 && nt == 49)  // the 7x7 stems (resnet_models.py:115-117): one row of seven taps per grid.y slice
             hipLaunchKernelGGL((wgrad_narrow_in_kernel<3, 7, 4>), dim3((unsigned)nblk, 7), blk, 0, st, p, NL, RL, rows_per_split);
@@ -3618,6 +3693,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_xcd = (v & 8192) ? 0 : 1;        // bit 13: XCD-aware block order of the weight-gradient kernel off (A/B)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
+    g_wgrad_stem = (v & 8388608) ? 0 : 1;    // bit 23: specialised MobileNetV2-stem weight gradient off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
     g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 3 : ((v & 4194304) ? 2 : 1));   // bit 15: backward-data only for the 128x64 tiles; bit 22: forward only   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
     g_wgrad_dma = ((v >> 20) & 1 ? 0 : 1) | ((v >> 21) & 1 ? 2 : 0);   // bit 20: LDS-DMA weight-gradient kernel of the 128-wide tiles off; bit 21: 64x64 tiles on
