@@ -3300,15 +3300,20 @@ static BnFusePlan bn_fuse_plan_bwd(const ConvParams& p, const ConvPlan& pl, bool
     if (!(g_conv_bn_fuse & 4) || !vec || p.stats || p.in_scale || p.bias || p.epi.gamma || p.epi.res || p.epi.act != 0 || p.accumulate || p.bwd_stride > 1 ||
         p.stride != 1 || p.Cn % 32 != 0 || (int64_t)p.B * p.H * p.W * p.ldx >= (1ll << 31) - (1ll << 24))
         return f;
-    if (ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride)) {
+    // the fused form also takes the 1/8-resolution expands (8192 rows, K = 192: 32-channel block outputs) through the in-block split-K
+    // kernel: as 64 single-pass 128x32 tiles their K loop is twelve exposed global-load latencies (29 us measured), as grid split-K
+    // they need the second launch this fusion removes
+    const bool ks_wide = g_conv_ksplit && (g_conv_bn_fuse & 8) && p.taps.n == 1 && p.M <= 2 * (int64_t)g_direct_rows_max && p.Ck >= 128 &&
+                         p.Cn >= 32 && p.Cn <= 512 && p.Ck % 4 == 0;
+    const bool ks_plain = ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride);
+    if (ks_plain || ks_wide) {
         // few-row, deep-K pointwise layers (the expand convolutions' backward-data at 1/16 resolution): the in-block split-K kernel
-        if (!(g_conv_bn_fuse & 8) || p.Cout % 4 != 0 || (int64_t)p.Cin * p.Cout >= (1ll << 31) - (1ll << 24)) return f;
         const KsplitCfg kc = ksplit_choose(p.M, p.Cn, true, g_conv_ksplit - 1);
-        if (kc.tm != 1) return f;                            // (a forced forward candidate)
         const int64_t blocks = cdiv(p.M, 32) * cdiv(p.Cn, 32 * kc.tn);
-        if (blocks > ksplit_bn_bwd_capacity(kc.tn == 2 ? 1 : 0) / 2) return f;
-        f.kind = 2; f.R = (int)cdiv(p.M, 32); f.blocks = blocks; f.kc = kc;
-        return f;
+        const bool ok = (g_conv_bn_fuse & 8) && p.Cout % 4 == 0 && (int64_t)p.Cin * p.Cout < (1ll << 31) - (1ll << 24) && kc.tm == 1 &&
+                        blocks <= ksplit_bn_bwd_capacity(kc.tn == 2 ? 1 : 0) / 2;
+        if (ok) { f.kind = 2; f.R = (int)cdiv(p.M, 32); f.blocks = blocks; f.kc = kc; return f; }
+        if (ks_plain) return f;                              // (the unfused launch would take the split-K kernel: no tiled form for it)
     }
     const bool dma_ok = g_conv_dma64 == 1 && p.taps.n <= 32 && (int64_t)kMaxTaps * p.Cin * p.Cout < (1ll << 31);
     // (a plan with grid split-K - few tiles, deep K - runs as ONE pass here: the split's second launch is what the fusion removes)
