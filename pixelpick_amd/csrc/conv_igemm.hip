@@ -1475,6 +1475,97 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
     }
 }
 
+// Backward-data of the pointwise expand convolutions at 1/2 and 1/4 resolution (mobilenet_v2.py:48: 16 -> 96 on 4 x 128 x 256 pixels,
+// 24 -> 144 on 4 x 64 x 128): dx[m][0..CN) = dy[m][0..Ck) . W^T with CN = 16 / 24 / 32 - a read of dy (50 MB for the first) with 6 KiB of
+// weights.  As 128 x 32 MFMA tiles the launch took 57 us (1 TB/s): sixteen-channel K steps read 64-byte pieces of every row, one step
+// in flight.  Here a block takes 64 rows WHOLE (their Ck floats are contiguous: the tile is one coalesced stream, every load of the
+// block in flight at once), parks them in LDS, and wave w computes output channels [w CN/4, (w+1) CN/4) of row `lane` on the VALU
+// with the weights as wave-uniform (scalar) operands; the 64 x CN result leaves through LDS as full rows.
+template <int CN, int MAXL>                                 // MAXL float4 loads per thread: 64 rows x Ck / 4 / 256 threads = Ck / 16, rounded up
+__global__ __launch_bounds__(256) void conv1x1_bwd_rows_kernel(ConvParams p, unsigned inv_kq)
+{
+    constexpr int CPW = CN / 4;                             // output channels per wave
+    extern __shared__ __attribute__((aligned(16))) float rows_smem[];
+    __shared__ int srcoff[64];                              // element offset of the rows' source pixels (< 0: outside the gradient map)
+    const int pitch = p.Ck + 4;                             // floats per LDS row (16-byte aligned, rows on different banks)
+    float* tile = rows_smem;                                // [64][pitch]
+    float* outt = rows_smem + 64 * pitch;                   // [64][CN]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int kq = p.Ck >> 2;                               // float4 per row
+    if (t < 64) {
+        const int64_t m = m0 + t;
+        int off = -1;
+        if (m < p.M) {
+            const unsigned mu = (unsigned)m;
+            const unsigned tq = mu / (unsigned)p.Wo;
+            const int ow = (int)(mu - tq * (unsigned)p.Wo);
+            const unsigned bb = tq / (unsigned)p.Ho;
+            const int oh = (int)(tq - bb * (unsigned)p.Ho);
+            const int ih = oh + p.taps.dh[0], iw = ow + p.taps.dw[0];
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) off = (((int)bb * p.H + ih) * p.W + iw) * (int)p.ldx;
+        }
+        srcoff[t] = off;
+    }
+    __syncthreads();
+    // every load of the block in flight at once: unconditional loads from clamped addresses, zero-fill where the tile is written
+    const int total = 64 * kq;
+    float4 v[MAXL];
+    unsigned okm = 0;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+        const int e = t + i * 256;
+        const int ec = e < total ? e : 0;
+        const int r = (int)(((unsigned)ec * inv_kq) >> 20), q = ec - r * kq;      // ec / kq, exact for ec < 3072 (host-checked)
+        const int off = srcoff[r];
+        const bool ok = e < total && off >= 0;
+        v[i] = *reinterpret_cast<const float4*>(p.x + (ok ? (size_t)(unsigned)off + (size_t)(q * 4) : 0));
+        okm |= ok ? (1u << i) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+        const int e = t + i * 256;
+        if (e < total) {
+            const int r = (int)(((unsigned)e * inv_kq) >> 20), q = e - r * kq;
+            *reinterpret_cast<float4*>(tile + r * pitch + q * 4) = ((okm >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + (int64_t)(wave * CPW) * p.Cout;   // W[n][k], k contiguous
+    float acc[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) acc[j] = 0.0f;
+    const float* trow = tile + lane * pitch;
+#pragma unroll 4
+    for (int k = 0; k < p.Ck; k += 4) {
+        const float4 x4 = *reinterpret_cast<const float4*>(trow + k);
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const float* wj = wr + (int64_t)j * p.Cout + k;
+            acc[j] = fmaf(x4.x, wj[0], acc[j]);
+            acc[j] = fmaf(x4.y, wj[1], acc[j]);
+            acc[j] = fmaf(x4.z, wj[2], acc[j]);
+            acc[j] = fmaf(x4.w, wj[3], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) outt[lane * CN + wave * CPW + j] = acc[j];
+    __syncthreads();
+    for (int e = t; e < 64 * (CN / 4); e += 256) {
+        const int r = e / (CN / 4), q = e - r * (CN / 4);
+        const int64_t m = m0 + r;
+        if (m >= p.M) continue;
+        float4 o = *reinterpret_cast<const float4*>(outt + r * CN + q * 4);
+        float* dst = p.y + m * p.ldy + q * 4;
+        if (p.accumulate) {
+            const float4 a = *reinterpret_cast<const float4*>(dst);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dst) = o;
+    }
+}
+
 // Tile / ring choice of conv1x1_ksplit_dma_kernel, from the measured table (profiles/r03_conv1x1_ksplit.txt; all six shapes x six
 // (TM, TN, NST) candidates at 2048 rows): the ring depth does not matter (3 vs 6 stages: +-0.5 us - the K loop is bound by the
 // MFMA chain of ONE wave per SIMD, not by bytes in flight), the tile does through the grid: 64x32 tiles while the grid stays within
@@ -3077,6 +3168,7 @@ static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-D
 static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
+static thread_local int g_conv_bwd_rows = 1;       // pp_debug_set_conv_variant bit 24 switches conv1x1_bwd_rows_kernel off (A/B)
 static thread_local int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
 static thread_local int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
 static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
@@ -3397,6 +3489,26 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         if (BWD || !pad0 || !(use_ksplit || (pl.cfg == 0 && vec)))
             return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape has no input-affine kernel (ask pp_conv2d_fwd_accepts_affine_in first)");
     }
+    if constexpr (BWD) {
+        // narrow-output pointwise backward-data on large maps: whole rows through LDS, VALU (conv1x1_bwd_rows_kernel)
+        const bool rows_ok = g_conv_bwd_rows && vec && p.taps.n == 1 && p.bwd_stride <= 1 && !p.stats && !p.in_scale && !p.bias && !p.epi.gamma &&
+                             !p.epi.res && p.epi.act == 0 && (p.Cn == 16 || p.Cn == 24 || p.Cn == 32) && p.Cin == p.Cn && p.Ck <= 192 &&
+                             p.M >= 16384 && p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
+                             (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31);
+        if (rows_ok) {
+            const size_t lds = (size_t)(64 * (p.Ck + 4) + 64 * p.Cn) * 4;
+            const dim3 grid((unsigned)cdiv(p.M, 64));
+            const unsigned inv_kq = (1u << 20) / (unsigned)(p.Ck / 4) + 1u;    // e / kq = (e * inv) >> 20 for e < 64 * 48
+#define PP_ROWS(CN_) do { if (p.Ck <= 96) hipLaunchKernelGGL((conv1x1_bwd_rows_kernel<CN_, 6>), grid, dim3(256), lds, st, p, inv_kq); \
+                          else if (p.Ck <= 144) hipLaunchKernelGGL((conv1x1_bwd_rows_kernel<CN_, 9>), grid, dim3(256), lds, st, p, inv_kq); \
+                          else hipLaunchKernelGGL((conv1x1_bwd_rows_kernel<CN_, 12>), grid, dim3(256), lds, st, p, inv_kq); } while (0)
+            if (p.Cn == 16)      PP_ROWS(16);
+            else if (p.Cn == 24) PP_ROWS(24);
+            else                 PP_ROWS(32);
+#undef PP_ROWS
+            return check_launch("conv1x1_bwd_rows_kernel");
+        }
+    }
     if (use_ksplit) {
         const KsplitCfg kc = ksplit_choose(p.M, p.Cn, BWD, g_conv_ksplit - 1);
         p.splits = 1;
@@ -3699,6 +3811,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_wgrad_stem = (v & 8388608) ? 0 : 1;    // bit 23: specialised MobileNetV2-stem weight gradient off (A/B)
+    g_conv_bwd_rows = (v & 16777216) ? 0 : 1;   // bit 24: whole-row backward-data kernel of the narrow pointwise layers off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
     g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 3 : ((v & 4194304) ? 2 : 1));   // bit 15: backward-data only for the 128x64 tiles; bit 22: forward only   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
     g_wgrad_dma = ((v >> 20) & 1 ? 0 : 1) | ((v >> 21) & 1 ? 2 : 0);   // bit 20: LDS-DMA weight-gradient kernel of the 128-wide tiles off; bit 21: 64x64 tiles on

@@ -116,6 +116,48 @@ def test_conv2d_fwd_bwd(case):
         close(nchw(xv.grad), xr.grad, what="conv dX")
 
 
+ROWS_BWD = [(4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 100, 83, 16, 96, 0), (1, 129, 131, 24, 144, 1), (3, 80, 90, 32, 192, 0),
+            (2, 96, 96, 32, 64, 1)]
+
+
+@pytest.mark.parametrize("case", ROWS_BWD, ids=[str(c) for c in ROWS_BWD])
+def test_pointwise_backward_data_of_the_narrow_layers(case):
+    """mobilenet_v2.py:48 expand convolutions at 1/2 and 1/4 resolution (16 -> 96, 24 -> 144; fixed padding folded in): their
+    backward-data is conv1x1_bwd_rows_kernel (whole rows through LDS, VALU).  Against torch autograd, against the MFMA path
+    (pp_debug_set_conv_variant bit 24) to fp32 rounding, with a gradient already present (the residual branch: accumulate), ragged row
+    counts; bit-reproducible."""
+    B, H, W, Cin, Cout, pad = case
+    gen = torch.Generator().manual_seed(H + W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / np.sqrt(Cin)
+    dy = torch.randn(B, Cout, H + 2 * pad, W + 2 * pad, generator=gen)
+    dres = torch.randn(B, Cin, H, W, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    (F.conv2d(xr, w, padding=pad) * dy).sum().backward()
+    L = _lib_mod().lib()
+    def run(variant, with_res):
+        L.pp_debug_set_conv_variant(variant)
+        try:
+            tape = E.Tape()
+            xv = E.Var(nhwc(x))
+            yv = E.conv2d(tape, xv, gparam(hwio(w)), None, 1, pad, 1)
+            if with_res:
+                g0 = nhwc(dres).clone()
+                g0._pp_owned = True
+                xv.grad = g0                    # what the residual branch left: the convolution adds into it
+            tape.backward(yv, nhwc(dy))
+            torch.cuda.synchronize()
+            return nchw(xv.grad)
+        finally:
+            L.pp_debug_set_conv_variant(0)
+    a, a2, b = run(0, False), run(0, False), run(1 << 24, False)
+    assert torch.equal(a, a2)
+    close(a, xr.grad, what="dx of the narrow pointwise layer")
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    c = run(0, True)
+    close(c, xr.grad + dres, what="dx added to the residual branch's gradient")
+
+
 STEM_WGRAD = [(4, 256, 512, 32), (2, 256, 256, 24), (3, 200, 260, 32), (1, 512, 258, 16)]
 
 
