@@ -1481,8 +1481,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_ksplit_dma_kernel(ConvPar
 // in flight.  Here a block takes 64 rows WHOLE (their Ck floats are contiguous: the tile is one coalesced stream, every load of the
 // block in flight at once), parks them in LDS, and wave w computes output channels [w CN/4, (w+1) CN/4) of row `lane` on the VALU
 // with the weights as wave-uniform (scalar) operands; the 64 x CN result leaves through LDS as full rows.
-template <int CN, int MAXL>                                 // MAXL float4 loads per thread: 64 rows x Ck / 4 / 256 threads = Ck / 16, rounded up
-__global__ __launch_bounds__(256) void conv1x1_bwd_rows_kernel(ConvParams p, unsigned inv_kq)
+// BWD == false: the forward of the narrow-OUTPUT pointwise layers (project convolutions 32 -> 16, 96 -> 24, 144 -> 24 / 32 on the same
+// maps): the same kernel with the weights read as W[k][n].
+template <int CN, int MAXL, bool BWD>                       // MAXL float4 loads per thread: 64 rows x Ck / 4 / 256 threads = Ck / 16, rounded up
+__global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvParams p, unsigned inv_kq)
 {
     constexpr int CPW = CN / 4;                             // output channels per wave
     extern __shared__ __attribute__((aligned(16))) float rows_smem[];
@@ -1532,7 +1534,8 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_rows_kernel(ConvParams p, uns
         }
     }
     __syncthreads();
-    const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + (int64_t)(wave * CPW) * p.Cout;   // W[n][k], k contiguous
+    // backward: W[n][k] (k contiguous), forward: W[k][n] (n contiguous); wave-uniform addresses: scalar loads
+    const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + (BWD ? (int64_t)(wave * CPW) * p.Cout : (int64_t)(wave * CPW));
     float acc[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) acc[j] = 0.0f;
@@ -1542,11 +1545,19 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_rows_kernel(ConvParams p, uns
         const float4 x4 = *reinterpret_cast<const float4*>(trow + k);
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
-            const float* wj = wr + (int64_t)j * p.Cout + k;
-            acc[j] = fmaf(x4.x, wj[0], acc[j]);
-            acc[j] = fmaf(x4.y, wj[1], acc[j]);
-            acc[j] = fmaf(x4.z, wj[2], acc[j]);
-            acc[j] = fmaf(x4.w, wj[3], acc[j]);
+            if constexpr (BWD) {
+                const float* wj = wr + (int64_t)j * p.Cout + k;
+                acc[j] = fmaf(x4.x, wj[0], acc[j]);
+                acc[j] = fmaf(x4.y, wj[1], acc[j]);
+                acc[j] = fmaf(x4.z, wj[2], acc[j]);
+                acc[j] = fmaf(x4.w, wj[3], acc[j]);
+            } else {
+                const float* wk = wr + (int64_t)k * p.Cout + j;
+                acc[j] = fmaf(x4.x, wk[0], acc[j]);
+                acc[j] = fmaf(x4.y, wk[p.Cout], acc[j]);
+                acc[j] = fmaf(x4.z, wk[2 * (int64_t)p.Cout], acc[j]);
+                acc[j] = fmaf(x4.w, wk[3 * (int64_t)p.Cout], acc[j]);
+            }
         }
     }
 #pragma unroll
@@ -1563,6 +1574,66 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_rows_kernel(ConvParams p, uns
             o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         *reinterpret_cast<float4*>(dst) = o;
+    }
+}
+
+// Forward of the narrow-INPUT pointwise layers (the expand convolutions 16 -> 96, 24 -> 144, 32 -> 192 on the 1/2- and 1/4-resolution
+// maps, fixed padding folded in): y[m][0..CN) = x[m][0..CK) . W, a WRITE of y (51 MB for the first) with CK x CN weights.  As 128 x 128
+// MFMA tiles with one K step the launch took 48 us.  Here: 64 rows per block, wave w computes the CN / 4 output channels
+// [w CN/4, (w+1) CN/4) of row `lane` on the VALU (weights as scalar operands), the 64 x CN tile leaves through LDS as full rows.
+template <int CK, int CN>
+__global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
+{
+    constexpr int NPW = CN / 4, XP = CK + 4, OP = CN + 4;   // outputs per wave, LDS pitches (rows on different banks)
+    static_assert(NPW % 4 == 0 && CK % 4 == 0, "float4 pieces");
+    __shared__ __attribute__((aligned(16))) float xt[64 * XP];
+    __shared__ __attribute__((aligned(16))) float ot[64 * OP];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    constexpr int KQ = CK / 4;
+    for (int e = t; e < 64 * KQ; e += 256) {
+        const int r = e / KQ, q = e - r * KQ;
+        const int64_t m = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < p.M) {
+            const unsigned mu = (unsigned)m;
+            const unsigned tq = mu / (unsigned)p.Wo;
+            const int ow = (int)(mu - tq * (unsigned)p.Wo);
+            const unsigned bb = tq / (unsigned)p.Ho;
+            const int oh = (int)(tq - bb * (unsigned)p.Ho);
+            const int ih = oh + p.taps.dh[0], iw = ow + p.taps.dw[0];
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(p.x + (((int64_t)bb * p.H + ih) * p.W + iw) * p.ldx + q * 4);
+        }
+        *reinterpret_cast<float4*>(xt + r * XP + q * 4) = v;
+    }
+    __syncthreads();
+    const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + wave * NPW;      // W[k][n], n contiguous
+    float acc[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) acc[j] = 0.0f;
+    float xr[CK];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xt + lane * XP + q * 4);
+        xr[q * 4 + 0] = v.x; xr[q * 4 + 1] = v.y; xr[q * 4 + 2] = v.z; xr[q * 4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const float* wk = wr + (int64_t)k * p.Cout;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) acc[j] = fmaf(xr[k], wk[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NPW; j += 4)
+        *reinterpret_cast<float4*>(ot + lane * OP + wave * NPW + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    __syncthreads();
+    constexpr int NQ = CN / 4;
+    for (int e = t; e < 64 * NQ; e += 256) {
+        const int r = e / NQ, q = e - r * NQ;
+        const int64_t m = m0 + r;
+        if (m < p.M) *reinterpret_cast<float4*>(p.y + m * p.ldy + q * 4) = *reinterpret_cast<const float4*>(ot + r * OP + q * 4);
     }
 }
 
@@ -3168,7 +3239,7 @@ static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-D
 static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
-static thread_local int g_conv_bwd_rows = 1;       // pp_debug_set_conv_variant bit 24 switches conv1x1_bwd_rows_kernel off (A/B)
+static thread_local int g_conv_bwd_rows = 1;       // pp_debug_set_conv_variant bit 24 switches conv1x1_rows_kernel / conv1x1_fwd_widen_kernel off (A/B)
 static thread_local int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
 static thread_local int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
 static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
@@ -3489,24 +3560,36 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         if (BWD || !pad0 || !(use_ksplit || (pl.cfg == 0 && vec)))
             return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape has no input-affine kernel (ask pp_conv2d_fwd_accepts_affine_in first)");
     }
-    if constexpr (BWD) {
-        // narrow-output pointwise backward-data on large maps: whole rows through LDS, VALU (conv1x1_bwd_rows_kernel)
-        const bool rows_ok = g_conv_bwd_rows && vec && p.taps.n == 1 && p.bwd_stride <= 1 && !p.stats && !p.in_scale && !p.bias && !p.epi.gamma &&
-                             !p.epi.res && p.epi.act == 0 && (p.Cn == 16 || p.Cn == 24 || p.Cn == 32) && p.Cin == p.Cn && p.Ck <= 192 &&
-                             p.M >= 16384 && p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
-                             (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31);
+    {
+        // narrow pointwise layers on large maps: whole rows through LDS, VALU (conv1x1_rows_kernel / conv1x1_fwd_widen_kernel)
+        const bool plain = g_conv_bwd_rows && vec && p.taps.n == 1 && p.stride == 1 && p.bwd_stride <= 1 && !p.stats && !p.in_scale && !p.bias &&
+                           !p.epi.gamma && !p.epi.res && p.epi.act == 0 && p.M >= 16384 && p.ldy % 4 == 0 &&
+                           (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31);
+        // (forward: only the 1/2-resolution map - at 32768 rows the two blocks per CU cannot hide the scalar weight loads of a deep K:
+        //  96 -> 24 / 144 -> 24 took 17.6 / 23.4 us against 13.8 / 16.4 us as 128 x 32 MFMA tiles)
+        const bool rows_ok = plain && (p.Cn == 16 || p.Cn == 24 || p.Cn == 32) && p.Ck <= 192 && p.Ck >= 16 && (BWD || p.M >= 65536);
         if (rows_ok) {
             const size_t lds = (size_t)(64 * (p.Ck + 4) + 64 * p.Cn) * 4;
             const dim3 grid((unsigned)cdiv(p.M, 64));
             const unsigned inv_kq = (1u << 20) / (unsigned)(p.Ck / 4) + 1u;    // e / kq = (e * inv) >> 20 for e < 64 * 48
-#define PP_ROWS(CN_) do { if (p.Ck <= 96) hipLaunchKernelGGL((conv1x1_bwd_rows_kernel<CN_, 6>), grid, dim3(256), lds, st, p, inv_kq); \
-                          else if (p.Ck <= 144) hipLaunchKernelGGL((conv1x1_bwd_rows_kernel<CN_, 9>), grid, dim3(256), lds, st, p, inv_kq); \
-                          else hipLaunchKernelGGL((conv1x1_bwd_rows_kernel<CN_, 12>), grid, dim3(256), lds, st, p, inv_kq); } while (0)
+#define PP_ROWS(CN_) do { if (p.Ck <= 96) hipLaunchKernelGGL((conv1x1_rows_kernel<CN_, 6, BWD>), grid, dim3(256), lds, st, p, inv_kq); \
+                          else if (p.Ck <= 144) hipLaunchKernelGGL((conv1x1_rows_kernel<CN_, 9, BWD>), grid, dim3(256), lds, st, p, inv_kq); \
+                          else hipLaunchKernelGGL((conv1x1_rows_kernel<CN_, 12, BWD>), grid, dim3(256), lds, st, p, inv_kq); } while (0)
             if (p.Cn == 16)      PP_ROWS(16);
             else if (p.Cn == 24) PP_ROWS(24);
             else                 PP_ROWS(32);
 #undef PP_ROWS
-            return check_launch("conv1x1_bwd_rows_kernel");
+            return check_launch("conv1x1_rows_kernel");
+        }
+        if constexpr (!BWD) {
+            const bool widen = plain && !p.accumulate && ((p.Ck == 16 && p.Cn == 96) || (p.Ck == 24 && p.Cn == 144) || (p.Ck == 32 && p.Cn == 192));
+            if (widen) {
+                const dim3 grid((unsigned)cdiv(p.M, 64));
+                if (p.Ck == 16)      hipLaunchKernelGGL((conv1x1_fwd_widen_kernel<16, 96>), grid, dim3(256), 0, st, p);
+                else if (p.Ck == 24) hipLaunchKernelGGL((conv1x1_fwd_widen_kernel<24, 144>), grid, dim3(256), 0, st, p);
+                else                 hipLaunchKernelGGL((conv1x1_fwd_widen_kernel<32, 192>), grid, dim3(256), 0, st, p);
+                return check_launch("conv1x1_fwd_widen_kernel");
+            }
         }
     }
     if (use_ksplit) {
@@ -3811,7 +3894,7 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_wgrad_stem = (v & 8388608) ? 0 : 1;    // bit 23: specialised MobileNetV2-stem weight gradient off (A/B)
-    g_conv_bwd_rows = (v & 16777216) ? 0 : 1;   // bit 24: whole-row backward-data kernel of the narrow pointwise layers off (A/B)
+    g_conv_bwd_rows = (v & 16777216) ? 0 : 1;   // bit 24: whole-row kernels of the narrow pointwise layers off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
     g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 3 : ((v & 4194304) ? 2 : 1));   // bit 15: backward-data only for the 128x64 tiles; bit 22: forward only   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
     g_wgrad_dma = ((v >> 20) & 1 ? 0 : 1) | ((v >> 21) & 1 ? 2 : 0);   // bit 20: LDS-DMA weight-gradient kernel of the 128-wide tiles off; bit 21: 64x64 tiles on

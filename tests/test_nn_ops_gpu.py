@@ -123,7 +123,7 @@ ROWS_BWD = [(4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 100, 83, 16,
 @pytest.mark.parametrize("case", ROWS_BWD, ids=[str(c) for c in ROWS_BWD])
 def test_pointwise_backward_data_of_the_narrow_layers(case):
     """mobilenet_v2.py:48 expand convolutions at 1/2 and 1/4 resolution (16 -> 96, 24 -> 144; fixed padding folded in): their
-    backward-data is conv1x1_bwd_rows_kernel (whole rows through LDS, VALU).  Against torch autograd, against the MFMA path
+    backward-data is conv1x1_rows_kernel<.., true> (whole rows through LDS, VALU).  Against torch autograd, against the MFMA path
     (pp_debug_set_conv_variant bit 24) to fp32 rounding, with a gradient already present (the residual branch: accumulate), ragged row
     counts; bit-reproducible."""
     B, H, W, Cin, Cout, pad = case
@@ -156,6 +156,46 @@ def test_pointwise_backward_data_of_the_narrow_layers(case):
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
     c = run(0, True)
     close(c, xr.grad + dres, what="dx added to the residual branch's gradient")
+
+
+ROWS_FWD = [(4, 128, 256, 32, 16, 0), (4, 64, 128, 96, 24, 0), (4, 64, 128, 144, 32, 0), (2, 100, 83, 144, 24, 0),      # narrow output: project
+            (4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 96, 96, 32, 192, 0), (1, 129, 131, 16, 96, 1)]        # narrow input: expand
+
+
+@pytest.mark.parametrize("case", ROWS_FWD, ids=[str(c) for c in ROWS_FWD])
+def test_pointwise_forward_of_the_narrow_layers(case):
+    """mobilenet_v2.py:48-56 on the 1/2- and 1/4-resolution maps: the project convolutions (32 -> 16, 96 -> 24, 144 -> 24 / 32) run
+    conv1x1_rows_kernel<.., false>, the expand convolutions (16 -> 96, 24 -> 144, 32 -> 192, fixed padding folded in)
+    conv1x1_fwd_widen_kernel - rows through LDS, VALU, weights as scalar operands.  Against torch, against the MFMA path
+    (pp_debug_set_conv_variant bit 24) to fp32 rounding, ragged row counts; bit-reproducible; the gradients of the same layers too."""
+    B, H, W, Cin, Cout, pad = case
+    gen = torch.Generator().manual_seed(H + W + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / np.sqrt(Cin)
+    dy = torch.randn(B, Cout, H + 2 * pad, W + 2 * pad, generator=gen)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=pad)
+    yr.backward(dy)
+    L = _lib_mod().lib()
+    def run(variant):
+        L.pp_debug_set_conv_variant(variant)
+        try:
+            tape = E.Tape()
+            xv, wg = E.Var(nhwc(x)), gparam(hwio(w))
+            yv = E.conv2d(tape, xv, wg, None, 1, pad, 1)
+            y = nchw(yv.t)
+            tape.backward(yv, nhwc(dy))
+            torch.cuda.synchronize()
+            return y, nchw(xv.grad), oihw(tape.param_grads[id(wg)])
+        finally:
+            L.pp_debug_set_conv_variant(0)
+    a, a2, b = run(0), run(0), run(1 << 24)
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
+    close(a[0], yr.detach(), what="forward of the narrow pointwise layer")
+    close(a[1], xr.grad, what="dx")
+    close(a[2], wr.grad, what="dW")
+    assert (a[0] - b[0]).abs().max().item() <= 2e-5 * b[0].abs().max().item()
 
 
 STEM_WGRAD = [(4, 256, 512, 32), (2, 256, 256, 24), (3, 200, 260, 32), (1, 512, 258, 16)]
