@@ -540,6 +540,7 @@ void pp_debug_set_bn_probe(void* device_buffer);
 int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);
 void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 12 (defaults 384 / 128) */
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
+void pp_debug_set_conv_rows(int bits);      /* whole-row VALU kernels of the narrow pointwise layers: bit 0 off, bit 1 forward rows kernel only from 65536 rows (A/B) */
 void pp_debug_set_conv_bn_fuse(int bits);   /* fused conv + BatchNorm launches offered: bit 0 tiled fwd, 1 split-K fwd, 2 bwd 64x64, 3 bwd split-K / 128x32 (default 15; A/B) */
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */
 void pp_debug_set_conv_variant(int v);

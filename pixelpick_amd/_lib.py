@@ -123,6 +123,7 @@ SIGNATURES = {
     "pp_debug_set_conv_thresholds": (None, [_int]),
     "pp_debug_conv_plan": (None, [_i64, _int, _int, _int, _p]),
     "pp_debug_set_conv_variant": (None, [_int]),
+    "pp_debug_set_conv_rows": (None, [_int]),
     "pp_debug_set_conv_bn_fuse": (None, [_int]),
     "pp_debug_set_x3": (None, [_int]),
     "pp_debug_set_kernel_events": (None, [_p, _p, _int]),

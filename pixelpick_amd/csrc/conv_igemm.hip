@@ -1496,6 +1496,23 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvParams p, unsigne
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     const int kq = p.Ck >> 2;                               // float4 per row
+    // the wave's weights - CPW output channels x Ck - live in CPW x NRJ registers, lane l of register (j, r) holding k = 64 r + l;
+    // the FMA loop broadcasts them with v_readlane (as scalar LOADS in that loop each K step waited for the scalar cache: with two
+    // blocks per CU the 96 -> 24 / 144 -> 24 layers took 18 / 23 us).  backward: W[n][k] (k contiguous), forward: W[k][n]
+    constexpr int NRJ = (MAXL * 16 + 63) / 64;
+    float wreg[CPW][NRJ];
+    {
+        const float* wbase = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j)
+#pragma unroll
+            for (int r = 0; r < NRJ; ++r) {
+                const int k = 64 * r + lane;
+                const int kc = k < p.Ck ? k : 0;
+                const float wv = BWD ? wbase[(int64_t)(wave * CPW + j) * p.Cout + kc] : wbase[(int64_t)kc * p.Cout + wave * CPW + j];
+                wreg[j][r] = k < p.Ck ? wv : 0.0f;
+            }
+    }
     if (t < 64) {
         const int64_t m = m0 + t;
         int off = -1;
@@ -1534,29 +1551,22 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvParams p, unsigne
         }
     }
     __syncthreads();
-    // backward: W[n][k] (k contiguous), forward: W[k][n] (n contiguous); wave-uniform addresses: scalar loads
-    const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + (BWD ? (int64_t)(wave * CPW) * p.Cout : (int64_t)(wave * CPW));
     float acc[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) acc[j] = 0.0f;
     const float* trow = tile + lane * pitch;
-#pragma unroll 4
-    for (int k = 0; k < p.Ck; k += 4) {
-        const float4 x4 = *reinterpret_cast<const float4*>(trow + k);
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if constexpr (BWD) {
-                const float* wj = wr + (int64_t)j * p.Cout + k;
-                acc[j] = fmaf(x4.x, wj[0], acc[j]);
-                acc[j] = fmaf(x4.y, wj[1], acc[j]);
-                acc[j] = fmaf(x4.z, wj[2], acc[j]);
-                acc[j] = fmaf(x4.w, wj[3], acc[j]);
-            } else {
-                const float* wk = wr + (int64_t)k * p.Cout + j;
-                acc[j] = fmaf(x4.x, wk[0], acc[j]);
-                acc[j] = fmaf(x4.y, wk[p.Cout], acc[j]);
-                acc[j] = fmaf(x4.z, wk[2 * (int64_t)p.Cout], acc[j]);
-                acc[j] = fmaf(x4.w, wk[3 * (int64_t)p.Cout], acc[j]);
+    for (int r = 0; r < NRJ; ++r) {
+        const int kend = p.Ck - 64 * r < 64 ? p.Ck - 64 * r : 64;
+        for (int kk = 0; kk < kend; kk += 4) {
+            const float4 x4 = *reinterpret_cast<const float4*>(trow + 64 * r + kk);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int wv = __float_as_int(wreg[j][r]);
+                acc[j] = fmaf(x4.x, __int_as_float(__builtin_amdgcn_readlane(wv, kk + 0)), acc[j]);
+                acc[j] = fmaf(x4.y, __int_as_float(__builtin_amdgcn_readlane(wv, kk + 1)), acc[j]);
+                acc[j] = fmaf(x4.z, __int_as_float(__builtin_amdgcn_readlane(wv, kk + 2)), acc[j]);
+                acc[j] = fmaf(x4.w, __int_as_float(__builtin_amdgcn_readlane(wv, kk + 3)), acc[j]);
             }
         }
     }
@@ -3239,7 +3249,8 @@ static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-D
 static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
 static thread_local int g_conv_n64 = 1;
 static thread_local int g_conv_tap_inner = 1;
-static thread_local int g_conv_bwd_rows = 1;       // pp_debug_set_conv_variant bit 24 switches conv1x1_rows_kernel / conv1x1_fwd_widen_kernel off (A/B)
+static thread_local int g_conv_bwd_rows = 1;       // pp_debug_set_conv_rows bit 0 switches conv1x1_rows_kernel / conv1x1_fwd_widen_kernel off (A/B)
+static thread_local int64_t g_rows_fwd_min = 16384;    // pp_debug_set_conv_rows bit 1: forward rows kernel only from 65536 rows (A/B)
 static thread_local int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
 static thread_local int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
 static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
@@ -3565,9 +3576,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         const bool plain = g_conv_bwd_rows && vec && p.taps.n == 1 && p.stride == 1 && p.bwd_stride <= 1 && !p.stats && !p.in_scale && !p.bias &&
                            !p.epi.gamma && !p.epi.res && p.epi.act == 0 && p.M >= 16384 && p.ldy % 4 == 0 &&
                            (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && (int64_t)p.B * p.H * p.W * p.ldx < (1ll << 31);
-        // (forward: only the 1/2-resolution map - at 32768 rows the two blocks per CU cannot hide the scalar weight loads of a deep K:
-        //  96 -> 24 / 144 -> 24 took 17.6 / 23.4 us against 13.8 / 16.4 us as 128 x 32 MFMA tiles)
-        const bool rows_ok = plain && (p.Cn == 16 || p.Cn == 24 || p.Cn == 32) && p.Ck <= 192 && p.Ck >= 16 && (BWD || p.M >= 65536);
+        const bool rows_ok = plain && (p.Cn == 16 || p.Cn == 24 || p.Cn == 32) && p.Ck <= 192 && p.Ck >= 16 && (BWD || p.M >= g_rows_fwd_min);
         if (rows_ok) {
             const size_t lds = (size_t)(64 * (p.Ck + 4) + 64 * p.Cn) * 4;
             const dim3 grid((unsigned)cdiv(p.M, 64));
@@ -3849,6 +3858,9 @@ void pp_debug_set_splitk(int v)
     g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
 
+/* whole-row VALU kernels of the narrow pointwise layers (A/B): bit 0 off, bit 1 forward rows kernel only from 65536 rows */
+void pp_debug_set_conv_rows(int bits) { g_conv_bwd_rows = (bits & 1) ? 0 : 1; g_rows_fwd_min = (bits & 2) ? 65536 : 16384; }
+
 /* which shapes pp_conv2d_fwd_bn_train_ok / pp_conv2d_bwd_data_bn_bwd_ok accept (A/B): bit 0 tiled forward kernels, 1 in-block split-K
  * forward, 2 backward form (64x64 tiles), 3 backward form of the in-block split-K and the 128x32 kernels; default 15 */
 void pp_debug_set_conv_bn_fuse(int bits) { g_conv_bn_fuse = bits & 15; }
@@ -3894,7 +3906,6 @@ void pp_debug_set_conv_variant(int v)
     g_wgrad_m64 = (v & 1024) ? 0 : 1;        // bit 10: 64-row weight-gradient tiles for ragged Cin off (A/B)
     g_wgrad_narrow = (v & 512) ? 0 : 1;      // bit 9 switches the narrow-layer weight-gradient kernels off (A/B)
     g_wgrad_stem = (v & 8388608) ? 0 : 1;    // bit 23: specialised MobileNetV2-stem weight gradient off (A/B)
-    g_conv_bwd_rows = (v & 16777216) ? 0 : 1;   // bit 24: whole-row kernels of the narrow pointwise layers off (A/B)
     g_conv_ablate_reduce = (v >> 16) & 3;    // bits 16/17: timing-only ablation, see above
     g_conv_dma = (v & 256) ? 0 : ((v & 32768) ? 3 : ((v & 4194304) ? 2 : 1));   // bit 15: backward-data only for the 128x64 tiles; bit 22: forward only   // bit 8: LDS-DMA kernel of the 128x128 tiles off; bit 15: also for backward-data
     g_wgrad_dma = ((v >> 20) & 1 ? 0 : 1) | ((v >> 21) & 1 ? 2 : 0);   // bit 20: LDS-DMA weight-gradient kernel of the 128-wide tiles off; bit 21: 64x64 tiles on

@@ -124,7 +124,7 @@ ROWS_BWD = [(4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 100, 83, 16,
 def test_pointwise_backward_data_of_the_narrow_layers(case):
     """mobilenet_v2.py:48 expand convolutions at 1/2 and 1/4 resolution (16 -> 96, 24 -> 144; fixed padding folded in): their
     backward-data is conv1x1_rows_kernel<.., true> (whole rows through LDS, VALU).  Against torch autograd, against the MFMA path
-    (pp_debug_set_conv_variant bit 24) to fp32 rounding, with a gradient already present (the residual branch: accumulate), ragged row
+    (pp_debug_set_conv_rows(1)) to fp32 rounding, with a gradient already present (the residual branch: accumulate), ragged row
     counts; bit-reproducible."""
     B, H, W, Cin, Cout, pad = case
     gen = torch.Generator().manual_seed(H + W + Cin)
@@ -136,7 +136,7 @@ def test_pointwise_backward_data_of_the_narrow_layers(case):
     (F.conv2d(xr, w, padding=pad) * dy).sum().backward()
     L = _lib_mod().lib()
     def run(variant, with_res):
-        L.pp_debug_set_conv_variant(variant)
+        L.pp_debug_set_conv_rows(variant)
         try:
             tape = E.Tape()
             xv = E.Var(nhwc(x))
@@ -149,8 +149,8 @@ def test_pointwise_backward_data_of_the_narrow_layers(case):
             torch.cuda.synchronize()
             return nchw(xv.grad)
         finally:
-            L.pp_debug_set_conv_variant(0)
-    a, a2, b = run(0, False), run(0, False), run(1 << 24, False)
+            L.pp_debug_set_conv_rows(0)
+    a, a2, b = run(0, False), run(0, False), run(1, False)
     assert torch.equal(a, a2)
     close(a, xr.grad, what="dx of the narrow pointwise layer")
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
@@ -167,7 +167,7 @@ def test_pointwise_forward_of_the_narrow_layers(case):
     """mobilenet_v2.py:48-56 on the 1/2- and 1/4-resolution maps: the project convolutions (32 -> 16, 96 -> 24, 144 -> 24 / 32) run
     conv1x1_rows_kernel<.., false>, the expand convolutions (16 -> 96, 24 -> 144, 32 -> 192, fixed padding folded in)
     conv1x1_fwd_widen_kernel - rows through LDS, VALU, weights as scalar operands.  Against torch, against the MFMA path
-    (pp_debug_set_conv_variant bit 24) to fp32 rounding, ragged row counts; bit-reproducible; the gradients of the same layers too."""
+    (pp_debug_set_conv_rows(1)) to fp32 rounding, ragged row counts; bit-reproducible; the gradients of the same layers too."""
     B, H, W, Cin, Cout, pad = case
     gen = torch.Generator().manual_seed(H + W + Cin + Cout)
     x = torch.randn(B, Cin, H, W, generator=gen)
@@ -178,7 +178,7 @@ def test_pointwise_forward_of_the_narrow_layers(case):
     yr.backward(dy)
     L = _lib_mod().lib()
     def run(variant):
-        L.pp_debug_set_conv_variant(variant)
+        L.pp_debug_set_conv_rows(variant)
         try:
             tape = E.Tape()
             xv, wg = E.Var(nhwc(x)), gparam(hwio(w))
@@ -188,8 +188,8 @@ def test_pointwise_forward_of_the_narrow_layers(case):
             torch.cuda.synchronize()
             return y, nchw(xv.grad), oihw(tape.param_grads[id(wg)])
         finally:
-            L.pp_debug_set_conv_variant(0)
-    a, a2, b = run(0), run(0), run(1 << 24)
+            L.pp_debug_set_conv_rows(0)
+    a, a2, b = run(0), run(0), run(1)
     for u, v in zip(a, a2):
         assert torch.equal(u, v)
     close(a[0], yr.detach(), what="forward of the narrow pointwise layer")
