@@ -118,8 +118,12 @@ def test_pointwise_conv_with_input_affine(case, act):
     wsn = int(L().pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, 1, 1, 1, 0, 1))
     ws = torch.empty(max(wsn, 256), dtype=torch.uint8, device=DEV)
     ref, y = torch.empty(B, H, W, Cout, device=DEV), torch.full((B, H, W, Cout), float("nan"), device=DEV)
-    _lib.check(L().pp_conv2d_fwd(xm.data_ptr(), Cin, B, H, W, Cin, w.data_ptr(), None, 1, 1, 1, 0, 1, ref.data_ptr(), Cout, Cout,
-                                 ws.data_ptr() if wsn else None, wsn, st()), "conv")
+    L().pp_debug_set_conv_rows(1)          # the reference through the same MFMA kernel (the whole-row VALU kernels add in another order)
+    try:
+        _lib.check(L().pp_conv2d_fwd(xm.data_ptr(), Cin, B, H, W, Cin, w.data_ptr(), None, 1, 1, 1, 0, 1, ref.data_ptr(), Cout, Cout,
+                                     ws.data_ptr() if wsn else None, wsn, st()), "conv")
+    finally:
+        L().pp_debug_set_conv_rows(0)
     _lib.check(L().pp_conv2d_fwd_affine_in(x.data_ptr(), Cin, B, H, W, Cin, scale.data_ptr(), shift.data_ptr(), act, w.data_ptr(), None, 1, 1, 1,
                                            0, 1, y.data_ptr(), Cout, Cout, ws.data_ptr() if wsn else None, wsn, st()), "conv affine")
     assert torch.equal(y, ref)                                    # same products in the same order

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_nn_ops_gpu.py -q -m gpu -k "narrow_layers or stem_weight" 2>&1 | grep -E "^E  |FAILED|passed|failed" | head -30
-for i in 1 2 3; do
-ROWS=1 STEPS=200 timeout 600 python tools/train_bench.py 2>&1 | tail -1
-ROWS=2 STEPS=200 timeout 600 python tools/train_bench.py 2>&1 | tail -1
-STEPS=200 timeout 600 python tools/train_bench.py 2>&1 | tail -1
-done
+O=gpurun_out/r4d; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -3 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_line.json 2> $O/bench.err; python - <<PY
+import json; d=json.loads(open("$O/bench_line.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["train"]["replay"], d["train"]["host_enqueue_ms_per_step"])
+PY
