@@ -339,6 +339,22 @@ int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
                     float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
                     void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream);
 
+/* Sparse output gradients.  The loss of a sparsely labelled batch (model.py:113-119: 20 labelled pixels per image, ignore_index
+ * elsewhere) has a gradient that is zero in all but a few hundred of the 32768 low-resolution rows.  pp_row_flags marks the non-zero
+ * rows of a [M, C] gradient (flags[r] = 1 when any entry of row r is non-zero); pp_conv1x1_bwd_data_sparse is the backward-data of a
+ * pointwise convolution (w: HWIO of a 1x1 kernel = [Cin][Cout]) that writes zeros for the unflagged rows of dx and computes the flagged
+ * ones; pp_bn_bwd_fused_sparse is pp_bn_bwd_fused told that the unflagged rows of dy are exact zeros: its statistics pass visits only
+ * the flagged rows (in the dense kernel's order: dgamma / dbeta / dx are bit-equal to pp_bn_bwd_fused on the same dy) and its dx pass
+ * never reads dy elsewhere.  A row cache variant of the kernel (small maps) ignores the flags. */
+int pp_row_flags(const float* dy, int64_t lddy, int64_t M, int C, unsigned char* flags, pp_stream_t stream);
+int pp_conv1x1_bwd_data_sparse(const float* dy, int64_t lddy, int64_t M, int Cout, const float* w, int Cin, const unsigned char* row_flags,
+                             float* dx, int64_t lddx, pp_stream_t stream);
+int pp_bn_bwd_fused_sparse(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+                         int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                         float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
+                         void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, const unsigned char* row_flags,
+                         pp_stream_t stream);
+
 /* nn.BatchNorm2d, eval mode: scale/shift from the running statistics. */
 int pp_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, pp_stream_t stream);

@@ -75,6 +75,9 @@ SIGNATURES = {
     "pp_dwconv3x3_bn_train_fwd_fused": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p, _p, _f, _f, _p, _p, _p, _p,
                                                _p, _i64, _int, _p, _i64, _p, _sz, _p, _sz, _p]),
     "pp_bn_bwd_fused": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _p, _sz, _p, _sz, _p]),
+    "pp_bn_bwd_fused_sparse": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _p, _sz, _p, _sz, _p, _p]),
+    "pp_row_flags": (_int, [_p, _i64, _i64, _int, _p, _p]),
+    "pp_conv1x1_bwd_data_sparse": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _i64, _p]),
     "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_weight": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _p, _p, _sz, _p]),

@@ -666,13 +666,20 @@ struct BnBwdArgs {
     float* dx; int64_t lddx; float* dres; int64_t lddr; xword* part; int* sync; BnFusedGeom g;
     float gscale;     // 1/(1-p) of a dropout fused after the activation (its mask is y_act == 0), else 1
     const float* beta_mask;   // non-NULL (and yact NULL): the activation mask is recomputed from x, z = x*scale + shift
+    const unsigned char* rowflag;   // SPARSE variant: rowflag[r] == 0 promises that row r of dy is all zeros (never read then)
 };
 
 // NC > 0: a thread's (at most NC, launcher-checked) rows of x and of the masked, scaled dy stay in registers between the
 // reduction pass and the dx pass (same values, same order; the mask source is not read twice either).
-template <int NC>
+// SPARSE (NC == 0 only): the gradient is zero except in the rows whose flag is set - the loss of a sparsely labelled batch
+// (model.py:113-119: 20 labelled pixels per image, ignore_index elsewhere) leaves <= 4 x 80 non-zero rows of 32768 behind the
+// classifier.  The statistics pass visits only those rows, in the order the dense kernel adds them (the skipped terms are exact
+// zeros: the sums are bit-equal), the dx pass reads dy and the mask source only there: x is read once and dy almost never.
+__device__ __attribute__((aligned(16))) float g_bn_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+template <int NC, bool SPARSE = false>
 __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
 {
+    static_assert(!SPARSE || NC == 0, "row flags: the uncached variant");
     __shared__ unsigned sh_tag;
     __shared__ float4 sh[2][kT];
     __shared__ double shd[kT];
@@ -752,6 +759,34 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
                 }
             }
         } else {
+            if constexpr (SPARSE) {
+                for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)g.nrl * 8) {   // flags of eight rows at a time (independent loads)
+                  unsigned char fl8[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) {
+                      const int64_t rj = rb + (int64_t)j * g.nrl;
+                      fl8[j] = rj < r1 ? a.rowflag[rj] : (unsigned char)0;
+                  }
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) {                           // the dense order: r, r + nrl, r + 2 nrl, ...
+                    if (fl8[j] == 0) continue;
+                    const int64_t r = rb + (int64_t)j * g.nrl;
+                    float4 v = *reinterpret_cast<const float4*>(xq + r * a.ldx);
+                    float4 u = *reinterpret_cast<const float4*>(gq + r * a.lddy);
+                    if (act != 0) {
+                        const float4 ya = remask ? make_float4(fmaf(v.x, zsc.x, zsf.x), fmaf(v.y, zsc.y, zsf.y), fmaf(v.z, zsc.z, zsf.z),
+                                                               fmaf(v.w, zsc.w, zsf.w))
+                                                 : *reinterpret_cast<const float4*>(aq + r * a.ldya);
+                        u.x *= act_mask(ya.x, act); u.y *= act_mask(ya.y, act); u.z *= act_mask(ya.z, act); u.w *= act_mask(ya.w, act);
+                    }
+                    const float ws_ = 1.0f * a.gscale;
+                    u.x *= ws_; u.y *= ws_; u.z *= ws_; u.w *= ws_;
+                    s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                    s1.x = fmaf(u.x, (v.x - mu.x) * is.x, s1.x); s1.y = fmaf(u.y, (v.y - mu.y) * is.y, s1.y);
+                    s1.z = fmaf(u.z, (v.z - mu.z) * is.z, s1.z); s1.w = fmaf(u.w, (v.w - mu.w) * is.w, s1.w);
+                  }
+                }
+            } else
             // large maps, one block per CU: four rows (8-12 float4 loads) in flight per thread (see the forward kernel)
             for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
                 float4 va[2], ga[2], yaa[2], vb[2], gb[2], yab[2];
@@ -806,15 +841,35 @@ __global__ __launch_bounds__(kT) void bn_fused_bwd_kernel(BnBwdArgs a)
         }
         return;
     }
+    unsigned char fnext[4] = {0, 0, 0, 0};
+    if constexpr (SPARSE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = r0 + rl + (int64_t)j * g.nrl;
+            fnext[j] = rr < r1 ? a.rowflag[rr] : (unsigned char)0;
+        }
+    }
     for (int64_t r = r0 + rl; r < r1; r += (int64_t)g.nrl * 4) {
         float4 uu[4], vv[4], yy[4];
+        unsigned char fcur[4] = {fnext[0], fnext[1], fnext[2], fnext[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t rr = r + (int64_t)j * g.nrl;
             const int64_t rc = rr < r1 ? rr : r;
-            uu[j] = *reinterpret_cast<const float4*>(gq + rc * a.lddy);
+            if constexpr (SPARSE) {
+                // unflagged rows: dy (and the mask source) come from a zero word - the load stays unconditional, the row is not read
+                const bool fl = rr < r1 && fcur[j] != 0;
+                {   // the flags of the next group fly with this group's loads
+                    const int64_t rn = rr + (int64_t)g.nrl * 4;
+                    fnext[j] = rn < r1 ? a.rowflag[rn] : (unsigned char)0;
+                }
+                uu[j] = *reinterpret_cast<const float4*>(fl ? gq + rc * a.lddy : g_bn_zero4);
+                yy[j] = (act != 0 && !remask) ? *reinterpret_cast<const float4*>(fl ? aq + rc * a.ldya : g_bn_zero4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                uu[j] = *reinterpret_cast<const float4*>(gq + rc * a.lddy);
+                yy[j] = (act != 0 && !remask) ? *reinterpret_cast<const float4*>(aq + rc * a.ldya) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             vv[j] = *reinterpret_cast<const float4*>(xq + rc * a.ldx);
-            yy[j] = (act != 0 && !remask) ? *reinterpret_cast<const float4*>(aq + rc * a.ldya) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -846,10 +901,11 @@ static int bn_fused_capacity()
         int dev = 0, cus = 0, a = 0, b = 0, c = 0;
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        int d = 0, e = 0, f = 0;
+        int d = 0, e = 0, f = 0, sp = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bn_fused_fwd_kernel<0, 0>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bn_fused_fwd_kernel<1, 0>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, bn_fused_bwd_kernel<0>, kT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&sp, (bn_fused_bwd_kernel<0, true>), kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, bn_fused_fwd_kernel<0, kBnRowCache>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, bn_fused_bwd_kernel<kBnRowCache>, kT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, bn_fused_fwd_kernel<1, kBnRowCache>, kT, 0) != hipSuccess) {
@@ -861,6 +917,7 @@ static int bn_fused_capacity()
         per = per < d ? per : d;
         per = per < e ? per : e;
         per = per < f ? per : f;
+        per = per < sp ? per : sp;
         return per * cus;
     }();
     return cap;
@@ -2245,10 +2302,93 @@ int pp_dwconv3x3_bn_train_fwd_fused(const float* in, int64_t ld_in, int B, int H
     return check_launch("bn_fused_fwd_kernel<dw>");
 }
 
+static int bn_bwd_fused_impl(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+                             int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                             float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
+                             void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream,
+                             const unsigned char* row_flags);
+
 int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
                     int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                     float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
                     void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream)
+{
+    return bn_bwd_fused_impl(x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr, grad_scale,
+                             beta, workspace, ws_bytes, sync, sync_ints, stream, nullptr);
+}
+
+int pp_bn_bwd_fused_sparse(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+                         int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                         float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
+                         void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, const unsigned char* row_flags,
+                         pp_stream_t stream)
+{
+    return bn_bwd_fused_impl(x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr, grad_scale,
+                             beta, workspace, ws_bytes, sync, sync_ints, stream, row_flags);
+}
+
+__global__ __launch_bounds__(256) void row_flags_kernel(const float* dy, int64_t ld, int64_t M, int C, unsigned char* flags)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    const float* p = dy + r * ld;
+    bool nz = false;
+    for (int c = 0; c < C; ++c) nz = nz || (p[c] != 0.0f);
+    flags[r] = nz ? 1 : 0;                                    // exactly 0 / 1 (conv1x1_bwd_data_rows_kernel relies on it)
+}
+
+int pp_row_flags(const float* dy, int64_t lddy, int64_t M, int C, unsigned char* flags, pp_stream_t stream)
+{
+    if (!dy || !flags || M < 1 || C < 1) return fail(PP_ERR_BAD_ARG, "row_flags: bad argument");
+    hipLaunchKernelGGL(row_flags_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, as_stream(stream), dy, lddy, M, C, flags);
+    return check_launch("row_flags_kernel");
+}
+
+// Backward-data of a pointwise convolution whose output gradient is zero outside the flagged rows (the classifier behind a sparsely
+// labelled loss, decoders.py:120: Conv2d(256, n_classes, 1)): unflagged rows of dx are written as zeros, flagged rows are
+// dx[r][c] = sum_k dy[r][k] W[c][k] (k ascending).  16 rows per block; a row's flag is block-uniform.
+__global__ __launch_bounds__(256) void conv1x1_bwd_data_rows_kernel(const float* dy, int64_t lddy, int64_t M, int Cout, const float* w, int Cin,
+                                                                     const unsigned char* flags, float* dx, int64_t lddx)
+{
+    __shared__ unsigned char fl[16];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const int cq = Cin / 4;
+    if (t < 16) fl[t] = (r0 + t < M) ? flags[r0 + t] : (unsigned char)2;       // 2: past the end (neither zeroed nor computed)
+    __syncthreads();
+    for (int e = t; e < 16 * cq; e += 256) {                 // zeros for the unflagged rows (float4, coalesced)
+        const int rr = e / cq, q = e - rr * cq;
+        if (fl[rr] == 0) *reinterpret_cast<float4*>(dx + (r0 + rr) * lddx + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+        const int64_t r = r0 + rr;
+        if (fl[rr] != 1) continue;
+        const float* g = dy + r * lddy;
+        for (int c = t; c < Cin; c += 256) {
+            const float* wc = w + (int64_t)c * Cout;
+            float acc = 0.0f;
+            for (int k = 0; k < Cout; ++k) acc = fmaf(g[k], wc[k], acc);
+            dx[r * lddx + c] = acc;
+        }
+    }
+}
+
+int pp_conv1x1_bwd_data_sparse(const float* dy, int64_t lddy, int64_t M, int Cout, const float* w, int Cin, const unsigned char* row_flags,
+                             float* dx, int64_t lddx, pp_stream_t stream)
+{
+    if (!dy || !w || !row_flags || !dx || M < 1 || Cout < 1 || Cin < 1) return fail(PP_ERR_BAD_ARG, "conv1x1_bwd_data_rows: bad argument");
+    if (Cin % 4 != 0 || lddx % 4 != 0 || (reinterpret_cast<uintptr_t>(dx) & 15) != 0)
+        return fail(PP_ERR_BAD_ARG, "conv1x1_bwd_data_rows: Cin and lddx must be multiples of 4, dx 16-byte aligned");
+    hipLaunchKernelGGL(conv1x1_bwd_data_rows_kernel, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, as_stream(stream), dy, lddy, M, Cout, w, Cin,
+                       row_flags, dx, lddx);
+    return check_launch("conv1x1_bwd_data_rows_kernel");
+}
+
+static int bn_bwd_fused_impl(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
+                             int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                             float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,
+                             void* workspace, size_t ws_bytes, int32_t* sync, size_t sync_ints, pp_stream_t stream,
+                             const unsigned char* row_flags)
 {
     if (!x || !dy || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: null");
     if (act != 0 && !y_act && !beta) return fail(PP_ERR_BAD_ARG, "bn_bwd_fused: the mask needs the activation output or beta");
@@ -2260,9 +2400,11 @@ int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
     BnFusedGeom g = bn_fused_geom(M, C);
     if (int rc = bn_fused_check("bn_bwd_fused", M, C, g, workspace, ws_bytes, sync, sync_ints)) return rc;
     BnBwdArgs a{x, ldx, dy, lddy, y_act, ldya, act, M, C, mean, invstd, gamma, dgamma, dbeta, dx, lddx, dres, lddr,
-                reinterpret_cast<xword*>(workspace), sync, g, grad_scale, y_act ? nullptr : beta};
+                reinterpret_cast<xword*>(workspace), sync, g, grad_scale, y_act ? nullptr : beta, row_flags};
     if (g_bn_row_cache && g.rows_per_chunk <= (int64_t)g.nrl * kBnRowCache)
         hipLaunchKernelGGL(bn_fused_bwd_kernel<kBnRowCache>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
+    else if (row_flags)
+        hipLaunchKernelGGL((bn_fused_bwd_kernel<0, true>), dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     else
         hipLaunchKernelGGL(bn_fused_bwd_kernel<0>, dim3((unsigned)(g.nstrips * g.R)), dim3(kT), 0, as_stream(stream), a);
     return check_launch("bn_fused_bwd_kernel");

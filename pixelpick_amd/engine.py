@@ -912,6 +912,16 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
         # x already has a gradient from another consumer (the residual branch): add into it in the kernel's epilogue
         acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
                               and tuple(x.grad.shape) == (B, H, W, Cin)) else None
+        flags = getattr(dy, "_pp_rowflags", None) if _SPARSE_ROWS else None
+        if (flags is not None and kh == 1 and kw == 1 and stride == 1 and pad == 0 and acc_into is None and lazy_in is None and Cin % 4 == 0
+                and flags.numel() == B * H * W and dyp is None):
+            # pointwise convolution behind a sparse gradient: rows stay rows - zeros for the unflagged ones, the flags travel on
+            dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+            rc = L.pp_conv1x1_bwd_data_sparse(dy.data_ptr(), lddy, B * H * W, Cout, w.data_ptr(), Cin, flags.data_ptr(), dx.data_ptr(), Cin, _stream())
+            _lib.check(rc, "pp_conv1x1_bwd_data_sparse")
+            dx._pp_rowflags = flags              # (not _pp_owned: nobody may add into it in place, the flags would go stale)
+            _acc(x, dx)
+            return
         dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
         if dyp is not None:
@@ -1046,6 +1056,9 @@ def _conv_bn_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
 
 
 _CONV_BN_FUSE_BWD = os.environ.get("PIXELPICK_CONV_BN_FUSE_BWD", "1") != "0"
+# PIXELPICK_SPARSE_ROWS (default on): the loss gradient's non-zero rows are flagged (cross_entropy_lowres) and the flags follow the
+# gradient through the classifier's backward-data (pp_conv1x1_bwd_data_sparse) into the BatchNorm backward (pp_bn_bwd_fused_sparse)
+_SPARSE_ROWS = os.environ.get("PIXELPICK_SPARSE_ROWS", "1") != "0"
 
 
 def _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
@@ -1298,10 +1311,18 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
         sync, ws = _bn_exchange(dev)
         # ReLU/ReLU6 mask: from the saved output, or - no residual, no fused dropout - recomputed from x (one tensor less)
         remask = (act != ACT_NONE and residual is None and gscale == 1.0) or lazy_out
-        rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
-                               mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                               dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),
-                               beta.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
+        flags = getattr(dy, "_pp_rowflags", None) if _SPARSE_ROWS else None
+        if flags is not None and flags.numel() == M:
+            rc = L.pp_bn_bwd_fused_sparse(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
+                                        mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                        dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),
+                                        beta.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), flags.data_ptr(), _stream())
+            tape._keepalive.append(flags)
+        else:
+            rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
+                                   mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                   dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),
+                                   beta.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_bn_bwd_fused")
     else:
         assert gscale == 1.0, "a fused dropout is only created together with the single-launch BatchNorm"
@@ -1583,4 +1604,10 @@ def cross_entropy_lowres(low: torch.Tensor, size, target: torch.Tensor, ignore_i
                                                 dlow.data_ptr() if dlow is not None else None, C, ws.data_ptr(), ws.numel(),
                                                 _stream())
     _lib.check(rc, "pp_sparse_ce_lowres_fwd_bwd")
+    if dlow is not None and _SPARSE_ROWS:
+        # 20 labelled pixels per image (model.py:113-119) touch <= 4 low-resolution rows each: the gradient is zero in all other rows.
+        # The flags ride on the tensor; the classifier's backward-data and the BatchNorm backward behind it skip the zero rows.
+        flags = torch.empty(B * h * w, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().pp_row_flags(dlow.data_ptr(), C, B * h * w, C, flags.data_ptr(), _stream()), "pp_row_flags")
+        dlow._pp_rowflags = flags
     return loss, dlow

@@ -158,6 +158,83 @@ def test_pointwise_backward_data_of_the_narrow_layers(case):
     close(c, xr.grad + dres, what="dx added to the residual branch's gradient")
 
 
+@pytest.mark.parametrize("shape,act", [((4, 64, 128, 256), 1), ((4, 64, 128, 256), 0), ((2, 100, 90, 48), 2), ((2, 33, 47, 64), 1)])
+def test_sparse_loss_gradient_rows(shape, act, monkeypatch):
+    """model.py:113-119: 20 labelled pixels per image -> the loss gradient is zero in all but a few hundred low-resolution rows.
+    pp_row_flags marks them; the classifier's backward-data (pp_conv1x1_bwd_data_sparse) writes zeros elsewhere and equals the dense
+    backward-data to fp32 rounding; the BatchNorm backward told about the flags (pp_bn_bwd_fused_sparse) returns dx / dgamma / dbeta
+    BIT-EQUAL to the dense kernel on the same gradient (the skipped terms are exact zeros) and equals torch autograd."""
+    B, H, W, C = shape
+    ncls = 19
+    gen = torch.Generator().manual_seed(C + act)
+    x = torch.randn(B, C, H, W, generator=gen) * 2 + 0.3
+    wc = torch.randn(ncls, C, 1, 1, generator=gen) / np.sqrt(C)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3
+    rows = torch.randperm(B * H * W, generator=gen)[:300]
+    dl_rows = torch.zeros(B * H * W, ncls)
+    dl_rows[rows] = torch.randn(300, ncls, generator=gen)
+    dlog = dl_rows.reshape(B, H, W, ncls).permute(0, 3, 1, 2).contiguous()
+    def run(sparse):
+        monkeypatch.setattr(E, "_SPARSE_ROWS", sparse)
+        tape = E.Tape()
+        xv = E.Var(nhwc(x))
+        gg, bg, wg = gparam(gamma), gparam(beta), gparam(hwio(wc))
+        y = E.batch_norm_act(tape, xv, gg, bg, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, act)
+        logits = E.conv2d(tape, y, wg, None, 1, 0, 1)
+        dl = nhwc(dlog)
+        if sparse:
+            flags = torch.empty(B * H * W, dtype=torch.uint8, device=DEV)
+            _lib_mod().check(_lib_mod().lib().pp_row_flags(dl.data_ptr(), ncls, B * H * W, ncls, flags.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "flags")
+            assert int(flags.sum().item()) == 300
+            dl._pp_rowflags = flags
+        tape.backward(logits, dl)
+        torch.cuda.synchronize()
+        return [xv.grad.clone(), tape.param_grads[id(gg)].clone(), tape.param_grads[id(bg)].clone(), tape.param_grads[id(wg)].clone()]
+    a, a2, b = run(True), run(True), run(False)
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
+    # the classifier's dx feeds the BatchNorm: with the SAME dy the two BatchNorm kernels are bit-equal; here dy itself comes from two
+    # different backward-data kernels, so compare to rounding ...
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= 2e-5 * (v.abs().max().item() + 1e-6)
+    # ... and bit-equal when both BatchNorm kernels see the same gradient tensor
+    L = _lib_mod().lib()
+    st = torch.cuda.current_stream().cuda_stream
+    M = B * H * W
+    xn = nhwc(x)
+    dy = torch.zeros(M, C, device=DEV)
+    dy[rows.to(DEV)] = torch.randn(300, C, generator=torch.Generator(device=DEV).manual_seed(1), device=DEV)
+    flags = torch.empty(M, dtype=torch.uint8, device=DEV)
+    _lib_mod().check(L.pp_row_flags(dy.data_ptr(), C, M, C, flags.data_ptr(), st), "flags")
+    mean = xn.reshape(M, C).mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(xn.reshape(M, C).var(0, unbiased=False) + 1e-5)).contiguous()
+    g_, b_ = gamma.to(DEV).contiguous(), beta.to(DEV).contiguous()
+    sync, ws = E._bn_exchange(torch.device(DEV))
+    outs = []
+    for fl in (None, flags):
+        dx, dg, db = torch.empty(M, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        args = [xn.data_ptr(), C, dy.data_ptr(), C, None, 0, act, M, C, mean.data_ptr(), invstd.data_ptr(), g_.data_ptr(), dg.data_ptr(),
+                db.data_ptr(), dx.data_ptr(), C, None, 0, 1.0, b_.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel()]
+        if fl is None:
+            _lib_mod().check(L.pp_bn_bwd_fused(*args, st), "dense")
+        else:
+            _lib_mod().check(L.pp_bn_bwd_fused_sparse(*args, fl.data_ptr(), st), "rows")
+        torch.cuda.synchronize()
+        outs.append((dx, dg, db))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    # torch autograd
+    xr, gr, br, wr = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), wc.clone().requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    z = F.relu(z) if act == 1 else (F.relu6(z) if act == 2 else z)
+    F.conv2d(z, wr).backward(dlog)
+    close(nchw(a[0]), xr.grad, what="dx through the sparse-row kernels")
+    close(a[1].cpu(), gr.grad, what="dgamma")
+    close(a[2].cpu(), br.grad, what="dbeta")
+    close(oihw(a[3]), wr.grad, what="classifier dW")
+
+
 ROWS_FWD = [(4, 128, 256, 32, 16, 0), (4, 64, 128, 96, 24, 0), (4, 64, 128, 144, 32, 0), (2, 100, 83, 144, 24, 0),      # narrow output: project
             (4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 96, 96, 32, 192, 0), (1, 129, 131, 16, 96, 1)]        # narrow input: expand
 

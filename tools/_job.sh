@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4d; mkdir -p $O
-timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -3 $O/tall.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $O/bench_line.json 2> $O/bench.err; python - <<PY
-import json; d=json.loads(open("$O/bench_line.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["train"]["replay"], d["train"]["host_enqueue_ms_per_step"])
-PY
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_nn_ops_gpu.py -q -m gpu -k "sparse_loss" 2>&1 | grep -E "^E  |FAILED|passed|failed|Error" | head -30
+for i in 1 2 3; do
+REPLAY=1 PIXELPICK_SPARSE_ROWS=0 STEPS=200 timeout 600 python tools/train_bench.py 2>&1 | tail -1
+REPLAY=1 STEPS=200 timeout 600 python tools/train_bench.py 2>&1 | tail -1
+done
+rm -rf /tmp/pt; STEPS=10 rocprofv3 --kernel-trace --stats -d /tmp/pt -o t --output-format csv -- python tools/train_bench.py > /dev/null 2>&1
+grep "bn_fused_bwd_kernel<0\|bwd_data_rows\|row_flags" $(find /tmp/pt -name "*kernel_stats.csv" | head -1) | cut -d, -f1-7

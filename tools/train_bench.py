@@ -48,6 +48,8 @@ def main():
     mp = os.environ.get("MAIN_PRIORITY")              # run the step on a stream of this HIP priority (default: the current stream)
     ctx = torch.cuda.stream(torch.cuda.Stream(priority=int(mp))) if mp is not None else contextlib.nullcontext()
     with ctx:
+        if os.environ.get("REPLAY"):                  # launch-plan replay (FlatTrainer.enable_replay) instead of eager steps
+            tr.enable_replay(x, y, warmup=1)
         for _ in range(warm):
             loss = tr.train_step(x, y)
         torch.cuda.synchronize()
