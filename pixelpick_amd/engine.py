@@ -836,14 +836,15 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
     if (w.requires_grad and x.needs_grad and lazy_in is None and _x3_planes(1, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
             and _x3_planes(2, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
         dyp = _x3_split(dy, lddy, B * Ho * Wo, Cout)       # one split of dy for backward-data and the weight gradient (main stream, before the fork)
-    if w.requires_grad:
+    big = _BIG_WGRAD_MAIN and 2.0 * B * Ho * Wo * Cin * Cout * kh * kw >= _BIG_WGRAD_FLOP
+
+    def _issue_wgrad():
         dw = tape.grad_buffer_for(w)
         db = tape.grad_buffer_for(bias) if (bias is not None and bias.requires_grad) else None
         # MFMA-bound layers (>= 8 GFLOP: the SegmentHead / ResNet 3x3 convolutions): their backward-data runs conv_x3_kernel with one
         # 512-thread block and 108-144 KiB of LDS per CU, which cannot become resident beside the weight-gradient blocks (647 / 751 us
         # in the trace instead of 210 / 350 alone) - and two MFMA-bound kernels gain nothing from sharing the matrix pipes anyway:
         # the weight gradient of such a layer goes out on the MAIN stream, behind nothing it could overlap with
-        big = _BIG_WGRAD_MAIN and 2.0 * B * Ho * Wo * Cin * Cout * kh * kw >= _BIG_WGRAD_FLOP
         with (_NULL_CTX if big else tape.side_stream_for(lazy_in[0] if lazy_in is not None else x.t, dy, dw, db)):
             if lazy_in is not None:
                 # the weight gradient needs act(bn(raw)), which the forward never wrote: one elementwise launch on the
@@ -871,69 +872,81 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
         tape.set_param_grad(w, dw)
         if db is not None:
             tape.set_param_grad(bias, db)
-    if x._closed:
-        raise RuntimeError("a second convolution's backward reached a BatchNorm output whose backward already ran (wrong `consumers` hint)")
-    bctx = x._bn_bwd_ctx if (x.needs_grad and _CONV_BN_FUSE_BWD and lazy_in is None) else None
-    if bctx is not None:
-        # every OTHER consumer's gradient must be here already (their backward ran earlier: they read x later in the forward);
-        # one other consumer = the residual add of the block behind, whose gradient is a contiguous tensor of x's shape
-        have = x.grad is not None
-        if bctx[7] != (2 if have else 1) or (have and not (x.grad.is_contiguous() and tuple(x.grad.shape) == (B, H, W, Cin))):
-            bctx = None
-    if bctx is not None and bctx[0].needs_grad and _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) and _bn_exchange_ok(dev):
-        # x is the output of a training BatchNorm (+ residual, activation) and this convolution's backward is the last of its
-        # consumers' to run: the BatchNorm's backward runs inside this backward-data launch (pp_conv2d_bwd_data_bn_bwd) - the BatchNorm
-        # node then finds no gradient on its output and is skipped
-        bin_, g_, b_, mean_, invstd_, act_, res_, _ = bctx
-        _, _, _, _, ldb = _geom(bin_.t)
-        dxbn = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-        dres = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev) if (res_ is not None and res_.needs_grad) else None
-        gin = x.grad
-        dg_, db_ = tape.grad_buffer_for(g_), tape.grad_buffer_for(b_)
-        sync, xws = _bn_exchange(dev)
-        rc = L.pp_conv2d_bwd_data_bn_bwd(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil, H, W, Cin,
-                                         bin_.t.data_ptr(), ldb, mean_.data_ptr(), invstd_.data_ptr(), g_.data_ptr(), b_.data_ptr(), act_,
-                                         dg_.data_ptr(), db_.data_ptr(), dxbn.data_ptr(), Cin,
-                                         gin.data_ptr() if gin is not None else None, Cin, dres.data_ptr() if dres is not None else None, Cin,
-                                         xws.data_ptr(), xws.numel(), sync.data_ptr(), sync.numel(), _stream())
-        _lib.check(rc, "pp_conv2d_bwd_data_bn_bwd")
-        tape.set_param_grad(g_, dg_)
-        tape.set_param_grad(b_, db_)
-        if gin is not None:
-            tape._keepalive.append(gin)
-        x.grad = None                    # consumed here: the BatchNorm node is skipped
-        x._closed = True
-        dxbn._pp_owned = True
-        _acc(bin_, dxbn)
-        if dres is not None:
-            dres._pp_owned = True
-            _acc(res_, dres)
-    elif x.needs_grad:
-        # x already has a gradient from another consumer (the residual branch): add into it in the kernel's epilogue
-        acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
-                              and tuple(x.grad.shape) == (B, H, W, Cin)) else None
-        flags = getattr(dy, "_pp_rowflags", None) if _SPARSE_ROWS else None
-        if (flags is not None and kh == 1 and kw == 1 and stride == 1 and pad == 0 and acc_into is None and lazy_in is None and Cin % 4 == 0
-                and flags.numel() == B * H * W and dyp is None):
-            # pointwise convolution behind a sparse gradient: rows stay rows - zeros for the unflagged ones, the flags travel on
-            dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-            rc = L.pp_conv1x1_bwd_data_sparse(dy.data_ptr(), lddy, B * H * W, Cout, w.data_ptr(), Cin, flags.data_ptr(), dx.data_ptr(), Cin, _stream())
-            _lib.check(rc, "pp_conv1x1_bwd_data_sparse")
-            dx._pp_rowflags = flags              # (not _pp_owned: nobody may add into it in place, the flags would go stale)
-            _acc(x, dx)
-            return
-        dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-        ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
-        if dyp is not None:
-            rc = L.pp_conv2d_bwd_data_pre(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                          dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, dyp.data_ptr(), _stream())
-        else:
-            rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                      dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
-        _lib.check(rc, "pp_conv2d_bwd_data")
-        if acc_into is None:
-            dx._pp_owned = True              # fresh tensor referenced by x.grad only: later consumers may add in place
-            _acc(x, dx)
+    def _issue_dx():
+        if x._closed:
+            raise RuntimeError("a second convolution's backward reached a BatchNorm output whose backward already ran (wrong `consumers` hint)")
+        bctx = x._bn_bwd_ctx if (x.needs_grad and _CONV_BN_FUSE_BWD and lazy_in is None) else None
+        if bctx is not None:
+            # every OTHER consumer's gradient must be here already (their backward ran earlier: they read x later in the forward);
+            # one other consumer = the residual add of the block behind, whose gradient is a contiguous tensor of x's shape
+            have = x.grad is not None
+            if bctx[7] != (2 if have else 1) or (have and not (x.grad.is_contiguous() and tuple(x.grad.shape) == (B, H, W, Cin))):
+                bctx = None
+        if bctx is not None and bctx[0].needs_grad and _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) and _bn_exchange_ok(dev):
+            # x is the output of a training BatchNorm (+ residual, activation) and this convolution's backward is the last of its
+            # consumers' to run: the BatchNorm's backward runs inside this backward-data launch (pp_conv2d_bwd_data_bn_bwd) - the BatchNorm
+            # node then finds no gradient on its output and is skipped
+            bin_, g_, b_, mean_, invstd_, act_, res_, _ = bctx
+            _, _, _, _, ldb = _geom(bin_.t)
+            dxbn = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+            dres = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev) if (res_ is not None and res_.needs_grad) else None
+            gin = x.grad
+            dg_, db_ = tape.grad_buffer_for(g_), tape.grad_buffer_for(b_)
+            sync, xws = _bn_exchange(dev)
+            rc = L.pp_conv2d_bwd_data_bn_bwd(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil, H, W, Cin,
+                                             bin_.t.data_ptr(), ldb, mean_.data_ptr(), invstd_.data_ptr(), g_.data_ptr(), b_.data_ptr(), act_,
+                                             dg_.data_ptr(), db_.data_ptr(), dxbn.data_ptr(), Cin,
+                                             gin.data_ptr() if gin is not None else None, Cin, dres.data_ptr() if dres is not None else None, Cin,
+                                             xws.data_ptr(), xws.numel(), sync.data_ptr(), sync.numel(), _stream())
+            _lib.check(rc, "pp_conv2d_bwd_data_bn_bwd")
+            tape.set_param_grad(g_, dg_)
+            tape.set_param_grad(b_, db_)
+            if gin is not None:
+                tape._keepalive.append(gin)
+            x.grad = None                    # consumed here: the BatchNorm node is skipped
+            x._closed = True
+            dxbn._pp_owned = True
+            _acc(bin_, dxbn)
+            if dres is not None:
+                dres._pp_owned = True
+                _acc(res_, dres)
+        elif x.needs_grad:
+            # x already has a gradient from another consumer (the residual branch): add into it in the kernel's epilogue
+            acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
+                                  and tuple(x.grad.shape) == (B, H, W, Cin)) else None
+            flags = getattr(dy, "_pp_rowflags", None) if _SPARSE_ROWS else None
+            if (flags is not None and kh == 1 and kw == 1 and stride == 1 and pad == 0 and acc_into is None and lazy_in is None and Cin % 4 == 0
+                    and flags.numel() == B * H * W and dyp is None):
+                # pointwise convolution behind a sparse gradient: rows stay rows - zeros for the unflagged ones, the flags travel on
+                dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+                rc = L.pp_conv1x1_bwd_data_sparse(dy.data_ptr(), lddy, B * H * W, Cout, w.data_ptr(), Cin, flags.data_ptr(), dx.data_ptr(), Cin, _stream())
+                _lib.check(rc, "pp_conv1x1_bwd_data_sparse")
+                dx._pp_rowflags = flags              # (not _pp_owned: nobody may add into it in place, the flags would go stale)
+                _acc(x, dx)
+                return
+            dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+            ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+            if dyp is not None:
+                rc = L.pp_conv2d_bwd_data_pre(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
+                                              dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, dyp.data_ptr(), _stream())
+            else:
+                rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
+                                          dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
+            _lib.check(rc, "pp_conv2d_bwd_data")
+            if acc_into is None:
+                dx._pp_owned = True              # fresh tensor referenced by x.grad only: later consumers may add in place
+                _acc(x, dx)
+
+    # PIXELPICK_WGRAD_LATE (default off; measured, profiles/r03_side_queue.txt): backward-data first, then the fork and the weight
+    # gradient - on the second queue it would then start when this layer's backward-data has finished and overlap the memory-bound
+    # BatchNorm backward behind it instead of the backward-data of its own layer.  Slower both eager and replayed (+0.05 ms).
+    if w.requires_grad and (big or not _WGRAD_LATE):
+        _issue_wgrad()
+        _issue_dx()
+    else:
+        _issue_dx()
+        if w.requires_grad:
+            _issue_wgrad()
 
 
 # ------------------------------------------------------------------------------------------------- depthwise conv
@@ -1059,6 +1072,7 @@ _CONV_BN_FUSE_BWD = os.environ.get("PIXELPICK_CONV_BN_FUSE_BWD", "1") != "0"
 # PIXELPICK_SPARSE_ROWS (default on): the loss gradient's non-zero rows are flagged (cross_entropy_lowres) and the flags follow the
 # gradient through the classifier's backward-data (pp_conv1x1_bwd_data_sparse) into the BatchNorm backward (pp_bn_bwd_fused_sparse)
 _SPARSE_ROWS = os.environ.get("PIXELPICK_SPARSE_ROWS", "1") != "0"
+_WGRAD_LATE = os.environ.get("PIXELPICK_WGRAD_LATE", "0") != "0"
 
 
 def _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
