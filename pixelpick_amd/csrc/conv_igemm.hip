@@ -62,6 +62,11 @@ struct BnTrain {
     const float* gin; int64_t ldgin; float* dres; int64_t lddr;
 };
 
+// dword-aligned wide loads (global loads need dword alignment only): the packed three-channel image of the stem
+struct __attribute__((packed, aligned(4))) StemF4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) StemF3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) StemF2 { float x, y; };
+
 struct ConvParams {
     const uint16_t* a_pre;   // bf16x3 planes of the A operand the CALLER already holds (pp_x3_split), or NULL: split here
     const float* x;   // A-side activations (X for fwd/wgrad, dY for bwd-data)
@@ -1647,6 +1652,59 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
     }
 }
 
+// Forward of the MobileNetV2 stem (mobilenet_v2.py:7-12: Conv2d(3, 32, 3, stride 2, padding 1, bias=False) on an even-sized image with
+// packed pixels): 6 MB in, 17 MB out.  As 128 x 32 MFMA tiles with scalar (non-vector: Cin = 3) operand loads the launch took 27 us.
+// Here: 64 output pixels per block; wave w computes output channels [8w, 8w + 8) of pixel `lane`; the 27 taps of a pixel are three runs
+// of nine contiguous floats (the weight gradient's wgrad_stem3x3s2_kernel reads them the same way), the 27 x 8 weights of a wave are
+// scalar operands; the 64 x 32 tile leaves through LDS as full 128-byte rows.
+__global__ __launch_bounds__(256) void conv_stem3x3s2_fwd_kernel(ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float ot[64 * 36];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * 64, m = m0 + lane;
+    float xv[27];
+    {
+        const bool rv = m < p.M;
+        const unsigned mu = (unsigned)(rv ? m : 0);
+        const unsigned tq = mu / (unsigned)p.Wo;
+        const int ow = (int)(mu - tq * (unsigned)p.Wo);
+        const unsigned bb = tq / (unsigned)p.Ho;
+        const int oh = (int)(tq - bb * (unsigned)p.Ho);
+        const bool left = ow > 0;
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const int ih = oh * 2 - 1 + th;
+            const bool ok = rv && (unsigned)ih < (unsigned)p.H;
+            const float* px = p.x + (ok ? (((int64_t)bb * p.H + ih) * p.W + ow * 2) * 3 : 3);
+            const StemF3 a = *reinterpret_cast<const StemF3*>(px - ((ok && left) ? 3 : 0));
+            const StemF4 b = *reinterpret_cast<const StemF4*>(px);
+            const StemF2 c = *reinterpret_cast<const StemF2*>(px + 4);
+            const bool oka = ok && left;
+            xv[th * 9 + 0] = oka ? a.x : 0.0f; xv[th * 9 + 1] = oka ? a.y : 0.0f; xv[th * 9 + 2] = oka ? a.z : 0.0f;
+            xv[th * 9 + 3] = ok ? b.x : 0.0f; xv[th * 9 + 4] = ok ? b.y : 0.0f; xv[th * 9 + 5] = ok ? b.z : 0.0f;
+            xv[th * 9 + 6] = ok ? b.w : 0.0f; xv[th * 9 + 7] = ok ? c.x : 0.0f; xv[th * 9 + 8] = ok ? c.y : 0.0f;
+        }
+    }
+    const float* __restrict__ wr = p.w + wave * 8;          // W[j][n], j = (th * 3 + tw) * 3 + c, n contiguous (HWIO)
+    float acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const float* wj = wr + j * 32;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[n] = fmaf(xv[j], wj[n], acc[n]);
+    }
+    *reinterpret_cast<float4*>(ot + lane * 36 + wave * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(ot + lane * 36 + wave * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    __syncthreads();
+    for (int e = t; e < 64 * 8; e += 256) {
+        const int r = e >> 3, q = e & 7;
+        if (m0 + r < p.M) *reinterpret_cast<float4*>(p.y + (m0 + r) * p.ldy + q * 4) = *reinterpret_cast<const float4*>(ot + r * 36 + q * 4);
+    }
+}
+
 // Tile / ring choice of conv1x1_ksplit_dma_kernel, from the measured table (profiles/r03_conv1x1_ksplit.txt; all six shapes x six
 // (TM, TN, NST) candidates at 2048 rows): the ring depth does not matter (3 vs 6 stages: +-0.5 us - the K loop is bound by the
 // MFMA chain of ONE wave per SIMD, not by bytes in flight), the tile does through the grid: 64x32 tiles while the grid stays within
@@ -2396,9 +2454,6 @@ __global__ __launch_bounds__(256) void wgrad_narrow_in_kernel(WgradParams p, int
 // only) instead of nine scalar ones - the generic kernel is bound by its 28 load instructions per output pixel - and the eight row lanes
 // of a block meet in LDS before the partial sums leave it (one slice of partials per BLOCK: 1/8 of the reduce's input).
 // W even, Wo = W / 2, pad 1: the right neighbour always exists, only iw0 - 1 (ow = 0) and ih (oh = 0) can fall outside.
-struct __attribute__((packed, aligned(4))) StemF4 { float x, y, z, w; };
-struct __attribute__((packed, aligned(4))) StemF3 { float x, y, z; };
-struct __attribute__((packed, aligned(4))) StemF2 { float x, y; };
 template <int U>
 __global__ __launch_bounds__(256) void wgrad_stem3x3s2_kernel(WgradParams p, int64_t rows_per_split)
 {
@@ -3570,6 +3625,18 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
         const bool pad0 = p.taps.n == 1 && p.taps.dh[0] == 0 && p.taps.dw[0] == 0 && p.stride == 1;
         if (BWD || !pad0 || !(use_ksplit || (pl.cfg == 0 && vec)))
             return fail(PP_ERR_UNSUPPORTED, "conv fwd: this shape has no input-affine kernel (ask pp_conv2d_fwd_accepts_affine_in first)");
+    }
+    if constexpr (!BWD) {
+        // the MobileNetV2 stem on an even-sized packed image (conv_stem3x3s2_fwd_kernel)
+        const bool stem = g_conv_bwd_rows && p.Cin == 3 && p.Cout == 32 && p.Cn == 32 && kh_kw == 9 && p.taps.n == 9 && p.stride == 2 &&
+                          p.taps.dh[0] == -1 && p.taps.dw[0] == -1 && p.taps.dh[8] == 1 && p.taps.dw[8] == 1 && p.W % 2 == 0 && p.H % 2 == 0 &&
+                          p.Wo * 2 == p.W && p.Ho * 2 == p.H && p.ldx == 3 && !p.bias && !p.stats && !p.in_scale && !p.epi.gamma && !p.epi.res &&
+                          p.epi.act == 0 && !p.accumulate && p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && p.M >= 16384 &&
+                          (int64_t)p.B * p.H * p.W * 3 < (1ll << 31);
+        if (stem) {
+            hipLaunchKernelGGL(conv_stem3x3s2_fwd_kernel, dim3((unsigned)cdiv(p.M, 64)), dim3(256), 0, st, p);
+            return check_launch("conv_stem3x3s2_fwd_kernel");
+        }
     }
     {
         // narrow pointwise layers on large maps: whole rows through LDS, VALU (conv1x1_rows_kernel / conv1x1_fwd_widen_kernel)

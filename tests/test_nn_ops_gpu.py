@@ -116,6 +116,30 @@ def test_conv2d_fwd_bwd(case):
         close(nchw(xv.grad), xr.grad, what="conv dX")
 
 
+@pytest.mark.parametrize("case", [(4, 256, 512), (2, 256, 256), (3, 200, 260), (1, 512, 258)], ids=str)
+def test_mobilenet_stem_forward(case):
+    """mobilenet_v2.py:7-12 Conv2d(3, 32, 3, stride 2, padding 1, bias=False) on an even-sized image: conv_stem3x3s2_fwd_kernel (nine
+    contiguous floats per tap row, weights as scalar operands) against torch and the MFMA path (pp_debug_set_conv_rows(1));
+    bit-reproducible."""
+    B, H, W = case
+    gen = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 3, H, W, generator=gen)
+    w = torch.randn(32, 3, 3, 3, generator=gen) / np.sqrt(27)
+    yr = F.conv2d(x, w, stride=2, padding=1)
+    L = _lib_mod().lib()
+    def run(off):
+        L.pp_debug_set_conv_rows(off)
+        try:
+            yv = E.conv2d(E.Tape(), E.Var(nhwc(x), needs_grad=False), gparam(hwio(w)), None, 2, 1, 1)
+            return nchw(yv.t)
+        finally:
+            L.pp_debug_set_conv_rows(0)
+    a, a2, b = run(0), run(0), run(1)
+    assert torch.equal(a, a2)
+    close(a, yr, what="stem forward")
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
 ROWS_BWD = [(4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 100, 83, 16, 96, 0), (1, 129, 131, 24, 144, 1), (3, 80, 90, 32, 192, 0),
             (2, 96, 96, 32, 64, 1)]
 
