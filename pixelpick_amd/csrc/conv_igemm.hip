@@ -1596,7 +1596,9 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvParams p, unsigne
 // maps, fixed padding folded in): y[m][0..CN) = x[m][0..CK) . W, a WRITE of y (51 MB for the first) with CK x CN weights.  As 128 x 128
 // MFMA tiles with one K step the launch took 48 us.  Here: 64 rows per block, wave w computes the CN / 4 output channels
 // [w CN/4, (w+1) CN/4) of row `lane` on the VALU (weights as scalar operands), the 64 x CN tile leaves through LDS as full rows.
-template <int CK, int CN>
+// BWD == true: the backward-data of the narrow-OUTPUT layers on the same maps (project 96 -> 24 / 144 -> 24: dy has 24 channels, dx 96 /
+// 144), the same kernel with the weights read as W[n][k] (k contiguous).
+template <int CK, int CN, bool BWD = false>
 __global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
 {
     constexpr int NPW = CN / 4, XP = CK + 4, OP = CN + 4;   // outputs per wave, LDS pitches (rows on different banks)
@@ -1607,6 +1609,18 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     constexpr int KQ = CK / 4;
+    // backward: the wave's NPW x CK weights (one contiguous run of W[n][k]) lane-distributed over NR registers, broadcast with v_readlane
+    // in the FMA loop: no memory access there (as scalar loads per output channel the 144-wide form stalled on the scalar cache: 34 us)
+    constexpr int NR = BWD ? (CK * NPW + 63) / 64 : 1;
+    float wreg[NR];
+    if constexpr (BWD) {
+        const float* wbase = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + (int64_t)(wave * NPW) * p.Cout;   // W[n0 + j][k]: one run of NPW * CK floats
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int f = r * 64 + lane;
+            wreg[r] = wbase[f < CK * NPW ? f : 0];
+        }
+    }
     for (int e = t; e < 64 * KQ; e += 256) {
         const int r = e / KQ, q = e - r * KQ;
         const int64_t m = m0 + r;
@@ -1624,7 +1638,6 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
         *reinterpret_cast<float4*>(xt + r * XP + q * 4) = v;
     }
     __syncthreads();
-    const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + wave * NPW;      // W[k][n], n contiguous
     float acc[NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j) acc[j] = 0.0f;
@@ -1634,11 +1647,24 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
         const float4 v = *reinterpret_cast<const float4*>(xt + lane * XP + q * 4);
         xr[q * 4 + 0] = v.x; xr[q * 4 + 1] = v.y; xr[q * 4 + 2] = v.z; xr[q * 4 + 3] = v.w;
     }
+    if constexpr (BWD) {
 #pragma unroll
-    for (int k = 0; k < CK; ++k) {
-        const float* wk = wr + (int64_t)k * p.Cout;
+        for (int j = 0; j < NPW; ++j)
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[j] = fmaf(xr[k], wk[j], acc[j]);
+            for (int k = 0; k < CK; ++k) {
+                const int f = j * CK + k;                                    // compile-time after unrolling
+                acc[j] = fmaf(xr[k], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[f / 64]), f % 64)), acc[j]);
+            }
+    } else {
+        // forward: W[k][n], n contiguous - a wave's NPW weights of a k are one run: scalar operands (measured against the v_readlane form:
+        // 16 -> 96 14.1 vs 20.5 us, 24 -> 144 14.6 vs 15.5 us)
+        const float* __restrict__ wr = p.w + (int64_t)p.taps.widx[0] * p.Cin * p.Cout + wave * NPW;
+#pragma unroll
+        for (int k = 0; k < CK; ++k) {
+            const float* wk = wr + (int64_t)k * p.Cout;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) acc[j] = fmaf(xr[k], wk[j], acc[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < NPW; j += 4)
@@ -1648,7 +1674,15 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_widen_kernel(ConvParams p)
     for (int e = t; e < 64 * NQ; e += 256) {
         const int r = e / NQ, q = e - r * NQ;
         const int64_t m = m0 + r;
-        if (m < p.M) *reinterpret_cast<float4*>(p.y + m * p.ldy + q * 4) = *reinterpret_cast<const float4*>(ot + r * OP + q * 4);
+        if (m < p.M) {
+            float4 o = *reinterpret_cast<const float4*>(ot + r * OP + q * 4);
+            float* dst = p.y + m * p.ldy + q * 4;
+            if (BWD && p.accumulate) {
+                const float4 a = *reinterpret_cast<const float4*>(dst);
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            *reinterpret_cast<float4*>(dst) = o;
+        }
     }
 }
 
@@ -3656,6 +3690,16 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
             else                 PP_ROWS(32);
 #undef PP_ROWS
             return check_launch("conv1x1_rows_kernel");
+        }
+        if constexpr (BWD) {
+            // backward-data of the project convolutions 96 -> 24 / 144 -> 24 (dy 24 channels wide, dx 96 / 144)
+            const bool widen = plain && p.Cout == p.Ck && p.Ck == 24 && (p.Cn == 96 || p.Cn == 144);
+            if (widen) {
+                const dim3 grid((unsigned)cdiv(p.M, 64));
+                if (p.Cn == 96) hipLaunchKernelGGL((conv1x1_fwd_widen_kernel<24, 96, true>), grid, dim3(256), 0, st, p);
+                else            hipLaunchKernelGGL((conv1x1_fwd_widen_kernel<24, 144, true>), grid, dim3(256), 0, st, p);
+                return check_launch("conv1x1_fwd_widen_kernel<bwd>");
+            }
         }
         if constexpr (!BWD) {
             const bool widen = plain && !p.accumulate && ((p.Ck == 16 && p.Cn == 96) || (p.Ck == 24 && p.Cn == 144) || (p.Ck == 32 && p.Cn == 192));
