@@ -1196,6 +1196,61 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, in
     }
 }
 
+// Stride 2, dilation 1 (the four strided depthwise layers of MobileNetV2): in the generic kernel above the lanes of a wave disagree
+// about which taps are live (the parity of ih / iw) - every lane walks all nine taps' branches, each load behind a branch (41 us for
+// the 51 MB dx of the first one).  Here a thread produces the 2 x 2 block of dx pixels with ih + pad in {2 ph, 2 ph + 1}, iw + pad in
+// {2 pw, 2 pw + 1}: it needs the four dy pixels (ph - 1 .. ph) x (pw - 1 .. pw) and all nine weights, no branches around the loads,
+// and adds each pixel's taps in the generic kernel's order (th, tw ascending): the results are bit-identical.
+__global__ __launch_bounds__(kT) void dwconv_s2_bwd_data_kernel(const float* dy, int64_t lddy, int B, int Ho, int Wo, int cq, const float* w,
+                                                               int pad, float* dx, int64_t lddx, int H, int W)
+{
+    const int C = cq * 4;
+    const int PH = (H + pad + 1) / 2 + 1, PW = (W + pad + 1) / 2 + 1;       // blocks in the padded coordinate (covers ih + pad up to H + pad - 1)
+    const int64_t total = (int64_t)B * PH * PW * cq;
+    for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kT) {
+        int q, pw, ph, b;
+        decode_bhwq(e, cq, PW, PH, q, pw, ph, b);
+        float4 g[2][2];                                      // g[a][c] = dy(ph - a, pw - c), zero outside
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int oh = ph - a, ow = pw - c;
+                const bool ok = (unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo;
+                const float4 v = *reinterpret_cast<const float4*>(dy + (ok ? (((int64_t)b * Ho + oh) * Wo + ow) * lddy : 0) + q * 4);
+                g[a][c] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float4 ww[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ww[i] = *reinterpret_cast<const float4*>(w + i * C + q * 4);
+        // dx pixel (ih, iw) = (2 ph + dr - pad, 2 pw + dc - pad); its live taps: th = dr + 2 a (a = 0, 1 while th <= 2), dy row ph - a
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc) {
+                const int ih = 2 * ph + dr - pad, iw = 2 * pw + dc - pad;
+                if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int th = dr + 2 * a;
+                    if (th > 2) continue;
+                    const bool rok = (unsigned)(ph - a) < (unsigned)Ho;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int tw = dc + 2 * c;
+                        if (tw > 2) continue;
+                        if (!rok || (unsigned)(pw - c) >= (unsigned)Wo) continue;       // the generic kernel skips these taps too
+                        const float4 gv = g[a][c], wv = ww[th * 3 + tw];
+                        acc.x = fmaf(gv.x, wv.x, acc.x); acc.y = fmaf(gv.y, wv.y, acc.y);
+                        acc.z = fmaf(gv.z, wv.z, acc.z); acc.w = fmaf(gv.w, wv.w, acc.w);
+                    }
+                }
+                *reinterpret_cast<float4*>(dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4) = acc;
+            }
+    }
+}
+
 // dw[t][c] = sum_{b,oh,ow} x[..]*dy[..]: per row-block partials [nblk][9][C], then fixed-order finalize
 __global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
                                                               const float* dy, int64_t lddy, int Ho, int Wo, int stride,
@@ -2135,6 +2190,7 @@ static thread_local int g_bil_sep = 1;   // separable bilinear backward for >= x
 static thread_local int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
 static thread_local int g_dw_wgrad_cq_blk = 0, g_dw_wgrad_passes = 0;      // column-block width / least rows per thread (pp_debug_set_dw_variant bits 13-17); 0 = by map size
 static thread_local int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
+static thread_local int g_dw_s2 = 1;     // bit 20: the 2 x 2-block backward-data kernel of the stride-2 layers off (A/B)
 
 static inline unsigned grid_for(int64_t total)
 {
@@ -2159,6 +2215,7 @@ extern "C" {
 void pp_debug_set_dw_variant(int v)
 {
     g_dw_x4 = (v & 1) ? 0 : 1;
+    g_dw_s2 = (v & 1048576) ? 0 : 1;                        // bit 20: 2 x 2-block backward-data kernel of the stride-2 layers off (A/B)
     g_bil_sep = (v & 256) ? 0 : 1;
     g_dw_wgrad_x4 = (v & 512) ? 0 : 1;                      // bit 9: four-pixel depthwise weight-gradient kernel off
     { const int s4 = (v >> 10) & 7; g_dw_wgrad_x4_blocks = s4 == 1 ? 128 : s4 == 2 ? 512 : s4 == 3 ? 1024 : s4 == 4 ? 64 : 256; }
@@ -2497,6 +2554,12 @@ int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, in
         hipLaunchKernelGGL((dwconv_s1_x4_kernel<true>), dim3(grid_for((int64_t)B * H * ((W + 3) / 4) * (C / 4))), dim3(kT), 0,
                            as_stream(stream), dy, lddy, B, Ho, Wo, C / 4, w, 2 - pad, dx, lddx, H, W, Epilogue{});
         return check_launch("dwconv_s1_x4_kernel");
+    }
+    if (stride == 2 && dil == 1 && pad >= 0 && pad <= 2 && g_dw_s2) {
+        const int64_t items = (int64_t)B * ((H + pad + 1) / 2 + 1) * ((W + pad + 1) / 2 + 1) * (C / 4);
+        hipLaunchKernelGGL(dwconv_s2_bwd_data_kernel, dim3(grid_for(items)), dim3(kT), 0, as_stream(stream), dy, lddy, B, Ho, Wo, C / 4, w, pad,
+                           dx, lddx, H, W);
+        return check_launch("dwconv_s2_bwd_data_kernel");
     }
     hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(kT), 0, as_stream(stream),
                        dy, lddy, B, Ho, Wo, C / 4, w, stride, pad, dil, dx, lddx, H, W);

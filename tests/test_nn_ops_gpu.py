@@ -140,6 +140,37 @@ def test_mobilenet_stem_forward(case):
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(4, 130, 258, 96, 0), (4, 66, 130, 144, 0), (2, 34, 66, 192, 0), (2, 33, 47, 32, 1), (1, 18, 34, 576, 0), (3, 21, 20, 8, 2)],
+                         ids=str)
+def test_depthwise_stride2_backward_data_is_bit_identical_to_the_generic_kernel(case):
+    """mobilenet_v2.py:50 stride-2 depthwise layers: dwconv_s2_bwd_data_kernel (one thread = a 2 x 2 block of dx pixels, four dy pixels,
+    no branches around the loads) adds every pixel's taps in the generic kernel's order - bit-identical to it
+    (pp_debug_set_dw_variant bit 20) - and equals torch autograd."""
+    B, H, W, C, pad = case
+    gen = torch.Generator().manual_seed(H + W + C)
+    x = torch.randn(B, C, H, W, generator=gen)
+    wd = torch.randn(C, 1, 3, 3, generator=gen) / 3
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wd, stride=2, padding=pad, groups=C)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    L = _lib_mod().lib()
+    def run(variant):
+        L.pp_debug_set_dw_variant(variant)
+        try:
+            tape = E.Tape()
+            xv = E.Var(nhwc(x))
+            yv = E.dwconv3x3(tape, xv, gparam(wd[:, 0].permute(1, 2, 0).contiguous()), 2, pad, 1)
+            tape.backward(yv, nhwc(dy))
+            torch.cuda.synchronize()
+            return xv.grad.clone()
+        finally:
+            L.pp_debug_set_dw_variant(0)
+    a, b = run(0), run(1 << 20)
+    assert torch.equal(a, b)
+    close(nchw(a), xr.grad, what="depthwise stride-2 dx")
+
+
 ROWS_BWD = [(4, 128, 256, 16, 96, 1), (4, 64, 128, 24, 144, 1), (2, 100, 83, 16, 96, 0), (1, 129, 131, 24, 144, 1), (3, 80, 90, 32, 192, 0),
             (2, 96, 96, 32, 64, 1)]
 
