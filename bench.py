@@ -553,8 +553,8 @@ def main():
             out = {"metric": "acquisition_throughput", "value": acqr["value"], "unit": "Mpixels/s", "ms_per_step": acqr["ms_per_step"]}
         out.update(head)
         out["config"] = {"workload": wl, "global_batch": world * a.train_batch,
-                         "sharding": f"images over {world} rank(s); train: the flat gradient is all-reduced per step in two pieces (everything "
-                                     f"behind the encoder under the encoder backward, the encoder after it); "
+                         "sharding": f"images over {world} rank(s); train: the flat gradient is all-reduced per step in three pieces (everything "
+                                     f"behind the encoder and then the late encoder blocks under the encoder backward, the early encoder after it); "
                                      f"acquisition: no collective"}
         if train is not None:
             out["train"] = {k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in train.items()}
