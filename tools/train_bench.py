@@ -29,6 +29,9 @@ def main():
     if os.environ.get("BNBYTES"):                     # pp_debug_set_bn_bytes_per_block word (-1: no row cache, -2: no reversed second pass)
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_bn_bytes_per_block(int(os.environ["BNBYTES"]))
+    if os.environ.get("BNTARGET"):                    # pp_debug_set_bn_target: blocks the single-launch BatchNorm kernels aim at (0 = one per CU)
+        from pixelpick_amd import _lib
+        _lib.lib().pp_debug_set_bn_target(int(os.environ["BNTARGET"]))
     if os.environ.get("ROWS"):                        # pp_debug_set_conv_rows bits (whole-row kernels of the narrow pointwise layers)
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_conv_rows(int(os.environ["ROWS"]))
