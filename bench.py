@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2516.6 # MI355X_MICROARCH.md: dense bf16 MFMA peak (16x the fp32 MFMA rate)
 
 
 class HipEvents:
@@ -154,6 +155,7 @@ def main():
                          "reference's ResNet50 model (networks/model.py FPNSeg, configs[2]); deeplab_r50 = the DeepLabv3+-ResNet50 "
                          "assembled from the reference's parts (SURVEY.md 0.1, an extra: the reference never builds it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the sub-records of the other BASELINE configurations")
     ap.add_argument("--tune-occ", type=int, default=0)
     ap.add_argument("--tune-ppt", type=int, default=0)
     ap.add_argument("--reduce-mode", type=int, default=0)
@@ -238,8 +240,8 @@ def main():
     line = {}
 
     # ------------------------------------------------------------------------------------ train step
-    train = None
-    if a.mode in ("both", "train"):
+    def train_leg(network, steps, warmup, Ht, Wt, Ct):
+        """K train steps of `network` at per-GPU batch --train-batch on [Ht, Wt] crops -> (record, trainer, model)."""
         from pixelpick_amd.trainer import FlatTrainer
         from pixelpick_amd.utils.utils import get_model
         from pixelpick_amd import engine as E
@@ -247,12 +249,12 @@ def main():
         torch.manual_seed(0)                         # identical replicas on every rank
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=a.network,
+            model = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=Ct, network_name=network,
                                         weight_type="random", n_layers=50, use_softmax=True, use_dilated_resnet=True,
                                         width_multiplier=1.0)).to(dev).train()
-        tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, ignore_index=C)
+        tr = FlatTrainer(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, ignore_index=Ct)
         E.set_dropout_seed(1234 + rank)
-        x, y = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
+        x, y = synth_train_batch(TB, Ct, Ht, Wt, a.n_labelled, dev, 1 + rank)       # disjoint shards per rank
         cores_per_rank = (os.cpu_count() or 1) / max(world, 1)
         replay = a.replay == "on" or (a.replay == "auto" and cores_per_rank < 8)
         replay_why = "forced" if a.replay == "on" else ("fewer than 8 host cores per rank" if replay else None)
@@ -286,12 +288,12 @@ def main():
             t = time.perf_counter()
             tr.train_step(x, y)
             host_s[0] += time.perf_counter() - t
-        for _ in range(a.warmup):
+        for _ in range(warmup):
             one_step()
         host_s[0] = 0.0
         tr.__dict__["comm_times"] = []
-        el = timed(one_step, a.steps, 0)
-        host_loop_ms = max_over_ranks(host_s[0]) / a.steps * 1e3
+        el = timed(one_step, steps, 0)
+        host_loop_ms = max_over_ranks(host_s[0]) / steps * 1e3
         # the enqueue cost proper: one step issued into EMPTY queues (in the loop above a host that runs ahead of the GPU is
         # throttled by the full queue, so the in-loop figure tends to the GPU step time whatever the host costs)
         solo = []
@@ -303,14 +305,26 @@ def main():
         torch.cuda.synchronize(dev)
         host_ms = max_over_ranks(sorted(solo)[len(solo) // 2]) * 1e3
         loss = float(tr.last_loss.item())
-        train = {"img_per_s": world * TB * a.steps / el, "ms_per_step": el / a.steps * 1e3, "loss_after": loss,
-                 "launch": ("launch-plan replay" if replay else "eager") + ", small weight gradients on a second stream",
+        native_plan = bool(replay and isinstance(tr._plan, _lib.NativePlan))
+        n_launches = None
+        if replay:
+            n_launches = sum(1 for fn, _ in tr._plan.calls if getattr(fn, "argtypes", None) is not None)     # C-ABI calls of one step
+        train = {"img_per_s": world * TB * steps / el, "ms_per_step": el / steps * 1e3, "loss_after": loss,
+                 "launch": (("launch-plan replay, " + ("native executor (pp_plan_replay: one foreign call per step)" if native_plan else "python list"))
+                            if replay else "eager") + ", small weight gradients on a second stream",
                  # host time spent inside train_step() per step (enqueue only, nothing synchronises): a host slower than the
                  # GPU step shows up HERE, not as an unexplained scaling loss
                  "host_enqueue_ms_per_step": host_ms, "host_in_loop_ms_per_step": host_loop_ms, "replay": bool(replay),
-                 "replay_reason": replay_why,
+                 "replay_reason": replay_why, "launches_per_step": n_launches,
                  "host_cores_per_rank": round(cores_per_rank, 1),
                  "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
+        return train, tr, model
+
+    train = None
+    if a.mode in ("both", "train"):
+        from pixelpick_amd import engine as E
+        TB = a.train_batch
+        train, tr, model = train_leg(a.network, a.steps, a.warmup, H, W, C)
         if dist is not None:
             # what the communicator really is, and what the gradient exchange costs on its own (both buckets back to back,
             # nothing else running): the overlapped step hides most of the first bucket under the encoder backward
@@ -365,14 +379,20 @@ def main():
             res[tag] = sum(cms) / len(cms)
         L.pp_debug_set_x3(1)
         cavg = res["bf16x3"]
-        X3_PEAK_TF = MFMA_F32_PEAK_TF * 16.0 / 6.0            # bf16 MFMA = 16x the fp32 MFMA rate, six bf16 MFMAs per fp32 product
+        # The kernel runs on the bf16 matrix pipe and spends six bf16 MFMAs per fp32 product: ITS roof is the dense bf16 peak / 6.
+        # (Rounds 2-3 divided by the fp32 MFMA peak and printed a "fraction" above 1 - the wrong roof; that ratio stays below as a
+        # secondary, clearly named key.)
+        X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
+        ach = flops / (cavg * 1e-3) / 1e12
         line["roofline_mfma"] = {"bound": "mfma", "kernel": "x3_split_kernel + x3_split_w_kernel + conv_x3_kernel<256,128>, SegmentHead 3x3 304->256 fwd",
                                  "arithmetic": "fp32 operands split exactly into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate",
-                                 "achieved": round(flops / (cavg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s (fp32-equivalent)",
-                                 "frac": round(flops / (cavg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
-                                 "peak_of_the_split": round(X3_PEAK_TF, 1), "frac_of_the_split_peak": round(flops / (cavg * 1e-3) / 1e12 / X3_PEAK_TF, 4),
+                                 "achieved": round(ach, 2), "peak": round(X3_PEAK_TF, 1), "unit": "TFLOP/s (fp32-equivalent: 2*M*N*K / time)",
+                                 "frac": round(ach / X3_PEAK_TF, 4),
+                                 "peak_note": f"dense bf16 MFMA peak {MFMA_BF16_PEAK_TF} TF / 6 MFMAs per fp32 product (MI355X_MICROARCH.md)",
+                                 "bf16_pipe_achieved_TF": round(6 * ach, 1), "bf16_pipe_peak_TF": MFMA_BF16_PEAK_TF,
+                                 "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4),
                                  "fp32_mfma_kernel": {"kernel": "conv_igemm_dma_kernel<128,128>", "kernel_ms_avg": round(res["fp32_mfma"], 4),
-                                                      "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2),
+                                                      "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF,
                                                       "frac": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
                                  "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
         # SURVEY 8(d) graded 1x1 shapes at the BASELINE batch: op time (split-K launch + its reduce where the plan
@@ -440,49 +460,50 @@ def main():
         line["roofline_mfma_1x1"] = {"unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "batch": TB, "batch_16x": BIG,
                                      "yardstick": "library_sgemm_* = torch.matmul fp32 (vendor BLAS) on the same M x K x N, measurement only",
                                      "shapes": rows1}
+        tr.disable_replay()
         del tr, model, xa, wa, ya
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------------------------ acquisition
-    acqr = None
-    if a.mode in ("both", "acq"):
-        B = a.batch
+    def acq_leg(B, Ca, Ha, Wa, ka, strategy, layout, steps, warmup, headline):
+        """K passes of pp_acq_score_topk over B resident images of [Ca, Ha, Wa] logits -> (record, roofline of acq_kernel).
+        headline: also the counter-traffic record, and the selection straight from 1/4-resolution logits."""
         gen = torch.Generator(device=dev).manual_seed(100 + rank)
-        logits = torch.randn((B, C, H, W), device=dev, generator=gen) * 3        # resident in HBM before timing
-        if a.layout == "nhwc":
+        logits = torch.randn((B, Ca, Ha, Wa), device=dev, generator=gen) * 3        # resident in HBM before timing
+        if layout == "nhwc":
             logits = logits.contiguous(memory_format=torch.channels_last)
-        excl = (torch.rand((B, H, W), device=dev, generator=gen) < 0.05).to(torch.uint8)
-        idx = torch.empty((B, k), dtype=torch.int32, device=dev)
-        val = torch.empty((B, k), dtype=torch.float32, device=dev)
-        ws = torch.empty(max(L.pp_acq_workspace_bytes(B, C, H, W, k), 256), dtype=torch.uint8, device=dev)
+        excl = (torch.rand((B, Ha, Wa), device=dev, generator=gen) < 0.05).to(torch.uint8)
+        idx = torch.empty((B, ka), dtype=torch.int32, device=dev)
+        val = torch.empty((B, ka), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(L.pp_acq_workspace_bytes(B, Ca, Ha, Wa, ka), 256), dtype=torch.uint8, device=dev)
         sB, sC, sH, sW = logits.stride()
-        sid = acq.STRATEGY_ID[a.strategy]
+        sid = acq.STRATEGY_ID[strategy]
 
         def acq_step():
-            rc = L.pp_acq_score_topk(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW, excl.data_ptr(), sid, k,
+            rc = L.pp_acq_score_topk(logits.data_ptr(), B, Ca, Ha, Wa, sB, sC, sH, sW, excl.data_ptr(), sid, ka,
                                      idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), stream)
             _lib.check(rc, "pp_acq_score_topk")
-        ev = HipEvents(a.steps)
-        el = timed(acq_step, a.steps, a.warmup, ev)
+        ev = HipEvents(steps)
+        el = timed(acq_step, steps, warmup, ev)
         kms = ev.elapsed_ms()
         ev.destroy()
-        alg_bytes = B * H * W * (4 * C + 1)                  # per launch of acq_kernel on ONE GPU
+        alg_bytes = B * Ha * Wa * (4 * Ca + 1)               # per launch of acq_kernel on ONE GPU (SURVEY §8d)
         kavg = sum(kms) / len(kms)
         achieved = alg_bytes / (kavg * 1e-3) / 1e9
-        acqr = {"value": round(world * B * H * W * a.steps / el / 1e6, 1), "unit": "Mpixels/s",
-                "ms_per_step": round(el / a.steps * 1e3, 4), "images_per_launch_per_gpu": B, "k": k,
-                "strategy": a.strategy, "layout": a.layout}
+        acqr = {"value": round(world * B * Ha * Wa * steps / el / 1e6, 1), "unit": "Mpixels/s",
+                "ms_per_step": round(el / steps * 1e3, 4), "images_per_launch_per_gpu": B, "k": ka,
+                "strategy": strategy, "layout": layout}
         # HBM traffic per launch: a counter pass cannot run inside this process, so it comes from the record a committed
         # script writes (tools/measure_acq_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as
         # MI355X_MICROARCH.md prescribes for gfx950).  The record carries the hash of the kernel source it measured; if this
         # build's source differs, or the configuration is another one, the line says null instead of a stale number.
         traffic, traffic_src = None, None
         rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "acq_traffic.json")
-        if os.path.exists(rec_path):
+        if headline and os.path.exists(rec_path):
             rec = json.load(open(rec_path))
             cfg = rec.get("config", {})
             same_cfg = (cfg.get("B"), cfg.get("C"), cfg.get("H"), cfg.get("W"), cfg.get("k"), cfg.get("strategy"), cfg.get("layout")) == \
-                       (B, C, H, W, k, a.strategy, a.layout)
+                       (B, Ca, Ha, Wa, ka, strategy, layout)
             if same_cfg and rec.get("acq_source_sha256") == _acq_source_hash():
                 traffic = rec["traffic_bytes_per_launch"]
                 traffic_src = f"profiles/acq_traffic.json ({rec['kernel'].split('(')[0]}, measured {rec['measured_unix']})"
@@ -491,7 +512,7 @@ def main():
         # yardstick, measurement only: a kernel that does nothing but read the same logits buffer (one wave per SIMD, eight 16-byte
         # loads in flight per lane - the fastest form tools/probe/hbm_rw.hip found): what "bandwidth-bound" can reach on this box
         yard = None
-        if a.layout == "nchw":
+        if layout == "nchw":
             sink = torch.zeros(4, device=dev)
             nbytes = logits.numel() * 4
             for _ in range(3):
@@ -505,32 +526,66 @@ def main():
             torch.cuda.synchronize(dev)
             yms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
             yard = nbytes / (yms * 1e-3) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                            "traffic_source": traffic_src,
-                            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
-                            "kernel_ms_min": round(min(kms), 4),
-                            "read_only_yardstick": ({"GB/s": round(yard, 1), "frac_of_peak": round(yard / HBM_PEAK_GBS, 4),
-                                                     "acq_kernel_vs_yardstick": round(achieved / yard, 4),
-                                                     "what": "pp_debug_stream_read: a kernel that only reads the same logits buffer"}
-                                                    if yard else None)}
+        roof = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg, 4),
+                "kernel_ms_min": round(min(kms), 4),
+                "read_only_yardstick": ({"GB/s": round(yard, 1), "frac_of_peak": round(yard / HBM_PEAK_GBS, 4),
+                                         "acq_kernel_vs_yardstick": round(achieved / yard, 4),
+                                         "what": "pp_debug_stream_read: a kernel that only reads the same logits buffer"}
+                                        if yard else None)}
 
         # the same selection straight from the classifier output at 1/4 resolution (what DeepLab's
         # head writes before deeplab.py:55-56), interpolated on the fly - the production path of QuerySelector for DeepLab
-        if a.layout == "nchw" and H % 4 == 0 and W % 4 == 0:
-            low = torch.randn((B, H // 4, W // 4, C), device=dev, generator=gen) * 3
-            ws2 = torch.empty(max(L.pp_acq_lowres_workspace_bytes(B, C, H, W, k), 256), dtype=torch.uint8, device=dev)
+        if headline and layout == "nchw" and Ha % 4 == 0 and Wa % 4 == 0:
+            low = torch.randn((B, Ha // 4, Wa // 4, Ca), device=dev, generator=gen) * 3
+            ws2 = torch.empty(max(L.pp_acq_lowres_workspace_bytes(B, Ca, Ha, Wa, ka), 256), dtype=torch.uint8, device=dev)
 
             def lowres_step():
-                rc = L.pp_acq_lowres_score_topk(low.data_ptr(), C, B, C, H // 4, W // 4, H, W, 1, H, W, excl.data_ptr(), sid, k,
+                rc = L.pp_acq_lowres_score_topk(low.data_ptr(), Ca, B, Ca, Ha // 4, Wa // 4, Ha, Wa, 1, Ha, Wa, excl.data_ptr(), sid, ka,
                                                 idx.data_ptr(), val.data_ptr(), None, ws2.data_ptr(), ws2.numel(), stream)
                 _lib.check(rc, "pp_acq_lowres_score_topk")
-            el2 = timed(lowres_step, a.steps, a.warmup)
-            acqr["from_lowres_logits"] = {"value": round(world * B * H * W * a.steps / el2 / 1e6, 1), "unit": "Mpixels/s",
-                                          "ms_per_step": round(el2 / a.steps * 1e3, 4), "kernel": "acq_lowres_kernel",
-                                          "input": f"[{B},{H // 4},{W // 4},{C}] channels-last logits, bilinear x4 align_corners folded in",
+            el2 = timed(lowres_step, steps, warmup)
+            acqr["from_lowres_logits"] = {"value": round(world * B * Ha * Wa * steps / el2 / 1e6, 1), "unit": "Mpixels/s",
+                                          "ms_per_step": round(el2 / steps * 1e3, 4), "kernel": "acq_lowres_kernel",
+                                          "input": f"[{B},{Ha // 4},{Wa // 4},{Ca}] channels-last logits, bilinear x4 align_corners folded in",
                                           "bound": "valu (interpolation + softmax arithmetic; 16x less input than the full-size logits)"}
             del low, ws2
+        del logits, excl, idx, val, ws
+        torch.cuda.empty_cache()
+        return acqr, roof
+
+    acqr = None
+    if a.mode in ("both", "acq"):
+        acqr, line["roofline"] = acq_leg(a.batch, C, H, W, k, a.strategy, a.layout, a.steps, a.warmup, True)
+
+    # ------------------------------------------------------------------------------------ the other BASELINE configurations
+    # Bounded sub-records in the SAME run (N = 1 only; the scaling runs stay short): every acquisition shape / strategy the
+    # BASELINE.json configs name plus the reference's default top-5 % mode (args.py:25), each with its own roofline of acq_kernel,
+    # and the ResNet50 train steps of configs[2] (the reference's ResNet50 model FPNSeg, and DeepLabv3+-ResNet50 as named).
+    if a.mode == "both" and world == 1 and not a.no_other_configs and a.network == "deeplab" and (C, H, W) == (19, 256, 512):
+        others = []
+        oc_steps, oc_warm = max(5, min(a.steps, 20)), 5
+        for name, (Bo, Co, Ho, Wo, ko, so) in (
+                ("configs[0] CamVid 360x480, C=11, entropy top-20", (128, 11, 360, 480, 20, "entropy")),
+                ("configs[1] Cityscapes 256x512, C=19, entropy, reference default top-5 % (k = 6553, args.py:25)", (256, 19, 256, 512, 6553, "entropy")),
+                ("configs[3] VOC 320x320 crops, C=21, margin top-20", (256, 21, 320, 320, 20, "margin_sampling")),
+                ("configs[4] Cityscapes 1024x2048, C=19, least-confidence top-20", (8, 19, 1024, 2048, 20, "least_confidence"))):
+            r, roof = acq_leg(Bo, Co, Ho, Wo, ko, so, "nchw", oc_steps, oc_warm, False)
+            roof.pop("traffic_source", None)
+            others.append({"config": name, "leg": "acquisition", "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                           "images_per_launch": Bo, "roofline": roof})
+        for name, net in (("configs[2] Cityscapes 256x512, ResNet50 model of the reference (FPNSeg), train step", "FPN"),
+                          ("configs[2] as named: DeepLabv3+-ResNet50 (assembled from the reference's parts), train step", "deeplab_r50")):
+            t2, tr2, m2 = train_leg(net, max(5, min(a.steps, 10)), 4, H, W, C)
+            tr2.disable_replay()
+            del tr2, m2
+            torch.cuda.empty_cache()
+            others.append({"config": name, "leg": "train", "value": round(t2["img_per_s"], 2), "unit": "images/s",
+                           "ms_per_step": round(t2["ms_per_step"], 4), "per_gpu_batch": a.train_batch, "replay": t2["replay"],
+                           "host_enqueue_ms_per_step": round(t2["host_enqueue_ms_per_step"], 3)})
+        line["other_configs"] = others
 
     if rank == 0:
         head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",

@@ -561,6 +561,47 @@ void pp_debug_set_conv_bn_fuse(int bits);   /* fused conv + BatchNorm launches o
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */
 void pp_debug_set_conv_variant(int v);
 
+/* ---------------------------------------------------------------------------------------------
+ * Launch plans: the train step of model.py:101-122 (model.train(); forward; cross_entropy; backward; optimizer.step()) as ONE
+ * foreign call.  The reference re-runs that Python per iteration (model.py:106 loop); with static shapes every C-ABI call of
+ * a step repeats with identical arguments, so the host records them once and this executor re-issues them (csrc/plan.hip).
+ * A recorded call goes through its entry point again - same planning, kernels, queues and results as the eager call.
+ *
+ *   pp_plan_add_call       fn = address of one of this library's enqueuing entry points; slots = its arguments, one 8-byte
+ *                          slot each (integers sign-extended, pointers as addresses, float in the low 4 bytes);
+ *                          PP_ERR_UNSUPPORTED for any other address, PP_ERR_BAD_ARG when n_slots is not its arity
+ *                          (pp_plan_entry_args(fn), -1 = not an entry point).
+ *   pp_plan_add_event_record / _stream_wait    hipEventRecord(event, stream) / hipStreamWaitEvent(stream, event):
+ *                          the fork of the weight-gradient queue; caller-owned hipEvent_t.
+ *   pp_plan_add_join       `waiting` waits for everything enqueued on `waited_for` so far (plan-owned event).
+ *   pp_plan_add_host_break pp_plan_replay returns here so that the caller can act (the gradient all-reduce of a data-parallel
+ *                          step, trainer.py) and resume.
+ *   pp_plan_replay         issues ops [from, ...) until the end or the next host break; *next = index to resume from
+ *                          (== pp_plan_size: finished).  Returns the failing entry point's code (then *next = its index).
+ * The plan stores addresses only: every buffer, stream and event it names must outlive it. */
+typedef void* pp_plan_t;
+pp_plan_t pp_plan_create(void);
+void pp_plan_destroy(pp_plan_t plan);
+int64_t pp_plan_size(pp_plan_t plan);
+int pp_plan_entry_args(const void* fn);
+int pp_plan_add_call(pp_plan_t plan, const void* fn, const uint64_t* slots, int n_slots);
+int pp_plan_add_event_record(pp_plan_t plan, void* event, pp_stream_t stream);
+int pp_plan_add_stream_wait(pp_plan_t plan, pp_stream_t stream, void* event);
+int pp_plan_add_join(pp_plan_t plan, pp_stream_t waiting, pp_stream_t waited_for);
+int pp_plan_add_host_break(pp_plan_t plan);
+int pp_plan_replay(pp_plan_t plan, int64_t from, int64_t* next);
+
+/* Data-parallel training (trainer.py: RCCL all-reduce of the flat gradient under the backward pass): `cus` compute units are set
+ * aside for the communication kernel that stays resident meanwhile.  Launches whose blocks wait for each other (the single-launch
+ * BatchNorm kernels, convolution + BatchNorm in one launch) size themselves against occupancy x (CUs - cus); shapes that no longer
+ * fit take their multi-launch form.  Default 0, or PIXELPICK_COMM_CU_RESERVE at load time.  Changes the launch plans: set it before
+ * the first step. */
+void pp_set_comm_cu_reserve(int cus);
+int pp_get_comm_cu_reserve(void);
+/* Test stand-in for such a resident kernel: `blocks` (<= 256) blocks that each take a whole CU's LDS and spin until *stop != 0 (a
+ * host-visible int) or max_ticks of the 100 MHz clock (<= 60 s) have passed; *started counts the blocks that got a CU. */
+int pp_debug_occupy_cus(int blocks, const int* stop, uint64_t max_ticks, uint64_t* started, pp_stream_t stream);
+
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The
  * i-th launch of a dominant kernel (acq_kernel, conv_igemm_kernel) after this call records starts[i] / stops[i] on its
  * stream immediately before / after the launch.  Pass (NULL, NULL, 0) to switch off.  The arrays must

@@ -6,6 +6,7 @@ libamdhip64.so.7) is the one our kernels, streams and pointers live in.
 """
 import ctypes
 import os
+import struct
 
 import torch  # noqa: F401  (loads PyTorch's libamdhip64 first)
 
@@ -130,9 +131,34 @@ SIGNATURES = {
     "pp_debug_set_conv_bn_fuse": (None, [_int]),
     "pp_debug_set_x3": (None, [_int]),
     "pp_debug_set_kernel_events": (None, [_p, _p, _int]),
+    "pp_set_comm_cu_reserve": (None, [_int]),
+    "pp_get_comm_cu_reserve": (_int, []),
+    "pp_debug_occupy_cus": (_int, [_int, _p, _u64, _p, _p]),
+    "pp_plan_create": (_p, []),
+    "pp_plan_destroy": (None, [_p]),
+    "pp_plan_size": (_i64, [_p]),
+    "pp_plan_entry_args": (_int, [_p]),
+    "pp_plan_add_call": (_int, [_p, _p, _p, _int]),
+    "pp_plan_add_event_record": (_int, [_p, _p, _p]),
+    "pp_plan_add_stream_wait": (_int, [_p, _p, _p]),
+    "pp_plan_add_join": (_int, [_p, _p, _p]),
+    "pp_plan_add_host_break": (_int, [_p]),
+    "pp_plan_replay": (_int, [_p, _i64, ctypes.POINTER(_i64)]),
 }
 
 _lib = None
+# Every pp_debug_set_* knob can change what the library plans for a shape; host-side memo tables of plan-dependent answers
+# (engine._wsbytes, _conv_ws, conv_accepts_lazy_input) are keyed on this epoch and refilled after a knob moved.
+knob_epoch = [0]
+
+
+def _knob_setter(fn):
+    def setter(*args):
+        knob_epoch[0] += 1
+        return fn(*args)
+    setter.__name__ = getattr(fn, "__name__", "pp_debug_set")
+    setter.__wrapped__ = fn
+    return setter
 
 
 class PixelPickHipError(RuntimeError):
@@ -159,6 +185,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
+            if name.startswith(("pp_debug_set_", "pp_set_")):
+                setattr(L, name, _knob_setter(fn))
         _lib = L
     return _recording[0] or _lib
 
@@ -170,11 +198,13 @@ def lib():
 # of those calls repeats with identical arguments, so the step is recorded ONCE as a flat list of (function, converted
 # arguments) and re-issued from a tight loop.  Unlike a hipGraph the replay keeps the two-queue eager schedule (main stream +
 # weight-gradient stream, the all-reduce under the encoder backward) - profiles/r02_graph_replay.txt shows why the graph loses.
-_NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_fused_rows_cached")
+_NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_fused_rows_cached", "pp_set_comm_cu_reserve",
+                 "pp_get_comm_cu_reserve")
 
 
 def _is_launch(name: str) -> bool:
-    return not (name in _NOT_LAUNCHES or name.startswith("pp_debug_") or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in", "_ok")))
+    return not (name in _NOT_LAUNCHES or name.startswith(("pp_debug_", "pp_plan_"))
+                or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in", "_ok")))
 
 
 class ReduceJob(ctypes.Structure):
@@ -200,6 +230,104 @@ class LaunchPlan:
         return len(self.calls)
 
 
+def _slot(v) -> int:
+    """One argument as the 8-byte slot pp_plan_add_call takes (see include/pixelpick_hip.h)."""
+    if isinstance(v, ctypes.c_float):
+        return struct.unpack("<I", struct.pack("<f", v.value))[0]
+    if isinstance(v, ctypes.c_void_p):
+        return (v.value or 0) & 0xFFFFFFFFFFFFFFFF
+    if isinstance(v, ctypes._SimpleCData):
+        return int(v.value) & 0xFFFFFFFFFFFFFFFF
+    if isinstance(v, (ctypes._Pointer, ctypes.Array)):
+        return (ctypes.cast(v, ctypes.c_void_p).value or 0) & 0xFFFFFFFFFFFFFFFF
+    raise TypeError(f"cannot record an argument of type {type(v)}")
+
+
+class NativePlan(LaunchPlan):
+    """The recorded step held by the library (pp_plan_*, csrc/plan.hip): replay() is ONE foreign call per stretch between host
+    breaks - none at all in a single-rank step - instead of one per launch.  The Python list of the base class is kept beside it
+    (same entries, same order): it keeps the recorded arguments alive and `replay_python()` re-issues it for A/B and tests."""
+    __slots__ = ("handle", "breaks", "host_notes", "_next", "_keep")
+
+    def __init__(self):
+        super().__init__()
+        L = lib_real()
+        self.handle = L.pp_plan_create()
+        if not self.handle:
+            raise PixelPickHipError("pp_plan_create failed")
+        self.breaks = {}            # op index of a host break -> (callable, args)
+        self.host_notes = []        # plan_note_host(): host-only counters, run after the native loop
+        self._next = ctypes.c_int64(0)
+        self._keep = []
+
+    def add_call(self, fn, cargs):
+        L = lib_real()
+        n = len(cargs)
+        slots = (ctypes.c_uint64 * max(n, 1))(*[_slot(a) for a in cargs])
+        check(L.pp_plan_add_call(self.handle, ctypes.cast(fn, ctypes.c_void_p), slots, n), "pp_plan_add_call")
+
+    def add_note(self, fn, args):
+        """A stream operation of torch (Event.record, Stream.wait_event, Stream.wait_stream) becomes a native op; anything else is
+        a host break: the native loop returns there, the callable runs in Python, the loop resumes."""
+        L = lib_real()
+        owner, name = getattr(fn, "__self__", None), getattr(fn, "__name__", "")
+        if isinstance(owner, torch.cuda.Event) and name == "record" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
+            check(L.pp_plan_add_event_record(self.handle, owner.cuda_event, args[0].cuda_stream), "pp_plan_add_event_record")
+        elif isinstance(owner, torch.cuda.Stream) and name == "wait_event" and len(args) == 1 and isinstance(args[0], torch.cuda.Event):
+            check(L.pp_plan_add_stream_wait(self.handle, owner.cuda_stream, args[0].cuda_event), "pp_plan_add_stream_wait")
+        elif isinstance(owner, torch.cuda.Stream) and name == "wait_stream" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
+            check(L.pp_plan_add_join(self.handle, owner.cuda_stream, args[0].cuda_stream), "pp_plan_add_join")
+        else:
+            check(L.pp_plan_add_host_break(self.handle), "pp_plan_add_host_break")
+            self.breaks[int(L.pp_plan_size(self.handle))] = (fn, args)      # keyed by the index the loop resumes from
+            return
+        self._keep.append((owner, args))
+
+    def replay(self):
+        L = lib_real()
+        h, nxt, n = self.handle, self._next, int(L.pp_plan_size(self.handle))
+        i = 0
+        while True:
+            rc = L.pp_plan_replay(h, i, ctypes.byref(nxt))
+            if rc:
+                raise PixelPickHipError(f"launch-plan replay failed at op {nxt.value}: {L.pp_last_error().decode('utf-8', 'replace')}")
+            i = nxt.value
+            if i in self.breaks:
+                fn, args = self.breaks[i]
+                fn(*args)
+            if i >= n:
+                break
+        for fn, args in self.host_notes:
+            fn(*args)
+
+    def replay_python(self):
+        LaunchPlan.replay(self)
+
+    def native_ops(self) -> int:
+        return int(lib_real().pp_plan_size(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib_real().pp_plan_destroy(self.handle)
+            self.handle = None
+        self.calls.clear()
+        self.breaks.clear()
+        self.host_notes.clear()
+        self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def lib_real():
+    """The library itself, also while a plan is being recorded."""
+    lib()
+    return _lib
+
+
 class _RecordingLib:
     """What lib() returns while a plan is being recorded: every launch is executed AND appended to the plan."""
 
@@ -212,13 +340,17 @@ class _RecordingLib:
         if not _is_launch(name):
             return fn
         calls, argtypes = self._plan.calls, fn.argtypes
+        native = self._plan if isinstance(self._plan, NativePlan) else None
 
         def rec(*args):
             rc = fn(*args)
             if rc == 0:
                 # converted once: ctypes passes instances of the declared types straight through
-                calls.append((fn, tuple(a if isinstance(a, (ctypes._SimpleCData, ctypes._Pointer, ctypes.Array)) else t(a)
-                                        for t, a in zip(argtypes, args))))
+                cargs = tuple(a if isinstance(a, (ctypes._SimpleCData, ctypes._Pointer, ctypes.Array)) else t(a)
+                              for t, a in zip(argtypes, args))
+                calls.append((fn, cargs))
+                if native is not None:
+                    native.add_call(fn, cargs)
             return rc
 
         self.__dict__[name] = rec
@@ -229,12 +361,16 @@ _recording = [None]
 
 
 class record_plan:
-    """with record_plan() as plan: ...   (not re-entrant, calling thread only)"""
+    """with record_plan() as plan: ...   (not re-entrant, calling thread only).  native=True (default): a NativePlan, replayed by
+    the library's own loop; native=False: the Python list only (round-2 form, kept for A/B)."""
+
+    def __init__(self, native: bool = True):
+        self.native = native
 
     def __enter__(self):
         if _recording[0] is not None:
             raise RuntimeError("a launch plan is already being recorded")
-        plan = LaunchPlan()
+        plan = NativePlan() if self.native else LaunchPlan()
         _recording[0] = _RecordingLib(lib(), plan)
         return plan
 
@@ -249,6 +385,21 @@ def plan_note(fn, *args):
     rec = _recording[0]
     if rec is not None:
         rec._plan.calls.append((fn, args))
+        if isinstance(rec._plan, NativePlan):
+            out = fn(*args)             # first: torch creates an event's handle at its first record
+            rec._plan.add_note(fn, args)
+            return out
+    return fn(*args)
+
+
+def plan_note_host(fn, *args):
+    """plan_note for a host-only side effect whose position among the launches does not matter (a step counter): a NativePlan
+    runs these after its native loop instead of returning to Python in the middle of the step for each of them."""
+    rec = _recording[0]
+    if rec is not None:
+        rec._plan.calls.append((fn, args))
+        if isinstance(rec._plan, NativePlan):
+            rec._plan.host_notes.append((fn, args))
     return fn(*args)
 
 

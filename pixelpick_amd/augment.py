@@ -20,6 +20,7 @@ There is no CPU fallback: the kernels live in csrc/augment.hip behind include/pi
 """
 import ctypes
 import math
+import random as _py_random
 import random
 from typing import List, Optional, Sequence
 
@@ -114,6 +115,17 @@ class DeviceAugmenter:
         # batch loop uploads nothing but the images
         self._tables = {}
         self.n_table_uploads = 0
+        self._rng = None                  # None: the process-wide generators, as the reference's datasets draw (single-process parity)
+
+    def use_private_rng(self, seed: int):
+        """Draw the augmentation parameters from generators of this augmenter's own (python / numpy / torch, all seeded with `seed`)
+        instead of the process-wide ones.  Data-parallel training: every rank holds IDENTICAL process-wide streams (the acquisition
+        round needs that), which would give every rank the same scale / crop / flip / jitter sequence on its different shard;
+        `Model` seeds each rank's augmenter from (args.seed, rank) - dist_utils.augment_seed - and leaves the global streams alone."""
+        g = torch.Generator()
+        g.manual_seed(int(seed))
+        self._rng = (random.Random(int(seed)), np.random.RandomState(int(seed) % (1 << 32)), g)
+        return self
 
     @classmethod
     def from_args(cls, args, device="cuda:0", crop_size=None):
@@ -149,6 +161,7 @@ class DeviceAugmenter:
     def draw(self, h: int, w: int) -> dict:
         p = {"h": h, "w": w}
         ch, cw = self.crop_size
+        random, nprand, g = self._rng if self._rng is not None else (_py_random, np.random, None)
         if self.geometric["random_scale"]:
             rs = random.uniform(0.5, 2.0)
             p["w_rs"], p["h_rs"] = int(w * rs), int(h * rs)
@@ -160,23 +173,23 @@ class DeviceAugmenter:
         p["flip"] = bool(self.geometric["random_hflip"] and random.random() > 0.5)
         ops = []
         if self.photometric["random_color_jitter"]:
-            if not (0.8 < float(torch.rand(1))):                    # RandomApply: `if self.p < torch.rand(1): return img`
-                fn_idx = torch.randperm(4).tolist()
-                b = float(torch.empty(1).uniform_(0.2, 1.8))
-                c = float(torch.empty(1).uniform_(0.2, 1.8))
-                s = float(torch.empty(1).uniform_(0.2, 1.8))
-                hue = float(torch.empty(1).uniform_(-0.2, 0.2))
+            if not (0.8 < float(torch.rand(1, generator=g))):       # RandomApply: `if self.p < torch.rand(1): return img`
+                fn_idx = torch.randperm(4, generator=g).tolist()
+                b = float(torch.empty(1).uniform_(0.2, 1.8, generator=g))
+                c = float(torch.empty(1).uniform_(0.2, 1.8, generator=g))
+                s = float(torch.empty(1).uniform_(0.2, 1.8, generator=g))
+                hue = float(torch.empty(1).uniform_(-0.2, 0.2, generator=g))
                 fac = {0: b, 1: c, 2: s, 3: hue}
                 ops += [(fn, fac[fn]) for fn in fn_idx]
         if self.photometric["random_grayscale"]:
-            if float(torch.rand(1)) < 0.2:
+            if float(torch.rand(1, generator=g)) < 0.2:
                 ops.append((4, 0.0))
         p["ops"] = ops
         p["blur"] = None
         if self.photometric["random_gaussian_blur"]:
             ks = int((0.1 * min(cw, ch) // 2 * 2) + 1)               # on the cropped image: x.size after the crop
-            if np.random.random_sample() < 0.5:
-                sigma = (2.0 - 0.1) * np.random.random_sample() + 0.1
+            if nprand.random_sample() < 0.5:
+                sigma = (2.0 - 0.1) * nprand.random_sample() + 0.1
                 p["blur"] = (ks, float(sigma))
         return p
 

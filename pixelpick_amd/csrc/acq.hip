@@ -18,10 +18,10 @@
 
 namespace pp {
 
-static thread_local int g_reduce_mode = 0;
-static thread_local int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel)
-static thread_local int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
-static thread_local int g_tune_ppt = 0;
+static int g_reduce_mode = 0;
+static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel)
+static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
+static int g_tune_ppt = 0;
 
 constexpr int kBlock = 256;
 constexpr int kSmallKMax = 48;        // fused per-wave extraction up to this k (measured: 0.74/0.70/0.62 of HBM at k=20/32/48, 0.37 at 64); beyond: map + radix select
@@ -1122,7 +1122,7 @@ static int run_merge(uint64_t* cand, int64_t n_cand, uint64_t* other, int64_t B,
     }
 }
 
-static thread_local int g_large_multiblock = 1;     // 0: the one-block-per-image radix select (pp_debug_set_reduce_mode bit 8), for A/B
+static int g_large_multiblock = 1;     // 0: the one-block-per-image radix select (pp_debug_set_reduce_mode bit 8), for A/B
 
 static size_t large_ws_bytes(int64_t B, int64_t k)
 {

@@ -1,6 +1,8 @@
 // capi.hip — version / error plumbing of the C ABI (include/pixelpick_hip.h).
 #include "pp_common.h"
 
+#include <stdlib.h>
+
 namespace pp {
 
 char* err_buf()
@@ -22,6 +24,29 @@ EventHook& event_hook()
 {
     static thread_local EventHook h{nullptr, nullptr, 0, 0};   // per calling thread, like every other debugging knob
     return h;
+}
+
+static int g_comm_cu_reserve = [] {
+    const char* e = getenv("PIXELPICK_COMM_CU_RESERVE");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 0;
+}();
+int comm_cu_reserve() { return g_comm_cu_reserve; }
+
+// Stand-in for a communication kernel that stays resident (tests/test_dist_gpu.py): every block takes a whole CU's LDS (no second
+// block of anything that uses LDS fits beside it) and spins until *stop != 0 or `max_ticks` of the constant 100 MHz clock have
+// passed - it cannot outlive its time limit whatever the host does.
+__global__ __launch_bounds__(1024) void occupy_kernel(const int* stop, unsigned long long max_ticks, unsigned long long* started)
+{
+    extern __shared__ int occ_lds[];
+    if (threadIdx.x == 0) {
+        occ_lds[0] = (int)blockIdx.x;
+        atomicAdd(started, 1ull);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < max_ticks)
+            __builtin_amdgcn_s_sleep(64);
+    }
+    __syncthreads();
 }
 
 // Yardstick (measurement only): what a kernel that does nothing but READ a buffer reaches - float4 per lane, eight loads in flight,
@@ -54,6 +79,25 @@ int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, p
     hipLaunchKernelGGL(pp::stream_read_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const float4*>(x), bytes / 16, sink);
     return hipGetLastError() == hipSuccess ? PP_OK : pp::fail(PP_ERR_LAUNCH, "stream_read_kernel launch failed");
+}
+
+void pp_set_comm_cu_reserve(int cus) { pp::g_comm_cu_reserve = cus > 0 ? cus : 0; }
+int pp_get_comm_cu_reserve(void) { return pp::g_comm_cu_reserve; }
+
+int pp_debug_occupy_cus(int blocks, const int* stop, uint64_t max_ticks, uint64_t* started, pp_stream_t stream)
+{
+    if (blocks < 1 || blocks > 256 || !stop || !started || max_ticks == 0 || max_ticks > 6000000000ull)
+        return pp::fail(PP_ERR_BAD_ARG, "occupy_cus: blocks in [1, 256], a stop flag, a start counter and at most 60 s of ticks");
+    static bool attr = false;
+    const int lds = 160 * 1024;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pp::occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return pp::fail(PP_ERR_LAUNCH, "occupy_cus: cannot ask for %d bytes of LDS", lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(pp::occupy_kernel, dim3((unsigned)blocks), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), stop,
+                       (unsigned long long)max_ticks, reinterpret_cast<unsigned long long*>(started));
+    return hipGetLastError() == hipSuccess ? PP_OK : pp::fail(PP_ERR_LAUNCH, "occupy_kernel launch failed");
 }
 
 void pp_debug_set_kernel_events(void** starts, void** stops, int n)

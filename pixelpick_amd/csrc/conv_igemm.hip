@@ -28,10 +28,10 @@ namespace pp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static thread_local int g_conv_xcd_remap = 1;
-static thread_local int g_conv_novec = 0;
-static thread_local int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
-static thread_local int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
+static int g_conv_xcd_remap = 1;
+static int g_conv_novec = 0;
+static int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
+static int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
 
 constexpr int kThreads = 256;
 constexpr int BK = 16;
@@ -3324,26 +3324,26 @@ struct ConvPlan {
     bool bn64;          // cfg 1 with 128x64 tiles
 };
 
-static thread_local int g_conv_splitk = 1;
-static thread_local int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_splitk_min_iters = 4;
+static int g_conv_splitk = 1;
+static int g_splitk_tiles = 192, g_splitk_target = 512, g_splitk_min_nk = 12, g_splitk_min_iters = 4;
 
-static thread_local int g_conv_deepk = 1;
-static thread_local int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
-static thread_local int g_conv_dma = 1;         // 128-row tiles, LDS-DMA three-stage kernel: 0 off, 1 (default) forward + backward-data, 2 forward only,
+static int g_conv_deepk = 1;
+static int g_conv_ablate_reduce = 0;   // TIMING ONLY (wrong results): bit 0 / 1 skip the split-K reduce launch of fwd / bwd-data
+static int g_conv_dma = 1;         // 128-row tiles, LDS-DMA three-stage kernel: 0 off, 1 (default) forward + backward-data, 2 forward only,
                                    // 3 forward + the backward-data of the 128x64-tiled layers only.  History: before the steady-state loop
                                    // lost its branches, backward-data through this kernel cost FPN 0.27 ms/step (48 KiB of LDS per block
                                    // beside the weight-gradient stream); after it: DeepLab 6.92 -> 6.89 ms/step, FPN 25.96 -> 26.02.
-static thread_local int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-DMA kernel: 0 off, 1 forward + backward-data (default: DeepLab 7.29 ->
+static int g_conv_dma64 = 1;       // 64x64 tiles through the LDS-DMA kernel: 0 off, 1 forward + backward-data (default: DeepLab 7.29 ->
                                    // 7.21 ms/step, FPN 28.06 -> 27.06), 2 forward only (7.25 / 27.42).  Replaces the 64-deep K step.
-static thread_local int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
-static thread_local int g_conv_n64 = 1;
-static thread_local int g_conv_tap_inner = 1;
-static thread_local int g_conv_bwd_rows = 1;       // pp_debug_set_conv_rows bit 0 switches conv1x1_rows_kernel / conv1x1_fwd_widen_kernel off (A/B)
-static thread_local int64_t g_rows_fwd_min = 16384;    // pp_debug_set_conv_rows bit 1: forward rows kernel only from 65536 rows (A/B)
-static thread_local int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
-static thread_local int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
-static thread_local int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
-static thread_local int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
+static int g_conv_big_bk32 = 0;    // 128x128 tiles with a 32-deep K step (A/B)
+static int g_conv_n64 = 1;
+static int g_conv_tap_inner = 1;
+static int g_conv_bwd_rows = 1;       // pp_debug_set_conv_rows bit 0 switches conv1x1_rows_kernel / conv1x1_fwd_widen_kernel off (A/B)
+static int64_t g_rows_fwd_min = 16384;    // pp_debug_set_conv_rows bit 1: forward rows kernel only from 65536 rows (A/B)
+static int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
+static int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
+static int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
+static int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
 {
@@ -3410,11 +3410,11 @@ static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
 }
 
 // bf16x3 path (conv_x3_kernel): which problems take it, and what the caller's workspace must hold for it
-static thread_local int g_conv_x3 = 1;
+static int g_conv_x3 = 1;
 struct X3Plan { bool ok; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes; };
-static thread_local int g_conv_x3_mid = 1;
-static thread_local double g_x3_mid_flop = 16e9, g_x3w_flop = 8e9;     // least work of a mid-size layer / a weight gradient (pp_debug_set_x3 bits 9-11 / 14-16)
-static thread_local int g_x3_mid_tiles = 256;                          // least 128 x 128 tiles of a mid-size layer (bits 12-13)
+static int g_conv_x3_mid = 1;
+static double g_x3_mid_flop = 16e9, g_x3w_flop = 8e9;     // least work of a mid-size layer / a weight gradient (pp_debug_set_x3 bits 9-11 / 14-16)
+static int g_x3_mid_tiles = 256;                          // least 128 x 128 tiles of a mid-size layer (bits 12-13)
 static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int n_rows, int ntaps_w, int ntaps_live, bool vec)
 {
     X3Plan x{};
@@ -3500,16 +3500,16 @@ static int conv_bn_capacity(int which = 0)        // 0: conv_igemm_dma_kernel<64
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<128, 64, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 32, 4, 1, false, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
-    return cap[which];
+    return reserve_scaled(cap[which], device_cus());      // minus the CUs set aside for a resident communication kernel
 }
-static thread_local int g_conv_bn_fuse = 15;     // bit 0: fused conv + BatchNorm epilogue of the tiled kernels, bit 1: of the in-block split-K kernel, bit 2: backward form,
+static int g_conv_bn_fuse = 15;     // bit 0: fused conv + BatchNorm epilogue of the tiled kernels, bit 1: of the in-block split-K kernel, bit 2: backward form,
                                                  // bit 3: backward form of the in-block split-K kernel
 static int ksplit_bn_capacity(int which)         // 0: <1,1,5>, 1: <2,1,3> (the forward candidates)
 {
     static const int cap[2] = {
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<1, 1, 5, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<2, 1, 3, false>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
-    return cap[which];
+    return reserve_scaled(cap[which], device_cus());      // minus the CUs set aside for a resident communication kernel
 }
 // How a convolution that is to finish a training BatchNorm in its own epilogue would run: kind 0 = no fused kernel for this shape,
 // 1 = conv_igemm_dma_kernel<64, 64>, 2 = conv1x1_ksplit_dma_kernel (forward candidates).  R = partial rows per strip = M tiles.
@@ -3548,14 +3548,14 @@ static int conv_bn_bwd_capacity(int which = 0)   // 0: conv_igemm_dma_kernel<64,
     static const int cap[2] = {
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_dma_kernel<64, 64, true, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<128, 32, 4, 1, true, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
-    return cap[which];
+    return reserve_scaled(cap[which], device_cus());      // minus the CUs set aside for a resident communication kernel
 }
 static int ksplit_bn_bwd_capacity(int which)     // 0: <1,1,5>, 1: <1,2,3> (the backward candidates)
 {
     static const int cap[2] = {
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<1, 1, 5, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }(),
         [] { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_ksplit_dma_kernel<1, 2, 3, true>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); return 0; } return n * device_cus(); }()};
-    return cap[which];
+    return reserve_scaled(cap[which], device_cus());      // minus the CUs set aside for a resident communication kernel
 }
 static BnFusePlan bn_fuse_plan_bwd(const ConvParams& p, const ConvPlan& pl, bool vec)
 {
@@ -3789,7 +3789,7 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     return PP_OK;
 }
 
-static thread_local int g_narrow_rows_min = 16, g_narrow_splits_max = 4096;   // narrow-layer weight gradient: split geometry
+static int g_narrow_rows_min = 16, g_narrow_splits_max = 4096;   // narrow-layer weight gradient: split geometry
 // These kernels are latency-bound row walks (27 or fewer accumulators per thread), so more, shorter splits win as long as
 // the partials stay small: up to 4096 splits while splits x taps x Cin x Cout x 4 B <= 16 MiB, never fewer than 1024
 // (measured on the train step: 1024 -> 4096 splits for the stem and the 16/32-channel pointwise layers, 7.08 -> 7.05 ms).
@@ -3800,16 +3800,16 @@ static int64_t narrow_splits_max(int64_t floats_per_split)
     if (s < 1024) s = 1024;
     return s;
 }
-static thread_local int g_wgrad_narrow = 1;
-static thread_local int g_wgrad_stem = 1;          // pp_debug_set_conv_variant bit 23 switches the specialised stem weight gradient off (A/B)
-static thread_local int g_wgrad_m64 = 1;
-static thread_local int g_wgrad_xcd = 1;
-static thread_local int g_wgrad_dma = 1;          // LDS-DMA weight-gradient kernels: bit 0 = the 128-wide tiles (default on: DeepLab 7.17 -> 7.12 ms/step,
+static int g_wgrad_narrow = 1;
+static int g_wgrad_stem = 1;          // pp_debug_set_conv_variant bit 23 switches the specialised stem weight gradient off (A/B)
+static int g_wgrad_m64 = 1;
+static int g_wgrad_xcd = 1;
+static int g_wgrad_dma = 1;          // LDS-DMA weight-gradient kernels: bit 0 = the 128-wide tiles (default on: DeepLab 7.17 -> 7.12 ms/step,
                                      // FPN 26.86 -> 26.77), bit 1 = the 64x64 tiles (off: 7.17 -> 7.20)
 static const int g_wgrad_lds_pad_default = 0;
-static thread_local int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
-static thread_local int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
-static thread_local int g_wgrad_balance = 1;     // pp_debug_set_wgrad_target bit 24: CU-balanced split choice of the MFMA-bound layers off (A/B)
+static int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
+static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
+static int g_wgrad_balance = 1;     // pp_debug_set_wgrad_target bit 24: CU-balanced split choice of the MFMA-bound layers off (A/B)
 
 static int device_cus()
 {

@@ -62,7 +62,7 @@ struct ColReduceGeom {
     int nblk_cols;     // grid.y
 };
 
-static thread_local int g_dw_wgrad_blocks = 1024;    // row blocks aimed at by the depthwise weight gradient (pp_debug_set_dw_variant bits 1..)
+static int g_dw_wgrad_blocks = 1024;    // row blocks aimed at by the depthwise weight gradient (pp_debug_set_dw_variant bits 1..)
 
 // cq_blk_max < 256: NARROW column blocks (wide maps get several block columns and 256 / cq_blk row lanes each: the 1/16-resolution
 // depthwise weight gradients - 2048 pixels x 384..960 channels - otherwise run one row lane per block and walk their rows in sequence);
@@ -324,7 +324,7 @@ struct BnFusedGeom {
     int64_t rows_per_chunk;
 };
 
-static thread_local int g_bn_target_blocks = 0;       // strips x row chunks aimed at (pp_debug_set_bn_target); 0 = one block per CU.  Round 1, in-process:
+static int g_bn_target_blocks = 0;       // strips x row chunks aimed at (pp_debug_set_bn_target); 0 = one block per CU.  Round 1, in-process:
                                          // 128: 7.77, 192: 7.47, 256-384: 7.30-7.36, 512: 7.36, 768: 7.60, 1024: 7.76 ms/step (384 chosen).
                                          // Round 2: the launches of the head's backward run beside the SegmentHead weight gradient, whose
                                          // 168-VGPR / 48 KiB blocks sit two per CU and leave room for exactly ONE more block per CU; a
@@ -344,8 +344,8 @@ static int bn_device_cus()
 }
 
 constexpr int kBnRowCache = 12;                   // rows per thread the single-launch BatchNorm kernels may keep in registers between passes
-static thread_local int g_bn_row_cache = 1;       // pp_debug_set_bn_bytes_per_block(-1) switches the register-cached variants off (A/B)
-static thread_local int g_bn_bytes_per_block = 0;   // > 0: large maps get one block per this many bytes of x.  Off: measured neutral in
+static int g_bn_row_cache = 1;       // pp_debug_set_bn_bytes_per_block(-1) switches the register-cached variants off (A/B)
+static int g_bn_bytes_per_block = 0;   // > 0: large maps get one block per this many bytes of x.  Off: measured neutral in
                                                    // isolation (tools/bn_bench.py: 33.6 MB forward 33.4 us with 384 blocks, 33.2-35.8 us with 640)
                                                    // and in the step (6.84 vs 6.86 ms) - a launch is ~13 us of fixed latency + bytes at ~5 TB/s
 
@@ -920,7 +920,7 @@ static int bn_fused_capacity()
         per = per < sp ? per : sp;
         return per * cus;
     }();
-    return cap;
+    return reserve_scaled(cap, bn_device_cus());      // minus the CUs set aside for a resident communication kernel
 }
 
 // ================================================================================================
@@ -2186,11 +2186,11 @@ __global__ __launch_bounds__(kT) void nhwc_to_nchw_kernel(const float* x, int64_
     }
 }
 
-static thread_local int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
-static thread_local int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
-static thread_local int g_dw_wgrad_cq_blk = 0, g_dw_wgrad_passes = 0;      // column-block width / least rows per thread (pp_debug_set_dw_variant bits 13-17); 0 = by map size
-static thread_local int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
-static thread_local int g_dw_s2 = 1;     // bit 20: the 2 x 2-block backward-data kernel of the stride-2 layers off (A/B)
+static int g_bil_sep = 1;   // separable bilinear backward for >= x3 up-sampling (bit 8 of pp_debug_set_dw_variant switches it off)
+static int g_dw_wgrad_x4 = 1, g_dw_wgrad_x4_blocks = 256;   // four-pixel items for the stride-1 depthwise weight gradient
+static int g_dw_wgrad_cq_blk = 0, g_dw_wgrad_passes = 0;      // column-block width / least rows per thread (pp_debug_set_dw_variant bits 13-17); 0 = by map size
+static int g_dw_x4 = 1;     // pp_debug_set_dw_variant(1) switches the 4-outputs-per-thread depthwise kernels off (A/B)
+static int g_dw_s2 = 1;     // bit 20: the 2 x 2-block backward-data kernel of the stride-2 layers off (A/B)
 
 static inline unsigned grid_for(int64_t total)
 {

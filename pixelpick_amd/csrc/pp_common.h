@@ -46,6 +46,18 @@ struct EventScope {
     }
 };
 
+// CUs the caller sets aside for kernels that stay resident beside ours for a long time (RCCL's channel blocks during an overlapped
+// all-reduce): pp_set_comm_cu_reserve / PIXELPICK_COMM_CU_RESERVE.  Every launch whose blocks wait for each other (single-launch
+// BatchNorm, convolution + BatchNorm epilogues) sizes itself against occupancy x (CUs - reserve) instead of occupancy x CUs.
+int comm_cu_reserve();
+inline int reserve_scaled(int cap, int cus)
+{
+    const int r = comm_cu_reserve();
+    if (r <= 0 || cus <= 0) return cap;
+    if (r >= cus) return 0;
+    return (int)((int64_t)cap * (cus - r) / cus);
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

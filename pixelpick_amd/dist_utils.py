@@ -44,7 +44,7 @@ def gather_records(records: list, world: int, group=None) -> list:
 # rank holding identical python / numpy / torch RNG states.  The helpers below shard at the INDEX level: each rank's loader only
 # ever touches its own items, and the order comes from an explicit seed shared by construction.
 import torch
-from torch.utils.data import DataLoader, RandomSampler, Sampler
+from torch.utils.data import DataLoader, RandomSampler, Sampler, SequentialSampler
 
 
 class ShardedBatchSampler(Sampler):
@@ -97,14 +97,45 @@ def shard_dataloader(dl, rank: int, world: int, equal_steps: bool, seed: int = 0
     the whole loader and skipping, with the identical-RNG requirement that implies)."""
     if not isinstance(dl, DataLoader) or dl.batch_size is None:
         return None
+    if type(dl.sampler) not in (RandomSampler, SequentialSampler) or getattr(dl.sampler, "replacement", False) \
+            or getattr(dl.sampler, "_num_samples", None) is not None:
+        return None                  # subset / weighted / user samplers: their draws cannot be re-stated here - enumerate and skip
     shuffle = isinstance(dl.sampler, RandomSampler)
     bs = ShardedBatchSampler(len(dl.dataset), dl.batch_size, rank, world, shuffle=shuffle, drop_last=dl.drop_last,
                              equal_steps=equal_steps, seed=seed)
     kw = dict(batch_sampler=bs, collate_fn=dl.collate_fn, num_workers=dl.num_workers, pin_memory=dl.pin_memory,
-              worker_init_fn=dl.worker_init_fn)
+              worker_init_fn=_rank_worker_init(dl.worker_init_fn, rank, seed), timeout=dl.timeout, generator=dl.generator)
     if dl.num_workers > 0:
-        kw.update(persistent_workers=dl.persistent_workers, prefetch_factor=dl.prefetch_factor)
+        kw.update(persistent_workers=dl.persistent_workers, prefetch_factor=dl.prefetch_factor,
+                  multiprocessing_context=dl.multiprocessing_context)
     return DataLoader(dl.dataset, **kw)
+
+
+class _rank_worker_init:
+    """worker_init_fn of a rank's sharded loader.  The acquisition round needs identical host RNG streams on every rank, so all ranks
+    seed alike - and their loader workers (base seed = a draw from that stream) would then apply the SAME augmentation sequence to their
+    different shards.  Each worker's python / numpy / torch generators are therefore re-seeded from (seed, rank, worker id) before the
+    caller's own worker_init_fn runs.  Picklable (spawned workers)."""
+
+    def __init__(self, inner, rank: int, seed: int):
+        self.inner, self.rank, self.seed = inner, int(rank), int(seed)
+
+    def __call__(self, worker_id: int):
+        import random
+
+        import numpy as np
+        s = (self.seed * 1000003 + self.rank * 9973 + worker_id * 101 + torch.initial_seed()) % (1 << 31)
+        random.seed(s)
+        np.random.seed(s)
+        torch.manual_seed(s)
+        if self.inner is not None:
+            self.inner(worker_id)
+
+
+def augment_seed(seed: int, rank: int) -> int:
+    """Seed of a rank's training-time augmentation draws (DeviceAugmenter generator): separate from the streams the
+    acquisition draws use, different per rank."""
+    return (int(seed) * 1000003 + 7919 * (int(rank) + 1)) % (1 << 31)
 
 
 def dataset_image_sizes(dataset):

@@ -127,11 +127,24 @@ def _materialise(lazy) -> torch.Tensor:
 
 
 _ACCEPTS_AFFINE = {}
+_MEMO_EPOCH = [0]
+
+
+def _memo_epoch():
+    """The memo tables below hold answers that depend on the library's plan for a shape; a pp_debug_set_* knob may have
+    changed it since (_lib.knob_epoch): start over."""
+    e = _lib.knob_epoch[0]
+    if e != _MEMO_EPOCH[0]:
+        _MEMO_EPOCH[0] = e
+        _ACCEPTS_AFFINE.clear()
+        _WS_BYTES.clear()
+        _CONV_WS_BYTES.clear()
 
 
 def conv_accepts_lazy_input(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
     """True when pp_conv2d_fwd_affine_in has a kernel for this dense convolution (memoised)."""
     key = (B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
+    _memo_epoch()
     r = _ACCEPTS_AFFINE.get(key)
     if r is None:
         r = _ACCEPTS_AFFINE[key] = bool(_lib.lib().pp_conv2d_fwd_accepts_affine_in(*key))
@@ -522,6 +535,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 def _wsbytes(fn_name: str, *args) -> int:
     """Memoised pp_*_workspace_bytes query (a ctypes round trip per layer per step otherwise)."""
     key = (fn_name,) + args
+    _memo_epoch()
     n = _WS_BYTES.get(key)
     if n is None:
         n = int(getattr(_lib.lib(), fn_name)(*args))
@@ -768,6 +782,7 @@ _CONV_WS_BUF = {}        # device -> one grow-only scratch buffer; forward / bac
 def _conv_ws(bwd: bool, device, *shape):
     """(pointer, bytes) of the split-K scratch for this conv shape, or (None, 0)."""
     key = (bwd,) + shape
+    _memo_epoch()
     need = _CONV_WS_BYTES.get(key)
     if need is None:
         L = _lib.lib()
@@ -882,7 +897,8 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
             have = x.grad is not None
             if bctx[7] != (2 if have else 1) or (have and not (x.grad.is_contiguous() and tuple(x.grad.shape) == (B, H, W, Cin))):
                 bctx = None
-        if bctx is not None and bctx[0].needs_grad and _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) and _bn_exchange_ok(dev):
+        if (bctx is not None and bctx[0].needs_grad and not ((dy.data_ptr() | w.data_ptr()) & 15) and lddy % 4 == 0
+                and _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) and _bn_exchange_ok(dev)):
             # x is the output of a training BatchNorm (+ residual, activation) and this convolution's backward is the last of its
             # consumers' to run: the BatchNorm's backward runs inside this backward-data launch (pp_conv2d_bwd_data_bn_bwd) - the BatchNorm
             # node then finds no gradient on its output and is skipped
@@ -1094,6 +1110,8 @@ def _conv_bn_train_fused(tape: Tape, x: Var, gamma, beta, running_mean, running_
     kh, kw, _, Cout = w.shape
     if not _conv_bn_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) or ldx % 4:
         return None
+    if (xin.t.data_ptr() | w.data_ptr()) & 15:
+        return None                                 # the one-launch kernels are the 16-byte-vector forms only: take the two-launch path
     dev = xin.t.device
     if not _bn_exchange_ok(dev):
         return None

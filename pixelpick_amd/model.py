@@ -90,6 +90,9 @@ class Model:
         if self.augmenter is None and getattr(args, "device_augment", False):
             from .augment import DeviceAugmenter
             self.augmenter = DeviceAugmenter.from_args(args, device=self.device)
+        if self.augmenter is not None and self.world > 1 and hasattr(self.augmenter, "use_private_rng"):
+            # identical process-wide RNG streams on every rank (the acquisition round needs them) must not mean identical augmentation
+            self.augmenter.use_private_rng(dist_utils.augment_seed(int(getattr(args, "seed", 0)), self.rank))
         self.on_train_batch = None        # optional callback(dict_data, x, y, mask, aug_params): tests / debugging
         self.running_loss, self.running_score = AverageMeter(), RunningScore(args.n_classes)
         self.history = []
@@ -162,6 +165,8 @@ class Model:
             loader = self._train_loader
             loader.batch_sampler.set_epoch(max(self.nth_query, 0) * self.n_epochs + epoch)   # a new shared permutation per epoch
             skip = False
+            if len(loader) == 0:
+                raise ValueError(f"{len(self.dataloader)} train batches for {self.world} ranks: every rank needs at least one step per epoch")
         else:
             loader = self.dataloader
             skip = self.world > 1

@@ -142,7 +142,7 @@ class BatchNorm2d(nn.Module):
             B, H, W, _ = E.shape_of(x)          # (does not launch a deferred depthwise convolution)
             if B * H * W <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.t.shape)}")
-            _lib.plan_note(_bump_nbt, self.__dict__)   # folded into the num_batches_tracked buffer when it is read (plain
+            _lib.plan_note_host(_bump_nbt, self.__dict__)   # folded into the num_batches_tracked buffer when it is read (plain
                                                        # dict write: nn.Module.__setattr__ costs ~2 us x 60 BN layers per step)
         drop_p = dropout.p if (dropout is not None and dropout.training and dropout.p > 0.0) else 0.0
         return E.batch_norm_act(tape, x, self.weight, self.bias, self.running_mean, self.running_var, training, act,

@@ -480,7 +480,10 @@ class QuerySelector:
             n_pixels += len(sel)
             if contrib is not None:
                 self.query_stats.apply(contrib)
-        if not human_labels and (y is not None or any(r[5] is not None for r in records)):
+        # the branch (it holds a barrier) is decided from the gathered records, identical on every rank - a rank with an empty shard
+        # has seen no `y` of its own
+        has_labels = any(r[5] is not None for r in records) or (world == 1 and y is not None)
+        if not human_labels and has_labels:
             if rank == 0:
                 self.query_stats.save(nth_query)
             print(f"{n_pixels} labelled pixels  are chosen by {self.query_strategy} strategy")

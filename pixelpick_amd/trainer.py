@@ -27,6 +27,9 @@ OVERLAP_ALLREDUCE = os.environ.get("PIXELPICK_OVERLAP_ALLREDUCE", "1") != "0"
 # last op is the x4 bilinear upsample (DeepLab)
 SPARSE_LOWRES_CE = os.environ.get("PIXELPICK_SPARSE_LOWRES_CE", "1") != "0"
 FORCE_COLLECTIVES = os.environ.get("PIXELPICK_FORCE_COLLECTIVES", "0") == "1"
+# PIXELPICK_NATIVE_PLAN=0: enable_replay() keeps the recorded step as a Python list and re-issues it call by call (the round-2
+# form) instead of handing it to the library's executor (pp_plan_replay, csrc/plan.hip: one foreign call per step)
+NATIVE_PLAN = os.environ.get("PIXELPICK_NATIVE_PLAN", "1") != "0"
 
 
 class FlatTrainer:
@@ -51,6 +54,15 @@ class FlatTrainer:
         self.collectives = self.world > 1 or (FORCE_COLLECTIVES and torch.distributed.is_available() and torch.distributed.is_initialized())
         if self.collectives and not E._BN_FUSED_DIST:
             E.disable_fused_bn_for_collectives()
+        if self.collectives:
+            # RCCL's channel blocks stay resident on some CUs for the whole of an overlapped all-reduce while launches whose blocks
+            # wait for each other (single-launch BatchNorm, convolution + BatchNorm) need their WHOLE grid resident: those launches
+            # size themselves against occupancy x (CUs - reserve).  PIXELPICK_COMM_CU_RESERVE (default 32 under RCCL, 0 otherwise;
+            # tests/test_dist_gpu.py parks an occupier kernel on 16 / 32 / 64 CUs for 200 two-rank steps).
+            default = "32" if torch.distributed.get_backend(self.pg) == "nccl" else "0"
+            reserve = int(os.environ.get("PIXELPICK_COMM_CU_RESERVE", default))
+            if reserve != _lib.lib().pp_get_comm_cu_reserve():
+                _lib.lib().pp_set_comm_cu_reserve(reserve)
         slow, fast = [], []
         seen = set()
         for name, p in model.named_parameters():
@@ -307,7 +319,7 @@ class FlatTrainer:
         self._stage_hyper()
         pool = torch.cuda.MemPool()
         with torch.cuda.use_mem_pool(pool, device=x.device):
-            with _lib.record_plan() as plan:
+            with _lib.record_plan(native=NATIVE_PLAN) as plan:
                 self._step_body(self._gx, self._gy, True, True)
         self._plan, self._plan_pool = plan, pool
         self._plan_stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -338,6 +350,8 @@ class FlatTrainer:
             self.last_loss = self.last_logits = None      # they live in the plan's memory pool
             # the plan holds bound methods of this trainer (all_reduce_grads, _early_all_reduce_on): clear it so that no
             # trainer <-> plan reference cycle keeps the memory pool (a full step of activations) alive until a GC pass
+            if hasattr(self._plan, "close"):
+                self._plan.close()
             self._plan.calls.clear()
             self._plan = self._plan_pool = None
             self._gx = self._gy = None

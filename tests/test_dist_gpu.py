@@ -144,6 +144,7 @@ def _rccl_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["PIXELPICK_COMM_CU_RESERVE"] = "0"       # the reference run below has no collectives: same launch plans on both sides
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
@@ -394,6 +395,97 @@ def test_two_ranks_200_steps_with_spin_barrier_batchnorm_side_stream_and_overlap
         assert finite and loss == loss
 
 
+def _occupied_worker(rank, world, port, q, cus_list, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+        from pixelpick_amd import _lib
+        from pixelpick_amd import engine as E
+        from pixelpick_amd.trainer import FlatTrainer
+        from pixelpick_amd.utils.utils import get_model
+        L = _lib.lib()
+        out = []
+        occ_stream = torch.cuda.Stream()
+        stop = torch.zeros(1, dtype=torch.int32).pin_memory()
+        started = torch.zeros(1, dtype=torch.int64, device="cuda")
+        g = torch.Generator().manual_seed(500 + rank)
+        x = torch.randn(4, 3, 256, 512, generator=g).cuda()
+        y = torch.full((4, 256, 512), 19, dtype=torch.int64)
+        for b in range(4):
+            idx = torch.randperm(256 * 512, generator=g)[:20]
+            y[b].view(-1)[idx] = torch.randint(0, 19, (20,), generator=g)
+        y = y.cuda()
+        for cus in cus_list:
+            os.environ["PIXELPICK_COMM_CU_RESERVE"] = str(cus)          # what a data-parallel run under RCCL sets (default 32 there)
+            torch.manual_seed(0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=19, network_name="deeplab")).cuda().train()
+            tr = FlatTrainer(m, ignore_index=19)
+            assert L.pp_get_comm_cu_reserve() == cus
+            E.set_dropout_seed(77 + rank)
+            tr.train_step(x, y)                                          # scratch buffers grow before the occupier sits down
+            torch.cuda.synchronize()
+            dist.barrier()
+            n_started = 0
+            if rank == 0:
+                # the stand-in for RCCL's channel blocks: `cus` blocks that each own a whole CU's LDS for the whole run (at most 40 s)
+                stop[0] = 0
+                started.zero_()
+                torch.cuda.synchronize()
+                _lib.check(L.pp_debug_occupy_cus(cus, stop.data_ptr(), 4_000_000_000, started.data_ptr(), occ_stream.cuda_stream), "occupy")
+                for _ in range(2000):
+                    n_started = int(started.cpu().item())
+                    if n_started == cus:
+                        break
+            dist.barrier()
+            for _ in range(steps):
+                tr.train_step(x, y)
+            torch.cuda.current_stream().synchronize()                    # (not the device: the occupier is still spinning)
+            others = [torch.empty_like(tr.flat_p) for _ in range(world)]
+            dist.all_gather(others, tr.flat_p)
+            same = all(torch.equal(others[0], o) for o in others[1:])
+            dist.barrier()
+            if rank == 0:
+                stop[0] = 1
+                occ_stream.synchronize()
+            dist.barrier()
+            out.append((cus, n_started, same, bool(torch.isfinite(tr.flat_p).all().item())))
+            del tr, m
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spin_wait_launches_survive_a_resident_occupier_kernel():
+    """with RCCL, channel blocks sit on CUs for the whole of an overlapped all-reduce while the single-launch
+    BatchNorm / convolution + BatchNorm grids wait for co-resident siblings.  Stand-in: an occupier kernel parked on 16 / 32 / 64
+    CUs (every block owns a CU's whole LDS) on a third stream for the whole of a run of two-rank steps at the BASELINE shape
+    (B = 4, 256 x 512; both processes' spin-waiting launches, side streams and the overlapped buckets concurrent on ONE device),
+    with PIXELPICK_COMM_CU_RESERVE = the occupied CUs.  Nothing may hang, the occupier must really have been resident, and the
+    replicas stay bit-identical."""
+    world, steps, cus_list = 2, 60, (16, 32, 64)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_occupied_worker, args=(r, world, port, q, cus_list, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert [o[0] for o in out] == list(cus_list)
+        for cus, n_started, same, finite in out:
+            assert same and finite, (rank, cus)
+            if rank == 0:
+                assert n_started == cus, f"only {n_started} of {cus} occupier blocks were resident"
+
+
 def test_bench_line_from_two_ranks_through_torch_distributed_run():
     """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
     --gpus N`), with two ranks sharing this box's one GPU over gloo (PIXELPICK_DIST_BACKEND: RCCL needs a device per rank):
@@ -420,8 +512,8 @@ def test_bench_line_from_two_ranks_through_torch_distributed_run():
     assert "roofline" in d and d["acquisition"]["value"] > 0
 
 
-@pytest.mark.parametrize("replay", ["off", "on"])
-def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay):
+@pytest.mark.parametrize("replay,ranks", [("off", 2), ("on", 2), ("on", 8)])
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay, ranks):
     """`python bench.py --gpus 2` typed WITHOUT torch.distributed.run re-launches itself through the driver's line (one wrong
     launch line used to end in an assertion): same single JSON line, plus the host enqueue time per step, whether the
     launch-plan replay was on, and what each gradient bucket cost INSIDE the step."""
@@ -432,17 +524,19 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay):
     env = dict(os.environ, PIXELPICK_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+    # ranks = 8: the driver's `--gpus 8` line with eight ranks sharing this box's one GPU over gloo - plumbing only (nranks, buckets,
+    # the global batch; the replayed step returns to Python for each of the three all-reduces)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--batch", "8",
            "--no-cpu-baseline", "--mode", "train", "--replay", replay]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 8
+    assert d["n_gpus"] == ranks and d["value"] > 0 and d["config"]["global_batch"] == 4 * ranks
     t = d["train"]
     assert t["replay"] == (replay == "on") and 0 < t["host_enqueue_ms_per_step"] < 1e3 and t["host_cores_per_rank"] > 0
     dd = d["distributed"]
-    assert dd["nranks"] == 2 and set(dd["allreduce_in_step_us"]) == {"behind_encoder", "encoder_late", "encoder_early"}
+    assert dd["nranks"] == ranks and set(dd["allreduce_in_step_us"]) == {"behind_encoder", "encoder_late", "encoder_early"}
     assert len(dd["buckets"]) == 3 and sum(dd["buckets"]) == dd["allreduce_bytes_per_step"] and dd["buckets"][2] < dd["buckets"][1]
     assert all(v > 0 for v in dd["allreduce_in_step_us"].values())

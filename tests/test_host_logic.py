@@ -46,6 +46,62 @@ def test_abi_argument_validation_without_gpu():
     assert L.pp_topk_select(None, 1, 10, 3, 1, None, None, None, 0, None) == -1
 
 
+def test_launch_plan_executor_knows_every_enqueuing_entry_point():
+    """csrc/plan.hip holds one typed thunk per entry point that enqueues work; its arity comes from the function's own prototype
+    and must agree with the ctypes table.  The plan API itself (create / add / host break / replay of an empty stretch) needs no GPU."""
+    import ctypes
+    _ensure_built()
+    L = _lib.lib()
+    for name, (_, args) in _lib.SIGNATURES.items():
+        fn = getattr(L, name)
+        got = L.pp_plan_entry_args(ctypes.cast(getattr(fn, "__wrapped__", fn), ctypes.c_void_p))
+        assert got == (len(args) if _lib._is_launch(name) else -1), name
+    h = L.pp_plan_create()
+    try:
+        slots = (ctypes.c_uint64 * 3)(1, 2, 3)
+        assert L.pp_plan_add_call(h, ctypes.cast(L.pp_version, ctypes.c_void_p), slots, 0) == -4     # not an enqueuing entry
+        assert L.pp_plan_add_call(h, ctypes.cast(L.pp_add2d, ctypes.c_void_p), slots, 3) == -1       # wrong arity
+        assert b"9 arguments" in L.pp_last_error()
+        assert L.pp_plan_add_host_break(h) == 0 and L.pp_plan_add_host_break(h) == 0 and L.pp_plan_size(h) == 2
+        nxt = ctypes.c_int64(-1)
+        assert L.pp_plan_replay(h, 0, ctypes.byref(nxt)) == 0 and nxt.value == 1
+        assert L.pp_plan_replay(h, 1, ctypes.byref(nxt)) == 0 and nxt.value == 2
+        assert L.pp_plan_replay(h, 2, ctypes.byref(nxt)) == 0 and nxt.value == 2
+    finally:
+        L.pp_plan_destroy(h)
+    # slot packing of the binding: float in the low four bytes, None pointer = 0, negative integers sign-extended
+    assert _lib._slot(ctypes.c_float(1.0)) == 0x3F800000
+    assert _lib._slot(ctypes.c_void_p(None)) == 0
+    assert _lib._slot(ctypes.c_int(-1)) == 0xFFFFFFFFFFFFFFFF
+
+
+def test_debug_knobs_invalidate_the_engine_memo_tables():
+    """plan-dependent answers memoised on the host (workspace sizes, `_ok` queries) are refilled after any
+    pp_debug_set_* knob moved."""
+    _ensure_built()
+    from pixelpick_amd import engine as E
+    L = _lib.lib()
+    E._wsbytes("pp_conv2d_fwd_workspace_bytes", 4, 16, 32, 960, 160, 1, 1, 1, 0, 1)
+    assert E._WS_BYTES
+    L.pp_debug_set_x3(1)
+    E._memo_epoch()
+    assert not E._WS_BYTES and not E._CONV_WS_BYTES and not E._ACCEPTS_AFFINE
+
+
+def test_shard_dataloader_declines_samplers_it_cannot_restate():
+    """subset / weighted / user samplers fall back to enumerate-and-skip instead of silently becoming a sequential pass."""
+    import torch
+    from torch.utils.data import DataLoader, SubsetRandomSampler, TensorDataset, WeightedRandomSampler
+    from pixelpick_amd import dist_utils
+    ds = TensorDataset(torch.arange(10))
+    assert dist_utils.shard_dataloader(DataLoader(ds, batch_size=2, sampler=SubsetRandomSampler([1, 2, 3])), 0, 2, False) is None
+    assert dist_utils.shard_dataloader(DataLoader(ds, batch_size=2, sampler=WeightedRandomSampler([1.0] * 10, 4)), 0, 2, False) is None
+    g = torch.Generator()
+    dl = dist_utils.shard_dataloader(DataLoader(ds, batch_size=2, shuffle=True, generator=g, timeout=0), 1, 2, True, seed=3)
+    assert dl is not None and dl.generator is g and len(dl) == 2
+    assert dist_utils.augment_seed(3, 0) != dist_utils.augment_seed(3, 1)
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpixelpick_hip.so")

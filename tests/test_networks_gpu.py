@@ -219,13 +219,18 @@ def test_deeplab_r50_matches_the_assembly_of_reference_parts(golden_dir):
     _check_grads(g, {k: tr._grad_view[id(p)] for k, p in m2.named_parameters()})
 
 
+@pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("network", ["deeplab", "FPN"])
-def test_launch_plan_replay_matches_eager_steps(network):
+def test_launch_plan_replay_matches_eager_steps(network, native, monkeypatch):
     """FlatTrainer.enable_replay: the recorded launch list (C-ABI calls + stream forks / joins, re-issued from a loop) must
     walk the same parameter trajectory as eager steps, bit for bit, with inputs that change from step to step, dropout
     active (device-side seed) and the BatchNorm step counters still advancing."""
+    from pixelpick_amd import _lib
     from pixelpick_amd import engine as E
+    from pixelpick_amd import trainer as T
     from pixelpick_amd.networks.layers import BatchNorm2d
+    # native: the plan lives in the library and a step is ONE pp_plan_replay call (csrc/plan.hip); otherwise the round-2 Python list
+    monkeypatch.setattr(T, "NATIVE_PLAN", native)
     C, B, H, W = 19, 2, 64, 96
     data = [(fi.formula_input(B, H, W, key=f"r{i}").to(DEV), fi.formula_labels(B, H, W, C, C, 20, key=f"r{i}").to(DEV)) for i in range(3)]
 
@@ -246,6 +251,10 @@ def test_launch_plan_replay_matches_eager_steps(network):
             elif i == 0:
                 tr.enable_replay(xb, yb, warmup=0)          # the recorded step is a real step
                 assert len(tr._plan) > 100
+                assert isinstance(tr._plan, _lib.NativePlan) == native
+                if native:
+                    # single rank: no host break - the whole step is one stretch; the BatchNorm step counters ride behind it
+                    assert not tr._plan.breaks and tr._plan.native_ops() > 100 and len(tr._plan.host_notes) > 10
                 losses.append(tr.last_loss.item())
             else:
                 losses.append(tr.train_step(xb, yb).item())
