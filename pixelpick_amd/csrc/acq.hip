@@ -22,6 +22,7 @@ static int g_reduce_mode = 0;
 static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel)
 static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
 static int g_tune_ppt = 0;
+static int g_tune_xcd = 0;        // 0: by plane size, 1: never, 2: always (pp_debug_set_acq_tuning bits 8-9 of `occ`)
 
 constexpr int kBlock = 256;
 constexpr int kSmallKMax = 48;        // fused per-wave extraction up to this k (measured: 0.74/0.70/0.62 of HBM at k=20/32/48, 0.37 at 64); beyond: map + radix select
@@ -43,6 +44,8 @@ struct AcqParams {
     int strategy;
     int reduce_mode;
     int from_prob;       // 1: input already holds probabilities (UncertaintySampler.__call__, query.py:246-247)
+    int xcd_per = 0;     // > 0: XCD-contiguous block order (acq_kernel only): hardware block b works on logical block
+    int nb = 0;          //      (b % 8) * xcd_per + b / 8 of nb, so that the blocks one XCD holds walk ONE contiguous eighth of the launch
 };
 
 // ---- per-pixel score ----------------------------------------------------------------------------
@@ -243,8 +246,16 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
     constexpr int PPT = VEC * G;
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
     __shared__ uint32_t s_cnt[kBlock / kWave];
-    const int img = blockIdx.x / p.blocks_per_image;
-    const int blk = blockIdx.x - img * p.blocks_per_image;
+    int lb = blockIdx.x;
+    if (p.xcd_per) {
+        // Large class planes (>= 4 MB: 1024 x 2048 logits): a block's C streams lie a whole plane apart, and with blocks dealt
+        // round-robin to the eight XCDs every XCD walks every plane end to end.  Giving each XCD one contiguous eighth of the
+        // launch lifts a pure read of this layout from 0.65 to 0.74 of 8 TB/s (tools/probe/plane_read.hip, profiles/r04_acq_layout.txt).
+        lb = (int)(blockIdx.x & 7u) * p.xcd_per + (int)(blockIdx.x >> 3);
+        if (lb >= p.nb) return;
+    }
+    const int img = lb / p.blocks_per_image;
+    const int blk = lb - img * p.blocks_per_image;
     const int tid = threadIdx.x;
     const bool largest = p.strategy != PP_ACQ_MARGIN;
     const float fill = largest ? 0.0f : 1.0f;
@@ -1059,6 +1070,7 @@ struct Plan {
     int ppt;              // pixels per thread
     int blocks_per_image;
     int waves_per_image;
+    bool xcd = false;     // XCD-contiguous block order (flat float4 path, class planes >= 4 MB)
 };
 
 static bool is_flat_vec4(const float* logits, const uint8_t* exclude, const float* out_map, int64_t H, int64_t W,
@@ -1086,6 +1098,9 @@ static Plan make_plan(int64_t B, int64_t N, bool vec4, bool force_ppt4 = false)
     // 16 pixels/thread spills, 4 waves/SIMD spills.
     const int64_t waves8 = B * cdiv(N, (int64_t)kBlock * 8) * (kBlock / kWave);
     pl.ppt = (waves8 >= 2048 && !force_ppt4) ? 8 : 4;
+    // class planes of 4 MB and more: XCD-contiguous block order (1024 x 2048, least confidence, B = 8: 0.655 -> 0.677 of 8 TB/s; on
+    // 512 KB planes it costs 5 %, on 2 MB planes it is neutral: profiles/r04_acq_layout.txt)
+    pl.xcd = vec4 && g_tune_xcd != 1 && (g_tune_xcd == 2 || N * 4 >= (4ll << 20));
     if (g_tune_ppt && vec4 && !force_ppt4) pl.ppt = g_tune_ppt;
     pl.blocks_per_image = (int)cdiv(N, (int64_t)kBlock * pl.ppt);
     pl.waves_per_image = pl.blocks_per_image * (kBlock / kWave);
@@ -1167,6 +1182,8 @@ static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int larg
     return check_launch("topk_large_sel_kernel");
 }
 
+constexpr int kAcqOcc21 = 2, kAcqOcc11 = 3;     // defaults of the C = 21 / C = 11 scorers (see launch_acq)
+
 template <int CMAX, bool EXACT>
 static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t st)
 {
@@ -1198,31 +1215,24 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
         else                      hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 0>), grid, block, 0, st, p); \
     } while (0)
     if (pl.vec4) {
-        if constexpr (CMAX == 19) {
-            if (!alt && g_tune_occ) {
-#define PP_TUNE(G)                                                                                          \
-    do {                                                                                                    \
-        if (g_tune_occ == 2)      hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 2>), grid, block, 0, st, p); \
-        else if (g_tune_occ == 4) hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 4>), grid, block, 0, st, p); \
-        else                      hipLaunchKernelGGL((acq_kernel<19, true, 4, G, 0, 3>), grid, block, 0, st, p); \
-    } while (0)
-                if (pl.ppt == 8) PP_TUNE(2);
-                else PP_TUNE(1);
-#undef PP_TUNE
-                return check_launch("acq_kernel");
-            }
-        }
-        if constexpr (CMAX == 21) {
-            // 21 class planes x 8 pixels do not fit the 170-VGPR budget of 3 waves/SIMD (23 spilled registers, 0.56 of
-            // the HBM roofline on VOC 320x320); at 2 waves/SIMD the kernel has 256 and no scratch traffic
+        if constexpr (CMAX == 11 || CMAX == 19 || CMAX == 21) {
+            // the three dataset class counts: pixels per thread x waves per SIMD chosen per count (profiles/r04_acq_layout.txt);
+            // pp_debug_set_acq_tuning overrides either for A/B.  C = 21: 21 planes x 8 pixels do not fit the 170-VGPR budget of
+            // 3 waves/SIMD (23 spilled registers, 0.56 of the HBM roofline on VOC 320x320) - 2 waves/SIMD, or 4 pixels per thread.
             if (!alt) {
-                if (g_tune_occ == 3) {
-                    if (pl.ppt == 8) hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 2, 0, 3>), grid, block, 0, st, p);
-                    else             hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 1, 0, 3>), grid, block, 0, st, p);
-                } else {
-                    if (pl.ppt == 8) hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 2, 0, 2>), grid, block, 0, st, p);
-                    else             hipLaunchKernelGGL((acq_kernel<21, EXACT, 4, 1, 0, 2>), grid, block, 0, st, p);
+                int occ = CMAX == 21 ? kAcqOcc21 : (CMAX == 11 ? kAcqOcc11 : 3);
+                const int g = pl.ppt == 8 ? 2 : 1;
+                if (g_tune_occ >= 2 && g_tune_occ <= 4) occ = g_tune_occ;
+                AcqParams q = p;
+                if (pl.xcd) {
+                    q.nb = (int)grid.x;
+                    q.xcd_per = (int)cdiv(q.nb, 8);
+                    grid = dim3((unsigned)(q.xcd_per * 8));
                 }
+#define PP_ACQ_GO(G, O) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, O>), grid, block, 0, st, q)
+                if (g == 2) { if (occ == 2) PP_ACQ_GO(2, 2); else if (occ == 4) PP_ACQ_GO(2, 4); else PP_ACQ_GO(2, 3); }
+                else        { if (occ == 2) PP_ACQ_GO(1, 2); else if (occ == 4) PP_ACQ_GO(1, 4); else PP_ACQ_GO(1, 3); }
+#undef PP_ACQ_GO
                 return check_launch("acq_kernel");
             }
         }
@@ -1365,6 +1375,8 @@ void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
 
 void pp_debug_set_acq_tuning(int occ, int ppt)
 {
+    g_tune_xcd = (occ >> 8) & 3;
+    occ &= 0xFF;
     g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9) ? occ : 0;
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
 }

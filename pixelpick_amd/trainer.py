@@ -274,7 +274,8 @@ class FlatTrainer:
     def _step_body(self, x, y, keep_logits, device_hyper):
         E.begin_step()
         loss = self.forward_backward(x, y, keep_logits)
-        _lib.plan_note(self.all_reduce_grads)
+        if self.collectives:
+            _lib.plan_note(self.all_reduce_grads)          # (a host break of a native plan: only where there is something to exchange)
         self.optimizer_step(device_hyper)
         return loss
 

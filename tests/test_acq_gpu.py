@@ -369,6 +369,30 @@ def test_full_size_properties(st, shape):
                                rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("C", [11, 19, 21])
+def test_block_order_and_tile_variants_are_bit_identical(C):
+    """The XCD-contiguous block order (default for class planes >= 4 MB, forced here on small ragged ones), 4 / 8 pixels per
+    thread and 2 / 3 / 4 waves per SIMD are schedules of the SAME arithmetic: picks, scores and the map must not move a bit."""
+    L = _lib.lib()
+    gen = torch.Generator(device=DEV).manual_seed(C)
+    for B, H, W, k in ((3, 36, 52, 20), (2, 200, 328, 7), (9, 64, 128, 48)):
+        logits = torch.randn((B, C, H, W), device=DEV, generator=gen) * 3
+        excl = torch.rand((B, H, W), device=DEV, generator=gen) < 0.1
+        for st in STRATS:
+            L.pp_debug_set_acq_tuning(0, 0)
+            ref = acq.score_topk(logits, excl, st, k, return_map=True)
+            try:
+                for occ in (2, 3, 4):
+                    for ppt in (4, 8):
+                        for xcd in (1, 2):
+                            L.pp_debug_set_acq_tuning(occ | (xcd << 8), ppt)
+                            got = acq.score_topk(logits, excl, st, k, return_map=True)
+                            for a, b in zip(ref, got):
+                                assert torch.equal(a, b), (C, st, occ, ppt, xcd)
+            finally:
+                L.pp_debug_set_acq_tuning(0, 0)
+
+
 def test_query_selector_batched_forward_gives_identical_queries(golden_dir):
     """query_batch_size > 1 (several equal-sized images per forward) must not change a single coordinate."""
     g4 = np.load(os.path.join(golden_dir, "acq_end_to_end.npz"))

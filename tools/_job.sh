@@ -1,6 +1,4 @@
-# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/job; mkdir -p $O
-timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
+O=gpurun_out/r4b; mkdir -p $O
+timeout 900 python -m pytest tests/test_acq_gpu.py -q -x -k "block_order or full_size" > $O/t_acq.txt 2>&1; tail -3 $O/t_acq.txt
+bash tools/acq_sweep.sh $O
