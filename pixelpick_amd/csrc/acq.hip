@@ -687,8 +687,9 @@ __global__ __launch_bounds__(kBlock) void cand_merge_kernel(const uint64_t* in, 
 // query.py:36 top_n_percent mode: k = int(h*w*0.05) (6553 at 256x512) value-sorted indices.
 __global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* scores, int64_t N, int k, int largest,
                                                                   uint64_t* gbuf, int P, int32_t* out_idx,
-                                                                  float* out_val)
+                                                                  float* out_val, const int* only_if = nullptr)
 {
+    if (only_if && !only_if[blockIdx.x]) return;      // fallback launch of the quantised select: flagged images only
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);            // 256
     uint32_t* misc = hist + 256;                                   // 64
@@ -1023,6 +1024,163 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_sel_kernel(const flo
 }
 
 
+// ---- large-k with a KNOWN score range: one quantised histogram pass, compaction, register / shuffle bitonic sort ------------
+// The scorers' outputs live in a known interval (entropy [0, ln C], least confidence and margin [0, 1]), so the 32-bit radix
+// digits of the generic select are not needed to find a threshold: kQBins LINEAR bins of the score - a monotone map of the order
+// key, so every element of a higher bin precedes every element of a lower one - are filled in ONE pass over the map, the bin that
+// holds the k-th element is found by a scan, and everything in that bin or above (k + the bin's population: k + ~130 of 131072
+// at the reference's default k = 6553) is dropped into LDS bin by bin and ranked exactly on the full (key, index) words.  Replaces four
+// histogram passes + a 66-barrier LDS sort; an image whose candidates do not fit (kQCap in all, kQMaxPop in a bin: heavy ties, constant
+// maps) raises its overflow flag and is redone by topk_large_kernel (the exact one-block radix select): the result never depends on the data.
+constexpr int kQBins = 1024;
+constexpr int kQSub = 8;             // sub-histograms per block (lane & 7)
+constexpr int kQCap = 8192;          // candidates per image held in LDS (64 KiB of (key, index) words)
+
+__device__ __forceinline__ uint32_t qbin(float s, bool lg, float scale)
+{
+    if (s != s) return lg ? (uint32_t)(kQBins - 1) : 0u;             // NaN: first for largest, last for smallest (order_key's policy)
+    const float t = s * scale;
+    const int qi = t >= (float)(kQBins - 1) ? kQBins - 1 : (t > 0.0f ? (int)t : 0);
+    return (uint32_t)(lg ? qi : kQBins - 1 - qi);
+}
+
+// hist: [B][kQBins], zeroed by the host
+__global__ __launch_bounds__(kBlock) void select_qhist_kernel(const float* scores, int64_t N, int largest, float scale, uint32_t* hist)
+{
+    __shared__ uint32_t lh[kQSub][kQBins];
+    const int b = blockIdx.y;
+    const float* s = scores + (int64_t)b * N;
+    const bool lg = largest != 0;
+    for (int i = threadIdx.x; i < kQSub * kQBins; i += kBlock) (&lh[0][0])[i] = 0u;
+    __syncthreads();
+    const int sub = threadIdx.x & (kQSub - 1);
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+    int64_t i = i0 + threadIdx.x;
+    if (i1 > i0 && (per & 3) == 0 && (reinterpret_cast<uintptr_t>(s + i0) & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(s + i0);
+        const int64_t n4 = (i1 - i0) >> 2;                      // (a ragged end of the last block goes through the scalar loop below)
+        int64_t j = threadIdx.x;
+        auto add4 = [&](const float4& q) {
+            atomicAdd(&lh[sub][qbin(q.x, lg, scale)], 1u); atomicAdd(&lh[sub][qbin(q.y, lg, scale)], 1u);
+            atomicAdd(&lh[sub][qbin(q.z, lg, scale)], 1u); atomicAdd(&lh[sub][qbin(q.w, lg, scale)], 1u);
+        };
+        for (; j + 3 * kBlock < n4; j += 4 * kBlock) {          // four 16-byte loads in flight per thread
+            const float4 q0 = s4[j], q1 = s4[j + kBlock], q2 = s4[j + 2 * kBlock], q3 = s4[j + 3 * kBlock];
+            add4(q0); add4(q1); add4(q2); add4(q3);
+        }
+        for (; j < n4; j += kBlock) add4(s4[j]);
+        i = i0 + 4 * n4 + threadIdx.x;
+    }
+    for (; i + 3 * kBlock < i1; i += 4 * kBlock) {            // four loads in flight per thread
+        const float v0 = s[i], v1 = s[i + kBlock], v2 = s[i + 2 * kBlock], v3 = s[i + 3 * kBlock];
+        atomicAdd(&lh[sub][qbin(v0, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v1, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v2, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v3, lg, scale)], 1u);
+    }
+    for (; i < i1; i += kBlock) atomicAdd(&lh[sub][qbin(s[i], lg, scale)], 1u);
+    __syncthreads();
+    uint32_t* H = hist + (int64_t)b * kQBins;
+    for (int d = threadIdx.x; d < kQBins; d += kBlock) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < kQSub; ++u) c += lh[u][d];
+        if (c) atomicAdd(&H[d], c);
+    }
+}
+
+// One 1024-thread block per image.  The histogram already IS the coarse sort: the number of elements in the bins above bin d is
+// where bin d's elements start in the value-sorted output.  Every candidate is dropped into its bin's segment of an LDS list (one
+// LDS atomic on the bin's cursor - no wave ballots, no ordering among the threads), then ranks itself inside its segment by
+// counting the segment's larger (key, index) words - ~130 comparisons per candidate at 1024 bins - and goes straight to its final
+// slot.  No sorting network at all: the round-3 kernel spent ~150 us in a 66-barrier bitonic sort of 8192 words per image.
+constexpr int kQMaxPop = 1024;
+constexpr int kQSelLds = kQCap * 8 + 2 * kQBins * 4 + 128;       // a bin holding more candidates than this (ties, constant regions) sends the image to the fallback
+
+__global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* scores, int64_t N, int k, int largest, float scale,
+                                                                 const uint32_t* hist, int32_t* out_idx, float* out_val, int* overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);                                   // kQCap candidates, grouped by bin
+    uint32_t* start = reinterpret_cast<uint32_t*>(smem + (size_t)kQCap * 8);             // [kQBins] first slot of a bin's segment
+    uint32_t* cursor = start + kQBins;                                                   // [kQBins] candidates dropped so far
+    uint32_t* misc = cursor + kQBins;                                                    // 32 words
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = scores + (int64_t)blockIdx.x * N;
+    const bool lg = largest != 0;
+    // thread t owns bin kQBins - 1 - t; an inclusive scan over the threads counts the elements at or above each bin
+    {
+        const int bin = kQBins - 1 - tid;
+        const uint32_t own = hist[(int64_t)blockIdx.x * kQBins + bin];
+        uint32_t incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) misc[8 + wave] = incl;
+        if (tid == 0) misc[2] = 0;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += misc[8 + w];
+        incl += base;
+        const uint32_t excl = incl - own;
+        start[bin] = excl;
+        cursor[bin] = 0;
+        if (excl < (uint32_t)k && (uint32_t)k <= incl) { misc[0] = (uint32_t)bin; misc[1] = incl; }
+        if (excl < (uint32_t)k && own > (uint32_t)kQMaxPop) misc[2] = 1;      // an over-full bin among those that hold candidates
+        __syncthreads();
+    }
+    const uint32_t tb = misc[0], count = misc[1];
+    if (count > (uint32_t)kQCap || misc[2]) {          // block-uniform: this image goes to the exact fallback launch
+        if (tid == 0) overflow[blockIdx.x] = 1;
+        return;
+    }
+    if (tid == 0) overflow[blockIdx.x] = 0;
+    auto drop = [&](float v, int64_t i) {
+        const uint32_t q = qbin(v, lg, scale);
+        if (q >= tb) {
+            const uint32_t pos = start[q] + atomicAdd(&cursor[q], 1u);
+            buf[pos] = ((uint64_t)order_key(v, lg) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+        }
+    };
+    if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 15) == 0) {
+        // one block reads its image's whole map (512 KB at 256 x 512): four 16-byte loads in flight per thread = 64 KB per CU
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        const int64_t n4 = N >> 2;
+        auto drop4 = [&](const float4& q, int64_t i4) { drop(q.x, 4 * i4); drop(q.y, 4 * i4 + 1); drop(q.z, 4 * i4 + 2); drop(q.w, 4 * i4 + 3); };
+        int64_t base = 0;
+        for (; base + 4 * kLargeThreads <= n4; base += 4 * kLargeThreads) {
+            const int64_t i = base + tid;
+            const float4 q0 = s4[i], q1 = s4[i + kLargeThreads], q2 = s4[i + 2 * kLargeThreads], q3 = s4[i + 3 * kLargeThreads];
+            drop4(q0, i); drop4(q1, i + kLargeThreads); drop4(q2, i + 2 * kLargeThreads); drop4(q3, i + 3 * kLargeThreads);
+        }
+        for (int64_t i = base + tid; i < n4; i += kLargeThreads) drop4(s4[i], i);
+    } else {
+        int64_t base = 0;
+        for (; base + 4 * kLargeThreads <= N; base += 4 * kLargeThreads) {        // four loads in flight per thread
+            const int64_t i = base + tid;
+            const float v0 = s[i], v1 = s[i + kLargeThreads], v2 = s[i + 2 * kLargeThreads], v3 = s[i + 3 * kLargeThreads];
+            drop(v0, i); drop(v1, i + kLargeThreads); drop(v2, i + 2 * kLargeThreads); drop(v3, i + 3 * kLargeThreads);
+        }
+        for (int64_t i = base + tid; i < N; i += kLargeThreads) drop(s[i], i);
+    }
+    __syncthreads();
+    // rank inside the bin's segment; neighbouring slots share a segment, so most of a wave's reads are broadcasts
+    for (uint32_t p = (uint32_t)tid; p < count; p += kLargeThreads) {
+        const uint64_t me = buf[p];
+        const uint32_t q = qbin(key_to_float((uint32_t)(me >> 32), lg), lg, scale);
+        const uint32_t a = start[q], b = a + cursor[q];
+        uint32_t rank = a;
+        for (uint32_t t = a; t < b; ++t) rank += buf[t] > me ? 1u : 0u;
+        if (rank < (uint32_t)k) {
+            out_idx[(int64_t)blockIdx.x * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)me);
+            if (out_val) out_val[(int64_t)blockIdx.x * k + rank] = key_to_float((uint32_t)(me >> 32), lg);
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 // Sum over T forward passes of softmax(logits[t]) per pixel and of the strategy's score of each pass (the MC-dropout
 // branch, query.py:181-187: `uc_map += uc_map_; prob += prob_`), scaled: p_c = exp(x_c - m) / S and the score formulas in
@@ -1138,16 +1296,25 @@ static int run_merge(uint64_t* cand, int64_t n_cand, uint64_t* other, int64_t B,
 }
 
 static int g_large_multiblock = 1;     // 0: the one-block-per-image radix select (pp_debug_set_reduce_mode bit 8), for A/B
+static int g_large_q = 1;              // 0: no quantised-histogram select (pp_debug_set_reduce_mode bit 9), for A/B
 
 static size_t large_ws_bytes(int64_t B, int64_t k)
 {
     const int P = next_pow2(k);
     const size_t g = P <= kLargeLdsMaxP ? 256 : align_up((size_t)B * P * 8, 256);
-    return g + align_up((size_t)B * kSelPasses * kSelBins * 4, 256);
+    // histograms: four 256-bin radix passes, or the 1024 linear bins of the quantised select (the same bytes) + its overflow flags
+    return g + align_up((size_t)B * kSelPasses * kSelBins * 4, 256) + align_up((size_t)B * 4, 256);
+}
+
+// The scorers' value range as bins per unit score (0: unknown - the generic radix select)
+static float score_qscale(int strategy, int64_t C)
+{
+    const float range = strategy == PP_ACQ_ENTROPY ? logf((float)(C > 1 ? C : 2)) : 1.0f;
+    return (float)kQBins / range;
 }
 
 static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int largest, void* ws,
-                     int32_t* out_idx, float* out_val, hipStream_t st)
+                     int32_t* out_idx, float* out_val, hipStream_t st, float qscale = 0.0f)
 {
     const int P = next_pow2(k);
     const bool in_lds = P <= kLargeLdsMaxP;
@@ -1160,11 +1327,32 @@ static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int larg
                             hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_large_sel_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_qsel_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kQSelLds);
         attr_set = true;
+    }
+    // known score range and room for the threshold bin's population beside the k picks: the quantised select
+    if (qscale > 0.0f && g_large_q && g_large_multiblock && B <= 65535 && k + (k / 8 > 256 ? k / 8 : 256) <= kQCap) {
+        static_assert(kQBins * 4 == kSelPasses * kSelBins * 4, "the two histogram layouts share their workspace slot");
+        int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + align_up((size_t)B * kQBins * 4, 256));
+        if (hipMemsetAsync(hist, 0, (size_t)B * kQBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+        int64_t bpi = cdiv(2048, B);
+        const int64_t by_size = cdiv(N, 4096);
+        if (bpi > by_size) bpi = by_size;
+        if (bpi < 1) bpi = 1;
+        hipLaunchKernelGGL(select_qhist_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, largest, qscale, hist);
+        if (int rc = check_launch("select_qhist_kernel")) return rc;
+        hipLaunchKernelGGL(topk_qsel_kernel, dim3((unsigned)B), dim3(kLargeThreads), kQSelLds, st, map, N, (int)k, largest, qscale,
+                           hist, out_idx, out_val, flags);
+        if (int rc = check_launch("topk_qsel_kernel")) return rc;
+        // images whose candidates did not fit (ties at the threshold, constant maps): the exact one-block radix select; the others return at once
+        hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest,
+                           in_lds ? (uint64_t*)nullptr : gbuf, P, out_idx, out_val, (const int*)flags);
+        return check_launch("topk_large_kernel");
     }
     if (!g_large_multiblock || B > 65535) {
         hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest,
-                           in_lds ? (uint64_t*)nullptr : gbuf, P, out_idx, out_val);
+                           in_lds ? (uint64_t*)nullptr : gbuf, P, out_idx, out_val, (const int*)nullptr);
         return check_launch("topk_large_kernel");
     }
     if (hipMemsetAsync(hist, 0, (size_t)B * kSelPasses * kSelBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
@@ -1367,6 +1555,7 @@ extern "C" {
 void pp_debug_set_reduce_mode(int mode)
 {
     g_large_multiblock = (mode & 256) ? 0 : 1;      // bit 8: large-k selection through the one-block-per-image radix select (A/B)
+    g_large_q = (mode & 512) ? 0 : 1;               // bit 9: no quantised-histogram select where the score range is known (A/B)
     mode &= 255;
     g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
@@ -1475,7 +1664,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
                 g_reduce_mode, 0};
     if (int rc = dispatch_acq(p, pl, B, st)) return rc;
-    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st);
+    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st, score_qscale(strategy, C));
 }
 
 size_t pp_acq_lowres_workspace_bytes(int64_t B, int64_t C, int64_t Hc, int64_t Wc, int64_t k)
@@ -1530,7 +1719,7 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
     uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
     p.out_map = map;
     if (int rc = dispatch_lowres(p, pl, B, st)) return rc;
-    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st);
+    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st, score_qscale(strategy, C));
 }
 
 int pp_acq_lowres_score_at(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w, int64_t H,

@@ -369,6 +369,48 @@ def test_full_size_properties(st, shape):
                                rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("st", STRATS)
+def test_quantised_select_equals_the_radix_select(st):
+    """k > 48 with a known score range (query.py:36 top_n_percent: k = 5 % of the pixels): one linear-bin histogram pass +
+    compaction + register / shuffle sort.  Must return exactly what the four-pass radix select + LDS sort returns
+    (pp_debug_set_reduce_mode bit 9 switches it off) - on random maps, with exclusions, with heavy ties (overflow -> the exact
+    fallback launch), with NaN scores, and in images whose every pixel is excluded - and what the oracle's stable sort gives."""
+    L = _lib.lib()
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    cases = []
+    B, C, H, W = 3, 19, 256, 512
+    logits = torch.randn((B, C, H, W), device=DEV, generator=gen) * 3
+    excl = torch.rand((B, H, W), device=DEV, generator=gen) < 0.05
+    cases.append(("random", logits, excl, 6553))
+    cases.append(("random-small-k", logits[:, :, :64, :96].contiguous(), excl[:, :64, :96].contiguous(), 307))
+    tied = torch.round(torch.randn((2, C, 128, 256), device=DEV, generator=gen))           # few distinct class vectors: heavy ties
+    cases.append(("ties", tied, None, 1638))
+    const = torch.zeros((2, C, 128, 256), device=DEV)
+    const[1] = logits[0, :, :128, :256]
+    ex2 = torch.zeros((2, 128, 256), dtype=torch.bool, device=DEV)
+    ex2[1, :100] = True                                                                    # 78 % of image 1 excluded: one huge bin
+    cases.append(("constant+mostly-excluded", const, ex2, 1638))
+    if st == "entropy":
+        nanl = logits[:2, :, :64, :128].clone()
+        nanl[0, 0, 3, 5:40] = 200.0                                                         # p -> 0 for the others: 0 * log 0 = NaN (query.py:230)
+        cases.append(("nan", nanl, None, 409))
+    for name, lg, ex, k in cases:
+        try:
+            L.pp_debug_set_reduce_mode(512)
+            ref = acq.score_topk(lg, ex, st, k, return_map=True)
+            L.pp_debug_set_reduce_mode(0)
+            got = acq.score_topk(lg, ex, st, k, return_map=True)
+        finally:
+            L.pp_debug_set_reduce_mode(0)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b) or (name == "nan" and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))), (name, st, k)
+        # oracle: stable sort of the device's own map (ties -> lower index first, NaN first for largest)
+        dmap = got[2].cpu().numpy()
+        for b in range(lg.shape[0]):
+            e_idx, _ = orc.topk(dmap[b], k, st != "margin_sampling")
+            assert got[0][b].cpu().numpy().tolist() == e_idx.tolist(), (name, st, b)
+
+
 @pytest.mark.parametrize("C", [11, 19, 21])
 def test_block_order_and_tile_variants_are_bit_identical(C):
     """The XCD-contiguous block order (default for class planes >= 4 MB, forced here on small ragged ones), 4 / 8 pixels per
