@@ -448,7 +448,11 @@ int pp_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, in
  *                       same pad (ignore_index / 0) / crop / flip; y_out int64 [ch,cw], q_out uint8 0/1 (base_dataset.py:114).
  *   pp_aug_jitter       in place; op 0 brightness, 1 contrast, 2 saturation (PIL ImageEnhance blends), 3 hue (PIL RGB->HSV,
  *                       uint8 wrap-around shift, HSV->RGB), 4 RandomGrayscale (convert("L") x3); contrast needs 8 scratch bytes.
- *   pp_aug_blur         cv2.GaussianBlur(img, (ks,ks), sigma) with a host-built float kernel; scratch [H*W*3] floats.
+ *   pp_aug_blur         cv2.GaussianBlur(img, (ks,ks), sigma) with a host-built float kernel; scratch [H*W*3] floats (the float32
+ *                       separable filter cv2 ran for 8-bit images before 3.4.2).
+ *   pp_aug_blur_q8      the same call as OpenCV >= 3.4.2 / 4.x computes it for 8-bit images (base_dataset.py:208 today): host-built
+ *                       8.8 fixed-point taps summing to 256 (device array), exact integer row pass into scratch [H*W*3] uint16,
+ *                       16.16 column pass, round half up; BORDER_REFLECT_101.
  *   pp_aug_to_tensor    TF.normalize(TF.to_tensor(x), mean, std): HWC uint8 -> CHW float32; mean3 / std3 are HOST arrays. */
 int pp_aug_resample_h(const uint8_t* src, int H, int W, const int32_t* bounds, const int32_t* kk, int ksize, int Wout, uint8_t* dst,
                       pp_stream_t stream);
@@ -459,6 +463,7 @@ int pp_aug_labels(const uint8_t* y, const uint8_t* q, int W, const int32_t* ty, 
                   uint8_t* q_out, pp_stream_t stream);
 int pp_aug_jitter(uint8_t* img, int64_t n_pixels, int op, float factor, unsigned long long* scratch_sum, pp_stream_t stream);
 int pp_aug_blur(uint8_t* img, int H, int W, const float* kernel, int ks, float* scratch, pp_stream_t stream);
+int pp_aug_blur_q8(uint8_t* img, int H, int W, const uint16_t* kernel_q8, int ks, uint16_t* scratch, pp_stream_t stream);
 int pp_aug_to_tensor(const uint8_t* img, int64_t n_pixels, const float* mean3, const float* std3, float* out, pp_stream_t stream);
 
 /* nn.Dropout2d (mobilenet_v2.py:114-115 on the high-level features in MC-dropout TRAINING, :127,133-134 on the low-level

@@ -12,7 +12,22 @@ restates torchvision.transforms.functional's PIL code paths, which are one-line 
   adjust_brightness/contrast/saturation     -> ImageEnhance.Brightness/Contrast/Color(img).enhance(f)
   adjust_hue                                -> HSV split, np.uint8 H += np.uint8(f * 255) (wraps), merge, convert RGB
   RandomGrayscale                           -> img.convert("L") replicated to 3 channels
-  cv2.GaussianBlur                          -> restated from OpenCV's documented algorithm ("parity unpinned": cv2 absent)
+  cv2.GaussianBlur                          -> OpenCV's 8-bit path restated (below).  "PARITY UNPINNED": cv2 is absent from this
+                                               image, so no cv2-generated fixture exists yet; tests hold the device kernel to THIS.
+
+cv2.GaussianBlur on CV_8U follows OpenCV 4.5 - 4.10, modules/imgproc/src/smooth.dispatch.cpp + fixedpoint.inl.hpp + smooth.simd.hpp
+(the path every default x86 build takes for 8-bit input that is not a sub-matrix: `GaussianBlurFixedPoint`):
+  1. getGaussianKernelBitExact: t_i = exp(-0.5 / sigma^2 * x_i^2), x_i = i - (n-1)/2, in IEEE double; the centre tap is exactly 1;
+     sum = 2 * sum(t_i, i < n/2) + 1; k_i = t_i * (1 / sum).  (OpenCV evaluates this in its `softdouble` class - IEEE-754 double in
+     software, so identical on every CPU - with its own exp(); numpy's double exp can differ from it in the last ulp, which the
+     8-bit quantisation below absorbs unless a scaled tap sits within 1e-13 of a rounding boundary.)
+  2. getGaussianKernelFixedPoint_ED: taps as ufixedpoint16 with 8 fractional bits, rounded WITH ERROR DIFFUSION from the outside
+     in - v_i = cvRound(k_i * 256 + err), err = (k_i * 256 + err) - v_i (cvRound: half to even), mirrored - and the centre tap
+     = 256 - 2 * sum(v_i): the taps sum to exactly 1.0, a constant image stays constant.
+  3. hlineSmooth: row pass in ufixedpoint16 (8.8): sum_j v_j * src[x + j - n/2] with BORDER_REFLECT_101 (cv2's default border);
+     <= 255 * 256, never saturates.  vlineSmooth: column pass of those 8.8 values in ufixedpoint32 (16.16), then
+     saturate_cast<uint8_t>: (acc + 0x8000) >> 16 - round half UP.  All integer: no dependence on summation order or fma.
+Before 3.4.2 / 4.0 (and for sub-matrix inputs) cv2 ran a float32 separable filter instead: kept below as gaussian_blur_float.
 """
 import numpy as np
 import torch
@@ -67,8 +82,67 @@ def jitter(img: Image.Image, op: int, factor: float) -> Image.Image:
     raise ValueError(op)
 
 
+def gaussian_kernel_q8(ksize: int, sigma: float) -> np.ndarray:
+    """The ufixedpoint16 taps (8 fractional bits, int64 here) cv2.GaussianBlur uses for 8-bit images, sigma > 0, odd ksize:
+    getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (see the module docstring)."""
+    assert ksize % 2 == 1 and ksize >= 1 and sigma > 0
+    n2 = (ksize - 1) // 2
+    scale2x = np.float64(-0.125) / (np.float64(sigma) * np.float64(sigma))       # x below is 2 * (i - (n-1)/2)
+    vals = []
+    total = np.float64(0.0)
+    x = 1 - ksize
+    for _ in range(n2):
+        t = np.exp(np.float64(x * x) * scale2x)
+        vals.append(t)
+        total = total + t
+        x += 2
+    total = total * np.float64(2.0) + np.float64(1.0)
+    mul1 = np.float64(1.0) / total
+    k = [v * mul1 for v in vals]                                                 # outer half; the centre is 1 * mul1
+    out = np.zeros(ksize, dtype=np.int64)
+    err = np.float64(0.0)
+    acc = 0
+    for i in range(n2):
+        adj = k[i] * np.float64(256.0) + err
+        v0 = int(np.rint(adj))                                                   # cvRound: round half to even
+        err = adj - np.float64(v0)
+        out[i] = out[ksize - 1 - i] = v0
+        acc += v0
+    out[n2] = 256 - 2 * acc
+    return out
+
+
+def _reflect101(idx: np.ndarray, n: int) -> np.ndarray:
+    if n == 1:
+        return np.zeros_like(idx)
+    while ((idx < 0) | (idx >= n)).any():
+        idx = np.where(idx < 0, -idx, idx)
+        idx = np.where(idx >= n, 2 * (n - 1) - idx, idx)
+    return idx
+
+
 def gaussian_blur(img_u8: np.ndarray, ksize: int, sigma: float) -> np.ndarray:
-    """cv2.GaussianBlur(img, (ksize, ksize), sigma) on HWC uint8: separable float32 filter, BORDER_REFLECT_101, cvRound."""
+    """cv2.GaussianBlur(img, (ksize, ksize), sigma) on HWC uint8 as OpenCV >= 3.4.2 / 4.x computes it: 8.8 fixed-point taps, exact
+    integer row pass, 16.16 column pass, round half up (see the module docstring; base_dataset.py:208)."""
+    kq = gaussian_kernel_q8(ksize, sigma)
+    half = ksize // 2
+    a = img_u8.astype(np.int64)
+    H, W = a.shape[:2]
+    ap = np.take(a, _reflect101(np.arange(-half, W + half), W), axis=1)
+    row = np.zeros_like(a)
+    for t in range(ksize):
+        row += kq[t] * ap[:, t:t + W]
+    assert row.max() <= 255 * 256
+    rp = np.take(row, _reflect101(np.arange(-half, H + half), H), axis=0)
+    col = np.zeros_like(a)
+    for t in range(ksize):
+        col += kq[t] * rp[t:t + H]
+    return np.clip((col + 0x8000) >> 16, 0, 255).astype(np.uint8)
+
+
+def gaussian_blur_float(img_u8: np.ndarray, ksize: int, sigma: float) -> np.ndarray:
+    """The float32 separable filter cv2 ran for 8-bit images before 3.4.2 (and still runs for sub-matrix inputs): float kernel,
+    BORDER_REFLECT_101, cvRound."""
     x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
     cf = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)
     s = 0.0
@@ -79,14 +153,7 @@ def gaussian_blur(img_u8: np.ndarray, ksize: int, sigma: float) -> np.ndarray:
     a = img_u8.astype(np.float32)
     for axis in (1, 0):
         n = a.shape[axis]
-        idx = np.arange(-half, n + half)
-        if n > 1:
-            while ((idx < 0) | (idx >= n)).any():
-                idx = np.where(idx < 0, -idx, idx)
-                idx = np.where(idx >= n, 2 * (n - 1) - idx, idx)
-        else:
-            idx = np.zeros_like(idx)
-        ap = np.take(a, idx, axis=axis)
+        ap = np.take(a, _reflect101(np.arange(-half, n + half), n), axis=axis)
         out = np.zeros_like(a)
         for t in range(ksize):
             sl = [slice(None)] * 3

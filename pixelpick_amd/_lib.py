@@ -102,6 +102,7 @@ SIGNATURES = {
     "pp_aug_labels": (_int, [_p, _p, _int, _p, _p, _p, _p] + [_int] * 8 + [_p, _p, _p]),
     "pp_aug_jitter": (_int, [_p, _i64, _int, _f, _p, _p]),
     "pp_aug_blur": (_int, [_p, _int, _int, _p, _int, _p, _p]),
+    "pp_aug_blur_q8": (_int, [_p, _int, _int, _p, _int, _p, _p]),
     "pp_aug_to_tensor": (_int, [_p, _i64, ctypes.POINTER(_f), ctypes.POINTER(_f), _p, _p]),
     "pp_sparse_ce_workspace_bytes": (_sz, []),
     "pp_sparse_ce_fwd_bwd": (_int, [_p, _int, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),

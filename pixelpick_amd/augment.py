@@ -91,6 +91,31 @@ def cv2_gaussian_kernel(ksize: int, sigma: float) -> np.ndarray:
     return (cf.astype(np.float64) * (1.0 / s)).astype(np.float32)
 
 
+def cv2_gaussian_kernel_q8(ksize: int, sigma: float) -> np.ndarray:
+    """The 8.8 fixed-point taps of cv2.GaussianBlur for 8-bit images (OpenCV >= 3.4.2 / 4.x, smooth.dispatch.cpp:
+    getGaussianKernelBitExact in double, then getGaussianKernelFixedPoint_ED - rounding with error diffusion from the outside in,
+    centre tap = 256 - the rest, so the taps sum to exactly 1.0), as uint16 for pp_aug_blur_q8."""
+    if ksize % 2 != 1 or ksize < 1 or not sigma > 0:
+        raise ValueError("cv2_gaussian_kernel_q8: odd ksize and sigma > 0")
+    n2 = (ksize - 1) // 2
+    x = (2.0 * np.arange(n2, dtype=np.float64) + (1 - ksize))                   # 2 * (i - (n-1)/2), exact
+    t = np.exp((x * x) * (np.float64(-0.125) / (np.float64(sigma) * np.float64(sigma))))
+    total = np.float64(0.0)
+    for v in t:                                                                  # OpenCV's summation order
+        total = total + v
+    mul1 = np.float64(1.0) / (total * 2.0 + 1.0)
+    out = np.zeros(ksize, dtype=np.int64)
+    err, acc = np.float64(0.0), 0
+    for i in range(n2):
+        adj = (t[i] * mul1) * 256.0 + err
+        v0 = int(np.rint(adj))
+        err = adj - v0
+        out[i] = out[ksize - 1 - i] = v0
+        acc += v0
+    out[n2] = 256 - 2 * acc
+    return out.astype(np.uint16)
+
+
 # ------------------------------------------------------------------------------------------------- the augmenter
 class DeviceAugmenter:
     def __init__(self, crop_size: Sequence[int], mean: Sequence[float], std: Sequence[float], ignore_index: int,
@@ -115,6 +140,7 @@ class DeviceAugmenter:
         # batch loop uploads nothing but the images
         self._tables = {}
         self.n_table_uploads = 0
+        self.blur_arithmetic = "fixed"    # "float": the float32 separable filter of cv2 < 3.4.2 (pp_aug_blur)
         self._rng = None                  # None: the process-wide generators, as the reference's datasets draw (single-process parity)
 
     def use_private_rng(self, seed: int):
@@ -246,9 +272,15 @@ class DeviceAugmenter:
                        "pp_aug_jitter")
         if p["blur"] is not None:
             ks, sigma = p["blur"]
-            kern = torch.from_numpy(cv2_gaussian_kernel(ks, sigma)).to(self.device, non_blocking=True)
-            fbuf = torch.empty(n * 3, dtype=torch.float32, device=self.device)
-            _lib.check(L.pp_aug_blur(crop.data_ptr(), ch, cw, kern.data_ptr(), ks, fbuf.data_ptr(), st), "pp_aug_blur")
+            if self.blur_arithmetic == "fixed":
+                # cv2's 8-bit path since 3.4.2: 8.8 fixed-point taps, integer passes (what the reference's cv2.GaussianBlur runs today)
+                kern = torch.from_numpy(cv2_gaussian_kernel_q8(ks, sigma).astype(np.int16)).to(self.device, non_blocking=True)
+                sbuf = torch.empty(n * 3, dtype=torch.int16, device=self.device)
+                _lib.check(L.pp_aug_blur_q8(crop.data_ptr(), ch, cw, kern.data_ptr(), ks, sbuf.data_ptr(), st), "pp_aug_blur_q8")
+            else:
+                kern = torch.from_numpy(cv2_gaussian_kernel(ks, sigma)).to(self.device, non_blocking=True)
+                fbuf = torch.empty(n * 3, dtype=torch.float32, device=self.device)
+                _lib.check(L.pp_aug_blur(crop.data_ptr(), ch, cw, kern.data_ptr(), ks, fbuf.data_ptr(), st), "pp_aug_blur")
         _lib.check(L.pp_aug_to_tensor(crop.data_ptr(), n, self._mean_c, self._std_c, x_out.data_ptr(), st), "pp_aug_to_tensor")
         return crop
 

@@ -209,6 +209,35 @@ __global__ __launch_bounds__(kAT) void aug_blur_kernel(const uint8_t* src8, cons
     }
 }
 
+// cv2.GaussianBlur on 8-bit images as OpenCV >= 3.4.2 / 4.x computes it (smooth.dispatch.cpp GaussianBlurFixedPoint): taps in 8.8 fixed
+// point (sum exactly 256), row pass exact in 16 bits (8.8), column pass in 32 bits (16.16), (acc + 0x8000) >> 16 - round half up.
+// Pure integer arithmetic: no dependence on summation order.  axis 1: src8 -> dst16 (row pass), axis 0: src16 -> dst8 (column pass).
+__global__ __launch_bounds__(kAT) void aug_blur_q8_kernel(const uint8_t* src8, const uint16_t* src16, int H, int W, const uint16_t* k, int ks,
+                                                         int axis, uint16_t* dst16, uint8_t* dst8)
+{
+    const int64_t total = (int64_t)H * W;
+    const int half = ks / 2;
+    for (int64_t e = (int64_t)blockIdx.x * kAT + threadIdx.x; e < total; e += (int64_t)gridDim.x * kAT) {
+        const int r = (int)(e / W), c = (int)(e - (int64_t)r * W);
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        const int n = axis == 1 ? W : H;
+        for (int t = 0; t < ks; ++t) {
+            int p = (axis == 1 ? c : r) + t - half;
+            if (n == 1) p = 0;
+            else { while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p; }        // BORDER_REFLECT_101
+            const int64_t o = ((axis == 1 ? (int64_t)r * W + p : (int64_t)p * W + c)) * 3;
+            const uint32_t w = k[t];
+            if (src8) { a0 += w * src8[o]; a1 += w * src8[o + 1]; a2 += w * src8[o + 2]; }
+            else { a0 += w * src16[o]; a1 += w * src16[o + 1]; a2 += w * src16[o + 2]; }
+        }
+        if (dst16) { dst16[3 * e] = (uint16_t)a0; dst16[3 * e + 1] = (uint16_t)a1; dst16[3 * e + 2] = (uint16_t)a2; }
+        else {
+            auto sat = [](uint32_t x) { const uint32_t t = (x + 0x8000u) >> 16; return (uint8_t)(t > 255u ? 255u : t); };
+            dst8[3 * e] = sat(a0); dst8[3 * e + 1] = sat(a1); dst8[3 * e + 2] = sat(a2);
+        }
+    }
+}
+
 // TF.normalize(TF.to_tensor(x), mean, std): HWC uint8 -> CHW float32, (v / 255 - mean) / std
 __global__ __launch_bounds__(kAT) void aug_to_tensor_kernel(const uint8_t* img, int64_t n, float m0, float m1, float m2, float s0, float s1,
                                                            float s2, float* out)
@@ -289,6 +318,18 @@ int pp_aug_blur(uint8_t* img, int H, int W, const float* kernel, int ks, float* 
     hipLaunchKernelGGL(aug_blur_kernel, dim3(aug_grid((int64_t)H * W)), dim3(kAT), 0, st, (const uint8_t*)nullptr, scratch, H, W, kernel, ks,
                        0, (float*)nullptr, img);
     return check_launch("aug_blur_kernel");
+}
+
+int pp_aug_blur_q8(uint8_t* img, int H, int W, const uint16_t* kernel_q8, int ks, uint16_t* scratch /*[H*W*3]*/, pp_stream_t stream)
+{
+    if (!img || !kernel_q8 || !scratch || H <= 0 || W <= 0 || ks < 1 || ks % 2 == 0) return fail(PP_ERR_BAD_ARG, "aug_blur_q8: bad argument");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(aug_blur_q8_kernel, dim3(aug_grid((int64_t)H * W)), dim3(kAT), 0, st, img, (const uint16_t*)nullptr, H, W, kernel_q8, ks, 1,
+                       scratch, (uint8_t*)nullptr);
+    if (int rc = check_launch("aug_blur_q8_kernel")) return rc;
+    hipLaunchKernelGGL(aug_blur_q8_kernel, dim3(aug_grid((int64_t)H * W)), dim3(kAT), 0, st, (const uint8_t*)nullptr, scratch, H, W, kernel_q8, ks,
+                       0, (uint16_t*)nullptr, img);
+    return check_launch("aug_blur_q8_kernel");
 }
 
 int pp_aug_to_tensor(const uint8_t* img, int64_t n_pixels, const float* mean3, const float* std3, float* out, pp_stream_t stream)

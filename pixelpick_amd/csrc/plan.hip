@@ -119,6 +119,7 @@ const Entry kEntries[] = {
     PP_PLAN_ENTRY(pp_aug_labels),
     PP_PLAN_ENTRY(pp_aug_jitter),
     PP_PLAN_ENTRY(pp_aug_blur),
+    PP_PLAN_ENTRY(pp_aug_blur_q8),
     PP_PLAN_ENTRY(pp_aug_to_tensor),
     PP_PLAN_ENTRY(pp_sparse_ce_fwd_bwd),
     PP_PLAN_ENTRY(pp_sparse_ce_lowres_fwd_bwd),

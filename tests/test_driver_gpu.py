@@ -223,8 +223,7 @@ def test_active_learning_round_on_the_device_data_path(tmp_path):
                 arr = orc.gaussian_blur(arr, *p["blur"])
                 n_blur += 1
             x_ref = orc.to_tensor_normalize(arr, MEAN, STD)
-            tol = (1.5 / 255) / min(STD) if p["blur"] is not None else 0.0
-            assert (x[b] - x_ref).abs().max().item() <= tol + 1e-7, (name, p)
+            assert (x[b] - x_ref).abs().max().item() <= 1e-7, (name, p)      # incl. the blur: integer arithmetic on both sides
             n_exact += p["blur"] is None
     assert n_lab > 0 and n_scaled > 0 and n_blur > 0 and n_exact > 0
     # the round itself: labels grew by 10 px per image per stage on both dataset views, artefacts written

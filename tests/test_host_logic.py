@@ -271,3 +271,22 @@ def test_launch_plan_records_and_replays_in_order():
     plan.calls.append((_Fake.pp_bad, (ctypes.c_int(1),)))
     with pytest.raises(_lib.PixelPickHipError):
         plan.replay()
+
+
+def test_cv2_fixed_point_gaussian_taps():
+    """oracle/augment.py's restatement of OpenCV's getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED and the product's own
+    builder (pixelpick_amd/augment.py) agree; taps are symmetric, sum to exactly 256 (8.8 fixed point), a sigma far below one pixel
+    is the identity, and a constant image stays constant through the integer passes."""
+    from oracle import augment as oa
+    from pixelpick_amd.augment import cv2_gaussian_kernel_q8
+    for ks in (1, 3, 5, 7, 25, 33):
+        for sigma in (0.1, 0.37, 0.83, 1.2, 1.97, 5.0):
+            a, b = oa.gaussian_kernel_q8(ks, sigma), cv2_gaussian_kernel_q8(ks, sigma)
+            assert np.array_equal(a, b.astype(np.int64)) and a.sum() == 256 and np.array_equal(a, a[::-1]) and (a >= 0).all()
+    assert oa.gaussian_kernel_q8(25, 0.1)[12] == 256
+    assert oa.gaussian_kernel_q8(3, 0.8).tolist() == [61, 134, 61]          # exp(-0.78125) / (1 + 2 exp(-0.78125)) * 256 = 61.2
+    x = np.full((9, 11, 3), 137, np.uint8)
+    assert (oa.gaussian_blur(x, 7, 1.3) == 137).all()
+    rng = np.random.RandomState(0)
+    x = rng.randint(0, 256, (20, 30, 3)).astype(np.uint8)
+    assert np.abs(oa.gaussian_blur(x, 7, 1.2).astype(int) - oa.gaussian_blur_float(x, 7, 1.2).astype(int)).max() <= 1
