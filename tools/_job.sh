@@ -1,13 +1,9 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4e; mkdir -p $O
-timeout 900 python -m pytest tests/test_acq_gpu.py tests/test_acq_lowres_gpu.py -q -x -k "quantised or large_k or select_modes or lowres" > $O/t_acq.txt 2>&1; tail -3 $O/t_acq.txt
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o lk -- python $GRAFT_REPO_ROOT/bench.py --mode acq --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 --k 6553 > $GRAFT_REPO_ROOT/$O/largek_line.json 2>/dev/null
+O=gpurun_out/r4h; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python tools/measure_acq_traffic.py > $O/traffic.txt 2>&1; tail -c 400 $O/traffic.txt; echo
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import sqlite3, json, glob
-cur=sqlite3.connect(glob.glob("gpurun_out/r4e/prof/*.db")[0]).cursor()
-rows=cur.execute("select name, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels group by name order by sum(end-start) desc").fetchall()
-for r in rows[:8]: print(f"{r[1]:5d} avg {r[2]:9.1f} us min {r[3]:9.1f}  {r[0][:90]}")
-d=json.loads(open("gpurun_out/r4e/largek_line.json").readline()); print(d["value"], d["ms_per_step"], d["acquisition"]["from_lowres_logits"]["value"])
-PY
+find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv; head -5 $O/bench_kernel_stats.csv | cut -c1-200
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 200 $O/bench_line.json
