@@ -3343,6 +3343,7 @@ static int64_t g_rows_fwd_min = 16384;    // pp_debug_set_conv_rows bit 1: forwa
 static int g_direct_rows_max = 4096;   // few-row pointwise layers (conv1x1_ksplit_dma_kernel): at most this many GEMM rows
 static int g_conv_ksplit = 1, g_ksplit_k_min = 256;   // in-block split-K LDS-DMA kernel of the deep-K few-row 1x1 layers: 0 off, 1 rule, 2..4 force tile candidate 1..3 (A/B)
 static int g_bwd_phases = 1;       // strided backward-data by pixel classes (below); pp_debug_set_conv_variant bit 24: masked-tap form (A/B)
+static int g_shortk64 = 1;
 static int g_big_tile_min = 384, g_wgrad_rows_min = 128;   // in-process sweep: rows_min 64/128: 7.30, 256: 7.32, 512: 7.66 ms
 
 static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
@@ -3351,7 +3352,10 @@ static ConvPlan plan_conv(int64_t M, int Cn, int Ck, int ntaps, bool vec = true)
     const int64_t mt128 = cdiv(M, 128), mt64 = cdiv(M, 64);
     if (Cn <= 32) {
         pl.cfg = 0; pl.n_tiles = 1; pl.tiles = mt128;
-    } else if (Cn > 64 && mt128 * cdiv(Cn, 128) >= g_big_tile_min) {
+    } else if (Cn > 64 && mt128 * cdiv(Cn, 128) >= g_big_tile_min && !(g_shortk64 && ntaps == 1 && Ck <= 256)) {
+        // (pointwise layers with a short reduction - ResNet50's 64 -> 256 at 32768 rows, 256 -> 1024 at 8192 - are all prologue and
+        // epilogue at 128 x 128: a tile has four or sixteen K steps to amortise its 64 KiB of output over.  64 x 64 tiles: 31.1 -> 25.0 us
+        // and 56.6 -> 51.0 us, tools/graded_1x1_sweep.py; thresholds bit 28 restores the large tiles)
         pl.cfg = 1;
         // ragged output width (backward-data of the 304-channel SegmentHead input): 128-wide tiles compute
         // cdiv(Cn,128)*128 columns (21 % waste at 304); 64-wide tiles are ~10 % slower per flop but waste 5 %
@@ -3998,6 +4002,7 @@ void pp_debug_set_wgrad_target(int v)
 /* v = big_tile_min | wgrad_rows_min << 12 (0 fields: defaults 384 / 128) */
 void pp_debug_set_conv_thresholds(int v)
 {
+    g_shortk64 = (v >> 28) & 1 ? 0 : 1;       // bit 28: 128 x 128 tiles also for pointwise layers with K <= 256 (A/B)
     g_big_tile_min = (v & 4095) ? (v & 4095) : 384;
     g_wgrad_rows_min = ((v >> 12) & 4095) ? ((v >> 12) & 4095) : 128;
     const int ns = (v >> 24) & 15;           // bits 24-27: narrow-layer weight gradient, 256 << (ns-1) splits at most, 2048 / max rows at least

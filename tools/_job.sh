@@ -1,9 +1,22 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4h; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python tools/measure_acq_traffic.py > $O/traffic.txt 2>&1; tail -c 400 $O/traffic.txt; echo
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
-cd $GRAFT_REPO_ROOT
-find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv; head -5 $O/bench_kernel_stats.csv | cut -c1-200
-python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 200 $O/bench_line.json
+O=gpurun_out/r4j; mkdir -p $O
+timeout 1200 python -m pytest tests/test_networks_gpu.py tests/test_fpn_configs_gpu.py tests/test_layerwise_parity_gpu.py -q -x > $O/t_net.txt 2>&1; tail -3 $O/t_net.txt
+for net in FPN deeplab_r50 deeplab; do
+  for thr in 0 268435456; do
+    python - <<PY >> $O/ab.txt
+import os
+os.environ["NET"]="$net"
+from pixelpick_amd import _lib
+_lib.lib().pp_debug_set_conv_thresholds($thr)
+import subprocess,sys
+PY
+    THR=$thr NET=$net STEPS=20 python -c "
+import os,sys
+sys.argv=['x']
+from pixelpick_amd import _lib
+_lib.lib().pp_debug_set_conv_thresholds(int(os.environ['THR']))
+sys.path.insert(0,'tools')
+import train_bench; train_bench.main()" 2>&1 | tail -1 | sed "s/^/$net thr=$thr /" >> $O/ab.txt
+  done
+done
+cat $O/ab.txt
