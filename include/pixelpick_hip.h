@@ -347,6 +347,13 @@ int pp_bn_bwd_fused(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
  * the flagged rows (in the dense kernel's order: dgamma / dbeta / dx are bit-equal to pp_bn_bwd_fused on the same dy) and its dx pass
  * never reads dy elsewhere.  A row cache variant of the kernel (small maps) ignores the flags. */
 int pp_row_flags(const float* dy, int64_t lddy, int64_t M, int C, unsigned char* flags, pp_stream_t stream);
+/* The weight (and, dbias != NULL, bias) gradient of that pointwise convolution over the flagged rows only: dw [Cin][Cout] (HWIO of a 1x1
+ * kernel) = sum_r x[r][:]^T dy[r][:], rows in ascending order inside fixed 512-row blocks, blocks in order (deterministic; equal to the
+ * dense gradient up to the order of the fp32 additions).  Cin * Cout + Cout <= 8192.  decoders.py:64 / :120 classifiers behind
+ * model.py:113-119's sparse labels. */
+size_t pp_conv1x1_bwd_weight_sparse_workspace_bytes(int64_t M, int Cin, int Cout);
+int pp_conv1x1_bwd_weight_sparse(const float* x, int64_t ldx, int64_t M, int Cin, const float* dy, int64_t lddy, int Cout,
+                                 const unsigned char* row_flags, float* dw, float* dbias, void* workspace, size_t ws_bytes, pp_stream_t stream);
 int pp_conv1x1_bwd_data_sparse(const float* dy, int64_t lddy, int64_t M, int Cout, const float* w, int Cin, const unsigned char* row_flags,
                              float* dx, int64_t lddx, pp_stream_t stream);
 int pp_bn_bwd_fused_sparse(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pp_bn_bwd_fused": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _p, _sz, _p, _sz, _p]),
     "pp_bn_bwd_fused_sparse": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _f, _p, _p, _sz, _p, _sz, _p, _p]),
     "pp_row_flags": (_int, [_p, _i64, _i64, _int, _p, _p]),
+    "pp_conv1x1_bwd_weight_sparse_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "pp_conv1x1_bwd_weight_sparse": (_int, [_p, _i64, _i64, _int, _p, _i64, _int, _p, _p, _p, _p, _sz, _p]),
     "pp_conv1x1_bwd_data_sparse": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _i64, _p]),
     "pp_dwconv3x3_fwd": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),
     "pp_dwconv3x3_bwd_data": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _p, _i64, _p]),

@@ -2441,6 +2441,104 @@ int pp_conv1x1_bwd_data_sparse(const float* dy, int64_t lddy, int64_t M, int Cou
     return check_launch("conv1x1_bwd_data_rows_kernel");
 }
 
+// Weight (and bias) gradient of the same pointwise convolution: dw[c][k] = sum over the FLAGGED rows r, ascending, of x[r][c] dy[r][k]
+// (db[k] = sum dy[r][k]) - 80 rows of 32768 (DeepLab's classifier) or of 524288 (FPNSeg's, at full resolution: the dense kernels read
+// 310 MB for them, 412 us).  Fixed partition, fixed order: a block owns kSwRows consecutive rows, lists its flagged ones in row
+// order (wave ballots), accumulates them one after the other - thread t owns elements t, t + 256, ... of the [Cin][Cout] (+ [Cout])
+// result - and writes a slice of partial sums only if it saw any row; the reduce adds the non-empty slices in block order.
+constexpr int kSwRows = 512, kSwAcc = 32;          // rows per block; accumulators per thread (Cin * Cout + Cout <= 8192)
+__global__ __launch_bounds__(256) void conv1x1_wgrad_rows_partial_kernel(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int Cin,
+                                                                          int Cout, const unsigned char* flags, int with_bias, float* part, int* cnt)
+{
+    __shared__ int list[kSwRows];
+    __shared__ int wcount[4], nlist;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * kSwRows;
+    if (t == 0) nlist = 0;
+    __syncthreads();
+    for (int base = 0; base < kSwRows; base += 256) {              // ordered compaction: rows base .. base + 255 of this block
+        const int64_t r = r0 + base + t;
+        const bool f = r < M && flags[r] != 0;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) wcount[wave] = (int)__popcll(bal);
+        __syncthreads();
+        int before = nlist;
+        for (int w = 0; w < wave; ++w) before += wcount[w];
+        if (f) list[before + (int)__popcll(bal & ((1ull << lane) - 1ull))] = base + t;
+        __syncthreads();
+        if (t == 0) nlist += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    const int n = nlist;
+    if (t == 0) cnt[blockIdx.x] = n;
+    if (n == 0) return;
+    const int cn = Cin * Cout, E = cn + (with_bias ? Cout : 0);
+    float acc[kSwAcc];
+    int ec[kSwAcc], ek[kSwAcc];                                    // element -> (input channel | -1 for the bias, output channel)
+#pragma unroll
+    for (int j = 0; j < kSwAcc; ++j) {
+        acc[j] = 0.0f;
+        const int e = t + 256 * j;
+        if (e < cn) { ec[j] = e / Cout; ek[j] = e - ec[j] * Cout; }
+        else { ec[j] = -1; ek[j] = e - cn; }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int64_t r = r0 + list[i];
+        const float* xr = x + r * ldx;
+        const float* g = dy + r * lddy;
+#pragma unroll
+        for (int j = 0; j < kSwAcc; ++j) {
+            if (t + 256 * j < E) {
+                const float gv = g[ek[j]];
+                acc[j] = ec[j] >= 0 ? fmaf(xr[ec[j]], gv, acc[j]) : acc[j] + gv;
+            }
+        }
+    }
+    float* dst = part + (int64_t)blockIdx.x * E;
+#pragma unroll
+    for (int j = 0; j < kSwAcc; ++j)
+        if (t + 256 * j < E) dst[t + 256 * j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_rows_reduce_kernel(const float* part, const int* cnt, int G, int E, int cn, float* dw, float* db)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    float s = 0.0f;
+    for (int b = 0; b < G; ++b)
+        if (cnt[b]) s += part[(int64_t)b * E + e];                  // block order: deterministic
+    if (e < cn) dw[e] = s;
+    else db[e - cn] = s;
+}
+
+size_t pp_conv1x1_bwd_weight_sparse_workspace_bytes(int64_t M, int Cin, int Cout)
+{
+    if (M < 1 || Cin < 1 || Cout < 1 || (int64_t)Cin * Cout + Cout > 256 * kSwAcc) return 0;
+    const int64_t G = cdiv(M, kSwRows);
+    return align_up((size_t)G * ((size_t)Cin * Cout + Cout) * 4, 256) + align_up((size_t)G * 4, 256);
+}
+
+int pp_conv1x1_bwd_weight_sparse(const float* x, int64_t ldx, int64_t M, int Cin, const float* dy, int64_t lddy, int Cout,
+                                 const unsigned char* row_flags, float* dw, float* dbias, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    if (!x || !dy || !row_flags || !dw || M < 1 || Cin < 1 || Cout < 1) return fail(PP_ERR_BAD_ARG, "conv1x1_bwd_weight_sparse: bad argument");
+    const size_t need = pp_conv1x1_bwd_weight_sparse_workspace_bytes(M, Cin, Cout);
+    if (need == 0) return fail(PP_ERR_UNSUPPORTED, "conv1x1_bwd_weight_sparse: Cin * Cout + Cout = %lld > %d", (long long)Cin * Cout + Cout, 256 * kSwAcc);
+    if (!workspace || ws_bytes < need) return fail(PP_ERR_WORKSPACE, "conv1x1_bwd_weight_sparse: workspace %zu B < required %zu B", ws_bytes, need);
+    const int64_t G = cdiv(M, kSwRows);
+    if (G > 0x7FFFFFFF) return fail(PP_ERR_UNSUPPORTED, "conv1x1_bwd_weight_sparse: too many rows");
+    const int cn = Cin * Cout, E = cn + (dbias ? Cout : 0);
+    float* part = reinterpret_cast<float*>(workspace);
+    int* cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + align_up((size_t)G * ((size_t)cn + Cout) * 4, 256));
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(conv1x1_wgrad_rows_partial_kernel, dim3((unsigned)G), dim3(256), 0, st, x, ldx, dy, lddy, M, Cin, Cout, row_flags,
+                       dbias ? 1 : 0, part, cnt);
+    if (int rc = check_launch("conv1x1_wgrad_rows_partial_kernel")) return rc;
+    hipLaunchKernelGGL(conv1x1_wgrad_rows_reduce_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, (const float*)part, (const int*)cnt, (int)G, E, cn,
+                       dw, dbias);
+    return check_launch("conv1x1_wgrad_rows_reduce_kernel");
+}
+
 static int bn_bwd_fused_impl(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y_act, int64_t ldya, int act,
                              int64_t M, int C, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                              float* dbeta, float* dx, int64_t lddx, float* dres, int64_t lddr, float grad_scale, const float* beta,

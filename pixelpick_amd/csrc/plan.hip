@@ -97,6 +97,7 @@ const Entry kEntries[] = {
     PP_PLAN_ENTRY(pp_bn_bwd_fused),
     PP_PLAN_ENTRY(pp_bn_bwd_fused_sparse),
     PP_PLAN_ENTRY(pp_row_flags),
+    PP_PLAN_ENTRY(pp_conv1x1_bwd_weight_sparse),
     PP_PLAN_ENTRY(pp_conv1x1_bwd_data_sparse),
     PP_PLAN_ENTRY(pp_dwconv3x3_fwd),
     PP_PLAN_ENTRY(pp_dwconv3x3_bwd_data),

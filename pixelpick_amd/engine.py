@@ -683,10 +683,17 @@ def _to_nchw_bwd(tape: Tape, dy, x: Var):
     if not x.needs_grad:
         return
     B, H, W, C, _ = _geom(x.t)
+    sparse = getattr(dy, "_pp_sparse_rows", False)
     dy = dy.contiguous()
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
     rc = _lib.lib().pp_nchw_to_nhwc(dy.data_ptr(), B, C, H * W, dx.data_ptr(), C, _stream())
     _lib.check(rc, "pp_nchw_to_nhwc")
+    if sparse and _SPARSE_ROWS and x.grad is None:
+        # the gradient of a sparsely labelled loss (cross_entropy_nchw marks it): non-zero in 20 rows per image.  The flags ride on the
+        # tensor; the classifier's backward-data and weight gradient visit those rows only
+        flags = torch.empty(B * H * W, dtype=torch.uint8, device=dy.device)
+        _lib.check(_lib.lib().pp_row_flags(dx.data_ptr(), C, B * H * W, C, flags.data_ptr(), _stream()), "pp_row_flags")
+        dx._pp_rowflags = flags
     _acc(x, dx)
 
 
@@ -867,7 +874,18 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
                 tape._keepalive.append(x.t)
             nws = _wsbytes("pp_conv2d_bwd_weight_workspace_bytes", B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
             slot = tape.defer_slot(nws, dev) if (not big and db is None) else None
-            if slot is not None:
+            flags = getattr(dy, "_pp_rowflags", None) if (_SPARSE_ROWS and _SPARSE_WGRAD) else None
+            nsp = (_wsbytes("pp_conv1x1_bwd_weight_sparse_workspace_bytes", B * H * W, Cin, Cout)
+                   if (flags is not None and kh == 1 and kw == 1 and stride == 1 and pad == 0 and lazy_in is None and xp is None and dyp is None
+                       and flags.numel() == B * H * W) else 0)
+            if nsp:
+                # the classifier behind a sparsely labelled loss: only the flagged rows of dy are non-zero (80 of 32768 for DeepLab, of
+                # 524288 for FPNSeg) - gather those instead of streaming x and dy whole
+                ws = _ws(nsp, dev)
+                rc = L.pp_conv1x1_bwd_weight_sparse(x.t.data_ptr(), ldx, B * H * W, Cin, dy.data_ptr(), lddy, Cout, flags.data_ptr(),
+                                                    dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(), _stream())
+                tape._keepalive.append(flags)
+            elif slot is not None:
                 job, wptr, _ = slot
                 rc = L.pp_conv2d_bwd_weight_partials(x.t.data_ptr(), ldx, B, H, W, Cin, dy.data_ptr(), lddy, Cout, kh, kw, stride, pad, dil,
                                                      dw.data_ptr(), None, wptr, nws, ctypes.addressof(job), _stream())
@@ -1089,6 +1107,9 @@ _CONV_BN_FUSE_BWD = os.environ.get("PIXELPICK_CONV_BN_FUSE_BWD", "1") != "0"
 # gradient through the classifier's backward-data (pp_conv1x1_bwd_data_sparse) into the BatchNorm backward (pp_bn_bwd_fused_sparse)
 _SPARSE_ROWS = os.environ.get("PIXELPICK_SPARSE_ROWS", "1") != "0"
 _WGRAD_LATE = os.environ.get("PIXELPICK_WGRAD_LATE", "0") != "0"
+# PIXELPICK_SPARSE_WGRAD (default on): the weight gradient of a pointwise convolution behind flagged rows gathers those rows
+# (pp_conv1x1_bwd_weight_sparse) instead of running the dense kernels
+_SPARSE_WGRAD = os.environ.get("PIXELPICK_SPARSE_WGRAD", "1") != "0"
 
 
 def _conv_bn_bwd_fusable(B, H, W, Cin, Cout, kh, kw, stride, pad, dil) -> bool:
@@ -1612,6 +1633,8 @@ def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index:
                                 int(ignore_index), loss.data_ptr(), count.data_ptr(), None,
                                 dl.data_ptr() if dl is not None else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "pp_sparse_ce_fwd_bwd")
+    if dl is not None:
+        dl._pp_sparse_rows = True        # zero wherever target == ignore_index (model.py:113-119: all but the labelled pixels)
     return loss, dl
 
 

@@ -213,6 +213,42 @@ def test_pointwise_backward_data_of_the_narrow_layers(case):
     close(c, xr.grad + dres, what="dx added to the residual branch's gradient")
 
 
+@pytest.mark.parametrize("M,Cin,Cout,nflag,bias", [(32768, 256, 19, 80, False), (524288, 128, 19, 80, True), (5000, 48, 7, 5000, True),
+                                                  (1537, 128, 32, 1, False), (4096, 256, 21, 0, True)])
+def test_sparse_pointwise_weight_gradient(M, Cin, Cout, nflag, bias):
+    """pp_conv1x1_bwd_weight_sparse: dw = sum over the flagged rows of x[r]^T dy[r] (+ db) - the classifier behind model.py:113-119's
+    sparse labels (decoders.py:64 at full resolution for FPNSeg, :120 for DeepLab).  Against a float64 sum of the same rows; bit-identical
+    run to run (fixed partition and order); every row flagged and no row flagged are ordinary cases."""
+    L = _lib_mod().lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=DEV).manual_seed(M + Cin)
+    x = torch.randn((M, Cin), device=DEV, generator=gen)
+    dy = torch.zeros((M, Cout), device=DEV)
+    rows = torch.randperm(M, device=DEV, generator=gen)[:nflag]
+    dy[rows] = torch.randn((nflag, Cout), device=DEV, generator=gen) + 0.1
+    flags = torch.empty(M, dtype=torch.uint8, device=DEV)
+    _lib_mod().check(L.pp_row_flags(dy.data_ptr(), Cout, M, Cout, flags.data_ptr(), st), "flags")
+    assert int(flags.sum().item()) == nflag
+    nws = int(L.pp_conv1x1_bwd_weight_sparse_workspace_bytes(M, Cin, Cout))
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cin, Cout), 7.0, device=DEV)
+        db = torch.full((Cout,), 7.0, device=DEV) if bias else None
+        _lib_mod().check(L.pp_conv1x1_bwd_weight_sparse(x.data_ptr(), Cin, M, Cin, dy.data_ptr(), Cout, Cout, flags.data_ptr(), dw.data_ptr(),
+                                                       db.data_ptr() if bias else None, ws.data_ptr(), nws, st), "sparse wgrad")
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and (not bias or torch.equal(outs[0][1], outs[1][1]))
+    ref = x[rows].double().t() @ dy[rows].double()
+    scale = ref.abs().max().item() + 1e-6
+    assert (outs[0][0].double() - ref).abs().max().item() <= 2e-6 * scale * max(1.0, nflag ** 0.5)
+    if bias:
+        rb = dy[rows].double().sum(0)
+        assert (outs[0][1].double() - rb).abs().max().item() <= 2e-6 * (rb.abs().max().item() + 1e-6) * max(1.0, nflag ** 0.5)
+    assert L.pp_conv1x1_bwd_weight_sparse_workspace_bytes(100, 512, 32) == 0         # 16416 accumulators: outside the kernel's range
+
+
 @pytest.mark.parametrize("shape,act", [((4, 64, 128, 256), 1), ((4, 64, 128, 256), 0), ((2, 100, 90, 48), 2), ((2, 33, 47, 64), 1)])
 def test_sparse_loss_gradient_rows(shape, act, monkeypatch):
     """model.py:113-119: 20 labelled pixels per image -> the loss gradient is zero in all but a few hundred low-resolution rows.
