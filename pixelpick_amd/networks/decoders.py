@@ -34,8 +34,10 @@ class UpsampleBlock(nn.Module):
                                    GroupNorm(n_groups, out_channels), ReLU(inplace=True))
         self.scale_factor = scale_factor
 
-    def run(self, tape, x):
+    def run(self, tape, x, upsample=True):
         h = self.block[1].run(tape, self.block[0].run(tape, x), relu=True)
+        if not upsample:                 # FPNDecoder.run(lowres=True): the x2 interpolation of the LAST block of a branch is applied later
+            return h
         _, H, W, _ = h.t.shape
         return E.bilinear(tape, h, (int(math.floor(H * self.scale_factor)), int(math.floor(W * self.scale_factor))), False,
                           float(self.scale_factor))
@@ -74,12 +76,19 @@ class FPNDecoder(nn.Module):
         return E.add(tape, E.bilinear(tape, x, (h, w), False, 0.0), y)
 
     @staticmethod
-    def _seq(tape, seq, x):
-        for blk in seq:
-            x = blk.run(tape, x)
+    def _seq(tape, seq, x, last_upsample=True):
+        n = len(seq)
+        for i, blk in enumerate(seq):
+            x = blk.run(tape, x, upsample=last_upsample or i + 1 < n)
         return x
 
-    def run(self, tape, feats):
+    def run(self, tape, feats, lowres=False):
+        """lowres (training with sparse labels, trainer.FlatTrainer): the four branches all end in the SAME x2 bilinear interpolation
+        (decoders.py:101), the branch sum (:79) and the 1x1 classifier (:81) are linear and the interpolation weights sum to one, so
+        pred = classifier(sum_i up2(q_i)) = up2(classifier(sum_i q_i)) - identical in exact arithmetic.  Returns the classifier
+        output at HALF resolution ("pred") and no "emb"; the loss interpolates it at the labelled pixels only
+        (engine.cross_entropy_lowres, align_corners False), so the four 268 MB full-resolution maps of a 4 x 256 x 512 batch, their three
+        sums, the full-resolution classifier and logits never exist.  forward() / acquisition keep the reference's operation order."""
         c2, c3, c4, c5 = feats
         c5 = self.lat_layer_0.run(tape, c5)
         c4 = self.lat_layer_1.run(tape, c4)
@@ -89,11 +98,13 @@ class FPNDecoder(nn.Module):
         p4 = self._upsample_add(tape, p5, c4)
         p3 = self._upsample_add(tape, p4, c3)
         p2 = self._upsample_add(tape, p3, c2)
-        p5 = self._seq(tape, self.upsample_blocks_0, p5)
-        p4 = self._seq(tape, self.upsample_blocks_1, p4)
-        p3 = self._seq(tape, self.upsample_blocks_2, p3)
-        p2 = self._seq(tape, self.upsample_blocks_3, p2)
+        p5 = self._seq(tape, self.upsample_blocks_0, p5, not lowres)
+        p4 = self._seq(tape, self.upsample_blocks_1, p4, not lowres)
+        p3 = self._seq(tape, self.upsample_blocks_2, p3, not lowres)
+        p2 = self._seq(tape, self.upsample_blocks_3, p2, not lowres)
         emb = E.add(tape, E.add(tape, E.add(tape, p2, p3), p4), p5)
+        if lowres:
+            return {"emb": None, "pred": self.classifier.run(tape, emb)}
         return {"emb": emb, "pred": self.classifier.run(tape, emb)}
 
 

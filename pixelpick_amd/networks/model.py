@@ -45,6 +45,12 @@ class _FpnFunction(torch.autograd.Function):
 
 
 class FPNSeg(nn.Module):
+    # trainer.FlatTrainer: _run(..., upsample=False) stops in front of the last x2 interpolation (FPNDecoder.run(lowres=True)); the
+    # logits it returns are at 1/2 resolution and interpolate with align_corners False (F.interpolate(scale_factor=2), decoders.py:101)
+    LOWRES_LOGITS = True
+    LOWRES_ALIGN_CORNERS = False
+    LOWRES_SCALE_FACTOR = 2.0
+
     def __init__(self, args, load_pretrained=True):
         super().__init__()
         self.encoder = Encoder(args, load_pretrained)
@@ -57,11 +63,13 @@ class FPNSeg(nn.Module):
     def turn_off_dropout(self):
         pass
 
-    def _run(self, tape, inputs):
+    def _run(self, tape, inputs, upsample=True):
         x = E.nchw_to_nhwc(inputs)
         feats = self.encoder.run(tape, x)
         tape.mark("encoder_done")             # backward: every decoder gradient is enqueued at this point
-        outs = self.decoder.run(tape, feats)
+        outs = self.decoder.run(tape, feats, lowres=not upsample)
+        if not upsample:
+            return outs["pred"], None         # [B, H/2, W/2, C] channels-last
         return E.nhwc_to_nchw(tape, outs["pred"]), outs["emb"]
 
     def forward(self, x):

@@ -152,8 +152,10 @@ class FlatTrainer:
             # at the labelled pixels only (80 of 524 288 here) and hand its gradient straight to the classifier conv
             low, _ = self.model._run(tape, x, upsample=False)
             size = tuple(x.shape[2:])
-            loss, dlow = E.cross_entropy_lowres(low.t, size, y, self.ignore_index)
-            self.last_logits = E.bilinear(E.Tape(False), low, size, True, 0.0, out_nchw=True).t if keep_logits else None
+            align = bool(getattr(self.model, "LOWRES_ALIGN_CORNERS", True))     # DeepLab: align_corners=True x4; FPNSeg: False, x2
+            loss, dlow = E.cross_entropy_lowres(low.t, size, y, self.ignore_index, align_corners=align)
+            self.last_logits = (E.bilinear(E.Tape(False), low, size, align, 0.0 if align else float(getattr(self.model, "LOWRES_SCALE_FACTOR", 0.0)),
+                                           out_nchw=True).t if keep_logits else None)
             tape.backward(low, dlow)
         else:
             pred, _ = self.model._run(tape, x)

@@ -69,9 +69,16 @@ def _run(network, C, ign, B, H, W, n_lab, force=True, key="lw"):
     y = fi.formula_labels(B, H, W, C, ign, n_lab, key=f"y{key}")
     trace, o_loss = _oracle_step(o, x, y, ign)
     tr = FlatTrainer(m, ignore_index=ign)
-    with LayerwiseParity(m, trace, force=force) as lp:
-        loss = tr.forward_backward(x.to(DEV), y.to(DEV))
-        lp.compare_param_grads({n: tr._grad_view[id(p)] for n, p in m.named_parameters()})
+    import pixelpick_amd.trainer as T
+    # module-by-module comparison needs the reference's operation order: FPNSeg's low-resolution training tail (classifier in front
+    # of the last x2 interpolation: same function, other tensors) is switched off here; test_networks_gpu.py holds it to the dense path
+    keep, T.SPARSE_LOWRES_CE = T.SPARSE_LOWRES_CE, (T.SPARSE_LOWRES_CE and network != "FPN")
+    try:
+        with LayerwiseParity(m, trace, force=force) as lp:
+            loss = tr.forward_backward(x.to(DEV), y.to(DEV))
+            lp.compare_param_grads({n: tr._grad_view[id(p)] for n, p in m.named_parameters()})
+    finally:
+        T.SPARSE_LOWRES_CE = keep
     return lp, loss.item(), o_loss, m, o
 
 

@@ -219,6 +219,32 @@ def test_deeplab_r50_matches_the_assembly_of_reference_parts(golden_dir):
     _check_grads(g, {k: tr._grad_view[id(p)] for k, p in m2.named_parameters()})
 
 
+def test_fpn_low_resolution_training_tail_equals_the_dense_order(monkeypatch):
+    """FPNSeg's train step computes the classifier at HALF resolution on the sum of the four branches and interpolates its output at the
+    labelled pixels only (FPNDecoder.run(lowres=True) + engine.cross_entropy_lowres(align_corners=False)): classifier, branch sum and x2
+    interpolation are linear, so this is the reference's decoders.py:79-81,101 + model.py:116 in another order.  Loss and EVERY parameter
+    gradient must equal the dense order (full-resolution emb / pred, dense loss) to fp32 rounding; with keep_logits the full-size logits too."""
+    import pixelpick_amd.trainer as T
+    C, B, H, W = 19, 2, 64, 96
+    x = fi.formula_input(B, H, W, key="fl").to(DEV)
+    y = fi.formula_labels(B, H, W, C, C, 20, key="fl").to(DEV)
+    res = {}
+    for lowres in (True, False):
+        monkeypatch.setattr(T, "SPARSE_LOWRES_CE", lowres)
+        m = _build(C, "FPN").train()
+        tr = FlatTrainer(m, ignore_index=C)
+        loss = tr.forward_backward(x, y, keep_logits=True)
+        torch.cuda.synchronize()
+        res[lowres] = (loss.item(), {k: tr._grad_view[id(p)].clone() for k, p in m.named_parameters()}, tr.last_logits.clone())
+    la, ga, za = res[True]
+    lb, gb, zb = res[False]
+    assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb))
+    assert tuple(za.shape) == tuple(zb.shape) == (B, C, H, W)
+    assert (za - zb).abs().max().item() <= 2e-5 * zb.abs().max().item()
+    worst = max(((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-12)).item() for k in gb)
+    assert worst <= 5e-5, worst
+
+
 @pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("network", ["deeplab", "FPN"])
 def test_launch_plan_replay_matches_eager_steps(network, native, monkeypatch):
