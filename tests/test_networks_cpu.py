@@ -145,3 +145,19 @@ def test_deeplab_r50_extra_has_the_surface_of_the_assembled_reference_parts(gold
     assert m.aspp.aspp2.atrous_conv.dilation == 12 and m.aspp.aspp4.atrous_conv.dilation == 36      # aspp.py:43-44, output stride 8
     opt = get_optimizer(a, m)
     assert [gr["lr"] for gr in opt.param_groups] == [5e-5, 5e-4, 5e-4, 5e-4]
+
+
+def test_fpn_tail_commutes_in_the_reference_arithmetic():
+    """The identity FPNSeg's training tail rests on (pixelpick_amd/networks/decoders.py FPNDecoder.run(lowres=True)), stated with
+    the reference's own operators: decoders.py:79-81,101  classifier(sum_i interpolate(q_i, x2))  ==  interpolate(classifier(sum_i q_i), x2)
+    - a 1x1 convolution with bias, a sum and a bilinear interpolation whose weights sum to one are linear and commute.  float64: exact to
+    rounding; float32: the two orders differ by ulps (why the acquisition path keeps the reference's order)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    for dt, tol in ((torch.float64, 1e-13), (torch.float32, 2e-6)):
+        qs = [torch.randn(2, 128, 12, 20, generator=g, dtype=dt) for _ in range(4)]
+        w = torch.randn(19, 128, 1, 1, generator=g, dtype=dt) / 11.0
+        b = torch.randn(19, generator=g, dtype=dt)
+        dense = F.conv2d(sum(F.interpolate(q, scale_factor=2, mode="bilinear") for q in qs), w, b)
+        low = F.interpolate(F.conv2d(sum(qs), w, b), scale_factor=2, mode="bilinear")
+        assert (dense - low).abs().max().item() <= tol * dense.abs().max().item()
