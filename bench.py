@@ -240,7 +240,7 @@ def main():
     line = {}
 
     # ------------------------------------------------------------------------------------ train step
-    def train_leg(network, steps, warmup, Ht, Wt, Ct):
+    def train_leg(network, steps, warmup, Ht, Wt, Ct, headline=False):
         """K train steps of `network` at per-GPU batch --train-batch on [Ht, Wt] crops -> (record, trainer, model)."""
         from pixelpick_amd.trainer import FlatTrainer
         from pixelpick_amd.utils.utils import get_model
@@ -318,13 +318,32 @@ def main():
                  "replay_reason": replay_why, "launches_per_step": n_launches,
                  "host_cores_per_rank": round(cores_per_rank, 1),
                  "grad_bytes_allreduced_per_step": tr.n * 4 if world > 1 else 0}
+        if headline and not replay and dist is None:
+            # the same step through the recorded launch list (native executor, csrc/plan.hip): what the host pays then, and what the GPU
+            # step costs - reported beside the eager figures above, which stay the headline while they are the faster ones
+            tr.enable_replay(x, y, warmup=1)
+            for _ in range(5):
+                tr.train_step(x, y)
+            el_r = timed(lambda: tr.train_step(x, y), steps, 0)
+            solo = []
+            for _ in range(5):
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                tr.train_step(x, y)
+                solo.append(time.perf_counter() - t)
+            torch.cuda.synchronize(dev)
+            train["native_replay"] = {"ms_per_step": round(el_r / steps * 1e3, 4), "img_per_s": round(world * TB * steps / el_r, 2),
+                                      "host_enqueue_ms_per_step": round(sorted(solo)[2] * 1e3, 4),
+                                      "c_abi_calls_per_step": sum(1 for fn, _ in tr._plan.calls if getattr(fn, "argtypes", None) is not None),
+                                      "executor": "pp_plan_replay (one foreign call per step)" if isinstance(tr._plan, _lib.NativePlan) else "python list"}
+            tr.disable_replay()
         return train, tr, model
 
     train = None
     if a.mode in ("both", "train"):
         from pixelpick_amd import engine as E
         TB = a.train_batch
-        train, tr, model = train_leg(a.network, a.steps, a.warmup, H, W, C)
+        train, tr, model = train_leg(a.network, a.steps, a.warmup, H, W, C, headline=True)
         if dist is not None:
             # what the communicator really is, and what the gradient exchange costs on its own (both buckets back to back,
             # nothing else running): the overlapped step hides most of the first bucket under the encoder backward
