@@ -1,7 +1,10 @@
+# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4t; mkdir -p $O
-( time python bench.py > $O/bench_line.json 2> $O/bench.err ) 2> $O/time.txt; tail -3 $O/time.txt
-python -c "
-import json; d=json.loads(open('$O/bench_line.json').readline()); t=d['train']; print(d['value'], d['ms_per_step'], t['host_enqueue_ms_per_step'], t['native_replay']); print([ (o['config'][:12], o['value']) for o in d['other_configs']])
-print(d['other_configs'][1]['roofline'].get('frac_incl_map_write'))"
-timeout 900 python -m pytest tests/test_dist_gpu.py -q -x -k "bench" > $O/t_bench.txt 2>&1; tail -2 $O/t_bench.txt
+O=gpurun_out/job; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
+cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
