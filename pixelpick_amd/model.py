@@ -47,9 +47,13 @@ class Model:
         self.best_miou = -1.0
         self.dataset_name = args.dataset_name
         self.debug = args.debug
-        # not in the reference: re-issue the train step's recorded launch list instead of walking the network in Python every
-        # step (args.replay_train_step / PIXELPICK_REPLAY_TRAIN=1; same parameters bit for bit, tests/test_networks_gpu.py)
-        self._replay_train = bool(getattr(args, "replay_train_step", False)) or os.environ.get("PIXELPICK_REPLAY_TRAIN", "0") == "1"
+        # not in the reference: re-issue the train step's recorded launch list (native executor, csrc/plan.hip) instead of walking the
+        # network in Python every step - same parameters bit for bit (tests/test_networks_gpu.py), a ragged batch falls back to an
+        # eager step.  Default ON since round 4: through this loop the host is the limit of an eager step (660-720 images/s against
+        # 733-735 replayed, tools/driver_bench.py).  args.replay_train_step = False or PIXELPICK_REPLAY_TRAIN=0 switch it off.
+        rt = getattr(args, "replay_train_step", None)
+        env = os.environ.get("PIXELPICK_REPLAY_TRAIN")
+        self._replay_train = (env != "0") if env is not None else (True if rt is None else bool(rt))
         self.device = device or torch.device("cuda:0")
         self.dir_checkpoints = f"{args.dir_root}/checkpoints/{args.experim_name}"
         self.experim_name = args.experim_name

@@ -19,7 +19,7 @@ with tempfile.TemporaryDirectory() as td:
     args = Namespace(dataset_name="cs", debug=False, dir_root=td, experim_name="drv", ignore_index=C, mc_n_steps=20, n_classes=C,
                      n_pixels_by_us=10, network_name="deeplab", weight_type="random", query_strategy="entropy", reverse_order=False, stride_total=16,
                      top_n_percent=0.0, use_mc_dropout=False, vote_type="hard", mc_dropout_p=0.2, n_init_pixels=20, max_budget=20,
-                     n_epochs=1, lr_scheduler_type="Poly",
+                     n_epochs=1, lr_scheduler_type="Poly", replay_train_step=(None if "REPLAY" not in os.environ else bool(int(os.environ["REPLAY"]))),
                      optimizer_params={"lr": 5e-4, "betas": (0.9, 0.999), "weight_decay": 2e-4, "eps": 1e-7})
     dev = torch.device("cuda:0")
     m = Model(args, mk(ds, 4, True), mk(ds, 1, False), mk(ds_val, 1, False), device=dev)
