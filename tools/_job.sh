@@ -1,4 +1,10 @@
+# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4v; mkdir -p $O
-timeout 1500 python -m pytest tests/test_driver_gpu.py tests/test_dist_gpu.py -q -x -k "not bench and not occupier" > $O/t_drv.txt 2>&1; tail -3 $O/t_drv.txt
-N=256 python tools/driver_bench.py 2>&1 | grep -v amdgpu | tee $O/driver_default.txt
+O=gpurun_out/job; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
+cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
