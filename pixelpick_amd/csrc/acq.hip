@@ -22,6 +22,7 @@ static int g_reduce_mode = 0;
 static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel)
 static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
 static int g_tune_ppt = 0;
+static int g_acq_strat_spec = 1;   // strategy-specialised scorers of the three dataset class counts (pp_debug_set_acq_tuning bit 10 of `occ`: off)
 static int g_tune_xcd = 0;        // 0: by plane size, 1: never, 2: always (pp_debug_set_acq_tuning bits 8-9 of `occ`)
 
 constexpr int kBlock = 256;
@@ -113,16 +114,20 @@ __device__ __forceinline__ float pixel_score(const float (&x)[CMAX], int C, int 
 // (query.py:230) is kept exactly: NaN iff the smallest p_c = exp(x_min - m)/S rounds to 0.
 __device__ __forceinline__ float fast_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896340736f); }
 
-template <int CMAX, bool EXACT>
-__device__ __forceinline__ float pixel_score_fast(const float (&x)[CMAX], int C, int strategy)
+// STRAT >= 0: the strategy is a compile-time constant - the chains the other two strategies need (second maximum: margin only;
+// minimum and the e * d sum: entropy only) are not computed at all (fewer VALU slots and registers: C = 21 fits three waves per SIMD).
+template <int CMAX, bool EXACT, int STRAT = -1>
+__device__ __forceinline__ float pixel_score_fast(const float (&x)[CMAX], int C, int strategy_rt)
 {
+    const int strategy = STRAT >= 0 ? STRAT : strategy_rt;
+    constexpr bool kX2 = STRAT < 0 || STRAT == PP_ACQ_MARGIN, kEnt = STRAT < 0 || STRAT == PP_ACQ_ENTROPY;
     float m = x[0], x2 = -INFINITY, xmin = x[0];
 #pragma unroll
     for (int c = 1; c < CMAX; ++c)
         if (EXACT || c < C) {
-            x2 = fmaxf(x2, fminf(m, x[c]));
+            if (kX2) x2 = fmaxf(x2, fminf(m, x[c]));
             m = fmaxf(m, x[c]);
-            xmin = fminf(xmin, x[c]);
+            if (kEnt) xmin = fminf(xmin, x[c]);
         }
     float S = 0.0f, T = 0.0f;
 #pragma unroll
@@ -131,7 +136,7 @@ __device__ __forceinline__ float pixel_score_fast(const float (&x)[CMAX], int C,
             const float d = x[c] - m;
             const float e = fast_exp(d);
             S += e;
-            T = fmaf(e, -d, T);
+            if (kEnt) T = fmaf(e, -d, T);
         }
     if (strategy == PP_ACQ_ENTROPY) {
         float ent = logf(S) + T / S;
@@ -240,7 +245,7 @@ __device__ __forceinline__ void wave_extract_topk_prefilter(uint32_t (&kh)[PPT],
 // VEC == 1: arbitrary element strides (NHWC views, cropped views), one pixel per load.
 // A block covers kBlock*VEC*G consecutive pixels of ONE image.
 // MATH: 0 = default scorer, 1 = reference operation order, 2 = input already holds probabilities.
-template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3>
+template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1>
 __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
 {
     constexpr int PPT = VEC * G;
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
                 uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    if constexpr (MATH == 0) s[v] = pixel_score_fast<CMAX, EXACT>(x[v], p.C, p.strategy);
+                    if constexpr (MATH == 0) s[v] = pixel_score_fast<CMAX, EXACT, STRAT>(x[v], p.C, p.strategy);
                     else s[v] = pixel_score<CMAX, EXACT>(x[v], p.C, p.strategy, MATH == 2);
                     if ((ex >> (8 * v)) & 0xFFu) s[v] = fill;
                     __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time (VGPR budget)
@@ -1418,8 +1423,24 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
                     grid = dim3((unsigned)(q.xcd_per * 8));
                 }
 #define PP_ACQ_GO(G, O) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, O>), grid, block, 0, st, q)
+#define PP_ACQ_SPEC(G, S) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, 3, S>), grid, block, 0, st, q)
+                if (g_acq_strat_spec && !g_tune_occ && !q.out_map) {            // (with the map written - large k - the generic kernel measured no slower)
+                    // the strategy as a compile-time constant: the chains the other two strategies need are not computed (100-145 VGPRs
+                    // instead of 168-184: entropy runs four waves per SIMD, C = 21 three instead of two); bit 10 of the tuning word: off
+                    if (g == 2) {
+                        if (q.strategy == PP_ACQ_ENTROPY) PP_ACQ_SPEC(2, PP_ACQ_ENTROPY);
+                        else if (q.strategy == PP_ACQ_LEAST_CONFIDENCE) PP_ACQ_SPEC(2, PP_ACQ_LEAST_CONFIDENCE);
+                        else PP_ACQ_SPEC(2, PP_ACQ_MARGIN);
+                    } else {
+                        if (q.strategy == PP_ACQ_ENTROPY) PP_ACQ_SPEC(1, PP_ACQ_ENTROPY);
+                        else if (q.strategy == PP_ACQ_LEAST_CONFIDENCE) PP_ACQ_SPEC(1, PP_ACQ_LEAST_CONFIDENCE);
+                        else PP_ACQ_SPEC(1, PP_ACQ_MARGIN);
+                    }
+                    return check_launch("acq_kernel");
+                }
                 if (g == 2) { if (occ == 2) PP_ACQ_GO(2, 2); else if (occ == 4) PP_ACQ_GO(2, 4); else PP_ACQ_GO(2, 3); }
                 else        { if (occ == 2) PP_ACQ_GO(1, 2); else if (occ == 4) PP_ACQ_GO(1, 4); else PP_ACQ_GO(1, 3); }
+#undef PP_ACQ_SPEC
 #undef PP_ACQ_GO
                 return check_launch("acq_kernel");
             }
@@ -1565,6 +1586,7 @@ void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
 void pp_debug_set_acq_tuning(int occ, int ppt)
 {
     g_tune_xcd = (occ >> 8) & 3;
+    g_acq_strat_spec = (occ >> 10) & 1 ? 0 : 1;
     occ &= 0xFF;
     g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9) ? occ : 0;
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
