@@ -500,7 +500,7 @@ struct LowresParams {
     int patch_cap;            // floats of dynamic LDS available for the patch
 };
 
-template <int CMAX, bool EXACT, int PPT, bool LDS, int MATH>
+template <int CMAX, bool EXACT, int PPT, bool LDS, int MATH, int STRAT = -1>
 __global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float s_patch[];
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
                 if (EXACT || c < C)
                     x[c] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, r0[o0 + c], r0[o1 + c], r1[o0 + c], r1[o1 + c]);
             float sc;
-            if constexpr (MATH == 0) sc = pixel_score_fast<CMAX, EXACT>(x, p.C, p.strategy);
+            if constexpr (MATH == 0) sc = pixel_score_fast<CMAX, EXACT, STRAT>(x, p.C, p.strategy);
             else sc = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, 0);
             const int64_t pix = (int64_t)Y * p.Wc + X;
             if (excl && excl[pix]) sc = fill;
@@ -1532,6 +1532,19 @@ static int launch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t B,
     if (g_exact_formula) {        // reference operation order: 4-row variant only
         if (pl.lds) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, true, 1>), grid, block, pl.lds_bytes, st, p);
         else        hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, false, 1>), grid, block, 0, st, p);
+    } else if (EXACT && pl.lds && g_acq_strat_spec) {
+        // the dataset class counts with the patch in LDS (every production shape): strategy-specialised scorer (this kernel is VALU-bound)
+#define PP_LOWRES_SPEC(P, S) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, P, true, 0, S>), grid, block, pl.lds_bytes, st, p)
+        if (pl.ppt == 8) {
+            if (p.strategy == PP_ACQ_ENTROPY) PP_LOWRES_SPEC(8, PP_ACQ_ENTROPY);
+            else if (p.strategy == PP_ACQ_LEAST_CONFIDENCE) PP_LOWRES_SPEC(8, PP_ACQ_LEAST_CONFIDENCE);
+            else PP_LOWRES_SPEC(8, PP_ACQ_MARGIN);
+        } else {
+            if (p.strategy == PP_ACQ_ENTROPY) PP_LOWRES_SPEC(4, PP_ACQ_ENTROPY);
+            else if (p.strategy == PP_ACQ_LEAST_CONFIDENCE) PP_LOWRES_SPEC(4, PP_ACQ_LEAST_CONFIDENCE);
+            else PP_LOWRES_SPEC(4, PP_ACQ_MARGIN);
+        }
+#undef PP_LOWRES_SPEC
     } else if (pl.ppt == 8) {
         if (pl.lds) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 8, true, 0>), grid, block, pl.lds_bytes, st, p);
         else        hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 8, false, 0>), grid, block, 0, st, p);
