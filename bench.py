@@ -609,6 +609,28 @@ def main():
             others.append({"config": name, "leg": "train", "value": round(t2["img_per_s"], 2), "unit": "images/s",
                            "ms_per_step": round(t2["ms_per_step"], 4), "per_gpu_batch": a.train_batch, "replay": t2["replay"],
                            "host_enqueue_ms_per_step": round(t2["host_enqueue_ms_per_step"], 3)})
+        # the acquisition ROUND of configs[2-4] end to end (QuerySelector.__call__: eval forward of the ResNet50 model, fused
+        # low-resolution tail, picks, codec, statistics; tools/query_bench.py) beside the reference-order path of the same build
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pp_query_bench", os.path.join(ROOT, "tools", "query_bench.py"))
+        qb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(qb)
+        for label, net, Cq, Hq, Wq, stq, dsn, ign, nimg, bs, nu in qb.CONFIGS:
+            mq = qb.build_model(net, Cq)
+            rf = qb.round_rate(net, Cq, Hq, Wq, stq, nimg, bs, dsn, ign, fused=True, model=mq, n_unique=nu)
+            torch.cuda.empty_cache()
+            ru = qb.round_rate(net, Cq, Hq, Wq, stq, nimg, bs, dsn, ign, fused=False, model=mq, n_unique=nu)
+            torch.cuda.empty_cache()
+            tt = qb.tail_times(mq, Cq, (Hq + 7) // 8 * 8, (Wq + 7) // 8 * 8, stq, batch=bs)
+            del mq
+            torch.cuda.empty_cache()
+            others.append({"config": label, "leg": "acquisition_round", "value": round(rf["images_per_s"], 2), "unit": "images/s",
+                           "ms_per_image": round(rf["ms_per_image"], 3), "images": nimg, "images_per_forward": bs, "k": 20,
+                           "peak_device_gib": round(rf["peak_gib"], 2),
+                           "reference_order_path": {"value": round(ru["images_per_s"], 2), "ms_per_image": round(ru["ms_per_image"], 3),
+                                                    "peak_device_gib": round(ru["peak_gib"], 2)},
+                           "tail_only_gpu_ms": {k2: round(v, 3) for k2, v in tt.items()},
+                           "tail_speedup": round(tt["tail_reference_order_ms"] / max(tt["tail_fused_ms"], 1e-6), 1)})
         line["other_configs"] = others
 
     if rank == 0:

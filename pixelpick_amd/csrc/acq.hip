@@ -1492,7 +1492,8 @@ struct LowresPlan {
     int patch_cap;
 };
 
-constexpr size_t kLowresLdsMax = 48 * 1024;
+constexpr size_t kLowresLdsMax = 54 * 1024;      // + 8.2 KB of static survivor lists = the 64 KB a block may ask for
+constexpr size_t kLowresLdsSoft = 32 * 1024;     // above this the 32-row tile gives way to the 16-row tile
 
 static void lowres_scales(int64_t h, int64_t w, int64_t H, int64_t W, int align, float& sh, float& sw)
 {
@@ -1511,6 +1512,14 @@ static LowresPlan make_lowres_plan(int64_t B, int64_t C, int64_t h, int64_t w, i
     LowresPlan pl;
     const int64_t tiles8 = cdiv(Wc, kWave) * cdiv(Hc, (kBlock / kWave) * 8);
     pl.ppt = (!force_ppt4 && B * tiles8 * (kBlock / kWave) >= 2048) ? 8 : 4;
+    // x2 models (FPNSeg, decoders.py:101): a 32-row tile interpolates from 19 x 35 source pixels = 50.5 KB at C = 19; the 16-row
+    // tile's patch (29 KB) keeps the LDS path and two more blocks per CU
+    if (pl.ppt == 8 && g_tune_ppt != 8) {      // pp_debug_set_acq_tuning(., 4 | 8) forces a tile height (A/B)
+        const int64_t pw8 = std::min<int64_t>(w, (int64_t)std::ceil((double)sw * (kWave - 1)) + 3);
+        const int64_t ph8 = std::min<int64_t>(h, (int64_t)std::ceil((double)sh * ((kBlock / kWave) * 8 - 1)) + 3);
+        if ((size_t)(ph8 * pw8 * (C | 1)) * 4 > kLowresLdsSoft) pl.ppt = 4;
+    }
+    if (g_tune_ppt == 4) pl.ppt = 4;
     pl.tiles_x = (int)cdiv(Wc, kWave);
     pl.tiles_y = (int)cdiv(Hc, (kBlock / kWave) * pl.ppt);
     pl.waves_per_image = pl.tiles_x * pl.tiles_y * (kBlock / kWave);

@@ -70,6 +70,7 @@ class DeepLab(nn.Module):
     never instantiates it (its "ResNet50" model is FPNSeg), so it is pinned per component and against the same assembly of
     the imported reference parts (tools/gen_golden_net.py --r50)."""
     LOWRES_LOGITS = True      # _run(..., upsample=False) stops in front of the final x4 bilinear (deeplab.py:55-56)
+    LOWRES_ALIGN_CORNERS = True
 
     def __init__(self, args, backbone='mobilenet', output_stride=16):
         super().__init__()

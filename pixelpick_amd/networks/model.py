@@ -72,6 +72,20 @@ class FPNSeg(nn.Module):
             return outs["pred"], None         # [B, H/2, W/2, C] channels-last
         return E.nhwc_to_nchw(tape, outs["pred"]), outs["emb"]
 
+    def forward_lowres(self, inputs):
+        """Inference forward that stops in front of the decoder's last x2 interpolation: the four branches end in the same
+        F.interpolate(scale_factor=2) (decoders.py:101), the branch sum (:75) and the 1x1 classifier (:77) are linear and the
+        interpolation weights sum to one, so classifier(sum_i up2(q_i)) == up2(classifier(sum_i q_i)) in exact arithmetic
+        (FPNDecoder.run(lowres=True), the order the train step has used since round 4).  -> (classifier logits
+        [B,H/2,W/2,C] channels-last, (H, W) = the size the reference's "pred" has).  `acquisition.score_topk_lowres(...,
+        align_corners=False)` interpolates them on the fly, so an acquisition round never writes the four 128-channel
+        full-resolution branch maps, their sums ("emb": 1.07 GB per 1024x2048 image) or the full-size logits."""
+        if not inputs.is_cuda:
+            raise RuntimeError("pixelpick_amd.FPNSeg runs on the GPU only (no CPU fallback)")
+        pred_v, _ = self._run(E.Tape(enabled=False), inputs.to(torch.float32), upsample=False)
+        low = pred_v.t
+        return low, (2 * low.shape[1], 2 * low.shape[2])
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("pixelpick_amd.FPNSeg runs on the GPU only (no CPU fallback)")

@@ -225,6 +225,8 @@ class QuerySelector:
         # enqueued, so host and GPU overlap.
         pipelined = (QUERY_PIPELINE and FUSED_LOWRES and not self.use_mc_dropout and hasattr(model, "forward_lowres")
                      and not self.reverse_order and not is_random and torch.device(self.device).type == "cuda")
+        # DeepLab: x4 align_corners=True (deeplab.py:55-56); FPNSeg: x2 align_corners=False (decoders.py:101)
+        lowres_align = bool(getattr(model, "LOWRES_ALIGN_CORNERS", True))
         copy_stream = self.__dict__.get("_copy_stream")
         if pipelined and copy_stream is None:
             copy_stream = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
@@ -268,14 +270,14 @@ class QuerySelector:
                 it.x.record_stream(main)
             low, full_size = model.forward_lowres(xs)
             k = self._k_topk(h, w)
-            idx, _, _ = acq.score_topk_lowres(low, full_size, excl_dev, self.query_strategy, k, crop=(h, w))
+            idx, _, _ = acq.score_topk_lowres(low, full_size, excl_dev, self.query_strategy, k, crop=(h, w), align_corners=lowres_align)
             n = len(pending)
             idx_host = torch.empty((n, k), dtype=torch.int32, pin_memory=True)
             idx_host.copy_(idx, non_blocking=True)
             ent_host = None
             if want_any_stats and all(it.y is not None for it in pending):
                 img = torch.arange(n, device=idx.device, dtype=torch.int32).repeat_interleave(k)
-                ent = acq.score_at_lowres(low, full_size, img, idx.reshape(-1), "entropy", crop=(h, w))
+                ent = acq.score_at_lowres(low, full_size, img, idx.reshape(-1), "entropy", crop=(h, w), align_corners=lowres_align)
                 ent_host = torch.empty((n, k), dtype=torch.float32, pin_memory=True)
                 ent_host.copy_(ent.reshape(n, k), non_blocking=True)
             ev = torch.cuda.Event()
@@ -322,7 +324,7 @@ class QuerySelector:
                     idx_h = self._random_topk(np.stack([it.draws["rmap"] for it in pending]), excl, self._k_launch(h, w))
                 elif fused:
                     idx, _, _ = acq.score_topk_lowres(low, full_size, torch.from_numpy(excl), self.query_strategy,
-                                                      self._k_launch(h, w), crop=(h, w))
+                                                      self._k_launch(h, w), crop=(h, w), align_corners=lowres_align)
                     idx_h = idx.cpu().numpy().astype(np.int64)
                 else:
                     idx, _, _ = acq.score_topk(lg, torch.from_numpy(excl), self.query_strategy, self._k_launch(h, w))
@@ -334,7 +336,7 @@ class QuerySelector:
                     flat = np.concatenate(chosen)
                     img = np.repeat(np.arange(len(pending)), [len(c) for c in chosen])
                     if fused:
-                        ent_all = acq.score_at_lowres(low, full_size, img, flat, "entropy", crop=(h, w)).cpu().numpy()
+                        ent_all = acq.score_at_lowres(low, full_size, img, flat, "entropy", crop=(h, w), align_corners=lowres_align).cpu().numpy()
                     else:
                         dev = lg.device
                         picked = lg[torch.from_numpy(img).to(dev), :, torch.from_numpy(flat // w).to(dev), torch.from_numpy(flat % w).to(dev)]

@@ -12,6 +12,7 @@ Reference call sites exercised:
   query.py:71-142    encode_query / decode_queries                                    (G5)
   query.py:320-351   merge_previous_query_files                                       (G5)
   deeplab.py:55-56 + query.py:190   low-res logits -> interpolate -> crop -> score  (--lowres, §8f-1)
+  networks/model.py:6-14 + decoders.py:57-77 + query.py:144-221   FPNSeg-ResNet50 acquisition round (--fpn)
 """
 import os
 import sys
@@ -548,7 +549,93 @@ def gen_lowres():
     print("lowres written", os.path.getsize(os.path.join(OUT, "acq_lowres.npz")))
 
 
+def gen_fpn_round():
+    """BASELINE configs[2-4] network leg: the reference's FPNSeg-ResNet50 (networks/model.py:6-14, decoders.py:57-77: four
+    UpsampleBlock outputs summed at full resolution, 128 channels, then the 1x1 classifier) driven by the reference's
+    QuerySelector.__call__ (query.py:144-221) on a fake loader.  Weights and images are formula-initialised
+    (tests/formula_init.py), so the fixture holds only labels, previous queries and what the reference picked.  `dict_queries`
+    holds the picks in row-major order (np.where), so only the SET is pinned: keys are searched until the 20th and 21st
+    score of every image are >= 2e-3 (entropy / least confidence) or 2e-2 (margin: scores near 0) apart, relative - the build's
+    half-resolution order (classifier in front of the last x2 interpolation) differs from the reference's by fp32 rounding
+    only."""
+    import contextlib, io
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import formula_init as fi
+    from utils.utils import get_model
+    out = {}
+    cases = [("cs_entropy", "cs", 19, 19, "entropy", [(64, 96)] * 3),
+             ("cs_least_confidence", "cs", 19, 19, "least_confidence", [(64, 96)] * 2),
+             ("voc_margin", "voc", 21, 255, "margin_sampling", [(43, 61), (50, 37)])]
+    for tag, ds_name, C, ign, st, sizes in cases:
+        margs = Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name="FPN", weight_type="random",
+                          use_dilated_resnet=True, n_layers=50, width_multiplier=1.0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = get_model(margs)
+        model.load_state_dict(fi.formula_state_dict(model.state_dict()))
+        model.eval()
+        largest = st in ["entropy", "least_confidence"]
+        guard = 2e-3 if largest else 2e-2
+        attempt = 0
+        while True:
+            rng = np.random.RandomState(900 + attempt)
+            keys = [f"fpnacq_{tag}_{attempt}_{i}" for i in range(len(sizes))]
+            xs = [fi.formula_input(1, h, w, key=k)[0] for k, (h, w) in zip(keys, sizes)]
+            ys, prev = [], []
+            for (h, w) in sizes:
+                y = rng.randint(0, C, size=(h, w)).astype(np.int64)
+                y[rng.rand(h, w) < 0.06] = ign
+                ys.append(torch.from_numpy(y))
+                q = np.zeros((h, w), dtype=bool)
+                q.reshape(-1)[rng.choice(h * w, 30, replace=False)] = True
+                prev.append(q)
+            ok, gaps = True, []
+            with torch.no_grad():
+                for i, (h, w) in enumerate(sizes):
+                    x = xs[i][None]
+                    if ds_name == "voc":
+                        x = F.pad(x, pad=(0, -w % 8, 0, -h % 8), mode="reflect")
+                    prob = F.softmax(model(x)["pred"][:, :, :h, :w], dim=1)
+                    uc = refq.UncertaintySampler(st)(prob)[0]
+                    uc[torch.from_numpy(prev[i])] = FILL[st]
+                    uc[ys[i] == ign] = FILL[st]
+                    srt = torch.sort(uc.flatten(), descending=largest).values.numpy()
+                    a, b = float(srt[19]), float(srt[20])
+                    gaps.append(abs(a - b) / max(abs(a), abs(b), 1e-30))
+                    ok = ok and gaps[-1] >= guard
+            print(tag, "attempt", attempt, "min rel gap at k", min(gaps), "ok" if ok else "retry", flush=True)
+            if ok:
+                break
+            attempt += 1
+        names = [f"/data/{tag}_{i:03d}.png" for i in range(len(sizes))]
+        ds = FakeDataset(xs, ys, prev, names)
+        with tempfile.TemporaryDirectory() as td:
+            args = mk_args(st, C, k=20, dir_root=td, dataset_name=ds_name, ignore_index=ign)
+            args.network_name = "FPN"
+            qs = refq.QuerySelector(args, FakeLoader(ds), device=torch.device("cpu"))
+            dq = qs(nth_query=1, model=model)
+            stats = pkl.load(open(f"{td}/checkpoints/golden/1_query/query_stats.pkl", "rb"))
+        out[f"{tag}_keys"] = np.array(keys)
+        out[f"{tag}_names"] = np.array(names)
+        out[f"{tag}_sizes"] = np.array(sizes, dtype=np.int64)
+        out[f"{tag}_meta"] = np.array([C, ign], dtype=np.int64)
+        out[f"{tag}_min_rel_gap"] = np.float64(min(gaps))
+        for i, nme in enumerate(names):
+            out[f"{tag}_y_{i}"] = ys[i].numpy().astype(np.uint8 if ign < 256 else np.int64)
+            out[f"{tag}_prev_{i}"] = np.packbits(prev[i].reshape(-1))
+            out[f"{tag}_xc_{i}"] = np.asarray(dq[nme]["x_coords"], dtype=np.int64)
+            out[f"{tag}_yc_{i}"] = np.asarray(dq[nme]["y_coords"], dtype=np.int64)
+        out[f"{tag}_stats_label_cnt"] = np.array([stats["label_distribution"][l] for l in range(C)], dtype=np.int64)
+        out[f"{tag}_stats_avg_entropy"] = np.float64(stats["avg_entropy"])
+        out[f"{tag}_stats_avg_n_unique"] = np.float64(stats["avg_n_unique_labels"])
+        out[f"{tag}_stats_avg_cov"] = np.float64(stats["avg_spatial_coverage"])
+    np.savez_compressed(os.path.join(OUT, "acq_fpn_round.npz"), **out)
+    print("fpn round written", os.path.getsize(os.path.join(OUT, "acq_fpn_round.npz")))
+
+
 if __name__ == "__main__":
+    if "--fpn" in sys.argv:
+        gen_fpn_round()
+        sys.exit(0)
     if "--lowres" in sys.argv:
         gen_lowres()
         sys.exit(0)
