@@ -126,6 +126,41 @@ def cpu_baseline_acq(C, H, W, k, strategy, budget_s=8.0):
     return round(done * H * W / el / 1e6, 3), f"{done} images {H}x{W}x{C} one at a time (query.py:159 loop), {el:.1f} s"
 
 
+def cpu_baseline_pick_flips(dev):
+    """Checker leg (outside every timed region, rank 0 at N = 1 only, part of the cpu_baseline block): the picks of the HIP path
+    with the default scorer (algebraic entropy form, v_exp_f32) and with the reference's operation order
+    (pp_debug_set_exact_formula: p = exp(x - m) / S, sum(-p log p), query.py:190,229-239) against oracle/acq_oracle.c on UNGUARDED
+    random logits - how often a device pick differs from the oracle's (a k-th / (k+1)-th score pair closer than the rounding
+    difference of the two evaluations).  8 images of 256x512x19, 8 of 320x320x21, one 1024x2048x19; k = 20."""
+    from oracle import acq as orc
+    from pixelpick_amd import _lib
+    from pixelpick_amd import acquisition as acq
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    out = {"k": 20, "what": "device picks vs oracle/acq_oracle.c (reference operation order, libm) on unguarded randn*3 logits; "
+                          "set_flips = picks not in the oracle's set, order_flips = positions of the value-sorted list that differ"}
+    for label, B, C, H, W, strategies in (("256x512x19", 8, 19, 256, 512, ("entropy", "least_confidence", "margin_sampling")),
+                                          ("320x320x21", 8, 21, 320, 320, ("margin_sampling", "entropy")),
+                                          ("1024x2048x19", 1, 19, 1024, 2048, ("least_confidence", "entropy"))):
+        logits = torch.randn((B, C, H, W), device=dev, generator=gen) * 3
+        excl = (torch.rand((B, H, W), device=dev, generator=gen) < 0.05).to(torch.uint8)
+        lg_np, ex_np = logits.cpu().numpy(), excl.cpu().numpy()
+        for st in strategies:
+            o_idx, _ = orc.score_topk(lg_np, ex_np, st, 20)
+            rec = {"images": B, "picks": B * 20}
+            for name, exact in (("default", 0), ("exact_formula", 1)):
+                L.pp_debug_set_exact_formula(exact)
+                idx, _, _ = acq.score_topk(logits, excl, st, 20)
+                d = idx.cpu().numpy()
+                rec[name] = {"set_flips": int(sum(len(set(d[b].tolist()) - set(o_idx[b].tolist())) for b in range(B))),
+                             "order_flips": int((d != o_idx).sum())}
+            L.pp_debug_set_exact_formula(0)
+            out[f"{label} {st}"] = rec
+        del logits, excl
+    torch.cuda.empty_cache()
+    return out
+
+
 def _acq_source_hash():
     import hashlib
     h = hashlib.sha256()
@@ -583,6 +618,15 @@ def main():
     acqr = None
     if a.mode in ("both", "acq"):
         acqr, line["roofline"] = acq_leg(a.batch, C, H, W, k, a.strategy, a.layout, a.steps, a.warmup, True)
+        if not a.exact_formula and world == 1:
+            # the reference's operation order as the scorer (SURVEY 7.4 wanted it selectable; the default is the algebraic form):
+            # same launch, same traffic, more VALU work per pixel
+            L.pp_debug_set_exact_formula(1)
+            rx, roofx = acq_leg(a.batch, C, H, W, k, a.strategy, a.layout, max(5, min(a.steps, 10)), 3, False)
+            L.pp_debug_set_exact_formula(0)
+            acqr["exact_formula"] = {"value": rx["value"], "unit": rx["unit"], "ms_per_step": rx["ms_per_step"],
+                                     "kernel_ms_avg": roofx["kernel_ms_avg"], "frac_of_hbm_peak": roofx["frac"],
+                                     "what": "pp_debug_set_exact_formula(1): p = exp(x - m) / S, sum(-p log p) in query.py:190,230's order"}
 
     # ------------------------------------------------------------------------------------ the other BASELINE configurations
     # Bounded sub-records in the SAME run (N = 1 only; the scaling runs stay short): every acquisition shape / strategy the
@@ -690,6 +734,8 @@ def main():
                     cb["acquisition"] = {"value": best[0], "unit": "Mpixels/s", "sample": best[1], "cores": best[2]}
             torch.set_num_threads(default_threads)
             out["cpu_baseline"] = cb
+            if acqr is not None and not a.exact_formula:
+                out["acquisition"]["index_flips_vs_oracle"] = cpu_baseline_pick_flips(dev)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

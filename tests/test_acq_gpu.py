@@ -630,3 +630,57 @@ def test_query_selector_pipelined_round_equals_the_strict_order(monkeypatch):
         np.testing.assert_array_equal(a[0][nme]["y_coords"], b[0][nme]["y_coords"])
     assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
     assert a[5][1] == b[5][1] == 1 and list(a[5][0].keys()) == names
+
+
+# ------------------------------------------------------------------------ full size, oracle's OWN picks (gap-guarded by construction)
+def _guarded_full_size_case(C, H, W, st, seed, k=20):
+    """Random logits at a BASELINE size whose k + 1 leading scores are separated by construction, so that the picks of the
+    oracle (reference operation order, host libm) are the only right answer for any evaluation within the score tolerance:
+    every random pixel that could compete is made confident (+6 on its arg-max logit), then k + 6 planted pixels get the class
+    vector (a_j, 0, ..., 0): a_j = 1 + 0.04 j for entropy (2.86 .. 2.64 at C = 19) and least confidence (0.87 .. 0.70), falling with
+    j; a_j = 0.02 + 0.004 j for the margin (e^a - 1) / (e^a + C - 1) = 0.001 .. 0.0065, rising with j - each step >= 1e-3 relative.
+    The guard is asserted on the oracle's map, not assumed."""
+    rng = np.random.RandomState(seed)
+    logits = (rng.randn(1, C, H, W) * 3).astype(np.float32)
+    excl = (rng.rand(1, H, W) < 0.05).astype(np.uint8)
+    largest = st != "margin_sampling"
+    a0, da, slack = (1.0, 0.04, 0.05) if largest else (0.02, 0.004, 0.01)
+    m = orc.score_map(logits, st)[0]
+    a_max = a0 + da * (k + 6)
+    probe = np.zeros((1, C, 1, 1), dtype=np.float32)
+    probe[0, 0, 0, 0] = a_max
+    edge = float(orc.score_map(probe, st)[0, 0, 0])                      # the weakest planted score
+    rivals = (m > edge - slack) if largest else (m < edge + slack)
+    ys, xs = np.nonzero(rivals)
+    top = logits[0, :, ys, xs].argmax(axis=1)
+    logits[0, top, ys, xs] += 6.0
+    free = np.flatnonzero((excl[0] == 0).reshape(-1) & ~rivals.reshape(-1))
+    spots = rng.choice(free, k + 6, replace=False)
+    for j, p in enumerate(spots):
+        logits[0, :, p // W, p % W] = 0.0
+        logits[0, 0, p // W, p % W] = a0 + da * j
+    o_idx, o_val, o_map = orc.score_topk(logits, excl, st, k, want_map=True)
+    srt = np.sort(orc.apply_exclude(o_map, excl, st).reshape(-1).astype(np.float64))
+    lead = srt[::-1][:k + 1] if largest else srt[:k + 1]
+    gaps = np.abs(np.diff(lead)) / np.maximum(np.abs(lead[1:]), np.abs(lead[:-1]))
+    assert gaps.min() >= 1e-3, gaps.min()
+    assert o_idx[0].tolist() == spots[:k].tolist()
+    return logits, excl, o_idx, o_val
+
+
+@pytest.mark.parametrize("exact", [0, 1], ids=["default-scorer", "reference-order-scorer"])
+@pytest.mark.parametrize("C,H,W,st", [(19, 256, 512, "entropy"), (19, 256, 512, "least_confidence"), (19, 256, 512, "margin_sampling"),
+                                       (21, 320, 320, "margin_sampling"), (19, 1024, 2048, "least_confidence"), (19, 1024, 2048, "entropy")])
+def test_full_size_picks_equal_the_oracles_on_gap_guarded_input(C, H, W, st, exact):
+    """query.py:229-239,57-61 at the BASELINE sizes against the ORACLE'S picks (not the device's own map): value-sorted indices
+    identical, values within the score tolerance - for the default scorer and for the reference operation order."""
+    logits, excl, o_idx, o_val = _guarded_full_size_case(C, H, W, st, seed=H + C + len(st))
+    _lib.lib().pp_debug_set_exact_formula(exact)
+    try:
+        for name, t in (("nchw", torch.from_numpy(logits).to(DEV)),
+                        ("nhwc", torch.from_numpy(logits).to(DEV).contiguous(memory_format=torch.channels_last))):
+            idx, val, _ = acq.score_topk(t, torch.from_numpy(excl), st, 20)
+            assert idx[0].cpu().numpy().tolist() == o_idx[0].tolist(), name
+            np.testing.assert_allclose(val[0].cpu().numpy(), o_val[0], rtol=RTOL, atol=ATOL)
+    finally:
+        _lib.lib().pp_debug_set_exact_formula(0)

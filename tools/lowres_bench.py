@@ -28,7 +28,27 @@ def timeit(fn, iters=20, warm=5):
     return a.elapsed_time(b) / iters
 
 
+def x2_ab():
+    """FPNSeg's tail: half-resolution logits, x2 align_corners False - tile height 16 (29 KB patch) vs 32 rows (50.5 KB)."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    for name, C, size, st, B in (("cs", 19, (256, 512), "entropy", 64), ("voc", 21, (376, 504), "margin_sampling", 32),
+                                 ("cs-full", 19, (1024, 2048), "least_confidence", 1), ("cs-full", 19, (1024, 2048), "least_confidence", 8)):
+        torch.manual_seed(0)
+        low = torch.randn(B, size[0] // 2, size[1] // 2, C, device=DEV) * 3
+        excl = (torch.rand(B, *size, device=DEV) < 0.05).to(torch.uint8)
+        row = []
+        for ppt in (0, 4, 8):
+            L.pp_debug_set_acq_tuning(0, ppt)
+            row.append(timeit(lambda: acq.score_topk_lowres(low, size, excl, st, 20, align_corners=False)))
+        L.pp_debug_set_acq_tuning(0, 0)
+        npix = B * size[0] * size[1]
+        print(f"x2 {name:8s} B={B:3d} {st:18s}: auto {row[0]:.4f} ms ({npix / row[0] / 1e6:.1f} Gpix/s), 16-row tile {row[1]:.4f}, 32-row tile {row[2]:.4f}")
+
+
 def main():
+    if "--x2" in sys.argv:
+        return x2_ab()
     Bs = [int(v) for v in sys.argv[1:]] or [1, 8, 64, 256]
     cfgs = [("cs", 19, (64, 128), (256, 512), "entropy"), ("cv", 11, (90, 120), (360, 480), "margin_sampling"),
             ("voc", 21, (80, 80), (320, 320), "margin_sampling"), ("cs-full", 19, (256, 512), (1024, 2048), "least_confidence")]
