@@ -240,6 +240,49 @@ __device__ __forceinline__ void wave_extract_topk_prefilter(uint32_t (&kh)[PPT],
     for (int r = (int)total + lane; r < k; r += kWave) dst[r] = 0ull;
 }
 
+// ---- per-BLOCK candidate list --------------------------------------------------------------------------
+// Every wave extracts its own sorted top-k into LDS; wave 0 then merges the block's NW lists by rank (keys are unique - the pixel
+// index sits in the low word - so "how many of the NW*k candidates are greater" IS the slot) and ONE list of k leaves the block.
+// A quarter of the candidate traffic of per-wave lists, and at 256x512 (64 blocks per image -> 1280 candidates) the merge below needs
+// one level instead of two.  s_top: NW * kSmallKMax keys.  dst == nullptr: the merged list stays in s_top[0..k) (cand_merge_kernel).
+template <int PPT>
+__device__ __forceinline__ void block_emit_topk(uint32_t (&kh)[PPT], uint32_t (&kl)[PPT], int k, uint64_t* dst, int mode,
+                                                uint64_t (*s_surv)[kSurvCap], uint32_t* s_cnt, uint64_t* s_top)
+{
+    constexpr int NW = kBlock / kWave;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    if (mode == 2) wave_extract_topk<PPT>(kh, kl, k, s_top + wave * k, 0);
+    else wave_extract_topk_prefilter<PPT>(kh, kl, k, s_top + wave * k, mode, s_surv[wave], &s_cnt[wave]);
+    __syncthreads();
+    if (wave != 0) return;
+    const int n = NW * k;                                  // <= 192
+    constexpr int J = (NW * kSmallKMax + kWave - 1) / kWave;
+    uint64_t mine[J];
+    int rk[J];
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int i = lane + j * kWave;
+        mine[j] = i < n ? s_top[i] : 0ull;
+        rk[j] = 0;
+        nvalid += __popcll(__ballot(mine[j] != 0ull));
+    }
+    if (n <= kWave) {
+        for (int i = 0; i < n; ++i) rk[0] += s_top[i] > mine[0];
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const uint64_t v = s_top[i];
+#pragma unroll
+            for (int j = 0; j < J; ++j) rk[j] += v > mine[j];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                       // dst may be s_top itself: every lane has finished reading
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (mine[j] != 0ull && rk[j] < k) dst[rk[j]] = mine[j];
+    for (int r = nvalid + lane; r < k; r += kWave) dst[r] = 0ull;
+}
+
 // ---- main kernel ---------------------------------------------------------------------------------
 // VEC == 4: planes are flat & 16-B aligned (sW == 1, sH == W, N % 4 == 0): float4 per class plane.
 // VEC == 1: arbitrary element strides (NHWC views, cropped views), one pixel per load.
@@ -251,6 +294,7 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
     constexpr int PPT = VEC * G;
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
     __shared__ uint32_t s_cnt[kBlock / kWave];
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
     int lb = blockIdx.x;
     if (p.xcd_per) {
         // Large class planes (>= 4 MB: 1024 x 2048 logits): a block's C streams lie a whole plane apart, and with blocks dealt
@@ -317,15 +361,8 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (p.cand) {
-        const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
-        const int waves_per_image = p.blocks_per_image * (kBlock / kWave);
-        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
-        if (p.reduce_mode == 2)
-            wave_extract_topk<PPT>(kh, kl, p.k, dst, 0);
-        else
-            wave_extract_topk_prefilter<PPT>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
-    }
+    if (p.cand)
+        block_emit_topk<PPT>(kh, kl, p.k, p.cand + ((int64_t)img * p.blocks_per_image + blk) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
 }
 
 
@@ -341,6 +378,7 @@ __global__ __launch_bounds__(kBlock, 3) void acq_nhwc_kernel(AcqParams p)
     __shared__ __attribute__((aligned(16))) float s_x[kBlock * CMAX];
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
     __shared__ uint32_t s_cnt[kBlock / kWave];
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
     const int img = blockIdx.x / p.blocks_per_image;
     const int blk = blockIdx.x - img * p.blocks_per_image;
     const int tid = threadIdx.x;
@@ -379,13 +417,8 @@ __global__ __launch_bounds__(kBlock, 3) void acq_nhwc_kernel(AcqParams p)
         }
         __syncthreads();
     }
-    if (p.cand) {
-        const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
-        const int waves_per_image = p.blocks_per_image * (kBlock / kWave);
-        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
-        if (p.reduce_mode == 2) wave_extract_topk<G>(kh, kl, p.k, dst, 0);
-        else wave_extract_topk_prefilter<G>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
-    }
+    if (p.cand)
+        block_emit_topk<G>(kh, kl, p.k, p.cand + ((int64_t)img * p.blocks_per_image + blk) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
 }
 
 // ---- dense NHWC, asynchronous variant ------------------------------------------------------------------
@@ -419,6 +452,7 @@ __global__ __launch_bounds__(kBlock, (CMAX > 19 ? 2 : 3)) void acq_nhwc_dma_kern
     __shared__ __attribute__((aligned(256))) uint32_t s_e[NW][2][kWave];   // sub-dword LDS-DMA lands one DWORD per lane
     __shared__ uint64_t s_surv[NW][kSurvCap];
     __shared__ uint32_t s_cnt[NW];
+    __shared__ uint64_t s_top[NW * kSmallKMax];
     const int img = blockIdx.x / p.blocks_per_image;
     const int blk = blockIdx.x - img * p.blocks_per_image;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -470,13 +504,8 @@ __global__ __launch_bounds__(kBlock, (CMAX > 19 ? 2 : 3)) void acq_nhwc_dma_kern
             kh[g] = 0u; kl[g] = 0u;
         }
     }
-    if (p.cand) {
-        const int wave_in_image = blk * NW + wave;
-        const int waves_per_image = p.blocks_per_image * NW;
-        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
-        if (p.reduce_mode == 2) wave_extract_topk<G>(kh, kl, p.k, dst, 0);
-        else wave_extract_topk_prefilter<G>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
-    }
+    if (p.cand)
+        block_emit_topk<G>(kh, kl, p.k, p.cand + ((int64_t)img * p.blocks_per_image + blk) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
 }
 
 // ---- acquisition straight from the LOW-resolution classifier logits -------------------
@@ -506,6 +535,7 @@ __global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
     extern __shared__ __attribute__((aligned(16))) float s_patch[];
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
     __shared__ uint32_t s_cnt[kBlock / kWave];
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
     constexpr int TR = (kBlock / kWave) * PPT, TC = kWave;
     const int tiles = p.tiles_x * p.tiles_y;
     const int img = blockIdx.x / tiles;
@@ -570,13 +600,8 @@ __global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
         }
         __builtin_amdgcn_sched_barrier(0);   // one pixel's class vector live at a time
     }
-    if (p.cand) {
-        const int wave_in_image = t * (kBlock / kWave) + wv;
-        const int waves_per_image = tiles * (kBlock / kWave);
-        uint64_t* dst = p.cand + ((int64_t)img * waves_per_image + wave_in_image) * p.k;
-        if (p.reduce_mode == 2) wave_extract_topk<PPT>(kh, kl, p.k, dst, 0);
-        else wave_extract_topk_prefilter<PPT>(kh, kl, p.k, dst, p.reduce_mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
-    }
+    if (p.cand)
+        block_emit_topk<PPT>(kh, kl, p.k, p.cand + ((int64_t)img * tiles + t) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
 }
 
 // The strategy's score at a list of picked pixels (QueryStats: entropy at the queried pixels, query.py:262-266),
@@ -626,23 +651,21 @@ __global__ __launch_bounds__(kBlock) void topk_small_from_scores_kernel(const fl
     }
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
     __shared__ uint32_t s_cnt[kBlock / kWave];
-    const int wave_in_image = blk * (kBlock / kWave) + (tid >> 6);
-    const int waves_per_image = blocks_per_image * (kBlock / kWave);
-    uint64_t* dst = cand + ((int64_t)img * waves_per_image + wave_in_image) * k;
-    if (mode == 2)
-        wave_extract_topk<G>(kh, kl, k, dst, 0);
-    else
-        wave_extract_topk_prefilter<G>(kh, kl, k, dst, mode, s_surv[tid >> 6], &s_cnt[tid >> 6]);
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
+    block_emit_topk<G>(kh, kl, k, cand + ((int64_t)img * blocks_per_image + blk) * k, mode, s_surv, s_cnt, s_top);
 }
 
 // ---- candidate merge ---------------------------------------------------------------------------------
-// grid (nchunks, B): block (c,b) reduces up to kMergeChunk candidate keys of image b to their top-k.
-// The last level (nchunks == 1) decodes to out_idx / out_val.
+// grid (nchunks, B): block (c,b) reduces up to kMergeChunk candidate keys of image b to their top-k with the machinery the scoring
+// kernels end in - per-wave threshold prefilter + rank inside LDS (block_emit_topk) - instead of k rounds of a block-wide arg-max
+// with two barriers each (10.5 us per level at k = 20; this form: ~3 us).  The last level (nchunks == 1) decodes to out_idx / out_val.
 __global__ __launch_bounds__(kBlock) void cand_merge_kernel(const uint64_t* in, int64_t n_in, uint64_t* out_keys,
                                                            int32_t* out_idx, float* out_val, int k, int largest,
                                                            int mode)
 {
-    __shared__ uint32_t sh[2][kBlock / kWave];
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
     const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const uint64_t* src = in + (int64_t)b * n_in;
     const int64_t lo = (int64_t)c * kMergeChunk;
@@ -654,37 +677,19 @@ __global__ __launch_bounds__(kBlock) void cand_merge_kernel(const uint64_t* in, 
         kh[j] = (uint32_t)(v >> 32);
         kl[j] = (uint32_t)v;
     }
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int r = 0; r < k; ++r) {
-        uint32_t lh = 0;
-#pragma unroll
-        for (int j = 0; j < kMergeItems; ++j) lh = kh[j] > lh ? kh[j] : lh;
-        uint32_t ll = 0;
-#pragma unroll
-        for (int j = 0; j < kMergeItems; ++j) ll = (kh[j] == lh && kl[j] > ll) ? kl[j] : ll;
-        uint32_t wh = wave_umax(lh, mode);
-        if (lane == 0) sh[0][wave] = wh;
-        __syncthreads();
-        uint32_t mh = 0;
-#pragma unroll
-        for (int q = 0; q < kBlock / kWave; ++q) mh = sh[0][q] > mh ? sh[0][q] : mh;
-        uint32_t wl = wave_umax(lh == mh ? ll : 0u, mode);
-        if (lane == 0) sh[1][wave] = wl;
-        __syncthreads();
-        uint32_t ml = 0;
-#pragma unroll
-        for (int q = 0; q < kBlock / kWave; ++q) ml = sh[1][q] > ml ? sh[1][q] : ml;
-        if (tid == 0) {
-            if (out_keys) {
-                out_keys[((int64_t)b * gridDim.x + c) * k + r] = mh == 0u ? 0ull : (((uint64_t)mh << 32) | ml);
-            } else {
-                out_idx[(int64_t)b * k + r] = mh == 0u ? -1 : (int32_t)(0xFFFFFFFFu - ml);
-                if (out_val) out_val[(int64_t)b * k + r] = key_to_float(mh, largest != 0);
-            }
+    if (out_keys) {
+        block_emit_topk<kMergeItems>(kh, kl, k, out_keys + ((int64_t)b * gridDim.x + c) * k, mode, s_surv, s_cnt, s_top);
+        return;
+    }
+    block_emit_topk<kMergeItems>(kh, kl, k, s_top, mode, s_surv, s_cnt, s_top);      // merged list -> s_top[0..k)
+    if (tid < kWave) {
+        __builtin_amdgcn_wave_barrier();
+        for (int r = tid; r < k; r += kWave) {
+            const uint64_t v = s_top[r];
+            const uint32_t mh = (uint32_t)(v >> 32), ml = (uint32_t)v;
+            out_idx[(int64_t)b * k + r] = mh == 0u ? -1 : (int32_t)(0xFFFFFFFFu - ml);
+            if (out_val) out_val[(int64_t)b * k + r] = key_to_float(mh, largest != 0);
         }
-#pragma unroll
-        for (int j = 0; j < kMergeItems; ++j)
-            if (kh[j] == mh && kl[j] == ml) kh[j] = 0u;
     }
 }
 
@@ -1266,7 +1271,7 @@ static Plan make_plan(int64_t B, int64_t N, bool vec4, bool force_ppt4 = false)
     pl.xcd = vec4 && g_tune_xcd != 1 && (g_tune_xcd == 2 || N * 4 >= (4ll << 20));
     if (g_tune_ppt && vec4 && !force_ppt4) pl.ppt = g_tune_ppt;
     pl.blocks_per_image = (int)cdiv(N, (int64_t)kBlock * pl.ppt);
-    pl.waves_per_image = pl.blocks_per_image * (kBlock / kWave);
+    pl.waves_per_image = pl.blocks_per_image;          // candidate lists per image: one per BLOCK since round 5 (block_emit_topk)
     return pl;
 }
 
@@ -1522,7 +1527,7 @@ static LowresPlan make_lowres_plan(int64_t B, int64_t C, int64_t h, int64_t w, i
     if (g_tune_ppt == 4) pl.ppt = 4;
     pl.tiles_x = (int)cdiv(Wc, kWave);
     pl.tiles_y = (int)cdiv(Hc, (kBlock / kWave) * pl.ppt);
-    pl.waves_per_image = pl.tiles_x * pl.tiles_y * (kBlock / kWave);
+    pl.waves_per_image = pl.tiles_x * pl.tiles_y;      // candidate lists per image: one per block (tile)
     // a tile of T output pixels spans at most ceil(scale*(T-1)) + 3 source pixels (i0 of the first .. i1 of the last)
     const int64_t pw = std::min<int64_t>(w, (int64_t)std::ceil((double)sw * (kWave - 1)) + 3);
     const int64_t ph = std::min<int64_t>(h, (int64_t)std::ceil((double)sh * ((kBlock / kWave) * pl.ppt - 1)) + 3);

@@ -786,6 +786,9 @@ _CONV_WS_BYTES = {}      # (bwd, shape...) -> split-K workspace bytes (0: never 
 _CONV_WS_BUF = {}        # device -> one grow-only scratch buffer; forward / backward-data run on the main stream only
 
 
+_CONV_WS_MIN = 64 << 20      # first allocation of the shared convolution scratch (tests lower it to force a re-allocation)
+
+
 def _conv_ws(bwd: bool, device, *shape):
     """(pointer, bytes) of the split-K scratch for this conv shape, or (None, 0)."""
     key = (bwd,) + shape
@@ -800,7 +803,12 @@ def _conv_ws(bwd: bool, device, *shape):
     dk = (device.type, device.index)
     buf = _CONV_WS_BUF.get(dk)
     if buf is None or buf.numel() < need:
-        buf = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            # a recorded launch plan (LaunchPlan / NativePlan) holds this block's ADDRESS: keep it alive, like _ws() does - handing
+            # it back to the caching allocator would let later replays write split-K partials / bf16x3 planes into memory that
+            # belongs to other tensors (an eager forward at a larger shape between two replays is enough to get here)
+            _SCRATCH_RETIRED.append(buf)
+        buf = torch.empty(max(need, 2 * (buf.numel() if buf is not None else 0), _CONV_WS_MIN), dtype=torch.uint8, device=device)
         _CONV_WS_BUF[dk] = buf
     return buf.data_ptr(), buf.numel()
 

@@ -534,6 +534,8 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay, ranks):
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["value"] > 0 and d["config"]["global_batch"] == 4 * ranks
+    # `value` is the WHOLE-JOB aggregate: the images of all ranks (per-GPU batch 4 each) over the max-over-ranks step time
+    assert abs(d["value"] - 4 * ranks / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     t = d["train"]
     assert t["replay"] == (replay == "on") and 0 < t["host_enqueue_ms_per_step"] < 1e3 and t["host_cores_per_rank"] > 0
     dd = d["distributed"]

@@ -298,6 +298,49 @@ def test_launch_plan_replay_matches_eager_steps(network, native, monkeypatch):
     assert n_eager == n_plan and (not n_eager or set(n_eager) == {5})
 
 
+def test_replay_survives_a_larger_eager_forward_that_regrows_the_conv_scratch(monkeypatch):
+    """A recorded plan holds the ADDRESS of the shared convolution scratch (split-K partials, bf16x3 planes).  An eager forward
+    at a larger shape between two replays (the per-epoch validation, model.py:190-194) makes engine._conv_ws re-allocate it:
+    the replaced block must stay alive (engine._SCRATCH_RETIRED), otherwise later replays write into memory the caching
+    allocator has handed to other tensors.  The scratch floor is lowered so that the small test shapes force the re-allocation."""
+    from pixelpick_amd import engine as E
+    C, B, H, W = 19, 2, 64, 96
+    data = [(fi.formula_input(B, H, W, key=f"g{i}").to(DEV), fi.formula_labels(B, H, W, C, C, 20, key=f"g{i}").to(DEV)) for i in range(2)]
+    big = fi.formula_input(4, 192, 256, key="gbig").to(DEV)
+    big_y = fi.formula_labels(4, 192, 256, C, C, 20, key="gbig").to(DEV)
+
+    def run(disturb):
+        monkeypatch.setattr(E, "_CONV_WS_MIN", 1 << 16)
+        E._CONV_WS_BUF.clear()
+        m = _build(C, "deeplab")
+        tr = FlatTrainer(m.train(), ignore_index=C)
+        tr.enable_replay(*data[0], warmup=0)
+        first = next(iter(E._CONV_WS_BUF.values()))
+        ptr0, n0 = first.data_ptr(), first.numel()
+        sentinels = []
+        if disturb:
+            # an eager step of ANOTHER model at a larger shape (validation / a second trainer in the process): needs more scratch than
+            # the recorded step -> re-allocation
+            FlatTrainer(_build(C, "deeplab").train(), ignore_index=C).forward_backward(big, big_y)
+            cur = next(iter(E._CONV_WS_BUF.values()))
+            assert cur.numel() > n0 and cur.data_ptr() != ptr0
+            assert any(b.data_ptr() == ptr0 for b in E._SCRATCH_RETIRED)      # the plan's block is still owned
+            del first, cur
+            torch.cuda.synchronize()
+            # whatever the allocator would have re-used: blocks of the old scratch's size class, filled with a pattern
+            sentinels = [torch.full((n0 // 4,), 7.25, device=DEV) for _ in range(6)]
+        losses = [tr.train_step(*data[i % 2]).item() for i in range(1, 4)]
+        torch.cuda.synchronize()
+        assert all(bool((t == 7.25).all()) for t in sentinels)
+        p = tr.flat_p.clone()
+        tr.disable_replay()
+        return losses, p
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+
+
 @pytest.mark.parametrize("network,shape", [("deeplab", (2, 72, 88)), ("deeplab", (1, 128, 192)), ("FPN", (2, 64, 96))])
 def test_inference_with_fused_conv_bn_act_is_bit_identical(network, shape):
     """Inference folds eval-mode BatchNorm (+ residual + activation) into the producing convolution's epilogue
