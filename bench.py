@@ -759,7 +759,7 @@ def main():
     acqr = None
     if a.mode in ("both", "acq"):
         acqr, line["roofline"] = acq_leg(a.batch, C, H, W, k, a.strategy, a.layout, a.steps, a.warmup, True)
-        if not a.exact_formula and world == 1:
+        if not a.exact_formula and world == 1 and not a.no_other_configs:
             # the reference's operation order as the scorer (SURVEY 7.4 wanted it selectable; the default is the algebraic form):
             # same launch, same traffic, more VALU work per pixel
             L.pp_debug_set_exact_formula(1)

@@ -32,7 +32,7 @@ def acq_source_hash():
 def one_pass(counter):
     d = os.path.join(OUT_DIR, counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "acq", "--steps", "6", "--warmup", "1", "--no-cpu-baseline"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "acq", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     vals, name = [], None
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -58,7 +58,7 @@ def main():
            "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "ratio": round(traffic / alg, 4),
            "acq_source_sha256": acq_source_hash(), "measured_unix": int(time.time()),
            "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py --mode acq "
-                      "--steps 6 --warmup 1 --no-cpu-baseline (two separate passes)"}
+                      "--steps 6 --warmup 1 --no-cpu-baseline --no-other-configs (two separate passes)"}
     with open(os.path.join(ROOT, "profiles", "acq_traffic.json"), "w") as f:
         json.dump(rec, f, indent=1)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

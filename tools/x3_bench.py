@@ -8,7 +8,7 @@ from pixelpick_amd import _lib, engine as E
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 L.pp_debug_set_conv_variant(int(os.environ.get("CONVVAR", "0")))
-modes = [int(m) for m in os.environ.get("MODES", "0,1,3,5").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,9,1").split(",")]
 shapes = [(4, 64, 128, 304, 256), (4, 64, 128, 256, 256)]
 for mode in modes:
     L.pp_debug_set_x3(mode)
@@ -21,7 +21,7 @@ for mode in modes:
         def fwd(): _lib.check(L.pp_conv2d_fwd(x.data_ptr(), Cin, B, H, W, Cin, w.data_ptr(), None, 3, 3, 1, 1, 1, y.data_ptr(), Cout, Cout, ws.data_ptr(), ws.numel(), st), "f")
         def bwd(): _lib.check(L.pp_conv2d_bwd_data(dy.data_ptr(), Cout, B, H, W, Cout, w.data_ptr(), 3, 3, 1, 1, 1, dx.data_ptr(), Cin, H, W, Cin, 0, ws.data_ptr(), ws.numel(), st), "b")
         def wgr(): _lib.check(L.pp_conv2d_bwd_weight(x.data_ptr(), Cin, B, H, W, Cin, dy.data_ptr(), Cout, Cout, 3, 3, 1, 1, 1, dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "w")
-        for name, fn in (("fwd", fwd), ("bwdD", bwd), ("wgrad", wgr)):
+        for name, fn in ((("fwd", fwd), ("bwdD", bwd), ("wgrad", wgr)) if not os.environ.get("FWD_ONLY") else (("fwd", fwd),)):
             for _ in range(3): fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
