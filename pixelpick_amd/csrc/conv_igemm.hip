@@ -2734,7 +2734,6 @@ struct X3Operands {
     uint32_t a_zero, b_zero;  // byte offset of the zero row inside a plane (chunk 0)
     uint32_t a_chunk, b_chunk;   // bytes per 16-channel chunk: (rows + 1) * 32
     int col_base;             // first output column of this launch (ragged widths run as a 128-wide launch + a 64-wide one)
-    int halo;                 // conv_x3_rows_kernel: max |dw| of the taps (<= 16)
 };
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
@@ -3059,251 +3058,6 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
         kstep(std::false_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
     }
     if (k < n) kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
-    conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
-}
-
-// ---- bf16x3 convolution with the A operand staged once per TAP ROW (round 5) ---------------------------------------------------
-// conv_x3_kernel moves 36 KiB of operand planes L2 -> LDS per 16-deep K step and CU (24 KiB of A rows + 12 KiB of B rows) and runs at
-// the pace that path sustains (profiles/r03_conv_x3.txt: MFMA pipe busy 52 %).  For a same-size, stride-1 convolution the taps of
-// one kernel row (dh fixed, dw = -d, 0, +d) read the SAME activation rows shifted by dw pixels: with the output rows of a tile
-// being consecutive pixels m0 .. m0 + 255, tap (dh, dw) of row m reads plane row m + dh*W + dw.  So ONE stage of 256 + 2d rows
-// (rows m0 - d + dh*W .. m0 + 255 + d + dh*W, 288 allocated = nine 1-KiB DMA pieces per plane) serves the three taps of a kernel row,
-// each through fragment addresses shifted by dw; the stage keeps d halo rows around every image-row segment of the tile (zero rows at
-// the ends of an image row, fetched from the planes' zero row), so a shifted read never reaches into the neighbouring image row;
-// rows above / below the image are zero rows at DMA time as before.  A traffic drops 3x (27 KiB per three steps instead of 72), the whole operand stream from 36 to 21 KiB per
-// step: below what the six MFMA groups of a step take to issue.  Separate rings: A three stages (one per tap row), B five stages
-// (one per step).  Same step order (chunk outer, tap inner), same MFMA order => results bit-identical to conv_x3_kernel.
-// Eligible (host): stride 1, output size == input size, all nine taps of a 3x3 live, image width a divisor or a multiple of the
-// 256-row tile, segments + halos within the 288-row stage, one K slice.
-template <int BN>
-__global__ __launch_bounds__(512, 2) void conv_x3_rows_kernel(ConvParams p, X3Operands o)
-{
-    constexpr int BM = 256, TM = 2, TN = BN / 64, WN = 2;
-    constexpr int AROWS = 288, NA = 3, NB = 5;
-    constexpr int A_PLANE = AROWS * 32, A_STAGE = 3 * A_PLANE;                 // 27 KiB
-    constexpr int B_PLANE = BN * 32, B_STAGE = 3 * B_PLANE;                    // 12 KiB (BN = 128)
-    constexpr int B_BASE = NA * A_STAGE;
-    constexpr int NBW = BN / 32;                                              // waves that DMA B rows
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NA * A_STAGE + NB * B_STAGE];
-    struct Frags { bf16x8_t a[3][TM], b[3][TN]; };
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    int mt, nt;
-    {
-        const int ntn = p.n_tiles, nblk = gridDim.x, bid = blockIdx.x, per_xcd = nblk / 8;
-        if (p.xcd_remap && per_xcd * 8 == nblk) {
-            const int lin = (bid & 7) * per_xcd + (bid >> 3);
-            mt = lin / ntn; nt = lin - mt * ntn;
-        } else {
-            mt = bid / ntn; nt = bid - mt * ntn;
-        }
-    }
-    const int64_t m0 = (int64_t)mt * BM;
-    const int n0 = o.col_base + nt * BN;
-    const int d = o.halo;
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
-    // the nine taps (host-checked): tap t = 3 * g + j has dh = dh[3 g], dw = dw[j], weight index t - everything the loop needs about
-    // them sits in scalar registers
-    const int dw0 = p.taps.dw[0], dw1 = p.taps.dw[1], dw2 = p.taps.dw[2];
-    const int gs0 = p.taps.dh[0] * p.W * 32, gs1 = p.taps.dh[3] * p.W * 32, gs2 = p.taps.dh[6] * p.W * 32;   // byte shift of a tap row's A rows
-    const uint32_t b_tap_bytes = (uint32_t)o.n_rows * 32u;                    // B rows of one tap
-
-    // ---- DMA addressing.  A: wave w owns piece w (stage rows 32w .. 32w + 31), wave 4 also piece 8; lane -> (row lane >> 1, 16-byte half
-    // swizzled by bit 3 of the row).  Stage row j holds plane row m0 - d + j (+ dh*W): valid while that is an output pixel whose
-    // image row + dh stays inside the image.
-    const int lr = lane >> 1;
-    const int lhalf = (lane & 1) ^ ((lr >> 3) & 1);
-    uint32_t a_e0[2] = {0u, 0u};
-    unsigned a_gm[2] = {0u, 0u};
-    // stage layout: the tile's image-row segments (seg_w = min(W, 256) output pixels each) with d halo rows on either side - real
-    // neighbours where the segment continues inside its image row (W > 256), zero rows at the ends of an image row, so that a
-    // shifted read never picks up a pixel of the neighbouring image row and nothing has to be masked in registers
-    const int seg_w = p.W < BM ? p.W : BM, seg_p = seg_w + 2 * d;             // host: BM % W == 0 or W % BM == 0
-    const int nseg = BM / seg_w;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int piece = q == 0 ? wave : 8;
-        const int j = piece * 32 + lr;
-        const int sg = j / seg_p, pos = j - sg * seg_p - d;                   // position inside the segment (halo: < 0 or >= seg_w)
-        const int64_t mj = m0 + (int64_t)sg * seg_w + pos;
-        const int ow0 = (int)((uint64_t)(m0 + (int64_t)sg * seg_w) % (uint64_t)p.W);      // image column of the segment's first pixel
-        if ((q == 0 || wave == 4) && sg < nseg && (unsigned)(ow0 + pos) < (unsigned)p.W && mj >= 0 && mj < p.M) {
-            const unsigned mu = (unsigned)mj;
-            const unsigned t = mu / (unsigned)p.W;
-            const unsigned bb = t / (unsigned)p.H;
-            const int oh = (int)(t - bb * (unsigned)p.H);
-            a_e0[q] = mu * 32u + (uint32_t)(lhalf * 16);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) a_gm[q] |= ((unsigned)(oh + p.taps.dh[g * 3]) < (unsigned)p.H) ? (1u << g) : 0u;
-        }
-    }
-    const bool two_a = wave == 4;
-    const bool loads_b = wave < NBW;
-    const int b_row = n0 + wave * 32 + lr;
-    const bool b_ok = loads_b && b_row < p.Cn;
-    const uint32_t b_e0 = (uint32_t)(b_row * 16 + lhalf * 8) * 2u;
-    const uint32_t a_zero = o.a_zero + (uint32_t)(lhalf * 16), b_zero = o.b_zero + (uint32_t)(lhalf * 16);
-    const uint16_t* a0 = o.a; const uint16_t* a1 = o.a + o.a_plane; const uint16_t* a2 = o.a + 2 * o.a_plane;
-    const uint16_t* b0 = o.b; const uint16_t* b1 = o.b + o.b_plane; const uint16_t* b2 = o.b + 2 * o.b_plane;
-
-    const int nchunk = o.Kp / 16;
-    const int n = 9 * nchunk;                          // K steps
-    const int nG = 3 * nchunk;                         // tap rows over all chunks
-    const int nA = two_a ? 6 : 3, nBs = loads_b ? 3 : 0;      // DMA operations per tap row (A) / per step (B) of this wave
-
-    // issue cursors (wave-uniform scalars, advanced incrementally: no division in the loop)
-    uint32_t ib_off = 0, ib_chunk = 0;                 // B: byte offset of the tap inside a chunk / of the chunk
-    int ib_t = 0, ib_slot = 0;                         //    tap 0..8, ring slot
-    uint32_t ia_chunk = 0;
-    int ia_g = 0, ia_slot = 0;
-    uint32_t st_vb = 0, st_ldsb = 0, st_va0 = 0, st_va1 = 0, st_ldsa = 0;
-    auto b_begin = [&]() {
-        st_vb = b_ok ? b_e0 + ib_off + ib_chunk : b_zero;
-        st_ldsb = lds0 + (uint32_t)(B_BASE + ib_slot * B_STAGE) + (uint32_t)(wave * 1024);
-        ib_off += b_tap_bytes;
-        if (++ib_t == 9) { ib_t = 0; ib_off = 0; ib_chunk += o.b_chunk; }
-        if (++ib_slot == NB) ib_slot = 0;
-    };
-    auto b_issue = [&]() { if (loads_b) x3_glds16x3(st_vb, b0, b1, b2, st_ldsb, B_PLANE); };
-    auto a_begin = [&]() {
-        const uint32_t sh = (uint32_t)(ia_g == 0 ? gs0 : (ia_g == 1 ? gs1 : gs2)) + ia_chunk;
-        st_va0 = ((a_gm[0] >> ia_g) & 1u) ? a_e0[0] + sh : a_zero;
-        st_va1 = ((a_gm[1] >> ia_g) & 1u) ? a_e0[1] + sh : a_zero;
-        st_ldsa = lds0 + (uint32_t)(ia_slot * A_STAGE);
-        if (++ia_g == 3) { ia_g = 0; ia_chunk += o.a_chunk; }
-        if (++ia_slot == NA) ia_slot = 0;
-    };
-    auto a_issue0 = [&]() { x3_glds16x3(st_va0, a0, a1, a2, st_ldsa + (uint32_t)(wave * 1024), A_PLANE); };
-    auto a_issue1 = [&]() { if (two_a) x3_glds16x3(st_va1, a0, a1, a2, st_ldsa + 8u * 1024u, A_PLANE); };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    int a_row[TM], b_slot[TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int r = (wm * TM + t) * 32 + l31;
-        a_row[t] = r + (r / seg_w) * 2 * d + d;                              // stage row of this lane's output pixel at dw = 0
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) { const int r = (wn * TN + t) * 32 + l31; b_slot[t] = r * 2 + (h ^ ((r >> 3) & 1)); }
-
-    int a_sl[TM];                                      // 16-byte slots of the fragments being read
-    auto frag_begin = [&](int phq) {
-        const int dw = phq == 0 ? dw0 : (phq == 1 ? dw1 : dw2);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            const int jj = a_row[t] + dw;
-            a_sl[t] = jj * 2 + (h ^ ((jj >> 3) & 1));
-        }
-    };
-    auto read_a = [&](int aslot, Frags& F, int pl) {
-        const bf16x8_t* S = reinterpret_cast<const bf16x8_t*>(smem + aslot * A_STAGE + pl * A_PLANE);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) F.a[pl][t] = S[a_sl[t]];
-    };
-    auto read_b = [&](int bslot, Frags& F, int pl) {
-        const bf16x8_t* S = reinterpret_cast<const bf16x8_t*>(smem + B_BASE + bslot * B_STAGE + pl * B_PLANE);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) F.b[pl][t] = S[b_slot[t]];
-    };
-    auto mma_term = [&](const Frags& F, int term) {
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[TA[term]][tm], F.b[TB[term]][tn], acc[tm][tn], 0, 0, 0);
-    };
-    auto wait_ops = [&](int ops) {                     // my own DMA operations: all but the newest `ops` have landed (multiples of 3)
-        if (ops >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else if (ops == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if (ops == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (ops == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if (ops == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (ops == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // what step j issued (j >= 0): B of step j + NB while it exists; at the first tap of tap row G = j / 3 >= 1, A of tap row G + 2
-    auto issued_at = [&](int j) -> int {
-        if (j < 0) return 0;
-        return (j + NB < n ? nBs : 0) + ((j % 3 == 0 && j >= 3 && j / 3 + 2 < nG) ? nA : 0);
-    };
-
-    // read cursors: phase (tap column) and ring slots of the CURRENT step
-    int ph = 0, a_cur = 0, b_cur = 0;
-    // step k (tap row Gk = k / 3, phase ph = k % 3).  Fragments of step k are in `cur`; those of k + 1 are read into `nxt` between the
-    // MFMA groups.  STEADY: every issue of this step and of the three before it exists - no k-dependent branch is left.
-    auto kstep = [&](auto steady_tag, int k, Frags& cur, Frags& nxt) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const bool rd = STEADY || k + 1 < n;
-        const bool dmB = STEADY || k + NB < n;
-        const bool dmA = ph == 0 && (STEADY || (k >= 3 && k / 3 + 2 < nG));
-        const int phn = ph == 2 ? 0 : ph + 1;
-        const int a_nxt = phn == 0 ? (a_cur + 1 == NA ? 0 : a_cur + 1) : a_cur;
-        const int b_nxt = b_cur + 1 == NB ? 0 : b_cur + 1;
-        if (rd) {
-            // B of step k + 1 was issued at step k - 4 and the A rows of its tap row before that: everything issued since may fly
-            if (STEADY) {
-                if (loads_b) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // 3 B steps + one tap row of A
-                else if (two_a) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            } else {
-                wait_ops(issued_at(k - 3) + issued_at(k - 2) + issued_at(k - 1));
-            }
-            __builtin_amdgcn_s_barrier();              // everyone's pieces of step k + 1; B slot b_cur and A slot a_cur - 1 are free
-            asm volatile("" ::: "memory");
-        }
-        if (dmB) b_begin();
-        if (dmA) a_begin();
-        if (rd) frag_begin(phn);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            mma_term(cur, g);
-            __builtin_amdgcn_sched_barrier(0);
-            if (rd) { if (g < 3) read_a(a_nxt, nxt, g); else read_b(b_nxt, nxt, g - 3); }
-            if (dmA && g == 0) a_issue0();
-            if (dmA && g == 1) a_issue1();
-            if (dmB && g == 3) b_issue();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ph = phn; a_cur = a_nxt; b_cur = b_nxt;
-    };
-
-    Frags F0, F1;
-    // prologue: A of the first NA tap rows, B of the first NB steps, everything landed before step 0
-    for (int G = 0; G < NA && G < nG; ++G) { a_begin(); a_issue0(); a_issue1(); }
-    for (int s0 = 0; s0 < NB && s0 < n; ++s0) { b_begin(); b_issue(); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    frag_begin(0);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
-
-    int k = 0;
-    // warm-in (steps 0 .. 3): the window of the counted wait still reaches into the prologue
-    for (; k < 4 && k + 1 < n; k += 2) {
-        kstep(std::false_type{}, k, F0, F1);
-        kstep(std::false_type{}, k + 1, F1, F0);
-    }
-    for (; k + 7 < n; k += 2) {                         // steady: steps k and k + 1 and every step in their windows issue in full
-        kstep(std::true_type{}, k, F0, F1);
-        kstep(std::true_type{}, k + 1, F1, F0);
-    }
-    for (; k + 1 < n; k += 2) {
-        kstep(std::false_type{}, k, F0, F1);
-        kstep(std::false_type{}, k + 1, F1, F0);
-    }
-    if (k < n) kstep(std::false_type{}, k, F0, F1);
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
@@ -3703,7 +3457,7 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
                        BWD ? 0 : 1, bp, x.Kp, x.b_plane);
     if (int rc = check_launch("x3_split_w_kernel")) return rc;
     X3Operands o{ap, bp, x.a_plane, x.b_plane, x.Kp, p.Cn, (uint32_t)(x.rows_a * 32), (uint32_t)(x.b_rows * 32),
-                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), 0, 0};
+                 (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), 0};
     p.n_tiles = pl.n_tiles;
     p.splits = 1;
     p.ks_per_split = 0;
@@ -3715,17 +3469,6 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
     const bool two = rem > 0 && rem <= 64 && full128 > 0 && !(g_conv_x3 & 4);
     const bool n128_only = !two && (rem == 0 || rem > 64 || (g_conv_x3 & 4));
     const int64_t mt256 = cdiv(p.M, 256);
-    // conv_x3_rows_kernel (A operand staged once per tap row): same-size stride-1 convolutions whose taps come in runs of three per dh
-    int halo = 0;
-    bool rows_ok = !(g_conv_x3 & 8) && p.stride == 1 && p.bwd_stride <= 1 && p.Ho == p.H && p.Wo == p.W && p.taps.n == 9;
-    for (int t = 0; rows_ok && t < 9; ++t) {          // all nine taps live, tap t = (row t / 3, column t % 3), weight index t
-        if (p.taps.dh[t] != p.taps.dh[t - t % 3] || p.taps.dw[t] != p.taps.dw[t % 3] || p.taps.widx[t] != t) rows_ok = false;
-        halo = std::max(halo, std::abs(p.taps.dw[t]));
-    }
-    // the stage (288 rows) holds the tile's image-row segments with 2 * halo extra rows each
-    const int seg_w = p.W < 256 ? p.W : 256;
-    rows_ok = rows_ok && x.Kp >= 32 && (p.W < 256 ? 256 % p.W == 0 : p.W % 256 == 0) && (256 / seg_w) * (seg_w + 2 * halo) <= 288;
-    o.halo = halo;
     auto go = [&](bool n128, int ntile, int col_base) {
         // (the 64-wide remainder launch of a ragged width decides for itself: 128 blocks of 256 x 64 leave half of the CUs idle for
         // as long as a full tile column takes - 96 us for 16 % of the layer; 256 blocks of 128 x 64 do it in one short round)
@@ -3734,10 +3477,7 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
         o.col_base = col_base;
         p.n_tiles = ntile;
         const dim3 grid((unsigned)(mtiles * ntile));
-        if (m256 && rows_ok) {
-            if (n128) hipLaunchKernelGGL((conv_x3_rows_kernel<128>), grid, dim3(512), 0, st, p, o);
-            else      hipLaunchKernelGGL((conv_x3_rows_kernel<64>), grid, dim3(512), 0, st, p, o);
-        } else if (m256) {
+        if (m256) {
             if (n128) hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
             else      hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
         } else {
@@ -4240,8 +3980,7 @@ void pp_debug_set_conv_rows(int bits) { g_conv_bwd_rows = (bits & 1) ? 0 : 1; g_
  * forward, 2 backward form (64x64 tiles), 3 backward form of the in-block split-K and the 128x32 kernels; default 15 */
 void pp_debug_set_conv_bn_fuse(int bits) { g_conv_bn_fuse = bits & 15; }
 
-/* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split);
- * bit 3 (8): conv_x3_rows_kernel (A operand staged once per tap row, round 5) off - conv_x3_kernel for every eligible layer (A/B; bit-identical) */
+/* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
 void pp_debug_set_x3(int v)
 {
     g_conv_x3 = v & 0xFF;

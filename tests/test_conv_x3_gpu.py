@@ -124,49 +124,3 @@ def test_bf16_split_is_exact():
     y = E.conv2d(E.Tape(False), E.Var(x), w, None, 1, 0, 1).t
     assert torch.equal(y, x)
 
-
-ROWS_CASES = [
-    (4, 64, 128, 304, 256, 3, 1, 1, False),     # SegmentHead conv1 (ragged 304-wide backward-data: a 128-wide + a 64-wide launch)
-    (4, 64, 128, 256, 256, 3, 1, 1, True),      # SegmentHead conv2 + bias
-    (3, 90, 100, 256, 304, 3, 1, 1, True),      # 27000 rows: the last tile is ragged, tiles straddle image rows and images
-    (4, 64, 128, 300, 256, 3, 2, 2, False),     # dilation 2 (halo 2), Cin padded to 304
-    (2, 128, 256, 128, 256, 3, 4, 4, False),    # dilation 4, W = 256: one image row per tile
-    (1, 256, 512, 64, 256, 3, 1, 1, False),     # W = 512 > tile: a tile is half an image row
-    (5, 40, 168, 144, 256, 3, 16, 16, False),   # halo 16 (the widest the 288-row stage holds), W not a power of two
-]
-
-
-@pytest.mark.parametrize("case", ROWS_CASES, ids=[str(c) for c in ROWS_CASES])
-def test_row_staged_bf16x3_kernel_is_bit_identical_to_the_per_tap_kernel(case):
-    """conv_x3_rows_kernel (round 5: one A stage of 256 + 2d rows per TAP ROW, the three taps of the row read it through shifted
-    fragment addresses, border-crossing rows zeroed in registers) against conv_x3_kernel (one A stage per tap): same step order,
-    same MFMA order - forward and backward-data must agree bit for bit, padding taps, image borders and ragged tiles included."""
-    L = _lib.lib()
-
-    def run(mode):
-        L.pp_debug_set_x3(mode)
-        try:
-            B, H, W, Cin, Cout, k, pad, dil, has_bias = case
-            gen = torch.Generator(device=DEV).manual_seed(Cin + 3 * Cout + dil)
-            x = torch.randn(B, H, W, Cin, device=DEV, generator=gen)
-            w = torch.randn(k, k, Cin, Cout, device=DEV, generator=gen) / np.sqrt(Cin * k * k)
-            bias = torch.randn(Cout, device=DEV, generator=gen) if has_bias else None
-            dy = torch.randn(B, H, W, Cout, device=DEV, generator=gen)
-            tape = E.Tape()
-            xv = E.Var(x)
-            yv = E.conv2d(tape, xv, w.requires_grad_(True), bias, 1, pad, dil)
-            y = yv.t.clone()
-            tape.backward(yv, dy)
-            torch.cuda.synchronize()
-            return x, w.detach(), bias, y, xv.grad.clone()
-        finally:
-            L.pp_debug_set_x3(1)
-
-    x, w, bias, y_rows, dx_rows = run(1)
-    _, _, _, y_tap, dx_tap = run(1 | 8)                # bit 3: conv_x3_rows_kernel off
-    assert torch.equal(y_rows, y_tap)
-    assert torch.equal(dx_rows, dx_tap)
-    # and it is the convolution (fp32 torch on the device as a sanity reference; the fp64 bars are in the test above)
-    B, H, W, Cin, Cout, k, pad, dil, has_bias = case
-    ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), bias, 1, pad, dil).permute(0, 2, 3, 1)
-    assert (y_rows - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()

@@ -8,7 +8,7 @@ from pixelpick_amd import _lib, engine as E
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 L.pp_debug_set_conv_variant(int(os.environ.get("CONVVAR", "0")))
-modes = [int(m) for m in os.environ.get("MODES", "0,9,1").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,1,3,5").split(",")]
 shapes = [(4, 64, 128, 304, 256), (4, 64, 128, 256, 256)]
 for mode in modes:
     L.pp_debug_set_x3(mode)
