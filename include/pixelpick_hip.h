@@ -30,13 +30,16 @@ enum {
     PP_ERR_BAD_ARG = -1,      /* null pointer, bad shape/stride, unknown enum */
     PP_ERR_BAD_K = -2,        /* k < 1 or k > H*W */
     PP_ERR_WORKSPACE = -3,    /* workspace too small */
-    PP_ERR_UNSUPPORTED = -4,  /* shape outside the supported range (e.g. C > PP_ACQ_MAX_CLASSES) */
+    PP_ERR_UNSUPPORTED = -4,  /* shape outside the supported range (e.g. an image of 2^31 pixels or more) */
     PP_ERR_LAUNCH = -5        /* hipLaunch failure (message holds hipGetErrorString) */
 };
 
 /* query.py:229-239 UncertaintySampler strategies.  (`random`, query.py:242-244, is host RNG.) */
 enum { PP_ACQ_ENTROPY = 0, PP_ACQ_LEAST_CONFIDENCE = 1, PP_ACQ_MARGIN = 2 };
 
+/* Class counts up to this are scored from registers (one read of the logits); wider heads take the streamed scorers (acq_stream_kernel:
+ * the class vector is read two or three times, the later passes from L2) - the reference softmaxes whatever width the model emits
+ * (query.py:190), so no class count is rejected. */
 #define PP_ACQ_MAX_CLASSES 64
 
 int pp_version(void);

@@ -54,6 +54,9 @@ struct AcqParams {
 template <int CMAX, bool EXACT>
 __device__ __forceinline__ float pixel_score(const float (&x)[CMAX], int C, int strategy, int from_prob)
 {
+    // (-p) * log p and the running sum are rounded separately, as torch and the oracle do (hipcc contracts a * b + c by default, and
+    // whether it does depends on how the loop was unrolled: the HIP __fmul_rn / __fadd_rn are plain operators and do not stop it)
+#pragma clang fp contract(off)
     if (from_prob) {  // x is prob: the UncertaintySampler formulas verbatim
         if (strategy == PP_ACQ_ENTROPY) {
             float acc = 0.0f;
@@ -626,6 +629,235 @@ __global__ __launch_bounds__(kBlock) void acq_lowres_at_kernel(const float* low,
     for (int c = 0; c < CMAX; ++c)
         if (EXACT || c < C) x[c] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, p00[c], p01[c], p10[c], p11[c]);
     out[i] = pixel_score_fast<CMAX, EXACT>(x, C, strategy);
+}
+
+// ---- any class count: C > PP_ACQ_REG_CLASSES ------------------------------------------------------------
+// The scorers above keep a pixel's class vector in registers (C <= 64).  The reference takes whatever class count the model emits
+// (query.py:190 softmaxes dim 1 of any width), so wider heads STREAM the class vector instead: two (default scorer) or three
+// (reference operation order) passes over the pixel's classes, the later ones served by L2, with the same expressions in the same
+// order as pixel_score_fast / pixel_score - forced onto a C <= 64 input (pp_debug_set_acq_tuning occ = 10) the maps are bit-equal
+// to the register kernels' (tests/test_acq_gpu.py).  Load(c, v) fills v[0..VEC) with class c of the thread's VEC pixels.
+template <int VEC, int MATH, typename Load>
+__device__ __forceinline__ void score_stream(Load load, int C, int strategy, float (&s)[VEC])
+{
+#pragma clang fp contract(off)      // as pixel_score; the default scorer's fused steps are spelled fmaf()
+    float v[VEC];
+    if constexpr (MATH == 2) {                       // input holds probabilities (UncertaintySampler.__call__)
+        float acc[VEC], t1[VEC], t2[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { acc[i] = 0.0f; t1[i] = -INFINITY; t2[i] = -INFINITY; }
+        for (int c = 0; c < C; ++c) {
+            load(c, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if (strategy == PP_ACQ_ENTROPY) acc[i] += (-v[i]) * logf(v[i]);
+                else { t2[i] = fmaxf(t2[i], fminf(t1[i], v[i])); t1[i] = fmaxf(t1[i], v[i]); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            s[i] = strategy == PP_ACQ_ENTROPY ? acc[i] : (strategy == PP_ACQ_LEAST_CONFIDENCE ? 1.0f - t1[i] : fabsf(t1[i] - t2[i]));
+        return;
+    }
+    float m[VEC], x2[VEC], xmin[VEC];
+    load(0, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { m[i] = v[i]; x2[i] = -INFINITY; xmin[i] = v[i]; }
+    for (int c = 1; c < C; ++c) {
+        load(c, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            x2[i] = fmaxf(x2[i], fminf(m[i], v[i]));
+            m[i] = fmaxf(m[i], v[i]);
+            xmin[i] = fminf(xmin[i], v[i]);
+        }
+    }
+    float S[VEC], T[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { S[i] = 0.0f; T[i] = 0.0f; }
+    if constexpr (MATH == 0) {
+        for (int c = 0; c < C; ++c) {
+            load(c, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float d = v[i] - m[i];
+                const float e = fast_exp(d);
+                S[i] += e;
+                T[i] = fmaf(e, -d, T[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            if (strategy == PP_ACQ_ENTROPY) {
+                float ent = logf(S[i]) + T[i] / S[i];
+                if (xmin[i] - m[i] < -87.0f) {
+                    if (expf(xmin[i] - m[i]) / S[i] == 0.0f) ent = __uint_as_float(0x7FC00000u);
+                }
+                s[i] = ent;
+            } else if (strategy == PP_ACQ_LEAST_CONFIDENCE) {
+                s[i] = 1.0f - 1.0f / S[i];
+            } else {
+                s[i] = fabsf(1.0f / S[i] - expf(x2[i] - m[i]) / S[i]);
+            }
+        }
+    } else {                                         // reference operation order (query.py:190,229-239)
+        for (int c = 0; c < C; ++c) {
+            load(c, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) S[i] += expf(v[i] - m[i]);
+        }
+        if (strategy == PP_ACQ_LEAST_CONFIDENCE) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s[i] = 1.0f - 1.0f / S[i];
+            return;
+        }
+        float t1[VEC], t2[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { T[i] = 0.0f; t1[i] = -INFINITY; t2[i] = -INFINITY; }
+        for (int c = 0; c < C; ++c) {
+            load(c, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float e = expf(v[i] - m[i]);
+                if (strategy == PP_ACQ_ENTROPY) {
+                    const float pr = e / S[i];
+                    T[i] += (-pr) * logf(pr);
+                } else {
+                    t2[i] = fmaxf(t2[i], fminf(t1[i], e));
+                    t1[i] = fmaxf(t1[i], e);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = strategy == PP_ACQ_ENTROPY ? T[i] : fabsf(t1[i] / S[i] - t2[i] / S[i]);
+    }
+}
+
+// acq_kernel's block geometry (a block covers kBlock * VEC * G consecutive pixels of one image), class vector streamed
+template <int VEC, int G, int MATH>
+__global__ __launch_bounds__(kBlock) void acq_stream_kernel(AcqParams p)
+{
+    constexpr int PPT = VEC * G;
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
+    const int img = blockIdx.x / p.blocks_per_image;
+    const int blk = blockIdx.x - img * p.blocks_per_image;
+    const int tid = threadIdx.x;
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const float* base = p.logits + (int64_t)img * p.sB;
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+    float* omap = p.out_map ? p.out_map + (int64_t)img * p.N : nullptr;
+    uint32_t kh[PPT], kl[PPT];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t pix0 = ((int64_t)blk * G + g) * (kBlock * VEC) + (int64_t)tid * VEC;
+        if (pix0 < p.N) {
+            float s[VEC];
+            if constexpr (VEC == 4) {
+                const float* px = base + pix0;
+                const int64_t sC = p.sC;
+                score_stream<4, MATH>([&](int c, float (&v)[4]) {
+                    const float4 q = *reinterpret_cast<const float4*>(px + (int64_t)c * sC);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                }, p.C, p.strategy, s);
+                const uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if ((ex >> (8 * v)) & 0xFFu) s[v] = fill;
+                if (omap) *reinterpret_cast<float4*>(omap + pix0) = make_float4(s[0], s[1], s[2], s[3]);
+            } else {
+                const int64_t h = pix0 / p.W, w = pix0 - h * p.W;
+                const float* px = base + h * p.sH + w * p.sW;
+                const int64_t sC = p.sC;
+                score_stream<1, MATH>([&](int c, float (&v)[1]) { v[0] = px[(int64_t)c * sC]; }, p.C, p.strategy, s);
+                if (excl && excl[pix0]) s[0] = fill;
+                if (omap) omap[pix0] = s[0];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                kh[g * VEC + v] = order_key(s[v], largest);
+                kl[g * VEC + v] = 0xFFFFFFFFu - (uint32_t)(pix0 + v);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { kh[g * VEC + v] = 0u; kl[g * VEC + v] = 0u; }
+        }
+    }
+    if (p.cand)
+        block_emit_topk<PPT>(kh, kl, p.k, p.cand + ((int64_t)img * p.blocks_per_image + blk) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
+}
+
+// acq_lowres_kernel's tile geometry (PPT = 4, no LDS patch): every class of a pixel is interpolated from the four low-resolution
+// neighbours in memory on each pass (bilerp(): the bits pp_bilinear_fwd writes)
+template <int MATH>
+__global__ __launch_bounds__(kBlock) void acq_lowres_stream_kernel(LowresParams p)
+{
+    constexpr int PPT = 4;
+    __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    __shared__ uint32_t s_cnt[kBlock / kWave];
+    __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
+    constexpr int TR = (kBlock / kWave) * PPT, TC = kWave;
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int img = blockIdx.x / tiles;
+    const int t = blockIdx.x - img * tiles;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const int64_t N = (int64_t)p.Hc * p.Wc;
+    const int X = tx * TC + lane;
+    const bool xin = X < p.Wc;
+    const Lerp lw = lerp_src(xin ? X : p.Wc - 1, p.w, p.sw, p.align);
+    const float* base = p.low + (int64_t)img * p.h * p.w * p.ldx;
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * N : nullptr;
+    float* omap = p.out_map ? p.out_map + (int64_t)img * N : nullptr;
+    uint32_t kh[PPT], kl[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int Y = ty * TR + wv * PPT + j;
+        if (Y < p.Hc && xin) {
+            const Lerp lh = lerp_src(Y, p.h, p.sh, p.align);
+            const float* p00 = base + ((int64_t)lh.i0 * p.w + lw.i0) * p.ldx;
+            const float* p01 = base + ((int64_t)lh.i0 * p.w + lw.i1) * p.ldx;
+            const float* p10 = base + ((int64_t)lh.i1 * p.w + lw.i0) * p.ldx;
+            const float* p11 = base + ((int64_t)lh.i1 * p.w + lw.i1) * p.ldx;
+            float s[1];
+            score_stream<1, MATH>([&](int c, float (&v)[1]) {
+                v[0] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, p00[c], p01[c], p10[c], p11[c]);
+            }, p.C, p.strategy, s);
+            const int64_t pix = (int64_t)Y * p.Wc + X;
+            if (excl && excl[pix]) s[0] = fill;
+            if (omap) omap[pix] = s[0];
+            kh[j] = order_key(s[0], largest);
+            kl[j] = 0xFFFFFFFFu - (uint32_t)pix;
+        } else {
+            kh[j] = 0u; kl[j] = 0u;
+        }
+    }
+    if (p.cand)
+        block_emit_topk<PPT>(kh, kl, p.k, p.cand + ((int64_t)img * tiles + t) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
+}
+
+__global__ __launch_bounds__(kBlock) void acq_lowres_at_stream_kernel(const float* low, int64_t ldx, int h, int w, float sh, float sw,
+                                                                     int align, int Wc, int C, int strategy, const int32_t* img_idx,
+                                                                     const int32_t* pix_idx, int64_t n, float* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int pix = pix_idx[i], Y = pix / Wc, X = pix - Y * Wc;
+    const Lerp lh = lerp_src(Y, h, sh, align), lw = lerp_src(X, w, sw, align);
+    const float* base = low + (int64_t)img_idx[i] * h * w * ldx;
+    const float* p00 = base + ((int64_t)lh.i0 * w + lw.i0) * ldx;
+    const float* p01 = base + ((int64_t)lh.i0 * w + lw.i1) * ldx;
+    const float* p10 = base + ((int64_t)lh.i1 * w + lw.i0) * ldx;
+    const float* p11 = base + ((int64_t)lh.i1 * w + lw.i1) * ldx;
+    float s[1];
+    score_stream<1, 0>([&](int c, float (&v)[1]) { v[0] = bilerp(lh.l0, lh.l1, lw.l0, lw.l1, p00[c], p01[c], p10[c], p11[c]); },
+                       C, strategy, s);
+    out[i] = s[0];
 }
 
 // ---- small-k selection straight from a score map (pp_topk_select) ------------------------------------
@@ -1203,30 +1435,39 @@ __global__ __launch_bounds__(kBlock) void softmax_sum_kernel(const float* logits
     if (pix >= N) return;
     const int64_t hh = pix / W, ww = pix - hh * W;
     const float* base = logits + hh * sH + ww * sW;
-    float acc[PP_ACQ_MAX_CLASSES];
-    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    // per-class sums live in registers, PP_ACQ_MAX_CLASSES at a time: wider heads repeat the T passes per chunk of classes (the
+    // per-pass maximum and sum are recomputed; the strategy's score is accumulated in the first chunk's round only)
     float uc = 0.0f;
-    for (int t = 0; t < T; ++t) {
-        const float* xt = base + (int64_t)t * sT;
-        float m = xt[0];
-        for (int c = 1; c < C; ++c) m = fmaxf(m, xt[(int64_t)c * sC]);
-        float S = 0.0f;
-        for (int c = 0; c < C; ++c) S += expf(xt[(int64_t)c * sC] - m);
-        float ent = 0.0f, t1 = -INFINITY, t2 = -INFINITY;
-        for (int c = 0; c < C; ++c) {
-            const float pc = expf(xt[(int64_t)c * sC] - m) / S;
-            acc[c] += pc;
-            ent += (-pc) * logf(pc);
-            t2 = fmaxf(t2, fminf(t1, pc));
-            t1 = fmaxf(t1, pc);
+    for (int c0 = 0; c0 < C; c0 += PP_ACQ_MAX_CLASSES) {
+        const int cn = C - c0 < PP_ACQ_MAX_CLASSES ? C - c0 : PP_ACQ_MAX_CLASSES;
+        float acc[PP_ACQ_MAX_CLASSES];
+        for (int c = 0; c < cn; ++c) acc[c] = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            const float* xt = base + (int64_t)t * sT;
+            float m = xt[0];
+            for (int c = 1; c < C; ++c) m = fmaxf(m, xt[(int64_t)c * sC]);
+            float S = 0.0f;
+            for (int c = 0; c < C; ++c) S += expf(xt[(int64_t)c * sC] - m);
+            if (c0 == 0) {
+                float ent = 0.0f, t1 = -INFINITY, t2 = -INFINITY;
+                for (int c = 0; c < C; ++c) {
+                    const float pc = expf(xt[(int64_t)c * sC] - m) / S;
+                    if (c < cn) acc[c] += pc;
+                    ent += (-pc) * logf(pc);
+                    t2 = fmaxf(t2, fminf(t1, pc));
+                    t1 = fmaxf(t1, pc);
+                }
+                uc += strategy == PP_ACQ_ENTROPY ? ent : (strategy == PP_ACQ_LEAST_CONFIDENCE ? 1.0f - t1 : fabsf(t1 - t2));
+            } else {
+                for (int c = 0; c < cn; ++c) acc[c] += expf(xt[(int64_t)(c0 + c) * sC] - m) / S;
+            }
         }
-        uc += strategy == PP_ACQ_ENTROPY ? ent : (strategy == PP_ACQ_LEAST_CONFIDENCE ? 1.0f - t1 : fabsf(t1 - t2));
+        if (out)
+            for (int c = 0; c < cn; ++c) {
+                const int64_t o = (int64_t)(c0 + c) * N + pix;
+                out[o] = accumulate ? fmaf(scale, acc[c], out[o]) : scale * acc[c];
+            }
     }
-    if (out)
-        for (int c = 0; c < C; ++c) {
-            const int64_t o = (int64_t)c * N + pix;
-            out[o] = accumulate ? fmaf(scale, acc[c], out[o]) : scale * acc[c];
-        }
     if (uc_out) uc_out[pix] = accumulate ? fmaf(scale, uc, uc_out[pix]) : scale * uc;
 }
 
@@ -1462,8 +1703,29 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
     return check_launch("acq_kernel");
 }
 
+// class counts beyond the register-resident scorers (or forced, for A/B): streamed class vector, 4 pixels per thread
+static bool stream_classes(int64_t C) { return C > PP_ACQ_MAX_CLASSES || g_tune_occ == 10; }
+
+static int launch_acq_stream(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t st)
+{
+    EventScope ev(st);
+    if (pl.ppt != 4) return fail(PP_ERR_BAD_ARG, "streamed scorer: plan with %d pixels per thread", pl.ppt);
+    dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
+    const int math = p.from_prob ? 2 : (g_exact_formula ? 1 : 0);
+#define PP_STREAM(VEC, G)                                                                                  \
+    do {                                                                                                   \
+        if (math == 2)      hipLaunchKernelGGL((acq_stream_kernel<VEC, G, 2>), grid, block, 0, st, p);     \
+        else if (math == 1) hipLaunchKernelGGL((acq_stream_kernel<VEC, G, 1>), grid, block, 0, st, p);     \
+        else                hipLaunchKernelGGL((acq_stream_kernel<VEC, G, 0>), grid, block, 0, st, p);     \
+    } while (0)
+    if (pl.vec4) PP_STREAM(4, 1); else PP_STREAM(1, 4);
+#undef PP_STREAM
+    return check_launch("acq_stream_kernel");
+}
+
 static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
 {
+    if (stream_classes(p.C)) return launch_acq_stream(p, pl, B, st);
     if (p.C > 32) pl.vec4 = false;  // 64-class bucket only on the scalar path (register budget)
     if (!pl.vec4 && g_tune_occ != 9)   // (tuning value 9 forces the generic strided path for A/B)
         pl.nhwc = is_dense_nhwc(p.logits, p.C, p.N / p.W, p.W, p.sB, p.sC, p.sH, p.sW);
@@ -1483,7 +1745,7 @@ static int validate(const float* logits, int64_t B, int64_t C, int64_t H, int64_
     if (!logits) return fail(PP_ERR_BAD_ARG, "logits is null");
     if (B < 1 || C < 1 || H < 1 || W < 1) return fail(PP_ERR_BAD_ARG, "bad shape B=%lld C=%lld H=%lld W=%lld",
                                                         (long long)B, (long long)C, (long long)H, (long long)W);
-    if (C > PP_ACQ_MAX_CLASSES) return fail(PP_ERR_UNSUPPORTED, "C=%lld > %d", (long long)C, PP_ACQ_MAX_CLASSES);
+    if (C > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "C=%lld", (long long)C);
     if (H * W > 0x7FFFFFFFll || B * H * W / 1024 > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "image too large");
     if (strategy < 0 || strategy > 2) return fail(PP_ERR_BAD_ARG, "unknown strategy %d", strategy);
     return PP_OK;
@@ -1571,6 +1833,14 @@ static int launch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t B,
 
 static int dispatch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t B, hipStream_t st)
 {
+    if (stream_classes(p.C)) {
+        EventScope ev(st);
+        if (pl.ppt != 4) return fail(PP_ERR_BAD_ARG, "streamed low-resolution scorer: plan with %d rows per wave", pl.ppt);
+        dim3 grid((unsigned)(B * pl.tiles_x * pl.tiles_y)), block(kBlock);
+        if (g_exact_formula) hipLaunchKernelGGL((acq_lowres_stream_kernel<1>), grid, block, 0, st, p);
+        else                 hipLaunchKernelGGL((acq_lowres_stream_kernel<0>), grid, block, 0, st, p);
+        return check_launch("acq_lowres_stream_kernel");
+    }
     switch (p.C) {
         case 11: return launch_lowres<11, true>(p, pl, B, st);
         case 19: return launch_lowres<19, true>(p, pl, B, st);
@@ -1615,7 +1885,7 @@ void pp_debug_set_acq_tuning(int occ, int ppt)
     g_tune_xcd = (occ >> 8) & 3;
     g_acq_strat_spec = (occ >> 10) & 1 ? 0 : 1;
     occ &= 0xFF;
-    g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9) ? occ : 0;
+    g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9 || occ == 10) ? occ : 0;   // 10: streamed class vector at any C (A/B, tests)
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
 }
 
@@ -1650,7 +1920,7 @@ int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64
     if (int rc = validate(logits, B, C, H, W, strategy)) return rc;
     if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
     const int64_t N = H * W;
-    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0);
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
     AcqParams p{logits, exclude, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
                 strategy, g_reduce_mode, 0};
     return dispatch_acq(p, pl, B, as_stream(stream));
@@ -1674,7 +1944,7 @@ int pp_uncertainty_from_prob(const float* prob, int64_t B, int64_t C, int64_t H,
     if (int rc = validate(prob, B, C, H, W, strategy)) return rc;
     if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
     const int64_t N = H * W;
-    Plan pl = make_plan(B, N, is_flat_vec4(prob, nullptr, out_map, H, W, sB, sC, sH, sW), true);
+    Plan pl = make_plan(B, N, is_flat_vec4(prob, nullptr, out_map, H, W, sB, sC, sH, sW), true);     // (4 pixels per thread: also what the streamed scorer needs)
     AcqParams p{prob, nullptr, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
                 strategy, g_reduce_mode, 1};
     return dispatch_acq(p, pl, B, as_stream(stream));
@@ -1696,7 +1966,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     const int largest = strategy != PP_ACQ_MARGIN;
 
     if (k <= kSmallKMax) {
-        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0);
+        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
         const int64_t n_cand = (int64_t)pl.waves_per_image * k;
         uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
         uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
@@ -1709,7 +1979,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     // large k: materialise the score map once, then radix-select + sort per image
     float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
     uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
-    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), g_exact_formula != 0);
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
     AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
                 g_reduce_mode, 0};
     if (int rc = dispatch_acq(p, pl, B, st)) return rc;
@@ -1741,7 +2011,7 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
                    (int)C, 0, 0, 0, strategy, g_reduce_mode, 0};
     if (k == 0) {     // score map only
         if (!out_map) return fail(PP_ERR_BAD_ARG, "k == 0 (map only) needs out_map");
-        LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0);
+        LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0 || stream_classes(C));
         p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.patch_cap = pl.patch_cap;
         return dispatch_lowres(p, pl, B, st);
     }
@@ -1752,7 +2022,7 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
         return fail(PP_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(PP_ERR_BAD_ARG, "workspace must be 256-B aligned");
     const int largest = strategy != PP_ACQ_MARGIN;
-    LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0);
+    LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0 || stream_classes(C));
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.patch_cap = pl.patch_cap;
     if (k <= kSmallKMax) {
         const int64_t n_cand = (int64_t)pl.waves_per_image * k;
@@ -1786,6 +2056,11 @@ int pp_acq_lowres_score_at(const float* low, int64_t ldx, int64_t B, int64_t C, 
 #define PP_AT(CM, EX)                                                                                                   \
     hipLaunchKernelGGL((acq_lowres_at_kernel<CM, EX>), grid, block, 0, st, low, ldx, (int)h, (int)w, sh, sw, al, (int)Wc, \
                        (int)C, strategy, img_idx, pix_idx, n, out)
+    if (stream_classes(C)) {
+        hipLaunchKernelGGL(acq_lowres_at_stream_kernel, grid, block, 0, st, low, ldx, (int)h, (int)w, sh, sw, al, (int)Wc, (int)C, strategy,
+                           img_idx, pix_idx, n, out);
+        return check_launch("acq_lowres_at_stream_kernel");
+    }
     switch (C) {
         case 11: PP_AT(11, true); break;
         case 19: PP_AT(19, true); break;
