@@ -590,6 +590,29 @@ def main():
                                                       "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF,
                                                       "frac": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
                                  "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
+        # What the matrix pipe SUSTAINS on this box under conv_x3_kernel's own MFMA stream and nothing else (pp_debug_mfma_stream:
+        # register-resident fragments, launches of the convolution's length): the spec peak assumes 2.4 GHz, and a chip-wide bf16 MFMA
+        # load on operands with random mantissas is power-limited well below it (profiles/r05_conv_x3_power.txt) - zeros are not.
+        sink = torch.zeros(64, device=dev)
+        mf = {}
+        for kind, tag in ((0, "zero_operands"), (2, "random_operands")):
+            it0 = 160
+            def stream_once():
+                _lib.check(L.pp_debug_mfma_stream(kind, it0, sink.data_ptr(), stream), "pp_debug_mfma_stream")
+            evs = HipEvents(nrep)
+            timed(stream_once, nrep, 12, evs)
+            sms = evs.elapsed_ms()
+            evs.destroy()
+            sm = sum(sms) / len(sms)
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            mf[tag] = {"bf16_TF": round(n_cu * 8 * it0 * 24 * 2.0 * 32 * 32 * 16 / (sm * 1e-3) / 1e12, 1), "kernel_ms_avg": round(sm, 4)}
+        sus = mf["random_operands"]["bf16_TF"] / 6.0
+        line["roofline_mfma"]["sustained"] = {
+            "what": "pp_debug_mfma_stream: conv_x3_kernel's six-term MFMA sequence from registers only (no LDS, no DMA, no barrier), 8 waves/CU, "
+                    "a launch of the convolution's length - the rate the power limit leaves on this box",
+            **mf, "fp32_equivalent_peak_random_operands_TF": round(sus, 1),
+            "frac_of_spec_peak": round(mf["random_operands"]["bf16_TF"] / MFMA_BF16_PEAK_TF, 4),
+            "conv_x3_frac_of_sustained": round(ach / sus, 4)}
         # SURVEY 8(d) graded 1x1 shapes at the BASELINE batch: op time (split-K launch + its reduce where the plan
         # splits) from HIP events; ceiling = min(MFMA peak, arithmetic intensity x HBM peak) for ONE pass over x, w, y.
         graded = [("ASPP fuse 1280->256 @16x32 (aspp.py:73-75)", 16, 32, 1280, 256),

@@ -573,6 +573,8 @@ void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
 void pp_debug_set_conv_rows(int bits);      /* whole-row VALU kernels of the narrow pointwise layers: bit 0 off, bit 1 forward rows kernel only from 65536 rows (A/B) */
 void pp_debug_set_conv_bn_fuse(int bits);   /* fused conv + BatchNorm launches offered: bit 0 tiled fwd, 1 split-K fwd, 2 bwd 64x64, 3 bwd split-K / 128x32 (default 15; A/B) */
+int pp_debug_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stream);   /* yardstick: conv_x3_kernel's MFMA stream from registers only; data_kind 0 zeros, 1 near-constant, 2 random operands (measurement, bench.py) */
+void pp_debug_set_x3_variant(int v);   /* experiment forms of conv_x3_kernel<256,128> (ring depth, priority, DMA placement, timing ablations); 0 = product */
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */
 void pp_debug_set_conv_variant(int v);
 

@@ -133,6 +133,8 @@ SIGNATURES = {
     "pp_debug_set_conv_rows": (None, [_int]),
     "pp_debug_set_conv_bn_fuse": (None, [_int]),
     "pp_debug_set_x3": (None, [_int]),
+    "pp_debug_set_x3_variant": (None, [_int]),
+    "pp_debug_mfma_stream": (_int, [_int, _int, _p, _p]),
     "pp_debug_set_kernel_events": (None, [_p, _p, _int]),
     "pp_set_comm_cu_reserve": (None, [_int]),
     "pp_get_comm_cu_reserve": (_int, []),

@@ -2863,7 +2863,13 @@ __device__ __forceinline__ void x3_glds16x3(uint32_t voff, const void* s0, const
                  : "=&s"(keep), "=&s"(t) : "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(d0), "s"(st) : "memory", "scc");
 }
 
-template <int BM, int BN>
+// VAR: experiment switch of the 256 x 128 form (pp_debug_set_x3_variant; 0 = the product kernel; profiles/r05_conv_x3_power.txt).
+// 11: the round-3 form (one barrier per K step, DMA four steps ahead); the others are changes to THAT form - 1 / 2: ring of 3 / 2 stages;
+// 3: s_setprio 1 for the second-dispatched half of the block; 4: the upper four waves (A rows only) issue their DMA two MFMA groups
+// later than their SIMD partners; 5 / 6 / 7: timing ablations with WRONG results - no MFMAs / MFMAs only (no DMA after the prologue, no
+// fragment reads, no barrier) / no barrier and no wait; 8: one barrier per two K steps (DMA three steps ahead); 10: the step's DMA
+// addresses derived behind its first MFMA group; 9: 8 + 10 = what VAR 0 is.
+template <int BM, int BN, int VAR = 0>
 __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(ConvParams p, X3Operands o)
 {
     // waves: (BM / 64) x 2, each a 64 x (BN / 2) tile; 256 x 128 = eight waves = ONE block per CU (108 KiB of LDS), 128 x BN = four
@@ -2871,7 +2877,12 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
     // k-1), so the DMA of step k+3 can overwrite the ring slot of step k right behind the barrier; the 24 (12) MFMAs of a step go
     // out in six groups (one per product term) with the fragment reads of step k+1 and one DMA piece behind each group.
     constexpr int TM = 2, TN = BN / 64, WN = 2, NWAVE = BM / 32;
-    constexpr int NSTAGE = (BM == 256 && BN == 128) ? 4 : (BM == 256 ? 5 : 3);      // one block per CU: as much ring as 160 KiB hold
+    constexpr int NSTAGE = VAR == 1 ? 3 : VAR == 2 ? 2 : (BM == 256 && BN == 128) ? 4 : (BM == 256 ? 5 : 3);      // one block per CU: as much ring as 160 KiB hold
+    // the 256 x 128 product form (VAR 0; 11 = the round-3 form, one barrier per step, for A/B): measured 1 - 1.5 % faster, bit-identical
+    constexpr bool PROD = VAR == 0 && BM == 256 && BN == 128;
+    constexpr bool PAIR = PROD || VAR == 8 || VAR == 9;           // one barrier per TWO K steps; the DMA runs NSTAGE - 1 steps ahead
+    constexpr bool LATE_BEGIN = PROD || VAR == 9 || VAR == 10;    // the step's DMA addresses (a table read from LDS) are derived behind the step's first MFMA group, not between the barrier and it
+    constexpr int PRE = PAIR ? NSTAGE - 1 : NSTAGE;
     constexpr int A_BYTES = BM * 32, B_BYTES = BN * 32;                    // one plane of one stage
     constexpr int STAGE_BYTES = 3 * (A_BYTES + B_BYTES);
     constexpr int NBW = BN / 32;                                          // waves that DMA B rows (32 rows each)
@@ -2949,6 +2960,11 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
         if (++is_ti == p.taps.n) { is_ti = 0; ++is_ch; }
     };
     auto issue_piece = [&](int i) {                      // two batches of three planes: A behind MFMA group 0, B behind group 3
+        if constexpr (VAR == 4) {
+            if (i == (loads_b ? 0 : 2)) x3_glds16x3(st_va, a0, a1, a2, st_lds, A_BYTES);
+            else if (i == 3 && loads_b) x3_glds16x3(st_vb, b0, b1, b2, st_lds + 3 * A_BYTES, B_BYTES);
+            return;
+        }
         if (i == 0) x3_glds16x3(st_va, a0, a1, a2, st_lds, A_BYTES);
         else if (i == 3 && loads_b) x3_glds16x3(st_vb, b0, b1, b2, st_lds + 3 * A_BYTES, B_BYTES);
     };
@@ -3008,13 +3024,18 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
     };
     // STEADY (compile time): at least NSTAGE steps remain, so every `if` of the step is taken - the steady-state loop has no branches
     // besides the wave-uniform "this wave loads B rows" one (runtime-uniform branches cost conv_igemm_dma_kernel ~10 %)
-    auto kstep = [&](auto steady_tag, int k, int stage, Frags& cur, Frags& nxt) {
+    auto kstep = [&](auto steady_tag, auto odd_tag, int k, int stage, Frags& cur, Frags& nxt) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const bool rd = STEADY || k + 1 < n, dm = STEADY || k + NSTAGE < n;
+        constexpr bool ODD = decltype(odd_tag)::value;
+        const bool rd = STEADY || k + 1 < n, dm = (STEADY || k + PRE < n) && VAR != 6;
         const int sn = stage + 1 == NSTAGE ? 0 : stage + 1;
-        if (rd) {
+        const int sd = PRE == NSTAGE ? stage : (stage == 0 ? NSTAGE - 1 : stage - 1);      // ring slot of step k + PRE
+        if (rd && VAR != 7 && VAR != 6 && !(PAIR && ODD)) {
             // step k+1 has landed; steps k+2 .. k+NSTAGE-1 (as far as they exist) may still fly
-            if (STEADY) {
+            if (PAIR) {
+                // (PAIR: this barrier also covers step k+1, which reads step k+2's fragments: everything issued so far has landed)
+                wait_pieces(0);
+            } else if (STEADY) {
                 wait_pieces(NSTAGE - 2);
             } else {
                 const int fly = n - (k + 2) < NSTAGE - 2 ? n - (k + 2) : NSTAGE - 2;
@@ -3023,42 +3044,91 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
             __builtin_amdgcn_s_barrier();                    // everyone's pieces of step k+1; ring slot k%NSTAGE is free
             asm volatile("" ::: "memory");
         }
-        if (dm) issue_begin(stage);
+        if (dm && !LATE_BEGIN) issue_begin(sd);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            mma_term(cur, g);
+            if constexpr (VAR != 5) mma_term(cur, g);
+            else if (g == 0) {                                   // keep the fragment reads alive without the MFMAs that consume them
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) asm volatile("" :: "v"(cur.a[pl][t]));
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) asm volatile("" :: "v"(cur.b[pl][t]));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (rd) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
+            if (rd && VAR != 6) { if (g < 3) read_a(sn, nxt, g); else read_b(sn, nxt, g - 3); }
+            if (LATE_BEGIN && g == 0 && dm) issue_begin(sd);
             if (dm) issue_piece(g);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    if constexpr (VAR == 3) {
+        if (wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);
+    }
     Frags F0, F1;
 #pragma unroll
-    for (int s0 = 0; s0 < NSTAGE; ++s0)
+    for (int s0 = 0; s0 < PRE; ++s0)
         if (s0 < n) issue_all(s0);
     if (n > 0) {
-        wait_pieces((n < NSTAGE ? n : NSTAGE) - 1);
+        wait_pieces((n < PRE ? n : PRE) - 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) { read_a(0, F0, pl); read_b(0, F0, pl); }
+        if constexpr (VAR == 6) { F1 = F0; asm volatile("" : "+v"(F1.a[0][0]), "+v"(F1.b[0][0])); }
     }
     // (unrolling the steady state over lcm(2, NSTAGE) steps so that ring slots become immediates was measured SLOWER: 203 -> 240 us
     // on the 256 -> 256 layer - the loop body no longer fits the instruction cache)
     int k = 0;
     for (; k + NSTAGE + 1 < n; k += 2) {
-        kstep(std::true_type{}, k, k % NSTAGE, F0, F1);
-        kstep(std::true_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
+        kstep(std::true_type{}, std::false_type{}, k, k % NSTAGE, F0, F1);
+        kstep(std::true_type{}, std::true_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
     }
     for (; k + 1 < n; k += 2) {
-        kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
-        kstep(std::false_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
+        kstep(std::false_type{}, std::false_type{}, k, k % NSTAGE, F0, F1);
+        kstep(std::false_type{}, std::true_type{}, k + 1, (k + 1) % NSTAGE, F1, F0);
     }
-    if (k < n) kstep(std::false_type{}, k, k % NSTAGE, F0, F1);
+    if (k < n) kstep(std::false_type{}, std::false_type{}, k, k % NSTAGE, F0, F1);
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
+}
+
+// pp_debug_mfma_stream: conv_x3_kernel's MFMA sequence from registers and nothing else (tools/probe/mfma_peak.hip holds the same kernel
+// as a stand-alone program)
+__device__ __forceinline__ unsigned probe_hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+template <int DATA>
+__global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters, unsigned seed)
+{
+    bf16x8_t a[3][2], b[3][2];
+    for (int pl = 0; pl < 3; ++pl)
+        for (int t = 0; t < 2; ++t)
+            for (int i = 0; i < 8; ++i) {
+                float va = 0.f, vb = 0.f;
+                if (DATA == 1) { va = 1.0f + threadIdx.x * 0.001f + i; vb = 1.0f - i; }
+                if (DATA == 2) {
+                    const unsigned h = probe_hash32(seed + ((blockIdx.x * 512 + threadIdx.x) * 3 + pl) * 32 + t * 8 + i), g = probe_hash32(h + 0x9e3779b9u);
+                    va = __uint_as_float((h & 0x807fffffu) | ((125u + (h >> 23) % 4u) << 23));
+                    vb = __uint_as_float((g & 0x807fffffu) | ((125u + (g >> 23) % 4u) << 23));
+                }
+                a[pl][t][i] = (__bf16)va; b[pl][t][i] = (__bf16)vb;
+            }
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 6; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[g]][i], b[TB[g]][j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 12345.678f) out[0] = s;
 }
 
 // ---- weight gradient on the bf16 matrix pipe (bf16x3 split) --------------------------------------------------------------------
@@ -3415,6 +3485,7 @@ static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
 
 // bf16x3 path (conv_x3_kernel): which problems take it, and what the caller's workspace must hold for it
 static int g_conv_x3 = 1;
+static int g_x3_var = 0;      // pp_debug_set_x3_variant: experiment forms of conv_x3_kernel<256,128> (see the kernel)
 struct X3Plan { bool ok; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes; };
 static int g_conv_x3_mid = 1;
 static double g_x3_mid_flop = 16e9, g_x3w_flop = 8e9;     // least work of a mid-size layer / a weight gradient (pp_debug_set_x3 bits 9-11 / 14-16)
@@ -3478,8 +3549,22 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
         p.n_tiles = ntile;
         const dim3 grid((unsigned)(mtiles * ntile));
         if (m256) {
-            if (n128) hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
-            else      hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
+            if (n128) {
+                switch (g_x3_var) {
+                    case 1: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 1>), grid, dim3(512), 0, st, p, o); break;
+                    case 2: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 2>), grid, dim3(512), 0, st, p, o); break;
+                    case 3: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 3>), grid, dim3(512), 0, st, p, o); break;
+                    case 4: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 4>), grid, dim3(512), 0, st, p, o); break;
+                    case 5: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 5>), grid, dim3(512), 0, st, p, o); break;
+                    case 6: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 6>), grid, dim3(512), 0, st, p, o); break;
+                    case 7: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 7>), grid, dim3(512), 0, st, p, o); break;
+                    case 8: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 8>), grid, dim3(512), 0, st, p, o); break;
+                    case 9: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 9>), grid, dim3(512), 0, st, p, o); break;
+                    case 10: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 10>), grid, dim3(512), 0, st, p, o); break;
+                    case 11: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 11>), grid, dim3(512), 0, st, p, o); break;
+                    default: hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
+                }
+            } else hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
         } else {
             if (n128) hipLaunchKernelGGL((conv_x3_kernel<128, 128>), grid, dim3(256), 0, st, p, o);
             else      hipLaunchKernelGGL((conv_x3_kernel<128, 64>), grid, dim3(256), 0, st, p, o);
@@ -3981,6 +4066,25 @@ void pp_debug_set_conv_rows(int bits) { g_conv_bwd_rows = (bits & 1) ? 0 : 1; g_
 void pp_debug_set_conv_bn_fuse(int bits) { g_conv_bn_fuse = bits & 15; }
 
 /* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
+/* Yardstick (bench.py roofline_mfma.sustained): nothing but conv_x3_kernel's MFMA stream - six product terms of three A x three B
+ * register-resident bf16 fragments on four accumulators, eight waves per CU - with operands of a chosen switching activity (0: zeros,
+ * 1: near-constant, 2: hash-random signs / mantissas as the planes of a real activation have).  Same instructions in all three; what
+ * differs is the clock the power limit leaves (profiles/r05_conv_x3_power.txt: 2.39-2.5 GHz on zeros, 1.77-1.92 GHz on random
+ * operands).  iters x 24 MFMAs per wave. */
+int pp_debug_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stream)
+{
+    if (!sink || iters < 1 || data_kind < 0 || data_kind > 2) return fail(PP_ERR_BAD_ARG, "mfma_stream: bad argument");
+    const dim3 grid((unsigned)device_cus()), block(512);
+    hipStream_t st = as_stream(stream);
+    EventScope ev(st);
+    if (data_kind == 0) hipLaunchKernelGGL(mfma_stream_kernel<0>, grid, block, 0, st, sink, iters, 7u);
+    else if (data_kind == 1) hipLaunchKernelGGL(mfma_stream_kernel<1>, grid, block, 0, st, sink, iters, 7u);
+    else hipLaunchKernelGGL(mfma_stream_kernel<2>, grid, block, 0, st, sink, iters, 7u);
+    return check_launch("mfma_stream_kernel");
+}
+
+void pp_debug_set_x3_variant(int v) { g_x3_var = (v >= 0 && v <= 11) ? v : 0; }
+
 void pp_debug_set_x3(int v)
 {
     g_conv_x3 = v & 0xFF;

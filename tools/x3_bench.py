@@ -10,10 +10,14 @@ st = torch.cuda.current_stream().cuda_stream
 L.pp_debug_set_conv_variant(int(os.environ.get("CONVVAR", "0")))
 modes = [int(m) for m in os.environ.get("MODES", "0,1,3,5").split(",")]
 shapes = [(4, 64, 128, 304, 256), (4, 64, 128, 256, 256)]
-for mode in modes:
+variants = [int(v) for v in os.environ.get("VARS", "0").split(",")]      # pp_debug_set_x3_variant forms of conv_x3_kernel<256,128>
+for mode, var in [(m, v) for m in modes for v in variants]:
     L.pp_debug_set_x3(mode)
+    L.pp_debug_set_x3_variant(var)
     for (B, H, W, Cin, Cout) in shapes:
         x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(3, 3, Cin, Cout, device="cuda") * 0.02
+        if os.environ.get("ZERO"):          # all-zero operands: the same instruction stream at a fraction of the switching power (clock check)
+            x.zero_(); w.zero_()
         y = torch.empty(B, H, W, Cout, device="cuda"); dy = torch.randn(B, H, W, Cout, device="cuda"); dx = torch.empty_like(x)
         wf = int(L.pp_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, 1, 1)); wb = int(L.pp_conv2d_bwd_data_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, 1, 1))
         ww = int(L.pp_conv2d_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, 1, 1)); dw = torch.empty_like(w)
@@ -29,5 +33,10 @@ for mode in modes:
             e1.record(); torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / 20 * 1e3
             gf = 2.0 * B * H * W * Cin * Cout * 9 / 1e9
-            print(f"mode {mode} {Cin}->{Cout} {name}: {t:7.1f} us per call (incl. operand splits) = {gf / t * 1e3:6.1f} TF-equivalent")
+            if name == "fwd" and os.environ.get("CHECK"):          # same MFMA order in every correct variant: bit-identical to the product kernel
+                L.pp_debug_set_x3_variant(0); y.zero_(); fwd(); y0 = y.clone()
+                L.pp_debug_set_x3_variant(var); y.zero_(); fwd()
+                print(f"   var {var} {Cin}->{Cout}: output {'bit-identical to' if torch.equal(y, y0) else 'DIFFERS from'} variant 0")
+            print(f"mode {mode} var {var} {Cin}->{Cout} {name}: {t:7.1f} us per call (incl. operand splits) = {gf / t * 1e3:6.1f} TF-equivalent")
 L.pp_debug_set_x3(1)
+L.pp_debug_set_x3_variant(0)
