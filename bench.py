@@ -838,7 +838,7 @@ def main():
                            "reference_order_path": {"value": round(ru["images_per_s"], 2), "ms_per_image": round(ru["ms_per_image"], 3),
                                                     "peak_device_gib": round(ru["peak_gib"], 2)},
                            "tail_only_gpu_ms": {k2: round(v, 3) for k2, v in tt.items()},
-                           "tail_speedup": round(tt["tail_reference_order_ms"] / max(tt["tail_fused_ms"], 1e-6), 1)})
+                           "tail_speedup": round(max(tt["tail_reference_order_ms"], 0.0) / max(tt["tail_fused_ms"], 1e-3), 1)})
         line["other_configs"] = others
 
     if rank == 0:

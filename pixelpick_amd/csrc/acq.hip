@@ -45,6 +45,8 @@ struct AcqParams {
     int strategy;
     int reduce_mode;
     int from_prob;       // 1: input already holds probabilities (UncertaintySampler.__call__, query.py:246-247)
+    uint32_t* qhist = nullptr;   // HIST kernels: [B][kQBins] bin counts of the scores written to out_map (zeroed by the host), qscale bins per unit score
+    float qscale = 0.0f;
     int xcd_per = 0;     // > 0: XCD-contiguous block order (acq_kernel only): hardware block b works on logical block
     int nb = 0;          //      (b % 8) * xcd_per + b / 8 of nb, so that the blocks one XCD holds walk ONE contiguous eighth of the launch
 };
@@ -286,16 +288,36 @@ __device__ __forceinline__ void block_emit_topk(uint32_t (&kh)[PPT], uint32_t (&
     for (int r = nvalid + lane; r < k; r += kWave) dst[r] = 0ull;
 }
 
+// ---- quantised score bins (the large-k selection's threshold search, see select_qhist_kernel) ----------------------------------
+constexpr int kQBins = 1024;
+__device__ __forceinline__ uint32_t qbin(float s, bool lg, float scale)
+{
+    if (s != s) return lg ? (uint32_t)(kQBins - 1) : 0u;             // NaN: first for largest, last for smallest (order_key's policy)
+    const float t = s * scale;
+    const int qi = t >= (float)(kQBins - 1) ? kQBins - 1 : (t > 0.0f ? (int)t : 0);
+    return (uint32_t)(lg ? qi : kQBins - 1 - qi);
+}
+
 // ---- main kernel ---------------------------------------------------------------------------------
 // VEC == 4: planes are flat & 16-B aligned (sW == 1, sH == W, N % 4 == 0): float4 per class plane.
 // VEC == 1: arbitrary element strides (NHWC views, cropped views), one pixel per load.
 // A block covers kBlock*VEC*G consecutive pixels of ONE image.
 // MATH: 0 = default scorer, 1 = reference operation order, 2 = input already holds probabilities.
-template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1>
+// HIST (map-writing launches of the large-k selection, VEC == 4): the block also counts its scores into the image's kQBins-bin histogram
+// (LDS bins in the survivor lists' storage - no candidates are extracted in that mode - then one global atomic per non-empty bin): what
+// select_qhist_kernel did in a second pass over the map.
+template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1, bool HIST = false>
 __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
 {
     constexpr int PPT = VEC * G;
+    static_assert(!HIST || VEC == 4, "histogram epilogue: the flat float4 form");
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
+    static_assert(sizeof(uint64_t) * (kBlock / kWave) * kSurvCap >= sizeof(uint32_t) * kQBins, "the bins live in the survivor lists");
+    uint32_t* lh = reinterpret_cast<uint32_t*>(&s_surv[0][0]);
+    if constexpr (HIST) {
+        for (int i = threadIdx.x; i < kQBins; i += kBlock) lh[i] = 0u;
+        __syncthreads();
+    }
     __shared__ uint32_t s_cnt[kBlock / kWave];
     __shared__ uint64_t s_top[(kBlock / kWave) * kSmallKMax];
     int lb = blockIdx.x;
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
                     if constexpr (MATH == 0) s[v] = pixel_score_fast<CMAX, EXACT, STRAT>(x[v], p.C, p.strategy);
                     else s[v] = pixel_score<CMAX, EXACT>(x[v], p.C, p.strategy, MATH == 2);
                     if ((ex >> (8 * v)) & 0xFFu) s[v] = fill;
+                    if constexpr (HIST) atomicAdd(&lh[qbin(s[v], largest, p.qscale)], 1u);
                     __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time (VGPR budget)
                 }
                 if (omap) *reinterpret_cast<float4*>(omap + pix0) = make_float4(s[0], s[1], s[2], s[3]);
@@ -364,6 +387,15 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (HIST) {
+        __syncthreads();
+        uint32_t* Hg = p.qhist + (int64_t)img * kQBins;
+        for (int d = threadIdx.x; d < kQBins; d += kBlock) {
+            const uint32_t c = lh[d];
+            if (c) atomicAdd(&Hg[d], c);
+        }
+        return;
+    }
     if (p.cand)
         block_emit_topk<PPT>(kh, kl, p.k, p.cand + ((int64_t)img * p.blocks_per_image + blk) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
 }
@@ -1274,17 +1306,8 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_sel_kernel(const flo
 // at the reference's default k = 6553) is dropped into LDS bin by bin and ranked exactly on the full (key, index) words.  Replaces four
 // histogram passes + a 66-barrier LDS sort; an image whose candidates do not fit (kQCap in all, kQMaxPop in a bin: heavy ties, constant
 // maps) raises its overflow flag and is redone by topk_large_kernel (the exact one-block radix select): the result never depends on the data.
-constexpr int kQBins = 1024;
 constexpr int kQSub = 8;             // sub-histograms per block (lane & 7)
 constexpr int kQCap = 8192;          // candidates per image held in LDS (64 KiB of (key, index) words)
-
-__device__ __forceinline__ uint32_t qbin(float s, bool lg, float scale)
-{
-    if (s != s) return lg ? (uint32_t)(kQBins - 1) : 0u;             // NaN: first for largest, last for smallest (order_key's policy)
-    const float t = s * scale;
-    const int qi = t >= (float)(kQBins - 1) ? kQBins - 1 : (t > 0.0f ? (int)t : 0);
-    return (uint32_t)(lg ? qi : kQBins - 1 - qi);
-}
 
 // hist: [B][kQBins], zeroed by the host
 __global__ __launch_bounds__(kBlock) void select_qhist_kernel(const float* scores, int64_t N, int largest, float scale, uint32_t* hist)
@@ -1564,13 +1587,25 @@ static float score_qscale(int strategy, int64_t C)
     return (float)kQBins / range;
 }
 
+// the quantised select's conditions and its histogram's place in the large-k scratch (also asked by the scorer launches that fill it)
+static bool large_q_ok(int64_t B, int64_t k, float qscale)
+{
+    return qscale > 0.0f && g_large_q && g_large_multiblock && B <= 65535 && k + (k / 8 > 256 ? k / 8 : 256) <= kQCap;
+}
+static uint32_t* large_hist(void* ws, int64_t B, int64_t k)
+{
+    const int P = next_pow2(k);
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + (P <= kLargeLdsMaxP ? 256 : align_up((size_t)B * P * 8, 256)));
+}
+
+// hist_done: the scorer launch already filled the (host-zeroed) quantised histogram
 static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int largest, void* ws,
-                     int32_t* out_idx, float* out_val, hipStream_t st, float qscale = 0.0f)
+                     int32_t* out_idx, float* out_val, hipStream_t st, float qscale = 0.0f, bool hist_done = false)
 {
     const int P = next_pow2(k);
     const bool in_lds = P <= kLargeLdsMaxP;
     uint64_t* gbuf = reinterpret_cast<uint64_t*>(ws);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + (in_lds ? 256 : align_up((size_t)B * P * 8, 256)));
+    uint32_t* hist = large_hist(ws, B, k);
     const size_t lds = (256 + 64) * 4 + (in_lds ? (size_t)P * 8 : 0);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1583,16 +1618,18 @@ static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int larg
         attr_set = true;
     }
     // known score range and room for the threshold bin's population beside the k picks: the quantised select
-    if (qscale > 0.0f && g_large_q && g_large_multiblock && B <= 65535 && k + (k / 8 > 256 ? k / 8 : 256) <= kQCap) {
+    if (large_q_ok(B, k, qscale)) {
         static_assert(kQBins * 4 == kSelPasses * kSelBins * 4, "the two histogram layouts share their workspace slot");
         int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + align_up((size_t)B * kQBins * 4, 256));
-        if (hipMemsetAsync(hist, 0, (size_t)B * kQBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
-        int64_t bpi = cdiv(2048, B);
-        const int64_t by_size = cdiv(N, 4096);
-        if (bpi > by_size) bpi = by_size;
-        if (bpi < 1) bpi = 1;
-        hipLaunchKernelGGL(select_qhist_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, largest, qscale, hist);
-        if (int rc = check_launch("select_qhist_kernel")) return rc;
+        if (!hist_done) {
+            if (hipMemsetAsync(hist, 0, (size_t)B * kQBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+            int64_t bpi = cdiv(2048, B);
+            const int64_t by_size = cdiv(N, 4096);
+            if (bpi > by_size) bpi = by_size;
+            if (bpi < 1) bpi = 1;
+            hipLaunchKernelGGL(select_qhist_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, largest, qscale, hist);
+            if (int rc = check_launch("select_qhist_kernel")) return rc;
+        }
         hipLaunchKernelGGL(topk_qsel_kernel, dim3((unsigned)B), dim3(kLargeThreads), kQSelLds, st, map, N, (int)k, largest, qscale,
                            hist, out_idx, out_val, flags);
         if (int rc = check_launch("topk_qsel_kernel")) return rc;
@@ -1668,6 +1705,12 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
                     q.xcd_per = (int)cdiv(q.nb, 8);
                     grid = dim3((unsigned)(q.xcd_per * 8));
                 }
+                if (q.qhist) {       // large-k selection: map + the image's score histogram in one pass (run_large skips its histogram pass)
+                    constexpr int O = CMAX == 21 ? kAcqOcc21 : (CMAX == 11 ? kAcqOcc11 : 3);
+                    if (g == 2) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 2, 0, O, -1, true>), grid, block, 0, st, q);
+                    else        hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 1, 0, O, -1, true>), grid, block, 0, st, q);
+                    return check_launch("acq_kernel<hist>");
+                }
 #define PP_ACQ_GO(G, O) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, O>), grid, block, 0, st, q)
 #define PP_ACQ_SPEC(G, S) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, 3, S>), grid, block, 0, st, q)
                 if (g_acq_strat_spec && !g_tune_occ && !q.out_map) {            // (with the map written - large k - the generic kernel measured no slower)
@@ -1721,6 +1764,14 @@ static int launch_acq_stream(const AcqParams& p, const Plan& pl, int64_t B, hipS
     if (pl.vec4) PP_STREAM(4, 1); else PP_STREAM(1, 4);
 #undef PP_STREAM
     return check_launch("acq_stream_kernel");
+}
+
+// which launches can take the histogram epilogue (acq_kernel<..., HIST>): the flat float4 form of the three dataset class counts
+static int g_hist_fuse = 1;        // pp_debug_set_reduce_mode bit 10: off (A/B)
+static bool acq_hist_fusable(const AcqParams& p, const Plan& pl)
+{
+    return g_hist_fuse && pl.vec4 && !p.from_prob && !g_exact_formula && !g_tune_occ && !stream_classes(p.C) && p.out_map && !p.cand &&
+           (p.C == 11 || p.C == 19 || p.C == 21);
 }
 
 static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
@@ -1874,6 +1925,7 @@ void pp_debug_set_reduce_mode(int mode)
 {
     g_large_multiblock = (mode & 256) ? 0 : 1;      // bit 8: large-k selection through the one-block-per-image radix select (A/B)
     g_large_q = (mode & 512) ? 0 : 1;               // bit 9: no quantised-histogram select where the score range is known (A/B)
+    g_hist_fuse = (mode & 1024) ? 0 : 1;            // bit 10: the score histogram in its own pass over the map (select_qhist_kernel), not in the scorer launch
     mode &= 255;
     g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
@@ -1982,8 +2034,15 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
     AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
                 g_reduce_mode, 0};
+    const float qs = score_qscale(strategy, C);
+    const bool fuse_hist = large_q_ok(B, k, qs) && acq_hist_fusable(p, pl);
+    if (fuse_hist) {
+        p.qhist = large_hist(gbuf, B, k);
+        p.qscale = qs;
+        if (hipMemsetAsync(p.qhist, 0, (size_t)B * kQBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+    }
     if (int rc = dispatch_acq(p, pl, B, st)) return rc;
-    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st, score_qscale(strategy, C));
+    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st, qs, fuse_hist);
 }
 
 size_t pp_acq_lowres_workspace_bytes(int64_t B, int64_t C, int64_t Hc, int64_t Wc, int64_t k)

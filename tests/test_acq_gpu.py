@@ -395,16 +395,22 @@ def test_quantised_select_equals_the_radix_select(st):
         nanl = logits[:2, :, :64, :128].clone()
         nanl[0, 0, 3, 5:40] = 200.0                                                         # p -> 0 for the others: 0 * log 0 = NaN (query.py:230)
         cases.append(("nan", nanl, None, 409))
+    for Cx in (11, 21):                                                                      # the other two dataset class counts (their own scorer instantiations)
+        lx = torch.randn((2, Cx, 96, 160), device=DEV, generator=gen) * 3
+        cases.append((f"random-C{Cx}", lx, torch.rand((2, 96, 160), device=DEV, generator=gen) < 0.05, 768))
     for name, lg, ex, k in cases:
         try:
             L.pp_debug_set_reduce_mode(512)
             ref = acq.score_topk(lg, ex, st, k, return_map=True)
-            L.pp_debug_set_reduce_mode(0)
+            L.pp_debug_set_reduce_mode(1024)       # the histogram in its own pass over the map (select_qhist_kernel), as before round 5
+            sep = acq.score_topk(lg, ex, st, k, return_map=True)
+            L.pp_debug_set_reduce_mode(0)          # default: the scorer launch counts its scores into the histogram (acq_kernel<..., HIST>)
             got = acq.score_topk(lg, ex, st, k, return_map=True)
         finally:
             L.pp_debug_set_reduce_mode(0)
-        for a, b in zip(ref, got):
-            assert torch.equal(a, b) or (name == "nan" and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))), (name, st, k)
+        for a, b, c in zip(ref, got, sep):
+            for other in (b, c):
+                assert torch.equal(a, other) or (name == "nan" and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(other, nan=-7.0))), (name, st, k)
         # oracle: stable sort of the device's own map (ties -> lower index first, NaN first for largest)
         dmap = got[2].cpu().numpy()
         for b in range(lg.shape[0]):

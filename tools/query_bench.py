@@ -92,7 +92,7 @@ def tail_times(model, C, H, W, strategy, batch=1, k=20, reps=5):
     """GPU time (torch events, median of `reps`) of: the forward up to the low-resolution logits; that + the fused interpolate /
     score / top-k launch; the reference-order path (full-resolution branch maps, sums, classifier, logits, scorer).
     -> dict(ms_forward_lowres, ms_fused, ms_reference_order, tail_fused_ms, tail_reference_order_ms): tail = what follows the
-    low-resolution logits (fused) / what the reference order adds to that same forward."""
+    low-resolution logits (fused: timed alone) / what the reference order adds to that same forward (difference of two forwards)."""
     from pixelpick_amd import acquisition as acq
     dev = next(model.parameters()).device
     g = torch.Generator(device=dev).manual_seed(3)
@@ -125,7 +125,22 @@ def tail_times(model, C, H, W, strategy, batch=1, k=20, reps=5):
                 ts.append(e0.elapsed_time(e1))
             out[name] = sorted(ts)[len(ts) // 2]
             torch.cuda.empty_cache()
-    out["tail_fused_ms"] = out["ms_fused"] - out["ms_forward_lowres"]
+    # the fused tail is ONE launch pair (scorer + candidate merge) of 0.02 - 0.3 ms behind a 10 - 20 ms forward: the difference of two
+    # forward timings is noise at that size (it came out negative on some boxes), so it is timed on its own, on logits held still
+    with torch.no_grad():
+        low, size = model.forward_lowres(x)
+        acq.score_topk_lowres(low, size, excl, strategy, k, align_corners=align)
+        ts = []
+        for _ in range(4 * reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            acq.score_topk_lowres(low, size, excl, strategy, k, align_corners=align)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        del low
+    out["tail_fused_ms"] = sorted(ts)[len(ts) // 2]
+    out["tail_fused_by_difference_ms"] = out["ms_fused"] - out["ms_forward_lowres"]
     out["tail_reference_order_ms"] = out["ms_reference_order"] - out["ms_forward_lowres"]
     return out
 
