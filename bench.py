@@ -366,6 +366,7 @@ def main():
 
     from pixelpick_amd import _lib
     from pixelpick_amd import acquisition as acq
+    from pixelpick_amd import dist_utils as du
     L = _lib.lib()
     L.pp_debug_set_acq_tuning(a.tune_occ, a.tune_ppt)
     L.pp_debug_set_reduce_mode(a.reduce_mode)
@@ -472,7 +473,11 @@ def main():
         n_launches = None
         if replay:
             n_launches = sum(1 for fn, _ in tr._plan.calls if getattr(fn, "argtypes", None) is not None)     # C-ABI calls of one step
-        train = {"img_per_s": world * TB * steps / el, "ms_per_step": el / steps * 1e3, "loss_after": loss,
+        # whole-job rate: every rank's images over the slowest rank's time (dist_utils.whole_job_rate: SUM of units, MAX of time;
+        # `timed` has already taken the MAX, so the second reduction is the identity)
+        job_rate, job_images, _ = du.whole_job_rate(TB * steps, el, device=dev if dist is not None else None)
+        assert world == 1 or abs(job_images - world * TB * steps) < 0.5, "ranks disagree on their batch"
+        train = {"img_per_s": job_rate, "ms_per_step": el / steps * 1e3, "loss_after": loss,
                  "launch": (("launch-plan replay, " + ("native executor (pp_plan_replay: one foreign call per step)" if native_plan else "python list"))
                             if replay else "eager") + ", small weight gradients on a second stream",
                  # host time spent inside train_step() per step (enqueue only, nothing synchronises): a host slower than the
@@ -708,7 +713,7 @@ def main():
         alg_bytes = B * Ha * Wa * (4 * Ca + 1)               # per launch of acq_kernel on ONE GPU
         kavg = sum(kms) / len(kms)
         achieved = alg_bytes / (kavg * 1e-3) / 1e9
-        acqr = {"value": round(world * B * Ha * Wa * steps / el / 1e6, 1), "unit": "Mpixels/s",
+        acqr = {"value": round(du.whole_job_rate(B * Ha * Wa * steps, el, device=dev if dist is not None else None)[0] / 1e6, 1), "unit": "Mpixels/s",
                 "ms_per_step": round(el / steps * 1e3, 4), "images_per_launch_per_gpu": B, "k": ka,
                 "strategy": strategy, "layout": layout}
         # HBM traffic per launch: a counter pass cannot run inside this process, so it comes from the record a committed

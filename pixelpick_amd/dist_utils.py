@@ -18,6 +18,21 @@ def rank_world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def whole_job_rate(units_local: float, elapsed_local: float, device=None, group=None) -> Tuple[float, float, float]:
+    """What bench.py reports as `value`: the units ALL ranks processed in the timed region / the slowest rank's time.
+    -> (rate, units over all ranks, max elapsed).  One all-reduce each (SUM, MAX) when torch.distributed runs, nothing otherwise."""
+    import torch
+    units, el = float(units_local), float(elapsed_local)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = device if device is not None else "cpu"
+        u = torch.tensor([units], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        units, el = float(u.item()), float(t.item())
+    return units / el, units, el
+
+
 def owner_rank(index: int, world: int) -> int:
     """Round-robin owner of item `index`."""
     return index % world

@@ -1625,8 +1625,10 @@ def _concat_bwd(tape: Tape, dy, parts):
 
 
 # ------------------------------------------------------------------------------------------------- loss
-def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index: int, want_grad: bool = True):
-    """F.cross_entropy(logits [B,C,H,W], target [B,H,W] int64, ignore_index) -> (loss [1], dlogits | None)."""
+def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index: int, want_grad: bool = True, sparse: bool = True):
+    """F.cross_entropy(logits [B,C,H,W], target [B,H,W] int64, ignore_index) -> (loss [1], dlogits | None).
+    sparse: the caller knows that only a few pixels are labelled (model.py:108-110) - the gradient is marked so that the backward
+    behind it may skip its zero rows; False for densely labelled targets (every row would be flagged: the dense kernels are faster)."""
     assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4
     B, C, H, W = logits.shape
     assert logits.stride(3) == 1 and logits.stride(2) == W, "logits planes must be contiguous"
@@ -1641,13 +1643,13 @@ def cross_entropy_nchw(logits: torch.Tensor, target: torch.Tensor, ignore_index:
                                 int(ignore_index), loss.data_ptr(), count.data_ptr(), None,
                                 dl.data_ptr() if dl is not None else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "pp_sparse_ce_fwd_bwd")
-    if dl is not None:
+    if dl is not None and sparse:
         dl._pp_sparse_rows = True        # zero wherever target == ignore_index (model.py:113-119: all but the labelled pixels)
     return loss, dl
 
 
 def cross_entropy_lowres(low: torch.Tensor, size, target: torch.Tensor, ignore_index: int, align_corners: bool = True,
-                         want_grad: bool = True):
+                         want_grad: bool = True, sparse: bool = True):
     """F.cross_entropy(F.interpolate(low, size, 'bilinear', align_corners), target, ignore_index) and its gradient w.r.t.
     `low`, without the full-size logits (deeplab.py:55-56 + model.py:116).  low [B,h,w,C] channels-last (the classifier
     output), target [B,H,W] int64 -> (loss [1], dlow [B,h,w,C] | None)."""
@@ -1667,7 +1669,7 @@ def cross_entropy_lowres(low: torch.Tensor, size, target: torch.Tensor, ignore_i
                                                 dlow.data_ptr() if dlow is not None else None, C, ws.data_ptr(), ws.numel(),
                                                 _stream())
     _lib.check(rc, "pp_sparse_ce_lowres_fwd_bwd")
-    if dlow is not None and _SPARSE_ROWS:
+    if dlow is not None and _SPARSE_ROWS and sparse:
         # 20 labelled pixels per image (model.py:113-119) touch <= 4 low-resolution rows each: the gradient is zero in all other rows.
         # The flags ride on the tensor; the classifier's backward-data and the BatchNorm backward behind it skip the zero rows.
         flags = torch.empty(B * h * w, dtype=torch.uint8, device=dev)

@@ -252,7 +252,7 @@ class Model:
         model = get_model(self.args).to(self.device)
         kind, slow_lr, lr, wd, momentum = optimizer_spec(self.args)          # utils/utils.py:112-306, quirks included
         trainer = FlatTrainer(model, lr=lr, slow_lr=slow_lr, weight_decay=wd, optimizer=kind, momentum=momentum,
-                              ignore_index=self.ignore_index)
+                              ignore_index=self.ignore_index, sparse_labels=self.n_pixels_by_us != 0)
         n_total = self.n_epochs * self._steps_per_epoch()
         try:
             for e in range(1, 1 + self.n_epochs):

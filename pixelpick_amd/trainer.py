@@ -35,7 +35,7 @@ NATIVE_PLAN = os.environ.get("PIXELPICK_NATIVE_PLAN", "1") != "0"
 class FlatTrainer:
     def __init__(self, model, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 2e-4,
                  ignore_index: int = 19, slow_module_names=("backbone", "encoder"), process_group=None,
-                 optimizer: str = "adam", momentum: float = 0.9, slow_lr: float = None):
+                 optimizer: str = "adam", momentum: float = 0.9, slow_lr: float = None, sparse_labels: bool = True):
         """optimizer "adam": torch.optim.Adam(lr/10 for the backbone|encoder, lr for the rest) - what the reference builds for
         cs / cv (utils/utils.py:114-141; NOTE it passes only lr and weight_decay to Adam, so betas/eps are torch's defaults
         (0.9, 0.999), 1e-8 whatever args.optimizer_params says).  "sgd": torch.optim.SGD(momentum) with `slow_lr` for the
@@ -46,6 +46,10 @@ class FlatTrainer:
         self.slow_lr = lr / 10 if slow_lr is None else slow_lr
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.ignore_index = ignore_index
+        # True (model.py:108-110 with n_pixels_by_us != 0: a handful of labelled pixels per image): the loss gradient carries row flags and
+        # the classifier / BatchNorm backward behind it visit only the flagged rows.  False (the reference's fully supervised mode,
+        # n_pixels_by_us == 0: every pixel labelled): no flags - with every row flagged the row-gather kernels are slower than the dense ones
+        self.sparse_labels = bool(sparse_labels)
         self.pg = process_group
         self.world = 1
         self.collectives = False
@@ -153,13 +157,13 @@ class FlatTrainer:
             low, _ = self.model._run(tape, x, upsample=False)
             size = tuple(x.shape[2:])
             align = bool(getattr(self.model, "LOWRES_ALIGN_CORNERS", True))     # DeepLab: align_corners=True x4; FPNSeg: False, x2
-            loss, dlow = E.cross_entropy_lowres(low.t, size, y, self.ignore_index, align_corners=align)
+            loss, dlow = E.cross_entropy_lowres(low.t, size, y, self.ignore_index, align_corners=align, sparse=self.sparse_labels)
             self.last_logits = (E.bilinear(E.Tape(False), low, size, align, 0.0 if align else float(getattr(self.model, "LOWRES_SCALE_FACTOR", 0.0)),
                                            out_nchw=True).t if keep_logits else None)
             tape.backward(low, dlow)
         else:
             pred, _ = self.model._run(tape, x)
-            loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index)
+            loss, dlogits = E.cross_entropy_nchw(pred.t, y, self.ignore_index, sparse=self.sparse_labels)
             self.last_logits = pred.t if keep_logits else None
             tape.backward(pred, dlogits)
         self.last_loss = loss

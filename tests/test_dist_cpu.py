@@ -56,6 +56,37 @@ def test_ownership_and_record_gather_world2():
     assert all(r[1] for r in res)
 
 
+def _rate_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank reports its own units and its own clock: the job's figure is the SUM of the units over the SLOWEST rank's time
+        q.put((rank,) + du.whole_job_rate(units_local=120.0 * (rank + 1), elapsed_local=1.0 + 0.25 * rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_job_rate_aggregates_all_eight_ranks():
+    """bench.py's `value` contract at N = 8 (the driver's SCALE run): total units of all ranks / max-over-ranks time, the same
+    number on every rank; a single process is its own total."""
+    assert du.whole_job_rate(30.0, 2.0) == (15.0, 30.0, 2.0)
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rate_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    units = 120.0 * sum(range(1, world + 1))
+    for r in res:
+        assert r[1:] == (units / 2.75, units, 2.75)
+
+
 def test_shard_indices_cover_everything_once():
     for n in (0, 1, 7, 2975):
         for w in (1, 2, 4, 8):
