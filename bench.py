@@ -150,10 +150,10 @@ def train_step_cost_model(tr, x, y):
             n *= int(d)
         return n
 
-    def rec_conv(tape, xv, w, bias, stride=1, pad=0, dil=1, dst=None):
+    def rec_conv(tape, xv, w, bias, stride=1, pad=0, dil=1, dst=None, **kw):
         B, H, W, Cin = E.shape_of(xv)
         convs.append((B, H, W, Cin, int(w.shape[3]), int(w.shape[0]), int(w.shape[1]), stride, pad, dil, bool(xv.needs_grad)))
-        return orig_conv(tape, xv, w, bias, stride, pad, dil, dst)
+        return orig_conv(tape, xv, w, bias, stride, pad, dil, dst, **kw)
 
     def rec_record(self, fn, ctx, out):
         if self.enabled and out is not None and getattr(fn, "__name__", "") != "_concat_bwd":

@@ -208,6 +208,17 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
  * inside, as the plain entry points do; planes are ignored by calls that do not run a bf16x3 kernel).
  * pp_conv2d_x3_planes_bytes(which, ...): 0 if the call (which = 0 forward, 1 backward-data, 2 weight gradient) would not use
  * planes, else the size of its activation planes (forward / weight gradient: of x; backward-data: of dy). */
+/* Backward-data of up to four convolutions that read ONE input, as one launch (+ its split-K reduce): the ASPP branches of
+ * /root/reference/networks/aspp.py:49-57,64-67 - x1..x4 = aspp1..4(x): a 1x1 and three dilated 3x3 convolutions, stride 1, "same"
+ * padding d*(k-1)/2 - whose input gradient torch forms as four conv-backward results added up.  dy [B,H,W,>= nb*Cout] holds branch b's
+ * output gradient in channels [b*Cout, (b+1)*Cout); w_b is HWIO [k_b,k_b,Cin,Cout]; dx [B,H,W,Cin] (+)= the sum over the branches.
+ * The workspace query returns 0 where the merged form is not offered (the caller then issues pp_conv2d_bwd_data per branch). */
+size_t pp_conv2d_bwd_data_multi_workspace_bytes(int B, int H, int W, int Cin, int Cout, int nb, int k0, int d0, int k1, int d1, int k2, int d2,
+                                                int k3, int d3);
+int pp_conv2d_bwd_data_multi(const float* dy, int64_t lddy, int B, int H, int W, int Cout, int nb, const float* w0, int k0, int d0,
+                             const float* w1, int k1, int d1, const float* w2, int k2, int d2, const float* w3, int k3, int d3, float* dx,
+                             int64_t lddx, int Cin, int accumulate, void* workspace, size_t ws_bytes, pp_stream_t stream);
+
 size_t pp_x3_planes_bytes(int64_t rows, int C);
 int pp_x3_split(const float* x, int64_t ldx, int64_t rows, int C, void* planes, size_t planes_bytes, pp_stream_t stream);
 size_t pp_conv2d_x3_planes_bytes(int which, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);

@@ -60,6 +60,9 @@ SIGNATURES = {
     "pp_x3_split": (_int, [_p, _i64, _i64, _int, _p, _sz, _p]),
     "pp_conv2d_x3_planes_bytes": (_sz, [_int] * 11),
     "pp_conv2d_fwd_pre": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p, _p]),
+    "pp_conv2d_bwd_data_multi_workspace_bytes": (_sz, [_int] * 14),
+    "pp_conv2d_bwd_data_multi": (_int, [_p, _i64, _int, _int, _int, _int, _int, _p, _int, _int, _p, _int, _int, _p, _int, _int, _p, _int, _int,
+                                       _p, _i64, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_data_pre": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p, _p]),
     "pp_conv2d_bwd_weight_pre": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p, _p, _p]),
     "pp_conv2d_bwd_weight_partials": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p, _p]),

@@ -93,6 +93,11 @@ struct ConvParams {
     const float* in_scale;   // forward of a 1x1 / pad-0 convolution BEHIND a training BatchNorm whose apply pass was skipped: the A
     const float* in_shift;   // operand is act(fma(x, in_scale[c], in_shift[c])) (bn_apply_kernel's arithmetic), applied where the
     int in_act;              // operand is read.  NULL: x as it is.  (conv_igemm_kernel VEC path, conv1x1_ksplit_dma_kernel)
+    // several convolutions' backward-data as ONE implicit GEMM (pp_conv2d_bwd_data_multi: the ASPP branches, aspp.py:49-57, all read
+    // one input): tap t of the merged reduction reads the A operand tap_coff[t] channels into its row and its weights tap_woff[t]
+    // elements behind `w` (conv_igemm_dma_kernel only; 0: the tap table's own addressing)
+    int multi;
+    int tap_coff[32], tap_woff[32];
     BnTrain bn;
     float* stats;     // training forward in front of a BatchNorm: per-wave column sums / sums of squares of the stored outputs,
                       // [rows_partial][2][Cn], rows_partial = m0 / (TM*32) + wm (see conv_epilogue); NULL: none
@@ -883,8 +888,8 @@ __global__ __launch_bounds__(kThreads, (BNF ? 3 : (BM * BN >= 128 * 128 ? 3 : 4)
     // and scalar loads force lgkmcnt(0) waits that also drain the fragment reads)
     __shared__ int s_tap[32][2];
     if (tid < p.taps.n) {
-        s_tap[tid][0] = (p.taps.dh[tid] * p.W + p.taps.dw[tid]) * (int)p.ldx;
-        s_tap[tid][1] = p.taps.widx[tid] * p.Cin * p.Cout;
+        s_tap[tid][0] = (p.taps.dh[tid] * p.W + p.taps.dw[tid]) * (int)p.ldx + (p.multi ? p.tap_coff[tid] : 0);
+        s_tap[tid][1] = p.multi ? p.tap_woff[tid] : p.taps.widx[tid] * p.Cin * p.Cout;
     }
     __syncthreads();
     // (tap, chunk) of the next step to issue, advanced incrementally (steps are issued strictly in order)
@@ -4480,6 +4485,112 @@ int pp_conv2d_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int
 {
     return conv2d_bwd_data_impl(dy, lddy, B, Ho, Wo, Cout, w, kh, kw, stride, pad, dil, dx, lddx, H, W, Cin, accumulate, workspace, ws_bytes,
                                 stream, nullptr);
+}
+
+// ---- backward-data of several convolutions that read ONE input, as one implicit GEMM --------------------------------------------------
+// aspp.py:49-57: the four ASPP branches (1x1 and three dilated 3x3, stride 1, "same" padding) all convolve the encoder output, so
+// its gradient is  dX = sum_b conv_bwd_data(dY_b, W_b)  - four launches, three split-K reduces and three adds in the per-layer form.
+// With the branch gradients side by side in one [B,H,W,nb*Cout] buffer the sum IS one convolution whose reduction runs over
+// (branch, tap, channel): the merged tap table carries each tap's channel offset into dY and its weight offset behind the lowest
+// weight pointer (the branch weights are separate tensors; their distances must fit 31 bits of elements).  Dead taps (a dilation
+// larger than the map) are dropped per branch as build_taps does.  Same products, summed in one fp32 accumulation per output instead of
+// four rounded partial results added afterwards.
+struct MultiBwd { ConvParams p; ConvPlan pl; bool ok; };
+static MultiBwd multi_bwd_setup(int B, int H, int W, int Cin, int Cout, int nb, const int* k, const int* d, int64_t lddy)
+{
+    MultiBwd m{};
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || nb < 2 || nb > 4) return m;
+    ConvParams& p = m.p;
+    p.ldx = lddy; p.B = B; p.H = H; p.W = W; p.Ho = H; p.Wo = W; p.Ck = Cout; p.Cn = Cin; p.Cin = Cin; p.Cout = Cout;
+    p.stride = 1; p.M = (int64_t)B * H * W; p.bwd_stride = 1; p.multi = 1;
+    p.taps.n = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (k[b] < 1 || (k[b] & 1) == 0 || d[b] < 1 || k[b] * k[b] > kMaxTaps) return m;
+        ConvTaps t;
+        build_taps(t, k[b], k[b], 1, d[b] * (k[b] - 1) / 2, d[b], H, W, H, W, true, 1);
+        for (int i = 0; i < t.n; ++i) {
+            if (p.taps.n >= 32) return m;
+            p.taps.dh[p.taps.n] = t.dh[i]; p.taps.dw[p.taps.n] = t.dw[i];
+            p.taps.widx[p.taps.n] = (b << 8) | t.widx[i];        // (branch, tap) until the pointers are known: multi_bwd_bind
+            p.tap_coff[p.taps.n] = b * Cout;
+            ++p.taps.n;
+        }
+    }
+    if (p.taps.n == 0 || p.M > 0x7FFFFFFFll) return m;
+    const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && lddy % 4 == 0;
+    m.pl = plan_conv(p.M, Cin, Cout, p.taps.n, vec);
+    if (m.pl.cfg == 2 && m.pl.splits > 1) {
+        // the merged reduction is 20 - 30 taps deep: aim at one full wave of blocks (4 per CU) rather than plan_conv's 512 - at the
+        // BASELINE shape 160 tiles x 4 slices left the CUs with 2 or 3 blocks each (130 us; 6 slices: one even round)
+        const int nk = p.taps.n * (int)cdiv(Cout, BK);
+        int64_t sp = (int64_t)device_cus() * 4 / m.pl.tiles;
+        if (sp > nk / g_splitk_min_iters) sp = nk / g_splitk_min_iters;
+        if (sp > 32) sp = 32;
+        if (sp > m.pl.splits) {
+            m.pl.ks_per_split = (int)cdiv(nk, sp);
+            m.pl.splits = (int)cdiv(nk, m.pl.ks_per_split);
+        }
+    }
+    // the kernel that knows the merged addressing: 64 x 64 tiles through the LDS-DMA pipeline
+    m.ok = vec && m.pl.cfg == 2 && g_conv_dma64 == 1 && (int64_t)B * H * W * lddy < (1ll << 31) - (1ll << 24);
+    return m;
+}
+
+size_t pp_conv2d_bwd_data_multi_workspace_bytes(int B, int H, int W, int Cin, int Cout, int nb, int k0, int d0, int k1, int d1, int k2, int d2,
+                                                int k3, int d3)
+{
+    const int k[4] = {k0, k1, k2, k3}, d[4] = {d0, d1, d2, d3};
+    const MultiBwd m = multi_bwd_setup(B, H, W, Cin, Cout, nb, k, d, (int64_t)nb * Cout);
+    if (!m.ok) return 0;                      // not offered for this shape: the caller keeps the per-layer calls
+    return align_up(m.pl.splits > 1 ? (size_t)m.pl.splits * m.p.M * Cin * 4 : 256, 256);
+}
+
+int pp_conv2d_bwd_data_multi(const float* dy, int64_t lddy, int B, int H, int W, int Cout, int nb, const float* w0, int k0, int d0,
+                             const float* w1, int k1, int d1, const float* w2, int k2, int d2, const float* w3, int k3, int d3, float* dx,
+                             int64_t lddx, int Cin, int accumulate, void* workspace, size_t ws_bytes, pp_stream_t stream)
+{
+    const int k[4] = {k0, k1, k2, k3}, d[4] = {d0, d1, d2, d3};
+    const float* w[4] = {w0, w1, w2, w3};
+    if (!dy || !dx || lddy < (int64_t)nb * Cout || lddx < Cin) return fail(PP_ERR_BAD_ARG, "conv bwd_data multi: null / leading dimension");
+    MultiBwd m = multi_bwd_setup(B, H, W, Cin, Cout, nb, k, d, lddy);
+    if (!m.ok) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data multi: not offered for this shape (ask the workspace query first)");
+    const float* base = nullptr;
+    for (int b = 0; b < nb; ++b) {
+        if (!w[b]) return fail(PP_ERR_BAD_ARG, "conv bwd_data multi: null weight");
+        if (!base || w[b] < base) base = w[b];
+    }
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15) || lddx % 4 != 0)
+        return fail(PP_ERR_BAD_ARG, "conv bwd_data multi: dy / dx must be 16-byte aligned");
+    ConvParams& p = m.p;
+    for (int t = 0; t < p.taps.n; ++t) {
+        const int b = p.taps.widx[t] >> 8, lt = p.taps.widx[t] & 255;
+        const int64_t off = (w[b] - base) + (int64_t)lt * Cin * Cout;
+        if ((reinterpret_cast<uintptr_t>(w[b]) & 15) || off + (int64_t)Cin * Cout >= (1ll << 31))
+            return fail(PP_ERR_UNSUPPORTED, "conv bwd_data multi: the branch weights must be 16-byte aligned and within 8 GiB of each other");
+        p.tap_woff[t] = (int)off;
+        p.taps.widx[t] = 0;
+    }
+    const size_t need = m.pl.splits > 1 ? (size_t)m.pl.splits * p.M * Cin * 4 : 0;
+    if (need && (!workspace || ws_bytes < need)) return fail(PP_ERR_WORKSPACE, "conv bwd_data multi: workspace %zu < %zu", ws_bytes, need);
+    hipStream_t st = as_stream(stream);
+    EventScope ev(st);
+    p.x = dy; p.w = base; p.bias = nullptr; p.y = dx; p.ldy = lddx; p.accumulate = accumulate ? 1 : 0;
+    p.xcd_remap = g_conv_xcd_remap;
+    p.tap_inner = g_conv_tap_inner;
+    p.n_tiles = m.pl.n_tiles;
+    p.splits = m.pl.splits;
+    p.ks_per_split = m.pl.ks_per_split;
+    p.part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<64, 64, true>), dim3((unsigned)m.pl.tiles, (unsigned)m.pl.splits), dim3(kThreads), 0, st, p);
+    if (int rc = check_launch("conv_igemm_dma_kernel<multi>")) return rc;
+    if (m.pl.splits > 1) {
+        int64_t nblk = cdiv(p.M * (p.Cn / 4), 256);
+        if (nblk > 8192) nblk = 8192;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p.part, m.pl.splits, p.M, p.Cn, p.bias, p.y, p.ldy, p.epi,
+                           p.accumulate);
+        return check_launch("splitk_reduce_kernel");
+    }
+    return PP_OK;
 }
 
 // ---- bf16x3 operand planes shared between the calls of a layer ---------------------------------------------------------------------

@@ -29,7 +29,7 @@ class Var:
     tensor does not exist yet.  If the next consumer is an eval-mode BatchNorm, conv + BN (+ residual) + activation go
     out as ONE launch (pp_conv2d_fwd_bn_act / pp_dwconv3x3_fwd_bn_act); any other consumer reads `.t`, which launches
     the plain convolution first."""
-    __slots__ = ("_t", "grad", "needs_grad", "_pending", "_lazy", "_bn_bwd_ctx", "_closed")
+    __slots__ = ("_t", "grad", "needs_grad", "_pending", "_lazy", "_bn_bwd_ctx", "_closed", "_grad_dst")
 
     def __init__(self, t: Optional[torch.Tensor], needs_grad: bool = True):
         self._t = t
@@ -45,6 +45,9 @@ class Var:
         # afterwards means the consumer count was wrong, and raises
         self._bn_bwd_ctx = None
         self._closed = False
+        # where this Var's gradient should be WRITTEN by the (single) op that produces it: a channel slice of a wider buffer (the
+        # ASPP branches' output gradients side by side, ConvBwdGroup).  None: the producer allocates.
+        self._grad_dst = None
 
     @property
     def t(self) -> torch.Tensor:
@@ -813,9 +816,79 @@ def _conv_ws(bwd: bool, device, *shape):
     return buf.data_ptr(), buf.numel()
 
 
+class ConvBwdGroup:
+    """Backward-data of several convolutions that read ONE input (the ASPP branches, aspp.py:49-57,64-67), issued as one launch
+    (pp_conv2d_bwd_data_multi) by the last of them whose backward runs.  The branches' output gradients sit side by side in `dbuf`
+    [B,H,W,n*Cout] - each branch's BatchNorm backward writes its slice there directly (Var._grad_dst) - and the input's gradient is
+    one implicit GEMM over (branch, tap, channel) instead of n launches, n split-K reduces and n - 1 adds."""
+
+    def __init__(self, x: Var, specs, ws_bytes: int):
+        B, H, W, Cin = shape_of(x)
+        self.x, self.specs, self.ws_bytes = x, specs, ws_bytes         # specs: [(w, k, dil)] in branch order
+        self.n = len(specs)
+        self.Cout = specs[0][0].shape[3]
+        self.dbuf = torch.empty((B, H, W, self.n * self.Cout), dtype=torch.float32, device=x.t.device)
+        self.arrived = [False] * self.n
+
+    def slice(self, i: int) -> torch.Tensor:
+        return self.dbuf[..., i * self.Cout:(i + 1) * self.Cout]
+
+    @staticmethod
+    def offered(x: Var, specs) -> int:
+        """Workspace bytes of the merged launch for these branches, 0 when it is not offered (odd kernel sizes with "same"
+        padding, stride 1, equal Cout, 2..4 branches, a shape the 64 x 64 LDS-DMA kernel takes)."""
+        if not (2 <= len(specs) <= 4):
+            return 0
+        B, H, W, Cin = shape_of(x)
+        Cout = specs[0][0].shape[3]
+        flat = []
+        for w, k, d in specs:
+            if tuple(w.shape) != (k, k, Cin, Cout) or w.data_ptr() & 15:
+                return 0
+            flat += [k, d]
+        flat += [0, 0] * (4 - len(specs))
+        # the merged launch addresses every branch's weights from the lowest pointer with 31-bit element offsets: the trainer's flat
+        # parameter buffer always qualifies, separately allocated tensors only when the allocator put them within 8 GiB
+        ptrs = [w.data_ptr() for w, _, _ in specs]
+        if max(ptrs) - min(ptrs) + max(w.numel() for w, _, _ in specs) * 4 >= (1 << 33) - (1 << 26):
+            return 0
+        return int(_lib.lib().pp_conv2d_bwd_data_multi_workspace_bytes(B, H, W, Cin, Cout, len(specs), *flat))
+
+    def arrive(self, tape: "Tape", i: int, dy: torch.Tensor):
+        if self.arrived[i]:
+            raise RuntimeError("ConvBwdGroup: a branch's backward ran twice")
+        sl = self.slice(i)
+        if dy.data_ptr() != sl.data_ptr() or dy.stride() != sl.stride():
+            sl.copy_(dy)                                   # the producer did not write in place (not the BatchNorm backward): one copy
+        self.arrived[i] = True
+        if not all(self.arrived):
+            return
+        x = self.x
+        if not x.needs_grad:
+            return
+        B, H, W, Cin = shape_of(x)
+        dev = self.dbuf.device
+        acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
+                              and tuple(x.grad.shape) == (B, H, W, Cin)) else None
+        dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        ws = _ws(self.ws_bytes, dev)
+        args = []
+        for w, k, d in self.specs:
+            args += [w.data_ptr(), k, d]
+        args += [None, 0, 0] * (4 - self.n)
+        rc = _lib.lib().pp_conv2d_bwd_data_multi(self.dbuf.data_ptr(), self.n * self.Cout, B, H, W, self.Cout, self.n, *args, dx.data_ptr(), Cin, Cin,
+                                                 1 if acc_into is not None else 0, ws.data_ptr(), ws.numel(), _stream())
+        _lib.check(rc, "pp_conv2d_bwd_data_multi")
+        tape._keepalive.append(self.dbuf)
+        if acc_into is None:
+            dx._pp_owned = True
+            _acc(x, dx)
+
+
 def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, dil=1,
-           dst: Optional[torch.Tensor] = None) -> Var:
-    """nn.Conv2d (groups=1).  w: HWIO [kh,kw,Cin,Cout].  dst: optional NHWC view to write into."""
+           dst: Optional[torch.Tensor] = None, bwd_group=None) -> Var:
+    """nn.Conv2d (groups=1).  w: HWIO [kh,kw,Cin,Cout].  dst: optional NHWC view to write into.
+    bwd_group: (ConvBwdGroup, branch index) - this convolution's backward-data is left to the group's merged launch."""
     B, H, W, Cin = shape_of(x)          # (no launch: x may be a deferred convolution or a skipped BatchNorm apply)
     kh, kw, wcin, Cout = w.shape
     assert wcin == Cin, f"conv2d: Cin {Cin} vs weight {tuple(w.shape)}"
@@ -830,7 +903,9 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
         # launches the plain convolution
         out = Var(None)
         out._pending = ("conv", x, w, bias, stride, pad, dil)
-        tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil), out)
+        if bwd_group is not None:
+            out._grad_dst = bwd_group[0].slice(bwd_group[1])
+        tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil, None, bwd_group), out)
         return out
     _, _, _, _, ldx = _geom(x.t)
     Ho, Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
@@ -849,11 +924,13 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
                                       kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, _stream())
     _lib.check(rc, "pp_conv2d_fwd")
     out = Var(y)
-    tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil, xp), out)
+    if bwd_group is not None and tape.enabled:
+        out._grad_dst = bwd_group[0].slice(bwd_group[1])
+    tape.record(_conv2d_bwd, (x, w, bias, stride, pad, dil, xp, bwd_group), out)
     return out
 
 
-def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil, xp=None):
+def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil, xp=None, bwd_group=None):
     L = _lib.lib()
     lazy_in = x._lazy if (x._t is None and x._lazy is not None) else None
     B, H, W, Cin, ldx = _geom(lazy_in[0] if lazy_in is not None else x.t)
@@ -982,6 +1059,12 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
     # PIXELPICK_WGRAD_LATE (default off; measured, profiles/r03_side_queue.txt): backward-data first, then the fork and the weight
     # gradient - on the second queue it would then start when this layer's backward-data has finished and overlap the memory-bound
     # BatchNorm backward behind it instead of the backward-data of its own layer.  Slower both eager and replayed (+0.05 ms).
+    if bwd_group is not None:
+        # the input gradient comes from the group's merged launch (issued by the last branch to arrive); the weight gradient is this layer's own
+        if w.requires_grad:
+            _issue_wgrad()
+        bwd_group[0].arrive(tape, bwd_group[1], dy)
+        return
     if w.requires_grad and (big or not _WGRAD_LATE):
         _issue_wgrad()
         _issue_dx()
@@ -1366,7 +1449,12 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
     dev = dy.device
     dgamma = tape.grad_buffer_for(gamma)
     dbeta = tape.grad_buffer_for(beta)
-    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    gd = x._grad_dst if x.grad is None else None          # the consumer of this gradient wants it in a slice of its own buffer
+    if gd is not None and not (tuple(gd.shape) == (B, H, W, C) and gd.stride(3) == 1 and gd.stride(2) % 4 == 0 and gd.data_ptr() % 16 == 0
+                               and gd.stride(1) == W * gd.stride(2) and gd.stride(0) == H * gd.stride(1)):
+        gd = None
+    dx = gd if gd is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+    lddx = dx.stride(2)
     dres = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (residual is not None and residual.needs_grad) else None
     if _BN_FUSED and M <= _BN_FUSED_MAXM and C <= 65536 and _bn_exchange_ok(dev):
         sync, ws = _bn_exchange(dev)
@@ -1376,20 +1464,20 @@ def _bn_bwd(tape: Tape, dy, x: Var, gamma, beta, mean, invstd, act, residual, ou
         if flags is not None and flags.numel() == M:
             rc = L.pp_bn_bwd_fused_sparse(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
                                         mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                        dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),
+                                        dx.data_ptr(), lddx, dres.data_ptr() if dres is not None else None, C, float(gscale),
                                         beta.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), flags.data_ptr(), _stream())
             tape._keepalive.append(flags)
         else:
             rc = L.pp_bn_bwd_fused(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, None if remask else out.t.data_ptr(), ldya, act, M, C,
                                    mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                   dx.data_ptr(), C, dres.data_ptr() if dres is not None else None, C, float(gscale),
+                                   dx.data_ptr(), lddx, dres.data_ptr() if dres is not None else None, C, float(gscale),
                                    beta.data_ptr(), ws.data_ptr(), ws.numel(), sync.data_ptr(), sync.numel(), _stream())
         _lib.check(rc, "pp_bn_bwd_fused")
     else:
         assert gscale == 1.0, "a fused dropout is only created together with the single-launch BatchNorm"
         ws = _ws(_wsbytes("pp_colreduce_workspace_bytes", M, C), dev)
         rc = L.pp_bn_bwd(x.t.data_ptr(), ldx, dy.data_ptr(), lddy, out.t.data_ptr(), ldya, act, M, C, mean.data_ptr(), invstd.data_ptr(),
-                         gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), C,
+                         gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), lddx,
                          dres.data_ptr() if dres is not None else None, C, ws.data_ptr(), ws.numel(), _stream())
         _lib.check(rc, "pp_bn_bwd")
     if gamma.requires_grad:

@@ -4,11 +4,15 @@ The five branches write straight into their channel slice of one [B,H,W,1280] bu
 torch.cat, aspp.py:73, costs nothing) and the image-pooling branch's bilinear upsample of a 1x1 map
 (aspp.py:69-70) is a broadcast.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import engine as E
 from .layers import BatchNorm2d, Conv2d, Dropout, ReLU
+
+_ASPP_MERGE = os.environ.get("PIXELPICK_ASPP_MERGE", "1") != "0"
 
 
 class _ASPPModule(nn.Module):
@@ -20,8 +24,8 @@ class _ASPPModule(nn.Module):
         self.bn = BatchNorm(planes)
         self.relu = ReLU()
 
-    def run(self, tape, x, dst=None):
-        return self.bn.run(tape, self.atrous_conv.run(tape, x), E.ACT_RELU, dst=dst)
+    def run(self, tape, x, dst=None, bwd_group=None):
+        return self.bn.run(tape, self.atrous_conv.run(tape, x, bwd_group=bwd_group), E.ACT_RELU, dst=dst)
 
 
 class ASPP(nn.Module):
@@ -51,10 +55,23 @@ class ASPP(nn.Module):
     def run(self, tape, x):
         B, H, W, _ = x.t.shape
         buf = torch.empty((B, H, W, 1280), dtype=torch.float32, device=x.t.device)
-        x1 = self.aspp1.run(tape, x, dst=buf[..., 0:256])
-        x2 = self.aspp2.run(tape, x, dst=buf[..., 256:512])
-        x3 = self.aspp3.run(tape, x, dst=buf[..., 512:768])
-        x4 = self.aspp4.run(tape, x, dst=buf[..., 768:1024])
+        # training: the four branches read one input, so its gradient is ONE backward-data launch over (branch, tap, channel)
+        # (engine.ConvBwdGroup / pp_conv2d_bwd_data_multi) instead of four launches + three split-K reduces + three adds;
+        # PIXELPICK_ASPP_MERGE=0: the per-layer form
+        grp = None
+        if tape.enabled and self.training and x.needs_grad and _ASPP_MERGE:
+            branches = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)
+            specs = [(m.atrous_conv.weight, m.atrous_conv.kernel_size, m.atrous_conv.dilation) for m in branches]
+            same = all(m.atrous_conv.stride == 1 and m.atrous_conv.bias is None and m.atrous_conv.weight.requires_grad and
+                       m.atrous_conv.padding == m.atrous_conv.dilation * (m.atrous_conv.kernel_size - 1) // 2 for m in branches)
+            nws = E.ConvBwdGroup.offered(x, specs) if same else 0
+            if nws:
+                grp = E.ConvBwdGroup(x, specs, nws)
+        g = (lambda i: (grp, i)) if grp is not None else (lambda i: None)
+        x1 = self.aspp1.run(tape, x, dst=buf[..., 0:256], bwd_group=g(0))
+        x2 = self.aspp2.run(tape, x, dst=buf[..., 256:512], bwd_group=g(1))
+        x3 = self.aspp3.run(tape, x, dst=buf[..., 512:768], bwd_group=g(2))
+        x4 = self.aspp4.run(tape, x, dst=buf[..., 768:1024], bwd_group=g(3))
         pooled = E.global_avg_pool(tape, x)
         x5 = self.global_avg_pool[2].run(tape, self.global_avg_pool[1].run(tape, pooled), E.ACT_RELU)
         x5 = E.broadcast_hw(tape, x5, H, W, dst=buf[..., 1024:1280])

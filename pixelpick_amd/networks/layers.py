@@ -94,12 +94,13 @@ class Conv2d(nn.Module):
         k = self.kernel_size
         return E.conv_accepts_lazy_input(B, H, W, C, self.out_channels, k, k, self.stride, self.padding + extra_pad, self.dilation)
 
-    def run(self, tape, x, dst=None, extra_pad: int = 0):
+    def run(self, tape, x, dst=None, extra_pad: int = 0, bwd_group=None):
         """extra_pad: zero padding applied to x in front of this convolution (F.pad(x, extra_pad) then conv), folded
-        into the kernel's own bounds handling instead of materialising the padded tensor."""
+        into the kernel's own bounds handling instead of materialising the padded tensor.
+        bwd_group: (engine.ConvBwdGroup, index) - several convolutions of one input share one backward-data launch."""
         if self.depthwise:
             return E.dwconv3x3(tape, x, self.weight, self.stride, self.padding + extra_pad, self.dilation)
-        return E.conv2d(tape, x, self.weight, self.bias, self.stride, self.padding + extra_pad, self.dilation, dst=dst)
+        return E.conv2d(tape, x, self.weight, self.bias, self.stride, self.padding + extra_pad, self.dilation, dst=dst, bwd_group=bwd_group)
 
     def forward(self, x):
         raise RuntimeError("pixelpick_amd layers execute through run(tape, x); call the network's forward()")

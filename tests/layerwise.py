@@ -155,8 +155,8 @@ class LayerwiseParity:
         self._saved = (L.Conv2d.run, L.BatchNorm2d.run, D.GroupNorm.run, E._conv2d_bwd, E._dwconv_bwd, E._bn_bwd, E._gn_bwd)
         conv_run, bn_run, gn_run, conv_bwd, dw_bwd, bn_bwd, gn_bwd = self._saved
 
-        def conv_run_p(self, tape, x, dst=None, extra_pad=0):
-            out = conv_run(self, tape, x, dst, extra_pad)
+        def conv_run_p(self, tape, x, dst=None, extra_pad=0, **kw):
+            out = conv_run(self, tape, x, dst, extra_pad, **kw)
             n = me.mod_name[id(self)]
             if out._pending is not None:
                 # deferred (the engine launches it when its consumer is known - with the statistics epilogue when that is a

@@ -148,3 +148,88 @@ def test_aspp(hw):
     got["input"] = nchw(xv.grad)
     for k in gr:
         _check(k, got[k], gr[k], gn[k], gd[k])
+
+
+@pytest.mark.parametrize("backbone,stride,hw", [("mobilenet", 16, (16, 32)), ("mobilenet", 16, (23, 30)), ("resnet", 8, (16, 24))])
+def test_aspp_merged_backward_equals_the_per_layer_form(backbone, stride, hw, monkeypatch):
+    """aspp.py:49-57,64-67: the four branches read one input.  Its gradient as ONE backward-data launch over (branch, tap, channel)
+    (engine.ConvBwdGroup / pp_conv2d_bwd_data_multi, the branch BatchNorms' backward writing straight into the merged operand) must
+    equal the per-layer form - four backward-data launches, their split-K reduces and the adds - up to fp32 summation order; every
+    parameter gradient is the same launch in both forms and must not move a bit."""
+    from pixelpick_amd.networks import aspp as aspp_mod
+    H, W = hw
+    mod = _formula(ASPP(backbone, stride, BatchNorm2d)).to(DEV).train()
+    # parameters in ONE buffer, as trainer.FlatTrainer holds them (the merged launch addresses the branch weights from the lowest pointer)
+    ps = list(mod.parameters())
+    flat = torch.empty(sum((p.numel() + 3) // 4 * 4 for p in ps), device=DEV)
+    off = 0
+    for p in ps:
+        flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+        p.data = flat[off:off + p.numel()].view_as(p)
+        off += (p.numel() + 3) // 4 * 4
+    cin = mod.aspp1.atrous_conv.in_channels
+    x0 = fi.fill((2, cin, H, W), "xm", -1, 1)
+    dy = fi.fill((2, 256, H, W), "dym", -1, 1)
+    res = {}
+    for merged in (False, True):
+        monkeypatch.setattr(aspp_mod, "_ASPP_MERGE", merged)
+        tape = E.Tape()
+        xv = E.Var(nhwc(x0))
+        if merged:
+            specs = [(m.atrous_conv.weight, m.atrous_conv.kernel_size, m.atrous_conv.dilation) for m in (mod.aspp1, mod.aspp2, mod.aspp3, mod.aspp4)]
+            assert E.ConvBwdGroup.offered(xv, specs) > 0, "the merged form is not offered for this shape: the test would compare the per-layer form with itself"
+        yv = mod.run(tape, xv)
+        tape.backward(yv, nhwc(dy))
+        torch.cuda.synchronize()
+        res[merged] = (nchw(yv.t), nchw(xv.grad), _grads_oihw(mod, tape))
+    assert torch.equal(res[True][0], res[False][0])
+    assert rel(res[True][1], res[False][1]) <= 2e-5
+    for k in res[False][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
+def test_conv_bwd_data_multi_op():
+    """pp_conv2d_bwd_data_multi against the sum of pp_conv2d_bwd_data results: branch gradients as channel slices of one buffer,
+    dead taps of a dilation larger than the map, accumulate into an existing gradient, weights at arbitrary distances."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(5)
+    B, H, W, Cin, Cout = 2, 16, 24, 64, 32
+    specs = [(1, 1), (3, 6), (3, 12), (3, 18)]
+    ws_ = [torch.randn(k, k, Cin, Cout, device=DEV) * 0.1 for k, _ in specs]
+    dbuf = torch.randn(B, H, W, 4 * Cout + 8, device=DEV)[..., :4 * Cout]          # a slice of a wider buffer: ld != n * Cout
+    nws = int(L.pp_conv2d_bwd_data_multi_workspace_bytes(B, H, W, Cin, Cout, 4, 1, 1, 3, 6, 3, 12, 3, 18))
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    ref = torch.zeros(B, H, W, Cin, device=DEV)
+    for b, ((k, d), w) in enumerate(zip(specs, ws_)):
+        dyb = dbuf[..., b * Cout:(b + 1) * Cout].contiguous()
+        dxb = torch.empty(B, H, W, Cin, device=DEV)
+        w1 = torch.empty(int(L.pp_conv2d_bwd_data_workspace_bytes(B, H, W, Cin, Cout, k, k, 1, d * (k - 1) // 2, d)) + 256, dtype=torch.uint8, device=DEV)
+        _lib.check(L.pp_conv2d_bwd_data(dyb.data_ptr(), Cout, B, H, W, Cout, w.data_ptr(), k, k, 1, d * (k - 1) // 2, d, dxb.data_ptr(), Cin, H, W, Cin, 0,
+                                        w1.data_ptr(), w1.numel(), st), "ref")
+        ref += dxb
+    for acc in (0, 1):
+        dx = torch.full((B, H, W, Cin), 0.5, device=DEV)
+        args = []
+        for (k, d), w in zip(specs, ws_):
+            args += [w.data_ptr(), k, d]
+        _lib.check(L.pp_conv2d_bwd_data_multi(dbuf.data_ptr(), dbuf.stride(2), B, H, W, Cout, 4, *args, dx.data_ptr(), Cin, Cin, acc, ws.data_ptr(), ws.numel(), st), "multi")
+        assert rel(dx.cpu(), (ref + 0.5 * acc).cpu()) <= 2e-5, acc
+    # two branches only, and the refusals
+    assert int(L.pp_conv2d_bwd_data_multi_workspace_bytes(B, H, W, Cin, Cout, 1, 3, 6, 0, 0, 0, 0, 0, 0)) == 0          # one branch: nothing to merge
+    assert int(L.pp_conv2d_bwd_data_multi_workspace_bytes(B, H, W, Cin, Cout, 2, 2, 1, 3, 6, 0, 0, 0, 0)) == 0          # even kernel size: no "same" padding
+    dx2 = torch.empty(B, H, W, Cin, device=DEV)
+    _lib.check(L.pp_conv2d_bwd_data_multi(dbuf.data_ptr(), dbuf.stride(2), B, H, W, Cout, 2, ws_[0].data_ptr(), 1, 1, ws_[1].data_ptr(), 3, 6, None, 0, 0, None, 0, 0,
+                                          dx2.data_ptr(), Cin, Cin, 0, ws.data_ptr(), ws.numel(), st), "multi2")
+    ref2 = torch.zeros(B, H, W, Cin, device=DEV)
+    for b in (0, 1):
+        k, d = specs[b]
+        dyb = dbuf[..., b * Cout:(b + 1) * Cout].contiguous()
+        dxb = torch.empty(B, H, W, Cin, device=DEV)
+        w1 = torch.empty(int(L.pp_conv2d_bwd_data_workspace_bytes(B, H, W, Cin, Cout, k, k, 1, d * (k - 1) // 2, d)) + 256, dtype=torch.uint8, device=DEV)
+        _lib.check(L.pp_conv2d_bwd_data(dyb.data_ptr(), Cout, B, H, W, Cout, ws_[b].data_ptr(), k, k, 1, d * (k - 1) // 2, d, dxb.data_ptr(), Cin, H, W, Cin, 0,
+                                        w1.data_ptr(), w1.numel(), st), "ref2")
+        ref2 += dxb
+    assert rel(dx2.cpu(), ref2.cpu()) <= 2e-5

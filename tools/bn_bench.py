@@ -36,20 +36,30 @@ def bench(M, C, iters=30):
         _lib.check(L.pp_bn_bwd_fused(x.data_ptr(), C, dy.data_ptr(), C, None, C, 2, M, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                      dg.data_ptr(), db.data_ptr(), dx.data_ptr(), C, None, 0, 1.0, beta.data_ptr(), ws.data_ptr(), ws.numel(),
                                      sync.data_ptr(), sync.numel(), st), "bwd")
+    # yardsticks with the same traffic through trivial elementwise launches: y = x (read S, write S) and dx = x + dy (read 2S, write S)
+    def copy():
+        y.copy_(x)
+
+    def add():
+        torch.add(x, dy, out=dx)
     out = []
-    for fn in (fwd, bwd):
+    for fn in (fwd, bwd, copy, add):
         fn()
-        ts = []
-        for _ in range(iters):
-            flush.zero_()                       # evict x from the 256 MiB MALL: every launch starts cold
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            fn()
-            b.record()
-            torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b) * 1e3)
-        ts.sort()
-        out.append(ts[len(ts) // 2])
+        for cold in (True, False):
+            ts = []
+            for _ in range(iters):
+                if cold:
+                    flush.zero_()                   # evict x from the 256 MiB MALL: the launch starts cold
+                else:
+                    fn()                            # warm: the tensors were touched by the launch before (in the step the producer has just written x)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3)
+            ts.sort()
+            out.append(ts[len(ts) // 2])
     return out
 
 
@@ -59,10 +69,12 @@ def main():
     for kb in knobs:
         L.pp_debug_set_bn_bytes_per_block(kb)
         print(f"== bytes per block {kb}")
+        print("  map                            bytes S | forward: cold, warm us (TB/s of 2S) | y = x: cold, warm us | backward: cold, warm us (TB/s of 3S) | dx = x + dy: cold, warm us")
         for name, M, C in SHAPES:
-            f, b = bench(M, C)
+            fc, fw, bc, bw, cc, cw, ac, aw = bench(M, C)
             S = M * C * 4
-            print(f"  {name:28s} {S / 1e6:6.1f} MB  fwd {f:7.1f} us ({2 * S / f / 1e6:5.2f} TB/s of 2S)   bwd {b:7.1f} us ({3 * S / b / 1e6:5.2f} TB/s of 3S)")
+            print(f"  {name:28s} {S / 1e6:6.1f} MB | {fc:6.1f} {fw:6.1f} ({2 * S / fc / 1e6:4.2f} {2 * S / fw / 1e6:4.2f}) | {cc:6.1f} {cw:6.1f} ({2 * S / cc / 1e6:4.2f} {2 * S / cw / 1e6:4.2f}) |"
+                  f" {bc:6.1f} {bw:6.1f} ({3 * S / bc / 1e6:4.2f} {3 * S / bw / 1e6:4.2f}) | {ac:6.1f} {aw:6.1f} ({3 * S / ac / 1e6:4.2f} {3 * S / aw / 1e6:4.2f})")
 
 
 if __name__ == "__main__":

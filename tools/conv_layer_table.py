@@ -27,11 +27,11 @@ def main():
     seen = collections.OrderedDict()
     orig = engine.conv2d
 
-    def rec(tape, xv, w, bias, stride=1, pad=0, dil=1, dst=None):
+    def rec(tape, xv, w, bias, stride=1, pad=0, dil=1, dst=None, **kw):
         Bn, Hh, Ww, Cin, _ = engine._geom(xv.t)
         key = (Bn, Hh, Ww, Cin, w.shape[3], w.shape[0], w.shape[1], stride, pad, dil, bool(xv.needs_grad))
         seen[key] = seen.get(key, 0) + 1
-        return orig(tape, xv, w, bias, stride, pad, dil, dst)
+        return orig(tape, xv, w, bias, stride, pad, dil, dst, **kw)
 
     engine.conv2d = rec
     for mod in list(sys.modules.values()):
