@@ -228,6 +228,17 @@ int pp_conv2d_fwd_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin,
 int pp_conv2d_bwd_data_pre(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
                            int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
                            void* workspace, size_t ws_bytes, const void* dy_planes, pp_stream_t stream);
+/* The WEIGHTS' planes as well (round 5): they change once per optimiser step, so a training loop may split them at the start of the step on
+ * another stream - transpose = 1: the forward's layout, 0: the backward-data's - and pass them to the *_pre2 forms (NULL = split inside;
+ * ignored by calls that do not run a bf16x3 kernel).  /root/reference/networks/decoders.py:107-114 (the SegmentHead convolutions). */
+size_t pp_x3_weight_planes_bytes(int kh_kw, int Cin, int Cout, int transpose);
+int pp_x3_split_weights(const float* w, int kh_kw, int Cin, int Cout, int transpose, void* planes, size_t planes_bytes, pp_stream_t stream);
+int pp_conv2d_fwd_pre2(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                       int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                       size_t ws_bytes, const void* x_planes, const void* w_planes, pp_stream_t stream);
+int pp_conv2d_bwd_data_pre2(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                            int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                            void* workspace, size_t ws_bytes, const void* dy_planes, const void* w_planes, pp_stream_t stream);
 int pp_conv2d_bwd_weight_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* dy, int64_t lddy,
                              int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
                              void* workspace, size_t ws_bytes, const void* x_planes, const void* dy_planes, pp_stream_t stream);

@@ -64,6 +64,10 @@ SIGNATURES = {
     "pp_conv2d_bwd_data_multi": (_int, [_p, _i64, _int, _int, _int, _int, _int, _p, _int, _int, _p, _int, _int, _p, _int, _int, _p, _int, _int,
                                        _p, _i64, _int, _int, _p, _sz, _p]),
     "pp_conv2d_bwd_data_pre": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p, _p]),
+    "pp_x3_weight_planes_bytes": (_sz, [_int, _int, _int, _int]),
+    "pp_x3_split_weights": (_int, [_p, _int, _int, _int, _int, _p, _sz, _p]),
+    "pp_conv2d_fwd_pre2": (_int, [_p, _i64, _int, _int, _int, _int, _p, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _p, _sz, _p, _p, _p]),
+    "pp_conv2d_bwd_data_pre2": (_int, [_p, _i64, _int, _int, _int, _int, _p, _int, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _p, _sz, _p, _p, _p]),
     "pp_conv2d_bwd_weight_pre": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p, _p, _p]),
     "pp_conv2d_bwd_weight_partials": (_int, [_p, _i64, _int, _int, _int, _int, _p, _i64, _int, _int, _int, _int, _int, _int, _p, _p, _p, _sz, _p, _p]),
     "pp_wgrad_reduce_batch": (_int, [_p, _int, _p]),

@@ -69,6 +69,7 @@ struct __attribute__((packed, aligned(4))) StemF2 { float x, y; };
 
 struct ConvParams {
     const uint16_t* a_pre;   // bf16x3 planes of the A operand the CALLER already holds (pp_x3_split), or NULL: split here
+    const uint16_t* b_pre;   // bf16x3 planes of the WEIGHTS the caller already holds (pp_x3_split_weights, the layout of this direction), or NULL
     const float* x;   // A-side activations (X for fwd/wgrad, dY for bwd-data)
     const float* w;   // HWIO weights
     const float* bias;
@@ -3528,10 +3529,14 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
                            reinterpret_cast<uint16_t*>(workspace), x.Kp, x.a_plane);
         if (int rc = check_launch("x3_split_kernel")) return rc;
     }
-    const int64_t tb = (x.b_rows + 1) * (x.Kp / 8);
-    hipLaunchKernelGGL(x3_split_w_kernel, dim3((unsigned)std::min<int64_t>(cdiv(tb, 256), 4096)), dim3(256), 0, st, p.w, kh_kw, p.Cin, p.Cout,
-                       BWD ? 0 : 1, bp, x.Kp, x.b_plane);
-    if (int rc = check_launch("x3_split_w_kernel")) return rc;
+    if (p.b_pre) {
+        bp = const_cast<uint16_t*>(p.b_pre);
+    } else {
+        const int64_t tb = (x.b_rows + 1) * (x.Kp / 8);
+        hipLaunchKernelGGL(x3_split_w_kernel, dim3((unsigned)std::min<int64_t>(cdiv(tb, 256), 4096)), dim3(256), 0, st, p.w, kh_kw, p.Cin, p.Cout,
+                           BWD ? 0 : 1, bp, x.Kp, x.b_plane);
+        if (int rc = check_launch("x3_split_w_kernel")) return rc;
+    }
     X3Operands o{ap, bp, x.a_plane, x.b_plane, x.Kp, p.Cn, (uint32_t)(x.rows_a * 32), (uint32_t)(x.b_rows * 32),
                  (uint32_t)((x.rows_a + 1) * 32), (uint32_t)((x.b_rows + 1) * 32), 0};
     p.n_tiles = pl.n_tiles;
@@ -3738,7 +3743,8 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
         // large-tile layers: six bf16 MFMAs per product instead of the fp32 MFMA (operands split once into the workspace)
         const X3Plan x = x3_plan(pl, p.M, (int64_t)p.B * p.H * p.W, p.Ck, p.Cn, kh_kw, p.taps.n, vec);
-        if (x.ok && workspace && ws_bytes >= x.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0)
+        if (x.ok && workspace && ws_bytes >= x.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.b_pre) & 255) == 0)
             return launch_conv_x3<BWD>(p, pl, x, kh_kw, workspace, st);
     }
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
@@ -4279,7 +4285,8 @@ size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout
 static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
                            int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, const Epilogue& epi,
                            void* workspace, size_t ws_bytes, pp_stream_t stream, float* stats = nullptr, size_t stats_floats = 0,
-                           const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, const void* x_planes = nullptr)
+                           const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, const void* x_planes = nullptr,
+                           const void* w_planes = nullptr)
 {
     if (int rc = conv_common_check(x, w, y, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (ldx % 4 != 0 && Cin % 4 == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: ldx must be a multiple of 4");
@@ -4292,6 +4299,7 @@ static int conv2d_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
     p.epi = epi;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     p.a_pre = reinterpret_cast<const uint16_t*>(x_planes);
+    p.b_pre = reinterpret_cast<const uint16_t*>(w_planes);
     build_taps(p.taps, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv fwd: no live tap");
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv fwd: more than 2^31 output pixels");
@@ -4358,6 +4366,43 @@ int pp_conv2d_fwd_pre(const float* x, int64_t ldx, int B, int H, int W, int Cin,
 {
     return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
                            ws_bytes, stream, nullptr, 0, nullptr, nullptr, 0, x_planes);
+}
+
+// The weights' planes off the step's critical path: they change once per optimiser step, so a caller may split them at the START of a
+// step on another stream (both layouts: transpose = 1 the forward's [tap][Cout][Kp(Cin)], 0 the backward-data's [tap][Cin][Kp(Cout)]) and
+// hand them to every *_pre2 call of the step instead of paying x3_split_w_kernel in front of each convolution (4 x ~10 us per step for
+// the two SegmentHead layers).  Ignored by calls that do not run a bf16x3 kernel.
+size_t pp_x3_weight_planes_bytes(int kh_kw, int Cin, int Cout, int transpose)
+{
+    if (kh_kw < 1 || Cin < 1 || Cout < 1) return 0;
+    const int n_rows = transpose ? Cout : Cin, K = transpose ? Cin : Cout;
+    const int64_t Kp = cdiv(K, 16) * 16, rows = (int64_t)kh_kw * n_rows;
+    return align_up((size_t)3 * (size_t)(rows + 1) * (size_t)Kp * 2, 256);
+}
+
+int pp_x3_split_weights(const float* w, int kh_kw, int Cin, int Cout, int transpose, void* planes, size_t planes_bytes, pp_stream_t stream)
+{
+    if (!w || !planes || kh_kw < 1 || Cin < 1 || Cout < 1) return fail(PP_ERR_BAD_ARG, "x3_split_weights: null / empty");
+    if (reinterpret_cast<uintptr_t>(planes) & 255) return fail(PP_ERR_BAD_ARG, "x3_split_weights: planes must be 256-byte aligned");
+    if (planes_bytes < pp_x3_weight_planes_bytes(kh_kw, Cin, Cout, transpose)) return fail(PP_ERR_WORKSPACE, "x3_split_weights: planes buffer");
+    const int n_rows = transpose ? Cout : Cin, K = transpose ? Cin : Cout;
+    const int Kp = (int)cdiv(K, 16) * 16;
+    const int64_t rows = (int64_t)kh_kw * n_rows, plane = (rows + 1) * Kp;
+    if (plane * 2 >= (1ll << 32) - 4096) return fail(PP_ERR_UNSUPPORTED, "x3_split_weights: plane of %lld bytes", (long long)(plane * 2));
+    hipStream_t st = as_stream(stream);
+    EventScope ev(st);
+    const int64_t tb = (rows + 1) * (Kp / 8);
+    hipLaunchKernelGGL(x3_split_w_kernel, dim3((unsigned)std::min<int64_t>(cdiv(tb, 256), 4096)), dim3(256), 0, st, w, kh_kw, Cin, Cout, transpose ? 1 : 0,
+                       reinterpret_cast<uint16_t*>(planes), Kp, plane);
+    return check_launch("x3_split_w_kernel");
+}
+
+int pp_conv2d_fwd_pre2(const float* x, int64_t ldx, int B, int H, int W, int Cin, const float* w, const float* bias,
+                       int kh, int kw, int stride, int pad, int dil, float* y, int64_t ldy, int Cout, void* workspace,
+                       size_t ws_bytes, const void* x_planes, const void* w_planes, pp_stream_t stream)
+{
+    return conv2d_fwd_impl(x, ldx, B, H, W, Cin, w, bias, kh, kw, stride, pad, dil, y, ldy, Cout, Epilogue{}, workspace,
+                           ws_bytes, stream, nullptr, 0, nullptr, nullptr, 0, x_planes, w_planes);
 }
 
 // ---- convolution + training BatchNorm (+ residual, activation) in one launch -----------------------------------------------------
@@ -4429,7 +4474,7 @@ int pp_conv2d_fwd_bn_act(const float* x, int64_t ldx, int B, int H, int W, int C
 
 static int conv2d_bwd_data_impl(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
                                 int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
-                                void* workspace, size_t ws_bytes, pp_stream_t stream, const void* dy_planes)
+                                void* workspace, size_t ws_bytes, pp_stream_t stream, const void* dy_planes, const void* w_planes = nullptr)
 {
     if (int rc = conv_common_check(dy, w, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)) return rc;
     if (Ho != out_size(H, kh, stride, pad, dil) || Wo != out_size(W, kw, stride, pad, dil))
@@ -4476,6 +4521,7 @@ static int conv2d_bwd_data_impl(const float* dy, int64_t lddy, int B, int Ho, in
     if (p.M > 0x7FFFFFFFll) return fail(PP_ERR_UNSUPPORTED, "conv bwd_data: more than 2^31 pixels");
     if (p.taps.n == 0) return fail(PP_ERR_BAD_ARG, "conv bwd_data: no live tap");
     p.a_pre = stride == 1 ? reinterpret_cast<const uint16_t*>(dy_planes) : nullptr;
+    p.b_pre = stride == 1 ? reinterpret_cast<const uint16_t*>(w_planes) : nullptr;
     return launch_conv<true>(p, workspace, ws_bytes, as_stream(stream), kh * kw);
 }
 
@@ -4681,6 +4727,14 @@ int pp_conv2d_bwd_data_pre(const float* dy, int64_t lddy, int B, int Ho, int Wo,
 {
     return conv2d_bwd_data_impl(dy, lddy, B, Ho, Wo, Cout, w, kh, kw, stride, pad, dil, dx, lddx, H, W, Cin, accumulate, workspace, ws_bytes,
                                 stream, dy_planes);
+}
+
+int pp_conv2d_bwd_data_pre2(const float* dy, int64_t lddy, int B, int Ho, int Wo, int Cout, const float* w, int kh, int kw,
+                            int stride, int pad, int dil, float* dx, int64_t lddx, int H, int W, int Cin, int accumulate,
+                            void* workspace, size_t ws_bytes, const void* dy_planes, const void* w_planes, pp_stream_t stream)
+{
+    return conv2d_bwd_data_impl(dy, lddy, B, Ho, Wo, Cout, w, kh, kw, stride, pad, dil, dx, lddx, H, W, Cin, accumulate, workspace, ws_bytes,
+                                stream, dy_planes, w_planes);
 }
 
 // bf16x3 weight gradient (conv_wgrad_x3_kernel): the MFMA-bound layers (>= 8 GFLOP, both channel counts > 64, 128-wide outputs)

@@ -86,6 +86,9 @@ const Entry kEntries[] = {
     PP_PLAN_ENTRY(pp_conv2d_fwd_pre),
     PP_PLAN_ENTRY(pp_conv2d_bwd_data_pre),
     PP_PLAN_ENTRY(pp_conv2d_bwd_data_multi),
+    PP_PLAN_ENTRY(pp_conv2d_fwd_pre2),
+    PP_PLAN_ENTRY(pp_conv2d_bwd_data_pre2),
+    PP_PLAN_ENTRY(pp_x3_split_weights),
     PP_PLAN_ENTRY(pp_conv2d_bwd_weight_pre),
     PP_PLAN_ENTRY(pp_conv2d_bwd_weight_partials),
     PP_PLAN_ENTRY(pp_wgrad_reduce_batch),

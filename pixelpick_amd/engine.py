@@ -13,6 +13,7 @@ import contextlib
 import math
 import ctypes
 import os
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -917,8 +918,10 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
             and _x3_planes(2, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
         xp = _x3_split(x.t, ldx, B * H * W, Cin)          # read by this forward and, in backward(), by the weight gradient
     if xp is not None:
-        rc = _lib.lib().pp_conv2d_fwd_pre(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                          kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, xp.data_ptr(), _stream())
+        wp = _weight_planes(w, 1)
+        _register_weight_planes(w, 1)
+        rc = _lib.lib().pp_conv2d_fwd_pre2(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, xp.data_ptr(), wp, _stream())
     else:
         rc = _lib.lib().pp_conv2d_fwd(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                       kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, _stream())
@@ -1046,8 +1049,11 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
             dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
             ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
             if dyp is not None:
-                rc = L.pp_conv2d_bwd_data_pre(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                              dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, dyp.data_ptr(), _stream())
+                wp = _weight_planes(w, 0) if stride == 1 else None
+                if stride == 1:
+                    _register_weight_planes(w, 0)
+                rc = L.pp_conv2d_bwd_data_pre2(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
+                                               dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, dyp.data_ptr(), wp, _stream())
             else:
                 rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
                                           dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
@@ -1627,6 +1633,77 @@ def set_dropout_device_seed(t: Optional[torch.Tensor]):
 def begin_step():
     if _dropout_seed_dev[0] is not None:
         _dropout_counter[0] = 0
+    _STEP_EPOCH[0] += 1
+    if _X3_WPRE and _X3_WPL:
+        _prefetch_weight_planes()
+
+
+# ---- bf16x3 weight planes off the step's critical path ---------------------------------------------------------------------------
+# The MFMA-bound convolutions (SegmentHead, decoders.py:107-114) split their fp32 weights into three bf16 planes in front of every
+# launch: x3_split_w_kernel, ~10 us, four times per step on the main queue.  Weights only change in the optimiser, so every layer that
+# took the bf16x3 path in an earlier step (registered by conv2d / _conv2d_bwd) has both layouts re-split at begin_step() on the
+# weight-gradient stream - idle during the forward - and the step's convolutions take the planes (pp_conv2d_*_pre2) after ONE stream
+# wait.  Planes are valid for the step they were made in only (_STEP_EPOCH); a forward outside a trainer step splits inline as before.
+# PIXELPICK_X3_WEIGHT_PREFETCH=0: off.
+_X3_WPRE = os.environ.get("PIXELPICK_X3_WEIGHT_PREFETCH", "1") != "0"
+_STEP_EPOCH = [0]
+_X3_WPL = {}          # id(w) -> {"w": weight, "planes": {1: forward layout, 0: backward-data layout}, "epoch": step the planes belong to}
+_X3_WPL_EVENT = {}    # device key -> (event recorded behind the splits, epoch, epoch the main stream last waited for it)
+
+
+def _register_weight_planes(w: torch.Tensor, transpose: int):
+    if not _X3_WPRE or w.dim() != 4:
+        return
+    ent = _X3_WPL.get(id(w))
+    if ent is None or ent["w"]() is not w:
+        ent = _X3_WPL[id(w)] = {"w": weakref.ref(w), "planes": {}, "epoch": -1}      # (weak: a new model per active-learning stage, model.py:250)
+    if transpose not in ent["planes"]:
+        kh, kw, Cin, Cout = w.shape
+        nb = int(_lib.lib().pp_x3_weight_planes_bytes(kh * kw, Cin, Cout, transpose))
+        ent["planes"][transpose] = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        ent["epoch"] = -1                       # a new layout: not filled yet
+
+
+def _prefetch_weight_planes():
+    L = _lib.lib()
+    by_dev = {}
+    for key, ent in list(_X3_WPL.items()):
+        w = ent["w"]()
+        if w is None or not w.is_cuda:
+            del _X3_WPL[key]
+            continue
+        by_dev.setdefault(w.device, []).append((ent, w))
+    for dev, ents in by_dev.items():
+        main = _main_stream_obj()
+        side = _side_stream(dev, 0)
+        ev = _fork_event(dev)
+        _lib.plan_note(ev.record, main)              # behind the previous step's optimiser
+        _lib.plan_note(side.wait_event, ev)
+        for ent, w in ents:
+            kh, kw, Cin, Cout = w.shape
+            for tr, planes in ent["planes"].items():
+                _lib.check(L.pp_x3_split_weights(w.data_ptr(), kh * kw, Cin, Cout, tr, planes.data_ptr(), planes.numel(), side.cuda_stream),
+                           "pp_x3_split_weights")
+            ent["epoch"] = _STEP_EPOCH[0]
+        dk = (dev.type, dev.index)
+        rec = _X3_WPL_EVENT.get(dk)
+        done = rec[0] if rec is not None else torch.cuda.Event()
+        _lib.plan_note(done.record, side)
+        _X3_WPL_EVENT[dk] = [done, _STEP_EPOCH[0], -1]
+
+
+def _weight_planes(w: torch.Tensor, transpose: int):
+    """Device pointer of this step's pre-split planes of w in the given layout (the main stream has waited for them), or None."""
+    ent = _X3_WPL.get(id(w))
+    if ent is None or ent["w"]() is not w or ent["epoch"] != _STEP_EPOCH[0] or transpose not in ent["planes"]:
+        return None
+    rec = _X3_WPL_EVENT.get((w.device.type, w.device.index))
+    if rec is None or rec[1] != _STEP_EPOCH[0]:
+        return None
+    if rec[2] != _STEP_EPOCH[0]:
+        _lib.plan_note(_main_stream_obj().wait_event, rec[0])
+        rec[2] = _STEP_EPOCH[0]
+    return ent["planes"][transpose].data_ptr()
 
 
 def dropout(tape: Tape, x: Var, p: float, training: bool) -> Var:

@@ -217,9 +217,11 @@ class Model:
                 self.on_train_batch(dict_data, x, y, mask, aug_params)
             if self.lr_scheduler_type == "Poly":                           # per-iteration poly decay (lr_scheduler.py:15-17)
                 trainer.set_poly_lr((epoch - 1) * self._steps_per_epoch() + local_it, n_iters_total)
-            if self._replay_train and trainer._plan is None:
+            if self._replay_train and trainer._plan is None and trainer.step_count >= 1:
                 # static shapes (drop_last loader): record this step's launches once, re-issue them afterwards (halves the
-                # host cost of a step; FlatTrainer.enable_replay).  The recorded step IS this iteration's step.
+                # host cost of a step; FlatTrainer.enable_replay).  The recorded step IS this iteration's step.  (The trainer's
+                # first step runs eagerly: it is the one in which the layers that keep per-step state register themselves - the
+                # bf16x3 weight planes split at begin_step, engine._X3_WPL - so that the recorded step contains that work.)
                 trainer._ensure_train_mode()
                 trainer.enable_replay(x, y, warmup=0)
             else:

@@ -451,3 +451,48 @@ def test_mc_dropout_training_variant_runs_through_dropout2d():
     assert np.isfinite(losses[0]) and losses[0] == losses[1] and torch.equal(grads[0], grads[1])
     tp = FlatTrainer(plain.train(), ignore_index=19)
     assert abs(tp.forward_backward(x, y).item() - losses[0]) > 1e-6
+
+
+@pytest.mark.parametrize("mode", ["eager", "replay"])
+def test_weight_planes_split_at_the_start_of_the_step_change_nothing(mode, monkeypatch):
+    """engine._X3_WPL: the bf16x3 layers' weight planes (SegmentHead, decoders.py:107-114) are split at begin_step() on the
+    weight-gradient stream from the second step on and handed to the convolutions (pp_conv2d_*_pre2) instead of being split in front
+    of each launch.  Same planes, same kernels: the parameter trajectory must not move a bit - eager, and with the step recorded
+    after the first eager step (what model.py does) and replayed."""
+    from pixelpick_amd import _lib
+    from pixelpick_amd import engine as E
+    C, B, H, W = 19, 4, 256, 384                    # 4 x 64 x 96 = 24576 rows at the head: the smallest map that takes the bf16x3 kernels
+    data = [(fi.formula_input(B, H, W, key=f"w{i}").to(DEV), fi.formula_labels(B, H, W, C, C, 20, key=f"w{i}").to(DEV)) for i in range(2)]
+    calls = []
+    real = _lib.lib().pp_x3_split_weights
+
+    def run(prefetch):
+        monkeypatch.setattr(E, "_X3_WPRE", prefetch)
+        E._X3_WPL.clear()
+        m = _build(C)
+        tr = FlatTrainer(m.train(), ignore_index=C)
+        E.set_dropout_device_seed(tr._seed_dev)
+        for i in range(4):
+            xb, yb = data[i % 2]
+            if mode == "replay" and i == 1:
+                tr.step_count += 0
+                tr.enable_replay(xb, yb, warmup=0)
+            elif mode == "replay" and i > 1:
+                tr.train_step(xb, yb)
+            else:
+                tr.step_count += 1
+                tr._stage_hyper()
+                tr._step_body(xb, yb, False, True)
+        torch.cuda.synchronize()
+        p = tr.flat_p.clone()
+        n_reg = sum(len(e["planes"]) for e in E._X3_WPL.values())
+        if mode == "replay":
+            tr.disable_replay()
+        E.set_dropout_device_seed(None)
+        return p, n_reg
+
+    p_off, n_off = run(False)
+    p_on, n_on = run(True)
+    assert n_off == 0 and n_on == 4, (n_off, n_on)          # two layers x (forward, backward-data) layouts registered
+    assert torch.equal(p_on, p_off)
+    E._X3_WPL.clear()
