@@ -595,6 +595,24 @@ def main():
                                                       "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF,
                                                       "frac": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
                                  "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
+        # conv_x3_kernel ALONE: both operands' planes held by the caller, as in the train step (the activation planes are shared with the
+        # weight gradient, the weight planes are split at begin_step on the second queue: pp_conv2d_fwd_pre2)
+        xpl = torch.empty(int(L.pp_x3_planes_bytes(TB * Hq * Wq, 304)), dtype=torch.uint8, device=dev)
+        wpl = torch.empty(int(L.pp_x3_weight_planes_bytes(9, 304, 256, 1)), dtype=torch.uint8, device=dev)
+        _lib.check(L.pp_x3_split(xa.data_ptr(), 304, TB * Hq * Wq, 304, xpl.data_ptr(), xpl.numel(), stream), "pp_x3_split")
+        _lib.check(L.pp_x3_split_weights(wa.data_ptr(), 9, 304, 256, 1, wpl.data_ptr(), wpl.numel(), stream), "pp_x3_split_weights")
+
+        def conv_only():
+            _lib.check(L.pp_conv2d_fwd_pre2(xa.data_ptr(), 304, TB, Hq, Wq, 304, wa.data_ptr(), None, 3, 3, 1, 1, 1, ya.data_ptr(), 256, 256,
+                                            wsx.data_ptr(), wsx.numel(), xpl.data_ptr(), wpl.data_ptr(), stream), "pp_conv2d_fwd_pre2")
+        evk = HipEvents(nrep)
+        timed(conv_only, nrep, 12, evk)
+        kms = evk.elapsed_ms()
+        evk.destroy()
+        kavg = sum(kms) / len(kms)
+        ach_k = flops / (kavg * 1e-3) / 1e12
+        line["roofline_mfma"]["kernel_only"] = {"what": "conv_x3_kernel<256,128> with both operands' planes held by the caller (pp_conv2d_fwd_pre2)",
+                                                "kernel_ms_avg": round(kavg, 4), "achieved": round(ach_k, 2), "frac": round(ach_k / X3_PEAK_TF, 4)}
         # What the matrix pipe SUSTAINS on this box under conv_x3_kernel's own MFMA stream and nothing else (pp_debug_mfma_stream:
         # register-resident fragments, launches of the convolution's length): the spec peak assumes 2.4 GHz, and a chip-wide bf16 MFMA
         # load on operands with random mantissas is power-limited well below it (profiles/r05_conv_x3_power.txt) - zeros are not.
@@ -617,7 +635,7 @@ def main():
                     "a launch of the convolution's length - the rate the power limit leaves on this box",
             **mf, "fp32_equivalent_peak_random_operands_TF": round(sus, 1),
             "frac_of_spec_peak": round(mf["random_operands"]["bf16_TF"] / MFMA_BF16_PEAK_TF, 4),
-            "conv_x3_frac_of_sustained": round(ach / sus, 4)}
+            "conv_x3_frac_of_sustained": round(ach / sus, 4), "conv_x3_kernel_only_frac_of_sustained": round(ach_k / sus, 4)}
         # SURVEY 8(d) graded 1x1 shapes at the BASELINE batch: op time (split-K launch + its reduce where the plan
         # splits) from HIP events; ceiling = min(MFMA peak, arithmetic intensity x HBM peak) for ONE pass over x, w, y.
         graded = [("ASPP fuse 1280->256 @16x32 (aspp.py:73-75)", 16, 32, 1280, 256),

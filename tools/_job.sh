@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_networks_gpu.py -x -q -k "weight_planes or replay" 2>&1 | tail -15
-for m in 0 1 0 1; do PIXELPICK_X3_WEIGHT_PREFETCH=$m STEPS=60 python tools/train_bench.py 2>&1 | tail -1; done
-for m in 0 1; do REPLAY=1 PIXELPICK_X3_WEIGHT_PREFETCH=$m STEPS=60 python tools/train_bench.py 2>&1 | tail -1; done
+O=gpurun_out/r5fin; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+STEPS=12 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o t -- python $GRAFT_REPO_ROOT/tools/train_bench.py > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/timeline.py $(find /tmp/tl -name "*kernel_trace.csv" | head -1) --list > $O/train_step_timeline.txt 2>&1; head -12 $O/train_step_timeline.txt
