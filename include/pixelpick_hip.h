@@ -560,13 +560,16 @@ int pp_nhwc_to_nchw(const float* x, int64_t ldx, int B, int C, int64_t HW, float
 /* Debug/bench knobs.
  * reduce mode: 0 = threshold-prefiltered per-wave top-k with DPP reductions (default), 1 = same with
  *              ds_bpermute (__shfl) reductions, 2 = plain k-round extraction loop (no prefilter).
+ *              bit 8: large-k selection through the one-block radix select, bit 9: no quantised-histogram select,
+ *              bit 10: the score histogram of the large-k selection in its own pass over the map instead of inside the scorer launch (A/B).
  * exact formula: 0 = default scorer (entropy = log S + sum e_c (m - x_c) / S, v_exp_f32 exponentials;
  *              identical NaN behaviour), 1 = the reference's operation order p_c = exp(x_c - m) / S,
  *              sum(-p_c log p_c) with libm-accurate exp/log (query.py:190,230). */
 void pp_debug_set_reduce_mode(int mode);
 void pp_debug_set_exact_formula(int on);
 /* Tuning knob for the C == 19 flat path: occupancy bound (2/3/4 waves per SIMD, 0 = default) and
- * pixels per thread (4/8, 0 = automatic). */
+ * pixels per thread (4/8, 0 = automatic).  occ 8 / 9: synchronous NHWC kernel / generic strided path; occ 10: the streamed scorers
+ * (class vector read from memory in passes) at ANY class count - the tests compare them bit for bit with the register kernels. */
 void pp_debug_set_acq_tuning(int occ, int ppt);
 /* Dense conv kernel A/B knobs: low 2 bits 0 = 128x128 large tile (default; measured fastest), 2 = 128x64 tiles;
  * bit 2 = linear instead of XCD-aware tile order; bit 3 = conditional (non-vector) loads; bits 4/5 = cap the large

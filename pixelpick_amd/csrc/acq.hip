@@ -562,6 +562,8 @@ struct LowresParams {
     int align;
     int C, tiles_x, tiles_y, k, strategy, reduce_mode;
     int patch_cap;            // floats of dynamic LDS available for the patch
+    uint32_t* qhist = nullptr;   // large-k selection: [B][kQBins] bin counts of the scores written to out_map (zeroed by the host); NULL: none
+    float qscale = 0.0f;
 };
 
 template <int CMAX, bool EXACT, int PPT, bool LDS, int MATH, int STRAT = -1>
@@ -578,6 +580,13 @@ __global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // large-k selection: the block counts its scores into the image's histogram (as acq_kernel<..., HIST>; bins in the survivor lists)
+    uint32_t* qbins = reinterpret_cast<uint32_t*>(&s_surv[0][0]);
+    const bool hist = p.qhist != nullptr;
+    if (hist) {
+        for (int i = tid; i < kQBins; i += kBlock) qbins[i] = 0u;
+        __syncthreads();
+    }
     const int C = EXACT ? CMAX : p.C;
     const int CP = C | 1;                     // odd pixel pitch: lanes 4 columns apart hit different banks
     const bool largest = p.strategy != PP_ACQ_MARGIN;
@@ -628,12 +637,22 @@ __global__ __launch_bounds__(kBlock, 2) void acq_lowres_kernel(LowresParams p)
             const int64_t pix = (int64_t)Y * p.Wc + X;
             if (excl && excl[pix]) sc = fill;
             if (omap) omap[pix] = sc;
+            if (hist) atomicAdd(&qbins[qbin(sc, largest, p.qscale)], 1u);
             kh[j] = order_key(sc, largest);
             kl[j] = 0xFFFFFFFFu - (uint32_t)pix;
         } else {
             kh[j] = 0u; kl[j] = 0u;
         }
         __builtin_amdgcn_sched_barrier(0);   // one pixel's class vector live at a time
+    }
+    if (hist) {
+        __syncthreads();
+        uint32_t* Hg = p.qhist + (int64_t)img * kQBins;
+        for (int d = tid; d < kQBins; d += kBlock) {
+            const uint32_t c = qbins[d];
+            if (c) atomicAdd(&Hg[d], c);
+        }
+        return;
     }
     if (p.cand)
         block_emit_topk<PPT>(kh, kl, p.k, p.cand + ((int64_t)img * tiles + t) * p.k, p.reduce_mode, s_surv, s_cnt, s_top);
@@ -2096,8 +2115,15 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
     float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
     uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
     p.out_map = map;
+    const float qs = score_qscale(strategy, C);
+    const bool fuse_hist = g_hist_fuse && large_q_ok(B, k, qs) && !stream_classes(C);      // (acq_lowres_kernel only: the streamed form has no histogram epilogue)
+    if (fuse_hist) {
+        p.qhist = large_hist(gbuf, B, k);
+        p.qscale = qs;
+        if (hipMemsetAsync(p.qhist, 0, (size_t)B * kQBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+    }
     if (int rc = dispatch_lowres(p, pl, B, st)) return rc;
-    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st, score_qscale(strategy, C));
+    return run_large(map, B, N, k, largest, gbuf, out_idx, out_val, st, qs, fuse_hist);
 }
 
 int pp_acq_lowres_score_at(const float* low, int64_t ldx, int64_t B, int64_t C, int64_t h, int64_t w, int64_t H,

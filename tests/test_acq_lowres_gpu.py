@@ -80,6 +80,8 @@ CASES = [
     (2, 7, (40, 60), (20, 30), None, True, 5),              # down-sampling (patch wider than the tile)
     (2, 19, (32, 64), (128, 256), None, False, 20),         # align_corners=False arithmetic
     (1, 19, (64, 128), (256, 512), None, True, 6553),       # top_n_percent mode: radix select
+    (3, 21, (40, 40), (160, 160), (157, 150), True, 1280),  # top_n_percent mode, cropped VOC shape: the scorer launch fills the selection's histogram
+    (2, 11, (45, 60), (90, 120), None, False, 540),         # the same with align_corners=False arithmetic (x2)
     (2, 40, (12, 20), (48, 80), None, True, 20),            # generic C <= 64 bucket
     (2, 26, (12, 20), (48, 80), (48, 77), True, 48),        # generic C <= 32 bucket, largest fused k
     (1, 19, (200, 300), (25, 40), None, True, 20),          # 8x down-sampling: patch exceeds LDS -> global-read variant
