@@ -1,21 +1,12 @@
+# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import torch, os, sys
-sys.path.insert(0, os.getcwd())
-from pixelpick_amd import acquisition as acq, _lib
-L=_lib.lib()
-torch.manual_seed(0)
-B,C,h,w,H,W=256,19,64,128,256,512
-low=torch.randn(B,h,w,C,device='cuda')*3
-k=H*W*5//100
-for _ in range(40): acq.score_topk_lowres(low,(H,W),None,'entropy',k)
-for mode in (0,1024,0,1024,0,1024):
-    L.pp_debug_set_reduce_mode(mode)
-    for _ in range(5): acq.score_topk_lowres(low,(H,W),None,'entropy',k)
-    ts=[]
-    for _ in range(30):
-        e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
-        e0.record(); acq.score_topk_lowres(low,(H,W),None,'entropy',k); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-    ts.sort(); print('lowres top-5% mode',mode,'op us',round(ts[15]*1e3,1), 'min', round(ts[0]*1e3,1))
-L.pp_debug_set_reduce_mode(0)
-PY
+O=gpurun_out/r5fin2; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+cp $(find $O/prof_head -name "*kernel_stats.csv" | head -1) $O/bench_headline_kernel_stats.csv
