@@ -496,3 +496,21 @@ def test_weight_planes_split_at_the_start_of_the_step_change_nothing(mode, monke
     assert n_off == 0 and n_on == 4, (n_off, n_on)          # two layers x (forward, backward-data) layouts registered
     assert torch.equal(p_on, p_off)
     E._X3_WPL.clear()
+
+
+def test_dense_labels_take_the_dense_backward_kernels():
+    """The reference's fully supervised mode (model.py:106-110 with n_pixels_by_us == 0: every pixel labelled): FlatTrainer(sparse_labels=False)
+    leaves the loss gradient unflagged, so the classifier's weight gradient and the BatchNorm backward behind the loss run their dense
+    kernels.  Same arithmetic as the row-gather kernels on an all-flagged gradient up to summation order: the gradients agree to 1e-5."""
+    C, B, H, W = 19, 2, 64, 96
+    x = fi.formula_input(B, H, W, key="dense").to(DEV)
+    y = ((torch.arange(B * H * W) * 7 + 3) % C).view(B, H, W).to(DEV)          # every pixel labelled
+    grads = {}
+    for sparse in (True, False):
+        m = _build(C)
+        tr = FlatTrainer(m.train(), ignore_index=C, sparse_labels=sparse)
+        tr.forward_backward(x, y)
+        torch.cuda.synchronize()
+        grads[sparse] = tr.flat_g.clone()
+    d = (grads[True].double() - grads[False].double()).norm().item() / grads[False].double().norm().item()
+    assert d <= 1e-5, d
