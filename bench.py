@@ -766,7 +766,19 @@ def main():
                 e1.record()
             torch.cuda.synchronize(dev)
             yms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
-            yard = nbytes / (yms * 1e-3) / 1e9
+            yard_plain = nbytes / (yms * 1e-3) / 1e9
+            # the same with non-temporal loads (blocks < 0) - what the scorers use since round 5; the yardstick is the better of the two
+            for _ in range(3):
+                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, -256, sink.data_ptr(), stream), "pp_debug_stream_read")
+            torch.cuda.synchronize(dev)
+            for e0, e1 in evs:
+                e0.record()
+                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, -256, sink.data_ptr(), stream), "pp_debug_stream_read")
+                e1.record()
+            torch.cuda.synchronize(dev)
+            yms_nt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
+            yard_nt = nbytes / (yms_nt * 1e-3) / 1e9
+            yard = max(yard_plain, yard_nt)
         roof = {"bound": "hbm", "kernel": "acq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -774,7 +786,8 @@ def main():
                 "kernel_ms_min": round(min(kms), 4),
                 "read_only_yardstick": ({"GB/s": round(yard, 1), "frac_of_peak": round(yard / HBM_PEAK_GBS, 4),
                                          "acq_kernel_vs_yardstick": round(achieved / yard, 4),
-                                         "what": "pp_debug_stream_read: a kernel that only reads the same logits buffer"}
+                                         "ordinary_loads_GB/s": round(yard_plain, 1), "non_temporal_loads_GB/s": round(yard_nt, 1),
+                                         "what": "pp_debug_stream_read: a kernel that only reads the same logits buffer (the better of ordinary and non-temporal loads)"}
                                         if yard else None)}
 
         if ka > 48:

@@ -593,7 +593,7 @@ int pp_bn_fused_capacity(void);
 void pp_debug_set_bn_probe(void* device_buffer);
 /* Yardstick, measurement only: a kernel that only reads `bytes` of x (float4 per lane, `blocks` blocks of 256 threads, 0 = 256).
  * bench.py reports acq_kernel's bandwidth against what this reaches on the same buffer. */
-int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);
+int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);   /* blocks < 0: -blocks blocks, non-temporal loads */
 void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 12 (defaults 384 / 128) */
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
 void pp_debug_set_conv_rows(int bits);      /* whole-row VALU kernels of the narrow pointwise layers: bit 0 off, bit 1 forward rows kernel only from 65536 rows (A/B) */

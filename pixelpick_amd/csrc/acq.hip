@@ -23,7 +23,10 @@ static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 d
 static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
 static int g_tune_ppt = 0;
 static int g_acq_strat_spec = 1;   // strategy-specialised scorers of the three dataset class counts (pp_debug_set_acq_tuning bit 10 of `occ`: off)
+static int g_nt_off = 0;          // A/B: ordinary instead of non-temporal logit loads in the strategy-specialised scorers (pp_debug_set_acq_tuning bit 11 of `occ`)
 static int g_tune_xcd = 0;        // 0: by plane size, 1: never, 2: always (pp_debug_set_acq_tuning bits 8-9 of `occ`)
+
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));      // (native vector type: __builtin_nontemporal_load does not take HIP's float4 struct)
 
 constexpr int kBlock = 256;
 constexpr int kSmallKMax = 48;        // fused per-wave extraction up to this k (measured: 0.74/0.70/0.62 of HBM at k=20/32/48, 0.37 at 64); beyond: map + radix select
@@ -306,7 +309,7 @@ __device__ __forceinline__ uint32_t qbin(float s, bool lg, float scale)
 // HIST (map-writing launches of the large-k selection, VEC == 4): the block also counts its scores into the image's kQBins-bin histogram
 // (LDS bins in the survivor lists' storage - no candidates are extracted in that mode - then one global atomic per non-empty bin): what
 // select_qhist_kernel did in a second pass over the map.
-template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1, bool HIST = false>
+template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1, bool HIST = false, bool NT = true>
 __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
 {
     constexpr int PPT = VEC * G;
@@ -349,8 +352,16 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
                     if (EXACT || c < p.C) {
+                        if constexpr (NT) {
+                            // the logits are read exactly once: non-temporal loads (no L2 / MALL allocation for a 2.6 GB stream that
+                            // nobody reads again) - measured 0.420-0.425 -> 0.392-0.396 ms per launch at B=256 x 256x512x19, i.e. 0.76 ->
+                            // 0.82 of 8 TB/s; pp_debug_set_acq_tuning bit 11 selects the ordinary loads for A/B
+                            const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(base + (int64_t)c * p.sC + pix0));
+                            x[0][c] = v.x; x[1][c] = v.y; x[2][c] = v.z; x[3][c] = v.w;
+                        } else {
                         const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * p.sC + pix0);
                         x[0][c] = v.x; x[1][c] = v.y; x[2][c] = v.z; x[3][c] = v.w;
+                        }
                     }
                 uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
 #pragma unroll
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
                 float x[CMAX];
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
-                    if (EXACT || c < p.C) x[c] = px[(int64_t)c * p.sC];
+                    if (EXACT || c < p.C) x[c] = NT ? __builtin_nontemporal_load(px + (int64_t)c * p.sC) : px[(int64_t)c * p.sC];
                 if constexpr (MATH == 0) s[0] = pixel_score_fast<CMAX, EXACT>(x, p.C, p.strategy);
                 else s[0] = pixel_score<CMAX, EXACT>(x, p.C, p.strategy, MATH == 2);
                 if (excl && excl[pix0]) s[0] = fill;
@@ -431,7 +442,8 @@ __global__ __launch_bounds__(kBlock, 3) void acq_nhwc_kernel(AcqParams p)
         if (npix > 0) {
             const int64_t nfl = npix * C;                                 // floats to stage (multiple of 4: N % 4 == 0)
             const float4* src = reinterpret_cast<const float4*>(base + pix_blk * C);
-            for (int64_t i = tid; i < nfl / 4; i += kBlock) reinterpret_cast<float4*>(s_x)[i] = src[i];
+            for (int64_t i = tid; i < nfl / 4; i += kBlock)         // (read once: non-temporal, as acq_kernel)
+                reinterpret_cast<f32x4_nt*>(s_x)[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(src) + i);
         }
         __syncthreads();
         const int64_t pix = pix_blk + tid;
@@ -1731,7 +1743,8 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
                     return check_launch("acq_kernel<hist>");
                 }
 #define PP_ACQ_GO(G, O) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, O>), grid, block, 0, st, q)
-#define PP_ACQ_SPEC(G, S) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, 3, S>), grid, block, 0, st, q)
+#define PP_ACQ_SPEC(G, S) do { if (g_nt_off) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, 3, S, false, false>), grid, block, 0, st, q); \
+                               else hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, 3, S>), grid, block, 0, st, q); } while (0)
                 if (g_acq_strat_spec && !g_tune_occ && !q.out_map) {            // (with the map written - large k - the generic kernel measured no slower)
                     // the strategy as a compile-time constant: the chains the other two strategies need are not computed (100-145 VGPRs
                     // instead of 168-184: entropy runs four waves per SIMD, C = 21 three instead of two); bit 10 of the tuning word: off
@@ -1955,6 +1968,7 @@ void pp_debug_set_acq_tuning(int occ, int ppt)
 {
     g_tune_xcd = (occ >> 8) & 3;
     g_acq_strat_spec = (occ >> 10) & 1 ? 0 : 1;
+    g_nt_off = (occ >> 11) & 1;
     occ &= 0xFF;
     g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9 || occ == 10) ? occ : 0;   // 10: streamed class vector at any C (A/B, tests)
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;

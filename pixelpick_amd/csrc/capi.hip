@@ -52,19 +52,30 @@ __global__ __launch_bounds__(1024) void occupy_kernel(const int* stop, unsigned 
 // Yardstick (measurement only): what a kernel that does nothing but READ a buffer reaches - float4 per lane, eight loads in flight,
 // one wave per SIMD (the form tools/probe/hbm_rw.hip found fastest on this chip: 6.3-6.7 TB/s).  bench.py times it on the very logits
 // buffer acq_kernel scores and reports acq_kernel against it next to the 8 TB/s specification figure.
+typedef float f32x4_ntl __attribute__((ext_vector_type(4)));
+// NT: non-temporal loads (what the single-pass acquisition scorers use since round 5)
+template <bool NT>
 __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ x, size_t n4, float* out)
 {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    auto ld = [&](size_t j) -> float4 {
+        if constexpr (NT) {
+            const f32x4_ntl q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ntl*>(x) + j);
+            return make_float4(q.x, q.y, q.z, q.w);
+        } else {
+            return x[j];
+        }
+    };
     for (; i + 7 * stride < n4; i += 8 * stride) {
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = x[i + u * stride];
+        for (int u = 0; u < 8; ++u) v[u] = ld(i + u * stride);
 #pragma unroll
         for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    for (; i < n4; i += stride) { const float4 v = x[i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    for (; i < n4; i += stride) { const float4 v = ld(i); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;       // (never true for the bench's data: keeps the loads alive)
 }
 
@@ -74,10 +85,17 @@ extern "C" {
 
 int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream)
 {
+    // blocks < 0: -blocks blocks with non-temporal loads
+    const bool nt = blocks < 0;
+    if (nt) blocks = -blocks;
     if (!x || !sink || bytes < 16 || (reinterpret_cast<uintptr_t>(x) & 15)) return pp::fail(PP_ERR_BAD_ARG, "stream_read: buffer");
     if (blocks < 1) blocks = 256;
-    hipLaunchKernelGGL(pp::stream_read_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(x), bytes / 16, sink);
+    if (nt)
+        hipLaunchKernelGGL(pp::stream_read_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const float4*>(x), bytes / 16, sink);
+    else
+        hipLaunchKernelGGL(pp::stream_read_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const float4*>(x), bytes / 16, sink);
     return hipGetLastError() == hipSuccess ? PP_OK : pp::fail(PP_ERR_LAUNCH, "stream_read_kernel launch failed");
 }
 
