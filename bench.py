@@ -934,7 +934,7 @@ def main():
                     cb["acquisition"] = {"value": best[0], "unit": "Mpixels/s", "sample": best[1], "cores": best[2]}
             torch.set_num_threads(default_threads)
             out["cpu_baseline"] = cb
-            if acqr is not None and not a.exact_formula:
+            if acqr is not None and not a.exact_formula and not a.no_other_configs:      # (--no-other-configs: the headline launches only - the kernel-stats run)
                 out["acquisition"]["index_flips_vs_oracle"] = cpu_baseline_pick_flips(dev)
             if train is not None and a.network == "deeplab":
                 torch.set_num_threads(cb.get("cores", 16))

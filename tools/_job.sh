@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
-for occ in 0 512 256 0 512; do python bench.py --mode acq --steps 30 --warmup 10 --no-cpu-baseline --no-other-configs --tune-occ $occ 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('tune $occ', d['acquisition']['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms_avg'])"; done
-python bench.py --mode acq --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-for c in d.get('other_configs',[]):
-    if c['leg']=='acquisition': print(c['config'][:72], c['value'], c['ms_per_step'], c['roofline']['frac'], c['roofline']['read_only_yardstick'])
-"
+O=gpurun_out/r5fin4; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rm -rf $GRAFT_REPO_ROOT/$O/prof_head
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > $GRAFT_REPO_ROOT/$O/headline_line_under_rocprof.json 2>/dev/null
+cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_head -name "*kernel_stats.csv" | head -1) $O/bench_headline_kernel_stats.csv
+grep "acq_kernel<19" $O/bench_headline_kernel_stats.csv | cut -c1-200
+python -c "
+import json; d=json.load(open('$O/headline_line_under_rocprof.json')); print(d['roofline']['frac'], d['roofline']['kernel_ms_avg'], d['value'])"
