@@ -1,10 +1,12 @@
+# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r5fin4; mkdir -p $O
+O=gpurun_out/job; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/$O/prof_head
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > $GRAFT_REPO_ROOT/$O/headline_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cp $(find $O/prof_head -name "*kernel_stats.csv" | head -1) $O/bench_headline_kernel_stats.csv
-grep "acq_kernel<19" $O/bench_headline_kernel_stats.csv | cut -c1-200
-python -c "
-import json; d=json.load(open('$O/headline_line_under_rocprof.json')); print(d['roofline']['frac'], d['roofline']['kernel_ms_avg'], d['value'])"
