@@ -2552,6 +2552,55 @@ __global__ __launch_bounds__(256) void wgrad_stem3x3s2_kernel(WgradParams p, int
     }
 }
 
+// The ResNet stem (resnet_models.py:115-117: Conv2d(3, 64, 7, stride 2, padding 3)) is, like MobileNetV2's, the LAST weight gradient of
+// the backward pass - the optimiser waits for it - and the generic kernel took 305 us on it at 4 x 256 x 512 (wgrad_narrow_in_kernel<3,7,4>
+// over seven grid.y slices: every lane of a wave issued the same 21 vector loads per pixel).  Here the roles are turned round: a LANE is one
+// of the 7 taps x 3 channels of a tap row (the 21 input values a pixel contributes to a tap row are contiguous in the packed image: input
+// row 2 oh - 3 + th, pixels 2 ow - 3 .. 2 ow + 3 - one coalesced load), three tap rows share a wave (63 lanes), three waves a block (rows
+// 0-2, 3-5, 6), and a thread keeps the 64 output channels of its (tap, channel) in registers.  dy[pixel][0..64) is the same for every lane:
+// four aligned 16-dword SCALAR loads per pixel, entering the 64 FMAs as scalar operands.  One slice of partial sums per block
+// ([49][3][Cout], the layout the reduce expects).  (First form, a lane per output channel with the 21 inputs as scalar loads: 203 us - the
+// unaligned window became 21 single-dword scalar loads per pixel and wave.)
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+// (Measured variants of the loop: the input values of four pixels prefetched 114 us, the block's input patch staged in LDS 119 us, the
+// FMAs as explicit v_fmac_f32 with scalar sources instead of the v_pk_fma_f32 pairs hipcc forms 202 us - this form 107 us: the loop is
+// paced by the scalar cache delivering 256 bytes of dy per pixel and wave, not by the input loads.)
+__global__ __launch_bounds__(192) void wgrad_stem7x7s2_kernel(WgradParams p, int64_t rows_per_block)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int th = wv * 3 + lane / 21, j = lane % 21;                       // tap row, (tap, channel) inside it
+    const bool lane_on = lane < 63 && th < 7;
+    const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t m1 = m0 + rows_per_block < p.M ? m0 + rows_per_block : p.M;
+    float acc[64];
+#pragma unroll
+    for (int n = 0; n < 64; ++n) acc[n] = 0.0f;
+    const float* __restrict__ xg = p.x;
+    const float* __restrict__ dyg = p.dy;
+    const int W3 = p.W * 3;
+    RowIter it;
+    it.init(m0 < p.M ? m0 : 0, p.Wo, p.Ho);
+    for (int64_t m = m0; m < m1; ++m) {
+        const int ih = it.oh * 2 - 3 + th, e = (it.ow * 2 - 3) * 3 + j;
+        const bool ok = lane_on && (unsigned)ih < (unsigned)p.H && (unsigned)e < (unsigned)W3;
+        const float xv = ok ? xg[((int64_t)it.bb * p.H + ih) * W3 + e] : 0.0f;
+        const f32x16s* __restrict__ g = reinterpret_cast<const f32x16s*>(dyg + __builtin_amdgcn_readfirstlane((int)m) * p.lddy);   // wave-uniform: scalar loads
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x16s gq = g[q];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q * 16 + r] = fmaf(xv, gq[r], acc[q * 16 + r]);
+        }
+        it.next(p.Wo, p.Ho);
+    }
+    if (lane_on) {
+        float* out = p.part + ((int64_t)blockIdx.x * 147 + th * 21 + j) * p.Cout;      // [block][tap = th*7 + tw][c][n], j = tw*3 + c
+#pragma unroll
+        for (int n = 0; n < 64; n += 4) *reinterpret_cast<float4*>(out + n) = make_float4(acc[n], acc[n + 1], acc[n + 2], acc[n + 3]);
+    }
+}
+
 //   lanes-over-Cin form (1x1 convolutions with a narrow OUTPUT): thread = input channel c, registers = the COUT
 //   outputs (dy values are wave-uniform loads).
 template <int COUT, int U>
@@ -3996,6 +4045,11 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
     const bool stem = g_wgrad_stem && form == 1 && p.Cin == 3 && nt == 9 && kh == 3 && kw == 3 && p.stride == 2 && p.taps.dh[0] == -1 &&
                       p.taps.dw[0] == -1 && p.W % 2 == 0 && p.Wo * 2 == p.W && p.Ho * 2 == p.H && p.ldx == 3 && p.Cout <= 32 && RL == 8 &&
                       (int64_t)p.B * p.H * p.W * 3 < (1ll << 31);
+    // the 3 -> <= 64 channel 7x7 / stride 2 / pad 3 stem of the ResNets on an even-sized packed image: seven waves = seven tap rows, scalar input loads
+    const bool stem7 = g_wgrad_stem && form == 1 && p.Cin == 3 && nt == 49 && kh == 7 && kw == 7 && p.stride == 2 && p.taps.dh[0] == -3 &&
+                       p.taps.dw[0] == -3 && p.taps.widx[48] == 48 && p.W % 2 == 0 && p.H % 2 == 0 && p.Wo * 2 == p.W && p.Ho * 2 == p.H && p.ldx == 3 &&
+                       p.Cout == 64 && p.lddy % 16 == 0 && (reinterpret_cast<uintptr_t>(p.dy) & 63) == 0 && p.M < (1ll << 31) &&
+                       (int64_t)p.B * p.H * p.W * 3 < (1ll << 31);
     const bool fuse_bias = form == 2 && dbias != nullptr && ws_bytes >= need + (size_t)splits * p.Cout * 4;
     p.bias_part = fuse_bias ? p.part + (size_t)splits * nt * cn : nullptr;
     if (nt != kh * kw)
@@ -4004,6 +4058,15 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
     if (stem) {
         hipLaunchKernelGGL((wgrad_stem3x3s2_kernel<4>), grid, blk, 0, st, p, rows_per_split);
         splits = nblk;                                    // one slice of partial sums per block from here on
+    } else if (stem7) {
+        // <= 2048 blocks of three waves, at least 32 output pixels each; one slice of partial sums per block (never more than the generic
+        // form's slices, which sized the workspace)
+        int64_t nb7 = std::min<int64_t>(2048, cdiv(p.M, 32));
+        if (nb7 > splits) nb7 = splits;
+        const int64_t rpb = cdiv(p.M, nb7);
+        nb7 = cdiv(p.M, rpb);
+        hipLaunchKernelGGL(wgrad_stem7x7s2_kernel, dim3((unsigned)nb7), dim3(192), 0, st, p, rpb);
+        splits = nb7;
     } else if (form == 1) {
         if (p.Cin == 3 && nt == 9)        hipLaunchKernelGGL((wgrad_narrow_in_kernel<3, 9, 4>), grid, blk, 0, st, p, NL, RL, rows_per_split);
         else if (p.Cin == 3 && nt == 49)  // the 7x7 stems (resnet_models.py:115-117): one row of seven taps per grid.y slice

@@ -401,6 +401,38 @@ def test_mobilenet_stem_weight_gradient(case):
     assert (a - b).abs().max().item() <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("case", [(4, 256, 512, 64), (2, 130, 256, 64), (1, 512, 128, 48)], ids=["cityscapes-batch", "ragged-rows", "narrow-48-generic"])
+def test_resnet_stem_weight_gradient(case):
+    """resnet_models.py:115-117 Conv2d(3, 64, 7, stride 2, padding 3) on an even-sized image: the specialised weight-gradient kernel
+    (wgrad_stem7x7s2_kernel: a lane per (tap, channel) of a tap row, dy read with wave-uniform loads; 64 output channels only) against torch in
+    fp64 and against the generic narrow-input kernel (pp_debug_set_conv_variant bit 23) - same sums in another order; bit-reproducible."""
+    B, H, W, C = case
+    gen = torch.Generator().manual_seed(B * H + C + 7)
+    x = torch.randn(B, 3, H, W, generator=gen)
+    w = torch.randn(C, 3, 7, 7, generator=gen) / np.sqrt(147)
+    dy = torch.randn(B, C, H // 2, W // 2, generator=gen)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wr, stride=2, padding=3).backward(dy.double())
+    L = _lib_mod().lib()
+    def run(variant):
+        L.pp_debug_set_conv_variant(variant)
+        try:
+            tape = E.Tape()
+            wg = gparam(hwio(w))
+            yv = E.conv2d(tape, E.Var(nhwc(x), needs_grad=False), wg, None, 2, 3, 1)
+            tape.backward(yv, nhwc(dy))
+            torch.cuda.synchronize()
+            return oihw(tape.param_grads[id(wg)])
+        finally:
+            L.pp_debug_set_conv_variant(0)
+    a, a2, b = run(0), run(0), run(1 << 23)
+    assert torch.equal(a, a2)
+    scale = wr.grad.abs().max().item()
+    assert (a.double() - wr.grad).abs().max().item() <= 2e-6 * scale * np.sqrt(B * H * W / 4) / 50, "stem dW vs fp64"
+    assert (b.double() - wr.grad).abs().max().item() <= 2e-6 * scale * np.sqrt(B * H * W / 4) / 50, "generic kernel vs fp64"
+    assert (a - b).abs().max().item() <= 1e-5 * scale
+
+
 STRIDED_BWD = [(2, 17, 23, 128, 128, 3, 2, 1, 1), (2, 16, 24, 256, 512, 1, 2, 0, 1), (1, 15, 15, 64, 96, 3, 2, 1, 1),
                (2, 19, 22, 32, 48, 3, 2, 2, 2), (1, 21, 20, 8, 32, 7, 2, 3, 1), (2, 14, 17, 16, 24, 3, 3, 0, 1), (2, 13, 11, 64, 64, 1, 2, 0, 1)]
 
