@@ -2739,8 +2739,21 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* dy,
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     float s = 0.0f;
-    if (c < C)
-        for (int64_t m = r0 + ry; m < r1; m += 4) s += dy[m * ld + c];
+    if (c < C) {
+        // eight rows in flight per thread (one load per trip made the FPN decoder's 67 MB gradients a chain of load latencies: 45 us per
+        // launch, 1.5 TB/s); fixed combination order
+        float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int64_t m = r0 + ry;
+        for (; m + 28 < r1; m += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dy[(m + 4 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] += v[u];
+        }
+        for (; m < r1; m += 4) q[0] += dy[m * ld + c];
+        s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
     sh[ry][threadIdx.x & 63] = s;
     __syncthreads();
     if (ry == 0 && c < C)
