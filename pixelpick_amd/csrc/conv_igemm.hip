@@ -33,6 +33,7 @@ static int g_conv_novec = 0;
 static int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 kernels: caps co-resident blocks per CU
 static int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
 
+typedef float f32x16s __attribute__((ext_vector_type(16)));      // sixteen consecutive floats at a wave-uniform, 64-byte aligned address: one s_load_dwordx16
 constexpr int kThreads = 256;
 constexpr int BK = 16;
 constexpr int kMaxTaps = 49;
@@ -2561,7 +2562,6 @@ __global__ __launch_bounds__(256) void wgrad_stem3x3s2_kernel(WgradParams p, int
 // four aligned 16-dword SCALAR loads per pixel, entering the 64 FMAs as scalar operands.  One slice of partial sums per block
 // ([49][3][Cout], the layout the reduce expects).  (First form, a lane per output channel with the 21 inputs as scalar loads: 203 us - the
 // unaligned window became 21 single-dword scalar loads per pixel and wave.)
-typedef float f32x16s __attribute__((ext_vector_type(16)));
 // (Measured variants of the loop: the input values of four pixels prefetched 114 us, the block's input patch staged in LDS 119 us, the
 // FMAs as explicit v_fmac_f32 with scalar sources instead of the v_pk_fma_f32 pairs hipcc forms 202 us - this form 107 us: the loop is
 // paced by the scalar cache delivering 256 bytes of dy per pixel and wave, not by the input loads.)
