@@ -1,6 +1,6 @@
 # scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r5fin6; mkdir -p $O
+O=gpurun_out/job; mkdir -p $O
 timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
