@@ -257,7 +257,7 @@ def cpu_baseline_grad_deviation(C, H, W, B, n_lab, dev):
 def cpu_baseline_pick_flips(dev):
     """Checker leg (outside every timed region, rank 0 at N = 1 only, part of the cpu_baseline block): the picks of the HIP path
     with the default scorer (algebraic entropy form, v_exp_f32) and with the reference's operation order
-    (pp_debug_set_exact_formula: p = exp(x - m) / S, sum(-p log p), query.py:190,229-239) against oracle/acq_oracle.c on UNGUARDED
+    (strategy | PP_ACQ_REFERENCE_ORDER: p = exp(x - m) / S, sum(-p log p), query.py:190,229-239) against oracle/acq_oracle.c on UNGUARDED
     random logits - how often a device pick differs from the oracle's (a k-th / (k+1)-th score pair closer than the rounding
     difference of the two evaluations).  8 images of 256x512x19, 8 of 320x320x21, one 1024x2048x19; k = 20."""
     from oracle import acq as orc
@@ -276,13 +276,11 @@ def cpu_baseline_pick_flips(dev):
         for st in strategies:
             o_idx, _ = orc.score_topk(lg_np, ex_np, st, 20)
             rec = {"images": B, "picks": B * 20}
-            for name, exact in (("default", 0), ("exact_formula", 1)):
-                L.pp_debug_set_exact_formula(exact)
-                idx, _, _ = acq.score_topk(logits, excl, st, 20)
+            for name, exact in (("default", False), ("exact_formula", True)):
+                idx, _, _ = acq.score_topk(logits, excl, st, 20, reference_order=exact)
                 d = idx.cpu().numpy()
                 rec[name] = {"set_flips": int(sum(len(set(d[b].tolist()) - set(o_idx[b].tolist())) for b in range(B))),
                              "order_flips": int((d != o_idx).sum())}
-            L.pp_debug_set_exact_formula(0)
             out[f"{label} {st}"] = rec
         del logits, excl
     torch.cuda.empty_cache()
@@ -324,6 +322,9 @@ def main():
     ap.add_argument("--reduce-mode", type=int, default=0)
     ap.add_argument("--exact-formula", type=int, default=0)
     ap.add_argument("--conv-variant", type=int, default=0)
+    ap.add_argument("--knobs-build", action="store_true",
+                    help="measure libpixelpick_hip_knobs.so (the test build: same sources + the pp_debug_* planner switches) instead of the "
+                         "product library; needed by --tune-occ / --tune-ppt / --reduce-mode / --conv-variant and by the fp32-MFMA A/B sub-record")
     ap.add_argument("--replay", default="auto", choices=["auto", "on", "off"],
                     help="re-issue the train step's recorded launch list (FlatTrainer.enable_replay: same GPU schedule, half the host "
                          "time per step).  auto: on when this process has fewer than 8 host cores per rank to enqueue from")
@@ -342,6 +343,7 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
 
+    rccl_log = None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -354,6 +356,11 @@ def main():
         backend = os.environ.get("PIXELPICK_DIST_BACKEND", "nccl")
         dev_index = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev_index)
+        if backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # the communicator's INIT lines (channel count) go to a scratch file per rank: bench.py reports `rccl_channels` from rank 0's
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), f"pixelpick_rccl_{os.getpid()}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -367,11 +374,18 @@ def main():
     from pixelpick_amd import _lib
     from pixelpick_amd import acquisition as acq
     from pixelpick_amd import dist_utils as du
+    if a.knobs_build:
+        _lib.use_knobs_build()
     L = _lib.lib()
-    L.pp_debug_set_acq_tuning(a.tune_occ, a.tune_ppt)
-    L.pp_debug_set_reduce_mode(a.reduce_mode)
-    L.pp_debug_set_exact_formula(a.exact_formula)
-    L.pp_debug_set_conv_variant(a.conv_variant)
+    KNOBS = _lib.knobs_build()
+    if KNOBS:
+        L.pp_debug_set_acq_tuning(a.tune_occ, a.tune_ppt)
+        L.pp_debug_set_reduce_mode(a.reduce_mode)
+        L.pp_debug_set_conv_variant(a.conv_variant)
+    else:
+        assert not (a.tune_occ or a.tune_ppt or a.reduce_mode or a.conv_variant), "planner switches exist in the test build only: add --knobs-build"
+    # the reference's operation order is a per-call flag of the product library (PP_ACQ_REFERENCE_ORDER), not a process switch
+    exact_flag = [0x100 if a.exact_formula else 0]
     stream = torch.cuda.current_stream(dev).cuda_stream
     C, H, W, k = a.classes, a.height, a.width, a.k
 
@@ -392,16 +406,17 @@ def main():
             step_fn()
         barrier()
         if events is not None:
-            L.pp_debug_set_kernel_events(events.starts, events.stops, events.n)
+            L.pp_set_kernel_events(events.starts, events.stops, events.n)
         t0 = time.perf_counter()
         for _ in range(steps):
             step_fn()
         barrier()
         el = time.perf_counter() - t0
-        L.pp_debug_set_kernel_events(None, None, 0)
+        L.pp_set_kernel_events(None, None, 0)
         return max_over_ranks(el)
 
     line = {}
+    library_build = "test build (libpixelpick_hip_knobs.so)" if KNOBS else "product (libpixelpick_hip.so: no pp_debug_* switches)"
 
     # ------------------------------------------------------------------------------------ train step
     def train_leg(network, steps, warmup, Ht, Wt, Ct, headline=False):
@@ -543,7 +558,56 @@ def main():
             for tag, e0, e1 in tr.__dict__.get("comm_times", []):
                 in_step.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e3)
             tr.time_collectives = False
+            # --- what the first run on a real multi-GPU node needs in order to be trusted (nobody has had one yet) ---
+            # (1) which device every rank really sits on; ranks sharing a device (the one-GPU plumbing runs over gloo) are flagged
+            import socket
+            rank_devs = [None] * world
+            dist.all_gather_object(rank_devs, {"rank": rank, "local_rank": local_rank, "device": dev_index, "host": socket.gethostname(),
+                                               "pci_bus_id": getattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id", None),
+                                               "uuid": str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", ""))})
+            shared = len({(d["host"], d["device"]) for d in rank_devs}) < world
+            # (2) the channels the communicator opened (each keeps a block resident on a CU during a collective) beside the CUs the
+            # spin-waiting launches leave free for them
+            channels = du.rccl_channels_from_log(rccl_log) if rccl_log else None
+            # (3) the N = 1 figure of THIS invocation: rank 0 alone on its device, its own one-rank group (no collective), the other
+            # ranks idle at the barrier - what SCALE's N = 1 point and BENCH's headline should both agree with on this box
+            solo_groups = [dist.new_group([r]) for r in range(world)]          # (every rank creates every group)
+            n1 = None
+            if rank == 0:
+                from pixelpick_amd.trainer import FlatTrainer
+                from pixelpick_amd.utils.utils import get_model
+                torch.manual_seed(0)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    m1 = get_model(Namespace(use_mc_dropout=False, mc_dropout_p=0.2, n_classes=C, network_name=a.network, weight_type="random",
+                                             n_layers=50, use_softmax=True, use_dilated_resnet=True, width_multiplier=1.0)).to(dev).train()
+                tr1 = FlatTrainer(m1, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, ignore_index=C, process_group=solo_groups[0])
+                assert tr1.world == 1 and not tr1.collectives
+                x1, y1 = synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1)
+                if train["replay"]:
+                    tr1.enable_replay(x1, y1, warmup=1)
+                for _ in range(max(a.warmup, 3)):
+                    tr1.train_step(x1, y1)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    tr1.train_step(x1, y1)
+                torch.cuda.synchronize(dev)
+                el1 = time.perf_counter() - t1
+                n1 = {"img_per_s": round(TB * a.steps / el1, 2), "ms_per_step": round(el1 / a.steps * 1e3, 4), "replay": bool(train["replay"]),
+                      "what": "rank 0 alone (one-rank group, no all-reduce) while the other ranks wait: the N = 1 point of this very run"}
+                tr1.close()
+                del tr1, m1, x1, y1
+                torch.cuda.empty_cache()
+            barrier()
             line["distributed"] = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                                   "rank_devices": rank_devs, "shared_device": bool(shared),
+                                   "comm_cu_reserve": int(L.pp_get_comm_cu_reserve()), "rccl_channels": channels,
+                                   "rccl_channels_source": ("NCCL_DEBUG=INFO log of this run (the 'coll channels' line of communicator init)" if channels is not None
+                                                            else ("not an RCCL communicator" if dist.get_backend() != "nccl" else "no channel line in the RCCL log")),
+                                   "rccl_env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "PIXELPICK_COMM_CU_RESERVE") if k in os.environ},
+                                   "n1_same_invocation": n1,
+                                   "scaling_vs_n1_same_invocation": (round(train["img_per_s"] / (world * n1["img_per_s"]), 4) if n1 else None),
                                    "allreduce_in_step_us": {k: round(sum(v) / len(v), 1) for k, v in in_step.items()},
                                    "allreduce_bytes_per_step": tr.n * 4,
                                    "buckets": ([int((tr.n - tr.n_split) * 4), int((tr.n_split - tr.n_mid) * 4), int(tr.n_mid * 4)] if tr.n_mid
@@ -561,7 +625,7 @@ def main():
         # the op as the train step runs it: operand splits (x3_split_kernel, x3_split_w_kernel) + conv_x3_kernel - the fp32
         # convolution on the bf16 matrix pipe (every operand = hi + mid + lo bf16, six MFMAs per product, fp32 accumulate;
         # error against float64 = that of the fp32-MFMA kernel, tests/test_conv_x3_gpu.py) - and, for reference, the fp32-MFMA
-        # kernel it replaced (pp_debug_set_x3(0))
+        # kernel it replaced (test build: pp_debug_set_x3(0))
         wsx = torch.empty(max(int(L.pp_conv2d_fwd_workspace_bytes(TB, Hq, Wq, 304, 256, 3, 3, 1, 1, 1)), 256), dtype=torch.uint8, device=dev)
 
         def conv_once():
@@ -571,13 +635,18 @@ def main():
         flops = 2.0 * TB * Hq * Wq * 256 * 9 * 304
         res = {}
         for tag, mode in (("bf16x3", 1), ("fp32_mfma", 0)):
-            L.pp_debug_set_x3(mode)
+            if not KNOBS and mode == 0:      # the fp32-MFMA kernel on this layer is a planner switch: test build only (--knobs-build)
+                res[tag] = None
+                continue
+            if KNOBS:
+                L.pp_debug_set_x3(mode)
             evc = HipEvents(nrep)
             timed(conv_once, nrep, 12, evc)      # warm: the first launches after the train loop read ~10 % low (clock ramp)
             cms = evc.elapsed_ms()
             evc.destroy()
             res[tag] = sum(cms) / len(cms)
-        L.pp_debug_set_x3(1)
+        if KNOBS:
+            L.pp_debug_set_x3(1)
         cavg = res["bf16x3"]
         # The kernel runs on the bf16 matrix pipe and spends six bf16 MFMAs per fp32 product: ITS roof is the dense bf16 peak / 6.
         # (Rounds 2-3 divided by the fp32 MFMA peak and printed a "fraction" above 1 - the wrong roof; that ratio stays below as a
@@ -591,9 +660,10 @@ def main():
                                  "peak_note": f"dense bf16 MFMA peak {MFMA_BF16_PEAK_TF} TF / 6 MFMAs per fp32 product (MI355X_MICROARCH.md)",
                                  "bf16_pipe_achieved_TF": round(6 * ach, 1), "bf16_pipe_peak_TF": MFMA_BF16_PEAK_TF,
                                  "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4),
-                                 "fp32_mfma_kernel": {"kernel": "conv_igemm_dma_kernel<128,128>", "kernel_ms_avg": round(res["fp32_mfma"], 4),
-                                                      "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF,
-                                                      "frac": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
+                                 "fp32_mfma_kernel": ({"kernel": "conv_igemm_dma_kernel<128,128>", "kernel_ms_avg": round(res["fp32_mfma"], 4),
+                                                       "achieved": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF,
+                                                       "frac": round(flops / (res["fp32_mfma"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+                                                      if res["fp32_mfma"] else "A/B against the fp32-MFMA kernel is a planner switch of the test build: python bench.py --knobs-build"),
                                  "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms_avg": round(cavg, 4)}
         # conv_x3_kernel ALONE: both operands' planes held by the caller, as in the train step (the activation planes are shared with the
         # weight gradient, the weight planes are split at begin_step on the second queue: pp_conv2d_fwd_pre2)
@@ -613,7 +683,7 @@ def main():
         ach_k = flops / (kavg * 1e-3) / 1e12
         line["roofline_mfma"]["kernel_only"] = {"what": "conv_x3_kernel<256,128> with both operands' planes held by the caller (pp_conv2d_fwd_pre2)",
                                                 "kernel_ms_avg": round(kavg, 4), "achieved": round(ach_k, 2), "frac": round(ach_k / X3_PEAK_TF, 4)}
-        # What the matrix pipe SUSTAINS on this box under conv_x3_kernel's own MFMA stream and nothing else (pp_debug_mfma_stream:
+        # What the matrix pipe SUSTAINS on this box under conv_x3_kernel's own MFMA stream and nothing else (pp_yardstick_mfma_stream:
         # register-resident fragments, launches of the convolution's length): the spec peak assumes 2.4 GHz, and a chip-wide bf16 MFMA
         # load on operands with random mantissas is power-limited well below it (profiles/r05_conv_x3_power.txt) - zeros are not.
         sink = torch.zeros(64, device=dev)
@@ -621,7 +691,7 @@ def main():
         for kind, tag in ((0, "zero_operands"), (2, "random_operands")):
             it0 = 160
             def stream_once():
-                _lib.check(L.pp_debug_mfma_stream(kind, it0, sink.data_ptr(), stream), "pp_debug_mfma_stream")
+                _lib.check(L.pp_yardstick_mfma_stream(kind, it0, sink.data_ptr(), stream), "pp_yardstick_mfma_stream")
             evs = HipEvents(nrep)
             timed(stream_once, nrep, 12, evs)
             sms = evs.elapsed_ms()
@@ -631,7 +701,7 @@ def main():
             mf[tag] = {"bf16_TF": round(n_cu * 8 * it0 * 24 * 2.0 * 32 * 32 * 16 / (sm * 1e-3) / 1e12, 1), "kernel_ms_avg": round(sm, 4)}
         sus = mf["random_operands"]["bf16_TF"] / 6.0
         line["roofline_mfma"]["sustained"] = {
-            "what": "pp_debug_mfma_stream: conv_x3_kernel's six-term MFMA sequence from registers only (no LDS, no DMA, no barrier), 8 waves/CU, "
+            "what": "pp_yardstick_mfma_stream: conv_x3_kernel's six-term MFMA sequence from registers only (no LDS, no DMA, no barrier), 8 waves/CU, "
                     "a launch of the convolution's length - the rate the power limit leaves on this box",
             **mf, "fp32_equivalent_peak_random_operands_TF": round(sus, 1),
             "frac_of_spec_peak": round(mf["random_operands"]["bf16_TF"] / MFMA_BF16_PEAK_TF, 4),
@@ -718,7 +788,7 @@ def main():
         val = torch.empty((B, ka), dtype=torch.float32, device=dev)
         ws = torch.empty(max(L.pp_acq_workspace_bytes(B, Ca, Ha, Wa, ka), 256), dtype=torch.uint8, device=dev)
         sB, sC, sH, sW = logits.stride()
-        sid = acq.STRATEGY_ID[strategy]
+        sid = acq.STRATEGY_ID[strategy] | exact_flag[0]
 
         def acq_step():
             rc = L.pp_acq_score_topk(logits.data_ptr(), B, Ca, Ha, Wa, sB, sC, sH, sW, excl.data_ptr(), sid, ka,
@@ -757,23 +827,23 @@ def main():
             sink = torch.zeros(4, device=dev)
             nbytes = logits.numel() * 4
             for _ in range(3):
-                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, 256, sink.data_ptr(), stream), "pp_debug_stream_read")
+                _lib.check(L.pp_yardstick_stream_read(logits.data_ptr(), nbytes, 256, sink.data_ptr(), stream), "pp_yardstick_stream_read")
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
             torch.cuda.synchronize(dev)
             for e0, e1 in evs:
                 e0.record()
-                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, 256, sink.data_ptr(), stream), "pp_debug_stream_read")
+                _lib.check(L.pp_yardstick_stream_read(logits.data_ptr(), nbytes, 256, sink.data_ptr(), stream), "pp_yardstick_stream_read")
                 e1.record()
             torch.cuda.synchronize(dev)
             yms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
             yard_plain = nbytes / (yms * 1e-3) / 1e9
             # the same with non-temporal loads (blocks < 0) - what the scorers use since round 5; the yardstick is the better of the two
             for _ in range(3):
-                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, -256, sink.data_ptr(), stream), "pp_debug_stream_read")
+                _lib.check(L.pp_yardstick_stream_read(logits.data_ptr(), nbytes, -256, sink.data_ptr(), stream), "pp_yardstick_stream_read")
             torch.cuda.synchronize(dev)
             for e0, e1 in evs:
                 e0.record()
-                _lib.check(L.pp_debug_stream_read(logits.data_ptr(), nbytes, -256, sink.data_ptr(), stream), "pp_debug_stream_read")
+                _lib.check(L.pp_yardstick_stream_read(logits.data_ptr(), nbytes, -256, sink.data_ptr(), stream), "pp_yardstick_stream_read")
                 e1.record()
             torch.cuda.synchronize(dev)
             yms_nt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
@@ -787,7 +857,7 @@ def main():
                 "read_only_yardstick": ({"GB/s": round(yard, 1), "frac_of_peak": round(yard / HBM_PEAK_GBS, 4),
                                          "acq_kernel_vs_yardstick": round(achieved / yard, 4),
                                          "ordinary_loads_GB/s": round(yard_plain, 1), "non_temporal_loads_GB/s": round(yard_nt, 1),
-                                         "what": "pp_debug_stream_read: a kernel that only reads the same logits buffer (the better of ordinary and non-temporal loads)"}
+                                         "what": "pp_yardstick_stream_read: a kernel that only reads the same logits buffer (the better of ordinary and non-temporal loads)"}
                                         if yard else None)}
 
         if ka > 48:
@@ -821,12 +891,12 @@ def main():
         if not a.exact_formula and world == 1 and not a.no_other_configs:
             # the reference's operation order as the scorer (SURVEY 7.4 wanted it selectable; the default is the algebraic form):
             # same launch, same traffic, more VALU work per pixel
-            L.pp_debug_set_exact_formula(1)
+            exact_flag[0] = 0x100
             rx, roofx = acq_leg(a.batch, C, H, W, k, a.strategy, a.layout, max(5, min(a.steps, 10)), 3, False)
-            L.pp_debug_set_exact_formula(0)
+            exact_flag[0] = 0
             acqr["exact_formula"] = {"value": rx["value"], "unit": rx["unit"], "ms_per_step": rx["ms_per_step"],
                                      "kernel_ms_avg": roofx["kernel_ms_avg"], "frac_of_hbm_peak": roofx["frac"],
-                                     "what": "pp_debug_set_exact_formula(1): p = exp(x - m) / S, sum(-p log p) in query.py:190,230's order"}
+                                     "what": "strategy | PP_ACQ_REFERENCE_ORDER: p = exp(x - m) / S, sum(-p log p) in query.py:190,230's order (a per-call flag of the C ABI)"}
 
     # ------------------------------------------------------------------------------------ the other BASELINE configurations
     # Bounded sub-records in the SAME run (N = 1 only; the scaling runs stay short): every acquisition shape / strategy the
@@ -879,10 +949,10 @@ def main():
 
     if rank == 0:
         head = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "library_build": library_build,
                 "dtype_note": "fp32 tensors and fp32 accumulation throughout; the MFMA-bound 3x3 / large 1x1 convolutions split each fp32 operand "
                               "exactly into three bf16 terms and run six bf16 MFMAs per product (error vs float64 equal to the fp32-MFMA "
-                              "kernels', tests/test_conv_x3_gpu.py; pp_debug_set_x3(0) selects the fp32-MFMA kernels)"}
+                              "kernels', tests/test_conv_x3_gpu.py; the test build's pp_debug_set_x3(0) selects the fp32-MFMA kernels)"}
         net_desc = {"deeplab": "BASELINE configs[1]: Cityscapes {}x{}, C={}, DeepLabv3+-MobileNetV2",
                     "FPN": "BASELINE configs[2] (per GPU): Cityscapes {}x{}, C={}, ResNet50 model of the reference (FPNSeg)",
                     "deeplab_r50": "BASELINE configs[2] as named (per GPU): Cityscapes {}x{}, C={}, DeepLabv3+-ResNet50 assembled from "

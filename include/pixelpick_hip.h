@@ -36,6 +36,11 @@ enum {
 
 /* query.py:229-239 UncertaintySampler strategies.  (`random`, query.py:242-244, is host RNG.) */
 enum { PP_ACQ_ENTROPY = 0, PP_ACQ_LEAST_CONFIDENCE = 1, PP_ACQ_MARGIN = 2 };
+/* OR-ed into `strategy` at any acquisition entry point: score in the reference's OPERATION ORDER - p_c = exp(x_c - m) / S, then
+ * sum(-p_c log p_c) with libm-accurate exp / log, each product and sum rounded separately (query.py:190,230) - instead of the default
+ * algebraic form (entropy = log S + sum e_c (m - x_c) / S, v_exp_f32 exponentials; identical NaN behaviour).  Both forms are held to the
+ * oracle's picks at full size; the reference-order form runs at about half the rate (0.40 of HBM).  Per call, no process state. */
+#define PP_ACQ_REFERENCE_ORDER 0x100
 
 /* Class counts up to this are scored from registers (one read of the logits); wider heads take the streamed scorers (acq_stream_kernel:
  * the class vector is read two or three times, the later passes from L2) - the reference softmaxes whatever width the model emits
@@ -61,6 +66,10 @@ const char* pp_last_error(void);
  *   out_map  f32 [B,H,W] or NULL — the score map after exclusion (what query.py calls uc_map).
  *   k larger than the number of un-excluded pixels is NOT an error (as in the reference, excluded
  *   pixels are then returned, lowest index first).
+ *   (SURVEY.md 8(b)'s sketch carries a `sorted` flag after k.  It is deliberately absent: the reference's torch.topk runs with its
+ *   default sorted=True and its callers rely on that order (query.py:50-54 takes the first n of the value-sorted candidates), and the
+ *   rank-merge that joins the per-block candidate lists yields the value-sorted order as a by-product - an unsorted mode would
+ *   neither match a reference call nor save a launch.)
  */
 size_t pp_acq_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_t k);
 
@@ -201,7 +210,7 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
                          int Cout, int kh, int kw, int stride, int pad, int dil, float* dw, float* dbias,
                          void* workspace, size_t ws_bytes, pp_stream_t stream);
 
-/* bf16x3 operand planes shared between the calls of one layer.  The MFMA-bound convolutions (see pp_debug_set_x3) read their
+/* bf16x3 operand planes shared between the calls of one layer.  The MFMA-bound convolutions (layers the planner puts on the bf16x3 kernels) read their
  * activation operand as three chunk-major bf16 planes; by default every call splits its operand into its workspace.  The
  * forward's operand x is also the weight gradient's, and the backward-data's operand dy is the weight gradient's other one:
  * a caller may split a tensor ONCE with pp_x3_split and pass the planes to every *_pre call that reads it (NULL = split
@@ -557,51 +566,22 @@ int pp_nchw_to_nhwc(const float* x, int B, int C, int64_t HW, float* y, int64_t 
 /* [B,H,W,C] (pixel stride ldx) -> [B,C,H,W] contiguous: the FPN model's "pred"/"emb" outputs (decoders.py:77). */
 int pp_nhwc_to_nchw(const float* x, int64_t ldx, int B, int C, int64_t HW, float* y, pp_stream_t stream);
 
-/* Debug/bench knobs.
- * reduce mode: 0 = threshold-prefiltered per-wave top-k with DPP reductions (default), 1 = same with
- *              ds_bpermute (__shfl) reductions, 2 = plain k-round extraction loop (no prefilter).
- *              bit 8: large-k selection through the one-block radix select, bit 9: no quantised-histogram select,
- *              bit 10: the score histogram of the large-k selection in its own pass over the map instead of inside the scorer launch (A/B).
- * exact formula: 0 = default scorer (entropy = log S + sum e_c (m - x_c) / S, v_exp_f32 exponentials;
- *              identical NaN behaviour), 1 = the reference's operation order p_c = exp(x_c - m) / S,
- *              sum(-p_c log p_c) with libm-accurate exp/log (query.py:190,230). */
-void pp_debug_set_reduce_mode(int mode);
-void pp_debug_set_exact_formula(int on);
-/* Tuning knob for the C == 19 flat path: occupancy bound (2/3/4 waves per SIMD, 0 = default) and
- * pixels per thread (4/8, 0 = automatic).  occ 8 / 9: synchronous NHWC kernel / generic strided path; occ 10: the streamed scorers
- * (class vector read from memory in passes) at ANY class count - the tests compare them bit for bit with the register kernels. */
-void pp_debug_set_acq_tuning(int occ, int ppt);
-/* Dense conv kernel A/B knobs: low 2 bits 0 = 128x128 large tile (default; measured fastest), 2 = 128x64 tiles;
- * bit 2 = linear instead of XCD-aware tile order; bit 3 = conditional (non-vector) loads; bits 4/5 = cap the large
- * tile at 2 / 1 blocks per CU; bit 6 split-K off; bit 7 64-deep K step of the 64x64 tiles off; bit 8 LDS-DMA kernel of the
- * 128-row tiles off (bit 15: backward-data only for the 128x64-tiled layers; bit 22: forward only); bits 9-14 weight-gradient / ragged-tile / K-order variants;
- * bit 12 32-deep K step for the 128x128 tiles; bits 16/17 TIMING-ONLY ablation (skips the split-K reduce: wrong results);
- * bit 18 LDS-DMA kernel of the 64x64 tiles off (bit 19: forward only); bit 20 LDS-DMA weight-gradient kernel of the
- * 128-wide tiles off; bit 21 LDS-DMA weight-gradient kernel for the 64x64 tiles on.
- * Findings: profiles/r01_conv_ablation.txt. */
-void pp_debug_set_dw_variant(int v);   /* bit 0: one-output-per-thread depthwise kernels (A/B); bit 8: separable bilinear backward off;
-                                        * bits 13-15 / 16-17: column-block width / least rows per thread of the depthwise weight gradient (0 = by map size) */
-void pp_debug_set_splitk(int v);       /* tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 */
-void pp_debug_set_wgrad_target(int blocks);   /* split-M target of the weight-gradient kernels (default 1024) */
-void pp_debug_set_bn_target(int blocks);   /* strips x row chunks of the single-launch BatchNorm (default 384, <= 1024) */
-void pp_debug_set_bn_bytes_per_block(int bytes);   /* large maps: one block per this many bytes (default 0 = off: measured neutral); -1: register-cached variants off */
 /* Blocks of the single-launch BatchNorm kernels that fit on the device at once (occupancy x CUs; 0 = no device).  A launch
  * uses at most half of it, so that two spin-waiting launches (second stream / second process) are always co-resident. */
 int pp_bn_fused_capacity(void);
-/* Debug: pp_bn_train_fwd_fused writes per-block wall-clock stamps (100 MHz; [blocks][8]: entry, statistics pass done, block
- * reduction done, partial published, strip combined, rows written) into this device buffer; NULL (default) = off. */
-void pp_debug_set_bn_probe(void* device_buffer);
-/* Yardstick, measurement only: a kernel that only reads `bytes` of x (float4 per lane, `blocks` blocks of 256 threads, 0 = 256).
- * bench.py reports acq_kernel's bandwidth against what this reaches on the same buffer. */
-int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);   /* blocks < 0: -blocks blocks, non-temporal loads */
-void pp_debug_set_conv_thresholds(int v);   /* big_tile_min | wgrad_rows_min << 12 (defaults 384 / 128) */
-void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* tile rows, tile cols, tiles, split-K slices */
-void pp_debug_set_conv_rows(int bits);      /* whole-row VALU kernels of the narrow pointwise layers: bit 0 off, bit 1 forward rows kernel only from 65536 rows (A/B) */
-void pp_debug_set_conv_bn_fuse(int bits);   /* fused conv + BatchNorm launches offered: bit 0 tiled fwd, 1 split-K fwd, 2 bwd 64x64, 3 bwd split-K / 128x32 (default 15; A/B) */
-int pp_debug_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stream);   /* yardstick: conv_x3_kernel's MFMA stream from registers only; data_kind 0 zeros, 1 near-constant, 2 random operands (measurement, bench.py) */
-void pp_debug_set_x3_variant(int v);   /* experiment forms of conv_x3_kernel<256,128> (ring depth, priority, DMA placement, timing ablations); 0 = product */
-void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */
-void pp_debug_set_conv_variant(int v);
+/* Measurement yardsticks (stateless launches; bench.py reports the product kernels against them).
+ * pp_yardstick_stream_read: a kernel that only reads `bytes` of x (float4 per lane, `blocks` blocks of 256 threads, 0 = 256;
+ * blocks < 0: -blocks blocks, non-temporal loads) - acq_kernel's bandwidth is quoted against what this reaches on the same buffer.
+ * pp_yardstick_mfma_stream: conv_x3_kernel's MFMA stream from registers only; data_kind 0 zeros, 1 near-constant, 2 random operands. */
+int pp_yardstick_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream);
+int pp_yardstick_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stream);
+
+/* The A/B and ablation switches of earlier rounds (process-global planner state, `pp_debug_*`) are NOT part of this library: they exist
+ * only in the test build, libpixelpick_hip_knobs.so (same sources + -DPP_DEBUG_KNOBS, see pixelpick_hip_knobs.h); `nm -D` of
+ * libpixelpick_hip.so shows none of them, and its planners run on their compiled-in defaults. */
+#ifdef PP_DEBUG_KNOBS
+#include "pixelpick_hip_knobs.h"
+#endif
 
 /* ---------------------------------------------------------------------------------------------
  * Launch plans: the train step of model.py:101-122 (model.train(); forward; cross_entropy; backward; optimizer.step()) as ONE
@@ -640,15 +620,12 @@ int pp_plan_replay(pp_plan_t plan, int64_t from, int64_t* next);
  * the first step. */
 void pp_set_comm_cu_reserve(int cus);
 int pp_get_comm_cu_reserve(void);
-/* Test stand-in for such a resident kernel: `blocks` (<= 256) blocks that each take a whole CU's LDS and spin until *stop != 0 (a
- * host-visible int) or max_ticks of the 100 MHz clock (<= 60 s) have passed; *started counts the blocks that got a CU. */
-int pp_debug_occupy_cus(int blocks, const int* stop, uint64_t max_ticks, uint64_t* started, pp_stream_t stream);
-
 /* Profiling hook for bench.py: `starts`/`stops` are HOST arrays of n caller-created hipEvent_t.  The
  * i-th launch of a dominant kernel (acq_kernel, conv_igemm_kernel) after this call records starts[i] / stops[i] on its
  * stream immediately before / after the launch.  Pass (NULL, NULL, 0) to switch off.  The arrays must
- * stay alive until then. */
-void pp_debug_set_kernel_events(void** starts, void** stops, int n);
+ * stay alive until then.  Process-global and meant for ONE measuring thread (the only state besides pp_set_comm_cu_reserve that a call
+ * can leave behind in this library). */
+void pp_set_kernel_events(void** starts, void** stops, int n);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,21 @@ import struct
 import torch  # noqa: F401  (loads PyTorch's libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpixelpick_hip.so")
+LIB_PATH = os.path.join(_HERE, "libpixelpick_hip.so")                # the product: no pp_debug_* symbol, planners on their defaults
+KNOBS_LIB_PATH = os.path.join(_HERE, "libpixelpick_hip_knobs.so")    # the test build: same sources + -DPP_DEBUG_KNOBS
+_use_knobs = [os.environ.get("PIXELPICK_KNOBS_BUILD", "0") not in ("", "0")]
+
+
+def use_knobs_build(on: bool = True):
+    """Select the test build (planner switches `pp_debug_*`, experiment kernels) for this process.  Must run before the first lib():
+    one process holds ONE library (two copies would each keep their own launch epochs and exchange tags)."""
+    if _lib is not None and _use_knobs[0] != bool(on):
+        raise PixelPickHipError("use_knobs_build() after the library was loaded")
+    _use_knobs[0] = bool(on)
+
+
+def knobs_build() -> bool:
+    return _use_knobs[0]
 
 _i64, _p, _int, _sz, _f = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
@@ -123,29 +137,12 @@ SIGNATURES = {
     "pp_add2d": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _p]),
     "pp_nhwc_to_nchw": (_int, [_p, _i64, _int, _int, _i64, _p, _p]),
     "pp_nchw_to_nhwc": (_int, [_p, _int, _int, _i64, _p, _i64, _p]),
-    "pp_debug_set_reduce_mode": (None, [_int]),
-    "pp_debug_set_exact_formula": (None, [_int]),
-    "pp_debug_set_acq_tuning": (None, [_int, _int]),
-    "pp_debug_set_dw_variant": (None, [_int]),
-    "pp_debug_set_splitk": (None, [_int]),
-    "pp_debug_set_wgrad_target": (None, [_int]),
-    "pp_debug_set_bn_target": (None, [_int]),
-    "pp_debug_set_bn_bytes_per_block": (None, [_int]),
     "pp_bn_fused_capacity": (_int, []),
-    "pp_debug_set_bn_probe": (None, [_p]),
-    "pp_debug_stream_read": (_int, [_p, _sz, _int, _p, _p]),
-    "pp_debug_set_conv_thresholds": (None, [_int]),
-    "pp_debug_conv_plan": (None, [_i64, _int, _int, _int, _p]),
-    "pp_debug_set_conv_variant": (None, [_int]),
-    "pp_debug_set_conv_rows": (None, [_int]),
-    "pp_debug_set_conv_bn_fuse": (None, [_int]),
-    "pp_debug_set_x3": (None, [_int]),
-    "pp_debug_set_x3_variant": (None, [_int]),
-    "pp_debug_mfma_stream": (_int, [_int, _int, _p, _p]),
-    "pp_debug_set_kernel_events": (None, [_p, _p, _int]),
+    "pp_yardstick_stream_read": (_int, [_p, _sz, _int, _p, _p]),
+    "pp_yardstick_mfma_stream": (_int, [_int, _int, _p, _p]),
+    "pp_set_kernel_events": (None, [_p, _p, _int]),
     "pp_set_comm_cu_reserve": (None, [_int]),
     "pp_get_comm_cu_reserve": (_int, []),
-    "pp_debug_occupy_cus": (_int, [_int, _p, _u64, _p, _p]),
     "pp_plan_create": (_p, []),
     "pp_plan_destroy": (None, [_p]),
     "pp_plan_size": (_i64, [_p]),
@@ -156,6 +153,27 @@ SIGNATURES = {
     "pp_plan_add_join": (_int, [_p, _p, _p]),
     "pp_plan_add_host_break": (_int, [_p]),
     "pp_plan_replay": (_int, [_p, _i64, ctypes.POINTER(_i64)]),
+}
+
+# The test build's planner switches (include/pixelpick_hip_knobs.h): exported by libpixelpick_hip_knobs.so only
+KNOB_SIGNATURES = {
+    "pp_debug_set_reduce_mode": (None, [_int]),
+    "pp_debug_set_exact_formula": (None, [_int]),
+    "pp_debug_set_acq_tuning": (None, [_int, _int]),
+    "pp_debug_set_dw_variant": (None, [_int]),
+    "pp_debug_set_splitk": (None, [_int]),
+    "pp_debug_set_wgrad_target": (None, [_int]),
+    "pp_debug_set_bn_target": (None, [_int]),
+    "pp_debug_set_bn_bytes_per_block": (None, [_int]),
+    "pp_debug_set_bn_probe": (None, [_p]),
+    "pp_debug_set_conv_thresholds": (None, [_int]),
+    "pp_debug_conv_plan": (None, [_i64, _int, _int, _int, _p]),
+    "pp_debug_set_conv_variant": (None, [_int]),
+    "pp_debug_set_conv_rows": (None, [_int]),
+    "pp_debug_set_conv_bn_fuse": (None, [_int]),
+    "pp_debug_set_x3": (None, [_int]),
+    "pp_debug_set_x3_variant": (None, [_int]),
+    "pp_debug_occupy_cus": (_int, [_int, _p, _u64, _p, _p]),
 }
 
 _lib = None
@@ -187,17 +205,21 @@ def lib():
     """Load (once) and return the shared library; raise loudly when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = KNOBS_LIB_PATH if _use_knobs[0] else LIB_PATH
+        if not os.path.exists(path):
             raise PixelPickHipError(
-                f"{LIB_PATH} not found: build the HIP extension first "
+                f"{path} not found: build the HIP extension first "
                 f"(python -m pixelpick_amd.build, or __graft_entry__.build()). No fallback path exists.")
         _preload_torch_hip()
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        L = ctypes.CDLL(path)
+        sigs = dict(SIGNATURES)
+        if _use_knobs[0]:
+            sigs.update(KNOB_SIGNATURES)
+        for name, (res, args) in sigs.items():
             fn = getattr(L, name)  # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
-            if name.startswith(("pp_debug_set_", "pp_set_")):
+            if name.startswith(("pp_debug_set_", "pp_set_comm")):
                 setattr(L, name, _knob_setter(fn))
         _lib = L
     return _recording[0] or _lib
@@ -215,7 +237,7 @@ _NOT_LAUNCHES = ("pp_version", "pp_last_error", "pp_bn_fused_capacity", "pp_bn_f
 
 
 def _is_launch(name: str) -> bool:
-    return not (name in _NOT_LAUNCHES or name.startswith(("pp_debug_", "pp_plan_"))
+    return not (name in _NOT_LAUNCHES or name.startswith(("pp_debug_", "pp_plan_", "pp_set_", "pp_yardstick_"))
                 or name.endswith(("_bytes", "_rows", "_ints", "_accepts_affine_in", "_ok")))
 
 

@@ -54,9 +54,14 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def score_topk(logits: torch.Tensor, exclude, strategy: str, k: int, return_map: bool = False
+REFERENCE_ORDER = 0x100      # PP_ACQ_REFERENCE_ORDER (include/pixelpick_hip.h): OR-ed into the strategy id of one call
+
+
+def score_topk(logits: torch.Tensor, exclude, strategy: str, k: int, return_map: bool = False, reference_order: bool = False
                ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """softmax -> score -> exclusion -> per-image top-k in one pass (query.py:190-204,57-61).
+    reference_order: score in query.py:190,230's own operation order (p = exp(x - m) / S, then sum(-p log p)) instead of the
+    default algebraic form - a per-call flag, about half the rate.
 
     logits [B,C,H,W] f32 on the GPU with any strides (NCHW, channels_last, cropped view).
     Returns (idx int32 [B,k] flat h*W+w value-sorted, val f32 [B,k], map f32 [B,H,W] | None).
@@ -74,14 +79,15 @@ def score_topk(logits: torch.Tensor, exclude, strategy: str, k: int, return_map:
     sB, sC, sH, sW = logits.stride()
     with torch.cuda.device(dev):
         rc = L.pp_acq_score_topk(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW,
-                                 ex.data_ptr() if ex is not None else None, strategy_id(strategy), k,
+                                 ex.data_ptr() if ex is not None else None,
+                                 strategy_id(strategy) | (REFERENCE_ORDER if reference_order else 0), k,
                                  idx.data_ptr(), val.data_ptr(), omap.data_ptr() if omap is not None else None,
                                  ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_acq_score_topk")
     return idx, val, omap
 
 
-def score_map(logits: torch.Tensor, exclude, strategy: str) -> torch.Tensor:
+def score_map(logits: torch.Tensor, exclude, strategy: str, reference_order: bool = False) -> torch.Tensor:
     """[B,C,H,W] logits -> [B,H,W] uncertainty map after exclusion (query.py:190-201)."""
     _require_cuda_f32(logits, "logits", 4)
     B, C, H, W = logits.shape
@@ -92,7 +98,8 @@ def score_map(logits: torch.Tensor, exclude, strategy: str) -> torch.Tensor:
     sB, sC, sH, sW = logits.stride()
     with torch.cuda.device(dev):
         rc = L.pp_acq_score_map(logits.data_ptr(), B, C, H, W, sB, sC, sH, sW,
-                                ex.data_ptr() if ex is not None else None, strategy_id(strategy),
+                                ex.data_ptr() if ex is not None else None,
+                                strategy_id(strategy) | (REFERENCE_ORDER if reference_order else 0),
                                 omap.data_ptr(), _lib.current_stream_ptr(dev))
     _lib.check(rc, "pp_acq_score_map")
     return omap

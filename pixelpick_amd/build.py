@@ -1,8 +1,12 @@
-"""Builds libpixelpick_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+"""Builds the HIP extension (hand-written HIP for gfx950) in-tree with hipcc, twice from the same sources:
 
-    python -m pixelpick_amd.build [--force]
+    libpixelpick_hip.so        the product - exactly the C ABI of include/pixelpick_hip.h, no `pp_debug_*` symbol
+    libpixelpick_hip_knobs.so  the test build - the same sources + -DPP_DEBUG_KNOBS: the planner switches of
+                               include/pixelpick_hip_knobs.h and the experiment kernels behind them (tests, tools/, A/B runs)
 
-The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+    python -m pixelpick_amd.build [--force] [--release-only]
+
+The .so files are git-ignored but travel to the GPU box with the gpurun snapshot.
 """
 import glob
 import os
@@ -13,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpixelpick_hip.so")
+OUT_KNOBS = os.path.join(HERE, "libpixelpick_hip_knobs.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
@@ -29,30 +34,36 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+def build(force=False, verbose=True, knobs=True):
+    """Compile every source for both builds in parallel, link both libraries; returns the product's path."""
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    objs = []
-    procs = []
-    for src in sources():
-        obj = os.path.join(HERE, "_obj", os.path.basename(src) + ".o")
-        objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
+    variants = [("_obj", [], OUT)] + ([("_obj_knobs", ["-DPP_DEBUG_KNOBS"], OUT_KNOBS)] if knobs else [])
+    procs, links = [], []
+    for sub, extra, out in variants:
+        os.makedirs(os.path.join(HERE, sub), exist_ok=True)
+        objs, fresh = [], False
+        for src in sources():
+            obj = os.path.join(HERE, sub, os.path.basename(src) + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [src] + hdrs):
+                cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((src, subprocess.Popen(cmd)))
+                fresh = True
+        links.append((out, objs, fresh))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    for out, objs, fresh in links:
+        if force or fresh or _stale(out, objs):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return OUT
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, knobs="--release-only" not in sys.argv)
     print(OUT)

@@ -19,7 +19,19 @@
 namespace pp {
 
 static int g_reduce_mode = 0;
-static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel)
+static int g_exact_formula = 0;   // 1: reference operation order (19 exp + 19 div + 19 log per pixel) as the process default (test build's knob)
+// The same choice PER CALL: `strategy | PP_ACQ_REFERENCE_ORDER` at an entry point.  The flag lives in a thread-local for the duration of
+// that call (the planners below read it where they used to read the global), so concurrent callers on other threads / streams do not see it.
+static thread_local int t_exact_call = 0;
+static inline int exact_formula() { return t_exact_call | g_exact_formula; }
+struct ExactScope {
+    int keep;
+    explicit ExactScope(int& strategy) : keep(t_exact_call)
+    {
+        if (strategy >= 0 && (strategy & PP_ACQ_REFERENCE_ORDER)) { t_exact_call = 1; strategy &= ~PP_ACQ_REFERENCE_ORDER; }
+    }
+    ~ExactScope() { t_exact_call = keep; }
+};
 static int g_tune_occ = 0;        // tuning knobs (C == 19 flat path only): waves/SIMD bound, pixels per thread
 static int g_tune_ppt = 0;
 static int g_acq_strat_spec = 1;   // strategy-specialised scorers of the three dataset class counts (pp_debug_set_acq_tuning bit 10 of `occ`: off)
@@ -1697,7 +1709,7 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
     EventScope ev(st);
     dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
     // the non-default scorers (reference-order, from-prob) are only built for the 4-pixel tile
-    const bool alt = p.from_prob || g_exact_formula;
+    const bool alt = p.from_prob || exact_formula();
     if (pl.nhwc) {
         if constexpr (EXACT && CMAX <= 21) {
             // asynchronous LDS-DMA variant for the three dataset class counts (tuning value 8 keeps the synchronous kernel)
@@ -1709,7 +1721,7 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
         }
         if constexpr (CMAX <= 32) {
             if (p.from_prob)          hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 2>), grid, block, 0, st, p);
-            else if (g_exact_formula) hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 1>), grid, block, 0, st, p);
+            else if (exact_formula()) hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 1>), grid, block, 0, st, p);
             else if (pl.ppt == 8)     hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 8, 0>), grid, block, 0, st, p);
             else                      hipLaunchKernelGGL((acq_nhwc_kernel<CMAX, EXACT, 4, 0>), grid, block, 0, st, p);
             return check_launch("acq_nhwc_kernel");
@@ -1718,7 +1730,7 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
 #define PP_LAUNCH_ACQ4(VEC, G)                                                                                    \
     do {                                                                                                          \
         if (p.from_prob)          hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 2>), grid, block, 0, st, p); \
-        else if (g_exact_formula) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 1>), grid, block, 0, st, p); \
+        else if (exact_formula()) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 1>), grid, block, 0, st, p); \
         else                      hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, VEC, G, 0>), grid, block, 0, st, p); \
     } while (0)
     if (pl.vec4) {
@@ -1786,7 +1798,7 @@ static int launch_acq_stream(const AcqParams& p, const Plan& pl, int64_t B, hipS
     EventScope ev(st);
     if (pl.ppt != 4) return fail(PP_ERR_BAD_ARG, "streamed scorer: plan with %d pixels per thread", pl.ppt);
     dim3 grid((unsigned)(B * pl.blocks_per_image)), block(kBlock);
-    const int math = p.from_prob ? 2 : (g_exact_formula ? 1 : 0);
+    const int math = p.from_prob ? 2 : (exact_formula() ? 1 : 0);
 #define PP_STREAM(VEC, G)                                                                                  \
     do {                                                                                                   \
         if (math == 2)      hipLaunchKernelGGL((acq_stream_kernel<VEC, G, 2>), grid, block, 0, st, p);     \
@@ -1802,7 +1814,7 @@ static int launch_acq_stream(const AcqParams& p, const Plan& pl, int64_t B, hipS
 static int g_hist_fuse = 1;        // pp_debug_set_reduce_mode bit 10: off (A/B)
 static bool acq_hist_fusable(const AcqParams& p, const Plan& pl)
 {
-    return g_hist_fuse && pl.vec4 && !p.from_prob && !g_exact_formula && !g_tune_occ && !stream_classes(p.C) && p.out_map && !p.cand &&
+    return g_hist_fuse && pl.vec4 && !p.from_prob && !exact_formula() && !g_tune_occ && !stream_classes(p.C) && p.out_map && !p.cand &&
            (p.C == 11 || p.C == 19 || p.C == 21);
 }
 
@@ -1812,7 +1824,7 @@ static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
     if (p.C > 32) pl.vec4 = false;  // 64-class bucket only on the scalar path (register budget)
     if (!pl.vec4 && g_tune_occ != 9)   // (tuning value 9 forces the generic strided path for A/B)
         pl.nhwc = is_dense_nhwc(p.logits, p.C, p.N / p.W, p.W, p.sB, p.sC, p.sH, p.sW);
-    if (pl.nhwc && (g_exact_formula || p.from_prob) && pl.ppt != 4) pl.nhwc = false;
+    if (pl.nhwc && (exact_formula() || p.from_prob) && pl.ppt != 4) pl.nhwc = false;
     switch (p.C) {
         case 11: return launch_acq<11, true>(p, pl, B, st);   // CamVid      (args.py:109-116)
         case 19: return launch_acq<19, true>(p, pl, B, st);   // Cityscapes  (args.py:89-94)
@@ -1888,7 +1900,7 @@ static int launch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t B,
 {
     EventScope ev(st);
     dim3 grid((unsigned)(B * pl.tiles_x * pl.tiles_y)), block(kBlock);
-    if (g_exact_formula) {        // reference operation order: 4-row variant only
+    if (exact_formula()) {        // reference operation order: 4-row variant only
         if (pl.lds) hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, true, 1>), grid, block, pl.lds_bytes, st, p);
         else        hipLaunchKernelGGL((acq_lowres_kernel<CMAX, EXACT, 4, false, 1>), grid, block, 0, st, p);
     } else if (EXACT && pl.lds && g_acq_strat_spec) {
@@ -1920,7 +1932,7 @@ static int dispatch_lowres(const LowresParams& p, const LowresPlan& pl, int64_t 
         EventScope ev(st);
         if (pl.ppt != 4) return fail(PP_ERR_BAD_ARG, "streamed low-resolution scorer: plan with %d rows per wave", pl.ppt);
         dim3 grid((unsigned)(B * pl.tiles_x * pl.tiles_y)), block(kBlock);
-        if (g_exact_formula) hipLaunchKernelGGL((acq_lowres_stream_kernel<1>), grid, block, 0, st, p);
+        if (exact_formula()) hipLaunchKernelGGL((acq_lowres_stream_kernel<1>), grid, block, 0, st, p);
         else                 hipLaunchKernelGGL((acq_lowres_stream_kernel<0>), grid, block, 0, st, p);
         return check_launch("acq_lowres_stream_kernel");
     }
@@ -1953,6 +1965,7 @@ using namespace pp;
 
 extern "C" {
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_reduce_mode(int mode)
 {
     g_large_multiblock = (mode & 256) ? 0 : 1;      // bit 8: large-k selection through the one-block-per-image radix select (A/B)
@@ -1961,9 +1974,13 @@ void pp_debug_set_reduce_mode(int mode)
     mode &= 255;
     g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
+#endif
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_exact_formula(int on) { g_exact_formula = on ? 1 : 0; }
+#endif
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_acq_tuning(int occ, int ppt)
 {
     g_tune_xcd = (occ >> 8) & 3;
@@ -1973,6 +1990,7 @@ void pp_debug_set_acq_tuning(int occ, int ppt)
     g_tune_occ = (occ == 2 || occ == 3 || occ == 4 || occ == 8 || occ == 9 || occ == 10) ? occ : 0;   // 10: streamed class vector at any C (A/B, tests)
     g_tune_ppt = (ppt == 4 || ppt == 8) ? ppt : 0;
 }
+#endif
 
 size_t pp_topk_workspace_bytes(int64_t B, int64_t N, int64_t k)
 {
@@ -2002,10 +2020,11 @@ int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64
                      int64_t sH, int64_t sW, const uint8_t* exclude, int strategy, float* out_map,
                      pp_stream_t stream)
 {
+    const ExactScope exact_scope(strategy);
     if (int rc = validate(logits, B, C, H, W, strategy)) return rc;
     if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
     const int64_t N = H * W;
-    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), exact_formula() != 0 || stream_classes(C));
     AcqParams p{logits, exclude, out_map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0,
                 strategy, g_reduce_mode, 0};
     return dispatch_acq(p, pl, B, as_stream(stream));
@@ -2014,6 +2033,7 @@ int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64
 int pp_acq_softmax_sum(const float* logits, int64_t T, int64_t C, int64_t H, int64_t W, int64_t sT, int64_t sC, int64_t sH,
                        int64_t sW, float* prob_out, float* uc_out, int strategy, float scale, int accumulate, pp_stream_t stream)
 {
+    const ExactScope exact_scope(strategy);
     if (int rc = validate(logits, T, C, H, W, strategy)) return rc;
     if (!prob_out && !uc_out) return fail(PP_ERR_BAD_ARG, "softmax_sum: both outputs are null");
     const int64_t N = H * W;
@@ -2026,6 +2046,7 @@ int pp_acq_softmax_sum(const float* logits, int64_t T, int64_t C, int64_t H, int
 int pp_uncertainty_from_prob(const float* prob, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC,
                              int64_t sH, int64_t sW, int strategy, float* out_map, pp_stream_t stream)
 {
+    const ExactScope exact_scope(strategy);
     if (int rc = validate(prob, B, C, H, W, strategy)) return rc;
     if (!out_map) return fail(PP_ERR_BAD_ARG, "out_map is null");
     const int64_t N = H * W;
@@ -2039,6 +2060,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
                       int64_t sH, int64_t sW, const uint8_t* exclude, int strategy, int64_t k, int32_t* out_idx,
                       float* out_val, float* out_map, void* workspace, size_t ws_bytes, pp_stream_t stream)
 {
+    const ExactScope exact_scope(strategy);
     if (int rc = validate(logits, B, C, H, W, strategy)) return rc;
     const int64_t N = H * W;
     if (k < 1 || k > N) return fail(PP_ERR_BAD_K, "k=%lld outside [1, H*W=%lld]", (long long)k, (long long)N);
@@ -2051,7 +2073,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     const int largest = strategy != PP_ACQ_MARGIN;
 
     if (k <= kSmallKMax) {
-        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
+        Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, out_map, H, W, sB, sC, sH, sW), exact_formula() != 0 || stream_classes(C));
         const int64_t n_cand = (int64_t)pl.waves_per_image * k;
         uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
         uint64_t* other = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) +
@@ -2064,7 +2086,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     // large k: materialise the score map once, then radix-select + sort per image
     float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
     uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
-    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), g_exact_formula != 0 || stream_classes(C));
+    Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), exact_formula() != 0 || stream_classes(C));
     AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
                 g_reduce_mode, 0};
     const float qs = score_qscale(strategy, C);
@@ -2094,6 +2116,7 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
                              int64_t k, int32_t* out_idx, float* out_val, float* out_map, void* workspace,
                              size_t ws_bytes, pp_stream_t stream)
 {
+    const ExactScope exact_scope(strategy);
     if (int rc = validate_lowres(low, ldx, B, C, h, w, H, W, Hc, Wc, strategy)) return rc;
     const int64_t N = Hc * Wc;
     hipStream_t st = as_stream(stream);
@@ -2103,7 +2126,7 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
                    (int)C, 0, 0, 0, strategy, g_reduce_mode, 0};
     if (k == 0) {     // score map only
         if (!out_map) return fail(PP_ERR_BAD_ARG, "k == 0 (map only) needs out_map");
-        LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0 || stream_classes(C));
+        LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, exact_formula() != 0 || stream_classes(C));
         p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.patch_cap = pl.patch_cap;
         return dispatch_lowres(p, pl, B, st);
     }
@@ -2114,7 +2137,7 @@ int pp_acq_lowres_score_topk(const float* low, int64_t ldx, int64_t B, int64_t C
         return fail(PP_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(PP_ERR_BAD_ARG, "workspace must be 256-B aligned");
     const int largest = strategy != PP_ACQ_MARGIN;
-    LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, g_exact_formula != 0 || stream_classes(C));
+    LowresPlan pl = make_lowres_plan(B, C, h, w, Hc, Wc, sh, sw, exact_formula() != 0 || stream_classes(C));
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.patch_cap = pl.patch_cap;
     if (k <= kSmallKMax) {
         const int64_t n_cand = (int64_t)pl.waves_per_image * k;
@@ -2144,6 +2167,7 @@ int pp_acq_lowres_score_at(const float* low, int64_t ldx, int64_t B, int64_t C, 
                            int64_t W, int align_corners, int64_t Hc, int64_t Wc, int strategy, const int32_t* img_idx,
                            const int32_t* pix_idx, int64_t n, float* out, pp_stream_t stream)
 {
+    const ExactScope exact_scope(strategy);
     if (int rc = validate_lowres(low, ldx, B, C, h, w, H, W, Hc, Wc, strategy)) return rc;
     if (n == 0) return PP_OK;
     if (n < 0 || !img_idx || !pix_idx || !out) return fail(PP_ERR_BAD_ARG, "score_at: null pointer or n < 0");

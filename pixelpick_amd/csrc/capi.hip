@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restri
 
 extern "C" {
 
-int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream)
+int pp_yardstick_stream_read(const void* x, size_t bytes, int blocks, float* sink, pp_stream_t stream)
 {
     // blocks < 0: -blocks blocks with non-temporal loads
     const bool nt = blocks < 0;
@@ -102,6 +102,7 @@ int pp_debug_stream_read(const void* x, size_t bytes, int blocks, float* sink, p
 void pp_set_comm_cu_reserve(int cus) { pp::g_comm_cu_reserve = cus > 0 ? cus : 0; }
 int pp_get_comm_cu_reserve(void) { return pp::g_comm_cu_reserve; }
 
+#ifdef PP_DEBUG_KNOBS
 int pp_debug_occupy_cus(int blocks, const int* stop, uint64_t max_ticks, uint64_t* started, pp_stream_t stream)
 {
     if (blocks < 1 || blocks > 256 || !stop || !started || max_ticks == 0 || max_ticks > 6000000000ull)
@@ -117,8 +118,9 @@ int pp_debug_occupy_cus(int blocks, const int* stop, uint64_t max_ticks, uint64_
                        (unsigned long long)max_ticks, reinterpret_cast<unsigned long long*>(started));
     return hipGetLastError() == hipSuccess ? PP_OK : pp::fail(PP_ERR_LAUNCH, "occupy_kernel launch failed");
 }
+#endif
 
-void pp_debug_set_kernel_events(void** starts, void** stops, int n)
+void pp_set_kernel_events(void** starts, void** stops, int n)
 {
     pp::EventHook& h = pp::event_hook();
     h.start = reinterpret_cast<hipEvent_t*>(starts);

@@ -3164,7 +3164,7 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 ? 2 : 2)) void conv_x3_kernel(Co
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn);
 }
 
-// pp_debug_mfma_stream: conv_x3_kernel's MFMA sequence from registers and nothing else (tools/probe/mfma_peak.hip holds the same kernel
+// pp_yardstick_mfma_stream: conv_x3_kernel's MFMA sequence from registers and nothing else (tools/probe/mfma_peak.hip holds the same kernel
 // as a stand-alone program)
 __device__ __forceinline__ unsigned probe_hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 template <int DATA>
@@ -3623,6 +3623,7 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
         if (m256) {
             if (n128) {
                 switch (g_x3_var) {
+#ifdef PP_DEBUG_KNOBS        // experiment forms (some of them timing ablations with WRONG results): compiled into the test build only
                     case 1: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 1>), grid, dim3(512), 0, st, p, o); break;
                     case 2: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 2>), grid, dim3(512), 0, st, p, o); break;
                     case 3: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 3>), grid, dim3(512), 0, st, p, o); break;
@@ -3634,6 +3635,7 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
                     case 9: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 9>), grid, dim3(512), 0, st, p, o); break;
                     case 10: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 10>), grid, dim3(512), 0, st, p, o); break;
                     case 11: hipLaunchKernelGGL((conv_x3_kernel<256, 128, 11>), grid, dim3(512), 0, st, p, o); break;
+#endif
                     default: hipLaunchKernelGGL((conv_x3_kernel<256, 128>), grid, dim3(512), 0, st, p, o);
                 }
             } else hipLaunchKernelGGL((conv_x3_kernel<256, 64>), grid, dim3(512), 0, st, p, o);
@@ -4129,14 +4131,17 @@ extern "C" {
 
 /* tools/conv_layer_table.py: the plan the forward / backward-data launcher picks for an (M x Cn x K = ntaps*Ck) problem:
  * out = {tile rows, tile cols, tiles, split-K slices} */
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out)
 {
     const ConvPlan pl = plan_conv(M, Cn, Ck, ntaps, Ck % 4 == 0 && Cn % 4 == 0);
     const int rows[5] = {128, 128, 64, 64, 128}, cols[5] = {32, pl.bn64 ? 64 : 128, 64, 64, 128};
     out[0] = rows[pl.cfg]; out[1] = cols[pl.cfg]; out[2] = (int)pl.tiles; out[3] = pl.splits;
 }
+#endif
 
 /* A/B of the split-K plan: v = tiles_threshold | target_blocks << 10 | min_k_steps << 20 | min_steps_per_slice << 26 (0: defaults) */
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_splitk(int v)
 {
     g_splitk_tiles = (v & 1023) ? (v & 1023) : 192;
@@ -4144,13 +4149,18 @@ void pp_debug_set_splitk(int v)
     g_splitk_min_nk = ((v >> 20) & 63) ? ((v >> 20) & 63) : 12;
     g_splitk_min_iters = ((v >> 26) & 15) ? ((v >> 26) & 15) : 4;
 }
+#endif
 
 /* whole-row VALU kernels of the narrow pointwise layers (A/B): bit 0 off, bit 1 forward rows kernel only from 65536 rows */
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_conv_rows(int bits) { g_conv_bwd_rows = (bits & 1) ? 0 : 1; g_rows_fwd_min = (bits & 2) ? 65536 : 16384; }
+#endif
 
 /* which shapes pp_conv2d_fwd_bn_train_ok / pp_conv2d_bwd_data_bn_bwd_ok accept (A/B): bit 0 tiled forward kernels, 1 in-block split-K
  * forward, 2 backward form (64x64 tiles), 3 backward form of the in-block split-K and the 128x32 kernels; default 15 */
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_conv_bn_fuse(int bits) { g_conv_bn_fuse = bits & 15; }
+#endif
 
 /* 0: fp32 MFMA kernels everywhere; 1 (default): the large-tile forward / backward-data layers run conv_x3_kernel (bf16x3 split) */
 /* Yardstick (bench.py roofline_mfma.sustained): nothing but conv_x3_kernel's MFMA stream - six product terms of three A x three B
@@ -4158,7 +4168,7 @@ void pp_debug_set_conv_bn_fuse(int bits) { g_conv_bn_fuse = bits & 15; }
  * 1: near-constant, 2: hash-random signs / mantissas as the planes of a real activation have).  Same instructions in all three; what
  * differs is the clock the power limit leaves (profiles/r05_conv_x3_power.txt: 2.39-2.5 GHz on zeros, 1.77-1.92 GHz on random
  * operands).  iters x 24 MFMAs per wave. */
-int pp_debug_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stream)
+int pp_yardstick_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stream)
 {
     if (!sink || iters < 1 || data_kind < 0 || data_kind > 2) return fail(PP_ERR_BAD_ARG, "mfma_stream: bad argument");
     const dim3 grid((unsigned)device_cus()), block(512);
@@ -4170,8 +4180,11 @@ int pp_debug_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t stre
     return check_launch("mfma_stream_kernel");
 }
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_x3_variant(int v) { g_x3_var = (v >= 0 && v <= 11) ? v : 0; }
+#endif
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_x3(int v)
 {
     g_conv_x3 = v & 0xFF;
@@ -4183,14 +4196,18 @@ void pp_debug_set_x3(int v)
     static const double wf[8] = {8e9, 6e9, 4e9, 3e9, 2e9, 1.5e9, 1e9, 0.5e9};
     g_x3w_flop = wf[(v >> 14) & 7];                        /* bits 14-16: least work of a bf16x3 weight gradient */
 }
+#endif
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_wgrad_target(int v)
 {
     g_wgrad_target = (v & 0xFFFF) > 0 ? (v & 0xFFFF) : 1024;
     g_wgrad_lds_pad = v > 0 ? ((v >> 16) & 0xFF) * 1024 : g_wgrad_lds_pad_default;   // bits 16-23: KiB of LDS padding (A/B)
     g_wgrad_balance = (v > 0 && ((v >> 24) & 1)) ? 0 : 1;                             // bit 24: CU-balanced split choice off
 }
+#endif
 /* v = big_tile_min | wgrad_rows_min << 12 (0 fields: defaults 384 / 128) */
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_conv_thresholds(int v)
 {
     g_shortk64 = (v >> 28) & 1 ? 0 : 1;       // bit 28: 128 x 128 tiles also for pointwise layers with K <= 256 (A/B)
@@ -4200,7 +4217,9 @@ void pp_debug_set_conv_thresholds(int v)
     g_narrow_splits_max = ns ? (256 << (ns - 1)) : 4096;
     g_narrow_rows_min = ns ? (ns >= 4 ? 16 : 64) : 16;
 }
+#endif
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_conv_variant(int v)
 {
     g_conv_xcd_remap = (v & 4) ? 0 : 1;      // bit 2 switches the XCD-aware tile order off (A/B)
@@ -4225,6 +4244,7 @@ void pp_debug_set_conv_variant(int v)
     v &= 3;
     g_conv_variant = (v >= 0 && v <= 2) ? v : 0;
 }
+#endif
 
 size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {

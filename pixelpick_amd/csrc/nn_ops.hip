@@ -2217,6 +2217,7 @@ using namespace pp;
 
 extern "C" {
 
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_dw_variant(int v)
 {
     g_dw_x4 = (v & 1) ? 0 : 1;
@@ -2229,14 +2230,21 @@ void pp_debug_set_dw_variant(int v)
     const int sel = (v >> 1) & 7;                 // 0: default, 1: 512, 2: 256, 3: 128, 4: 2048 row blocks for the weight gradient
     g_dw_wgrad_blocks = sel == 1 ? 512 : sel == 2 ? 256 : sel == 3 ? 128 : sel == 4 ? 2048 : 1024;
 }
+#endif
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_bn_target(int blocks) { g_bn_target_blocks = blocks > 0 ? (blocks > 1024 ? 1024 : blocks) : 0; }
+#endif
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_bn_bytes_per_block(int bytes)
 {
     g_bn_bytes_per_block = bytes > 0 ? bytes : 0;
     g_bn_row_cache = bytes == -1 ? 0 : 1;          // -1: the register-cached variants off (A/B)
 }
+#endif
 static thread_local unsigned long long* g_bn_probe = nullptr;
+#ifdef PP_DEBUG_KNOBS
 void pp_debug_set_bn_probe(void* device_buffer) { g_bn_probe = reinterpret_cast<unsigned long long*>(device_buffer); }
+#endif
 int pp_bn_fused_capacity(void) { return bn_fused_capacity(); }
 
 // ---- batch norm -----------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ inline int check_launch(const char* what)
 }
 
 // Optional profiling hook (bench.py): caller-owned hipEvent pairs recorded right around a dominant kernel's
-// launch (acq_kernel, conv_igemm_kernel), pair i for the i-th such launch after pp_debug_set_kernel_events().
+// launch (acq_kernel, conv_igemm_kernel), pair i for the i-th such launch after pp_set_kernel_events().
 struct EventHook {
     hipEvent_t* start;
     hipEvent_t* stop;

@@ -6,6 +6,7 @@ gather of the small per-image records (sorted picks + the statistics contributio
 global result on every rank.  `QuerySelector.__call__` uses exactly these helpers; the train step's only exchange is the
 all-reduce of the flat gradient in `trainer.FlatTrainer`.
 """
+import os
 from typing import List, Tuple
 
 import torch.distributed as dist
@@ -162,4 +163,24 @@ def dataset_image_sizes(dataset):
     fn = getattr(dataset, "image_size", None)
     if callable(fn):
         return [tuple(int(v) for v in fn(i)) for i in range(len(dataset))]
+    return None
+
+
+
+def rccl_channels_from_log(path_or_text: str):
+    """The number of collective channels an RCCL / NCCL communicator opened, from its NCCL_DEBUG=INFO (INIT) log: the line
+    `... NCCL INFO <n> coll channels, <m> collnet channels, ... p2p channels ...` of communicator setup (older builds:
+    `Channel <i>/<n> :` ring lines).  Each channel keeps one block resident on a CU for the length of a collective - the figure
+    pp_set_comm_cu_reserve / PIXELPICK_COMM_CU_RESERVE has to cover.  None when the log holds neither."""
+    import re
+    text = path_or_text
+    if "\n" not in path_or_text and os.path.exists(path_or_text):
+        with open(path_or_text, errors="replace") as f:
+            text = f.read()
+    m = re.findall(r"(\d+) coll channels", text)
+    if m:
+        return max(int(v) for v in m)
+    m = re.findall(r"Channel (\d+)/(\d+) ?:", text)
+    if m:
+        return max(int(n) for _, n in m)
     return None

@@ -867,6 +867,10 @@ class ConvBwdGroup:
         x = self.x
         if not x.needs_grad:
             return
+        if getattr(x, "_closed", False):
+            # as _issue_dx: the input's BatchNorm backward was already folded into another consumer's backward-data launch, so
+            # a gradient arriving now would be dropped silently.  (Group inputs must not carry _bn_bwd_ctx.)
+            raise RuntimeError("ConvBwdGroup: the input's gradient was already consumed by a fused BatchNorm backward")
         B, H, W, Cin = shape_of(x)
         dev = self.dbuf.device
         acc_into = x.grad if (x.grad is not None and getattr(x.grad, "_pp_owned", False) and x.grad.is_contiguous()
@@ -1636,6 +1640,13 @@ def begin_step():
     _STEP_EPOCH[0] += 1
     if _X3_WPRE and _X3_WPL:
         _prefetch_weight_planes()
+
+
+def end_step():
+    """The optimiser has run (or a recorded step was replayed): the weights moved, so the planes split at begin_step() are stale.
+    Bumping the epoch invalidates them - a forward / backward outside a trainer step (FlatTrainer.forward_backward after
+    train_step, evaluation with the tape on, a load_state_dict in between) splits inline from the current weights."""
+    _STEP_EPOCH[0] += 1
 
 
 # ---- bf16x3 weight planes off the step's critical path ---------------------------------------------------------------------------

@@ -32,6 +32,21 @@ FORCE_COLLECTIVES = os.environ.get("PIXELPICK_FORCE_COLLECTIVES", "0") == "1"
 NATIVE_PLAN = os.environ.get("PIXELPICK_NATIVE_PLAN", "1") != "0"
 
 
+_RESERVE = {"users": 0, "before": None}     # collective trainers alive in this process / the library's reserve before the first of them
+
+
+def default_comm_cu_reserve(backend: str) -> int:
+    """CUs set aside for the resident communication kernel (pp_set_comm_cu_reserve): one per RCCL channel - NCCL_MAX_NCHANNELS
+    when the job caps it, else 32 - and none for a backend whose collectives do not run on the CUs (gloo)."""
+    if backend != "nccl":
+        return 0
+    try:
+        n = int(os.environ.get("NCCL_MAX_NCHANNELS", "32"))
+    except ValueError:
+        n = 32
+    return max(0, min(n, 128))
+
+
 class FlatTrainer:
     def __init__(self, model, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 2e-4,
                  ignore_index: int = 19, slow_module_names=("backbone", "encoder"), process_group=None,
@@ -63,8 +78,14 @@ class FlatTrainer:
             # wait for each other (single-launch BatchNorm, convolution + BatchNorm) need their WHOLE grid resident: those launches
             # size themselves against occupancy x (CUs - reserve).  PIXELPICK_COMM_CU_RESERVE (default 32 under RCCL, 0 otherwise;
             # tests/test_dist_gpu.py parks an occupier kernel on 16 / 32 / 64 CUs for 200 two-rank steps).
-            default = "32" if torch.distributed.get_backend(self.pg) == "nccl" else "0"
-            reserve = int(os.environ.get("PIXELPICK_COMM_CU_RESERVE", default))
+            # Default under RCCL: one CU per channel the communicator may open - NCCL_MAX_NCHANNELS when the job sets it, else 32
+            # (RCCL's default channel ceiling on an 8-GPU xGMI node); 0 for any other backend.  The value in force before the first
+            # collective trainer is restored when the last one closes (close() / __del__): the library setting is process-wide.
+            reserve = int(os.environ.get("PIXELPICK_COMM_CU_RESERVE", default_comm_cu_reserve(torch.distributed.get_backend(self.pg))))
+            if _RESERVE["users"] == 0:
+                _RESERVE["before"] = _lib.lib().pp_get_comm_cu_reserve()
+            _RESERVE["users"] += 1
+            self._holds_reserve = True
             if reserve != _lib.lib().pp_get_comm_cu_reserve():
                 _lib.lib().pp_set_comm_cu_reserve(reserve)
         slow, fast = [], []
@@ -283,6 +304,7 @@ class FlatTrainer:
         if self.collectives:
             _lib.plan_note(self.all_reduce_grads)          # (a host break of a native plan: only where there is something to exchange)
         self.optimizer_step(device_hyper)
+        E.end_step()
         return loss
 
     def train_step(self, x: torch.Tensor, y: torch.Tensor, keep_logits: bool = False) -> torch.Tensor:
@@ -299,6 +321,7 @@ class FlatTrainer:
             if torch.cuda.current_stream().cuda_stream != self._plan_stream:
                 raise RuntimeError("train_step after enable_replay() must run on the stream the plan was recorded on")
             self._plan.replay()
+            E.end_step()               # (the replay does not run begin_step / end_step: the recorded step's planes die here as well)
             return self.last_loss
         return self._step_body(x, y, keep_logits, False)
 
@@ -365,10 +388,21 @@ class FlatTrainer:
         if E._dropout_seed_dev[0] is self._seed_dev:
             E.set_dropout_device_seed(None)
 
+    def close(self):
+        """Give back what this trainer changed process-wide: the recorded plan, the device seed word, and - when it is the last
+        collective trainer - the library's comm-CU reserve (back to the value in force before the first one set it)."""
+        self.disable_replay()
+        if self.__dict__.get("_holds_reserve"):
+            self._holds_reserve = False
+            _RESERVE["users"] -= 1
+            if _RESERVE["users"] == 0 and _RESERVE["before"] is not None:
+                if _lib.lib().pp_get_comm_cu_reserve() != _RESERVE["before"]:
+                    _lib.lib().pp_set_comm_cu_reserve(_RESERVE["before"])
+                _RESERVE["before"] = None
+
     def __del__(self):
         try:
-            if E._dropout_seed_dev[0] is self._seed_dev:
-                E.set_dropout_device_seed(None)
+            self.close()
         except Exception:
             pass
 

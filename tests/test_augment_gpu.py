@@ -107,6 +107,30 @@ def test_gaussian_blur_fixed_point_is_bit_exact_against_the_cv2_restatement(ks, 
     assert (c == 201).all()
 
 
+def test_blur_kernel_equals_cv2_fixture():
+    """pp_aug_blur_q8 against cv2.GaussianBlur's OWN outputs (tests/golden/aug_blur_cv2.npz, written by tools/gen_golden_blur_cv2.py
+    on a box with opencv).  Skips only while that file does not exist - this image has no cv2 - and hard-fails on any differing pixel."""
+    import os
+    import sys
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aug_blur_cv2.npz")
+    if not os.path.exists(p):
+        pytest.skip("no cv2-written fixture yet: python tools/gen_golden_blur_cv2.py on a box with opencv-python")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from gen_golden_blur_cv2 import image
+    from pixelpick_amd import _lib
+    from pixelpick_amd.augment import cv2_gaussian_kernel_q8
+    L = _lib.lib()
+    g = np.load(p)
+    for ks, sg, seed, ref in zip(g["ksize"], g["sigma"], g["seed"], g["blurred"]):
+        x = image(int(seed))
+        H, W = x.shape[:2]
+        d = torch.from_numpy(x.copy()).to(DEV)
+        k = torch.from_numpy(cv2_gaussian_kernel_q8(int(ks), float(sg)).astype(np.int16)).to(DEV)
+        sb = torch.empty(H * W * 3, dtype=torch.int16, device=DEV)
+        _lib.check(L.pp_aug_blur_q8(d.data_ptr(), H, W, k.data_ptr(), int(ks), sb.data_ptr(), _lib.current_stream_ptr()), "blur_q8")
+        assert np.array_equal(d.cpu().numpy(), ref), (int(ks), float(sg), str(g["cv2_version"]))
+
+
 @pytest.mark.parametrize("ks,sigma", [(25, 0.83), (7, 1.2)])
 def test_gaussian_blur_float_variant(ks, sigma):
     """pp_aug_blur: the float32 separable filter cv2 ran for 8-bit images before 3.4.2 (DeviceAugmenter.blur_arithmetic = "float")."""

@@ -154,3 +154,50 @@ def test_shard_dataloader_loads_only_own_items():
     assert len(got) == 2 and len(ds.loaded) == 4                     # 4 global batches of 2 -> 2 per rank; 4 items touched
     assert shard_dataloader([1, 2, 3], 0, 2, True) is None          # not a DataLoader: caller falls back
     assert dataset_image_sizes(ds) == [(4, 6)] * 9 and dataset_image_sizes(object()) is None
+
+
+def test_rccl_channel_count_is_read_from_the_init_log(tmp_path):
+    """bench.py --gpus N reports the channels the communicator opened (one resident block per channel) beside pp_get_comm_cu_reserve():
+    parsed from the NCCL_DEBUG=INFO INIT lines of the run."""
+    new = ("box:123:456 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 busId c000 - Init COMPLETE\n"
+           "box:123:456 [0] NCCL INFO 28 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 4 p2p channels per peer\n")
+    old = "box:1:2 [0] NCCL INFO Channel 00/16 :    0   1   2   3\nbox:1:2 [0] NCCL INFO Channel 15/16 :    0   3   2   1\n"
+    assert du.rccl_channels_from_log(new) == 28 and du.rccl_channels_from_log(old) == 16 and du.rccl_channels_from_log("nothing\nhere\n") is None
+    p = tmp_path / "rccl.log"
+    p.write_text(new)
+    assert du.rccl_channels_from_log(str(p)) == 28
+
+
+def test_comm_cu_reserve_default_and_restore(monkeypatch):
+    """trainer.py: the reserve defaults to one CU per RCCL channel (NCCL_MAX_NCHANNELS, else 32; 0 for gloo), and the last collective
+    trainer to close puts the library's process-wide setting back to what it was before the first one changed it."""
+    from pixelpick_amd import _lib, trainer as T
+    from pixelpick_amd import engine as E
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    assert T.default_comm_cu_reserve("nccl") == 32 and T.default_comm_cu_reserve("gloo") == 0
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "48")
+    assert T.default_comm_cu_reserve("nccl") == 48
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "junk")
+    assert T.default_comm_cu_reserve("nccl") == 32
+    L = _lib.lib()
+    L.pp_set_comm_cu_reserve(5)
+    try:
+        def fake():
+            t = T.FlatTrainer.__new__(T.FlatTrainer)
+            t._plan = t._plan_pool = t._gx = t._gy = None
+            t._seed_dev = object()
+            if T._RESERVE["users"] == 0:
+                T._RESERVE["before"] = L.pp_get_comm_cu_reserve()
+            T._RESERVE["users"] += 1
+            t._holds_reserve = True
+            L.pp_set_comm_cu_reserve(32)
+            return t
+        a, b = fake(), fake()
+        assert L.pp_get_comm_cu_reserve() == 32
+        a.close()
+        assert L.pp_get_comm_cu_reserve() == 32            # b still steps under a resident communicator
+        b.close()
+        b.close()                                          # idempotent
+        assert L.pp_get_comm_cu_reserve() == 5 and T._RESERVE == {"users": 0, "before": None}
+    finally:
+        L.pp_set_comm_cu_reserve(0)

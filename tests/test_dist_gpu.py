@@ -542,3 +542,11 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(replay, ranks):
     assert dd["nranks"] == ranks and set(dd["allreduce_in_step_us"]) == {"behind_encoder", "encoder_late", "encoder_early"}
     assert len(dd["buckets"]) == 3 and sum(dd["buckets"]) == dd["allreduce_bytes_per_step"] and dd["buckets"][2] < dd["buckets"][1]
     assert all(v > 0 for v in dd["allreduce_in_step_us"].values())
+    # the first-real-node diagnostics: every rank's device, the shared-device flag (all ranks sit on this box's one GPU), the comm-CU
+    # reserve beside the communicator's channels (gloo: none), and the N = 1 figure of the same invocation
+    assert [r["rank"] for r in dd["rank_devices"]] == list(range(ranks)) and all(r["device"] == 0 for r in dd["rank_devices"])
+    assert dd["shared_device"] is True and dd["devices_visible"] == 1
+    assert dd["comm_cu_reserve"] == 0 and dd["rccl_channels"] is None and dd["rccl_channels_source"] == "not an RCCL communicator"
+    n1 = dd["n1_same_invocation"]
+    assert n1["img_per_s"] > 0 and n1["replay"] == (replay == "on") and abs(n1["img_per_s"] - 4 / (n1["ms_per_step"] * 1e-3)) < 0.02 * n1["img_per_s"]
+    assert 0 < dd["scaling_vs_n1_same_invocation"] <= 1.05          # ranks sharing one device cannot beat one rank alone

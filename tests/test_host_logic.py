@@ -3,6 +3,7 @@ import os
 import pickle as pkl
 import re
 import subprocess
+import sys
 from argparse import Namespace
 
 import numpy as np
@@ -15,25 +16,62 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ensure_built():
-    if not os.path.exists(_lib.LIB_PATH):
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.KNOBS_LIB_PATH)):
         from pixelpick_amd import build
         build.build(verbose=False)
 
 
-def test_abi_exports_every_declared_symbol():
-    _ensure_built()
+def _declared(*headers):
     decl = set()
-    for hdr in os.listdir(os.path.join(ROOT, "include")):
+    for hdr in headers:
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         decl |= set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", txt))
-    assert decl, "no declarations parsed"
-    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
-    exported = set(re.findall(r" T (pp_[a-z0-9_]+)", out))
-    assert decl <= exported, f"declared but not exported: {decl - exported}"
-    assert decl == set(_lib.SIGNATURES), f"ctypes table out of sync: {decl ^ set(_lib.SIGNATURES)}"
-    L = _lib.lib()           # loads without a GPU
-    assert L.pp_version() >= 100
+    return decl
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return set(re.findall(r" T (pp_[a-z0-9_]+)", out)), out
+
+
+def test_abi_exports_every_declared_symbol():
+    """The PRODUCT library exports exactly include/pixelpick_hip.h and not one planner switch (no global mutable
+    state behind the ABI); the TEST BUILD adds exactly include/pixelpick_hip_knobs.h."""
+    _ensure_built()
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["pixelpick_hip.h", "pixelpick_hip_knobs.h"]
+    pub, knobs = _declared("pixelpick_hip.h"), _declared("pixelpick_hip_knobs.h")
+    assert pub and knobs and not (pub & knobs)
+    assert not any(n.startswith("pp_debug_") for n in pub) and all(n.startswith("pp_debug_") for n in knobs)
+    exported, raw = _exported(_lib.LIB_PATH)
+    assert "pp_debug_" not in raw, "the product library exports a planner switch"
+    assert pub == exported, f"header and product library differ: {pub ^ exported}"
+    assert pub == set(_lib.SIGNATURES), f"ctypes table out of sync: {pub ^ set(_lib.SIGNATURES)}"
+    exported_k, _ = _exported(_lib.KNOBS_LIB_PATH)
+    assert exported_k == pub | knobs, f"test build: {exported_k ^ (pub | knobs)}"
+    assert knobs == set(_lib.KNOB_SIGNATURES), f"ctypes knob table out of sync: {knobs ^ set(_lib.KNOB_SIGNATURES)}"
+    L = _lib.lib()           # loads without a GPU (the suite runs on the test build: tests/conftest.py)
+    assert _lib.knobs_build() and L.pp_version() >= 100
+
+
+def test_product_library_loads_and_validates_without_the_switches():
+    """A process of its own on libpixelpick_hip.so: every public symbol binds, no pp_debug_* attribute exists, argument validation and
+    the per-call PP_ACQ_REFERENCE_ORDER flag are accepted (a flag outside the enum is not)."""
+    _ensure_built()
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "from pixelpick_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "assert not _lib.knobs_build() and L._name.endswith('libpixelpick_hip.so')\n"
+        "assert not hasattr(L, 'pp_debug_set_x3')\n"
+        "for s in (0, 1, 2, 0x100, 0x102):\n"
+        "    assert L.pp_acq_score_topk(None, 1, 19, 4, 4, 0, 0, 0, 0, None, s, 5, None, None, None, None, 0, None) == -1 and b'null' in L.pp_last_error()\n"
+        "assert L.pp_acq_score_topk(1, 1, 19, 4, 4, 0, 0, 0, 0, None, 3, 5, None, None, None, None, 0, None) == -1 and b'strategy' in L.pp_last_error()\n"
+        "assert L.pp_acq_score_topk(1, 1, 19, 4, 4, 0, 0, 0, 0, None, 0x200, 5, None, None, None, None, 0, None) == -1\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, PIXELPICK_KNOBS_BUILD="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
 def test_abi_argument_validation_without_gpu():
@@ -105,6 +143,7 @@ def test_shard_dataloader_declines_samplers_it_cannot_restate():
 def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpixelpick_hip.so")
+    monkeypatch.setattr(_lib, "KNOBS_LIB_PATH", "/nonexistent/libpixelpick_hip_knobs.so")
     with pytest.raises(_lib.PixelPickHipError):
         _lib.lib()
 

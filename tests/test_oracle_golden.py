@@ -152,3 +152,25 @@ def test_lowres_path_matches_reference(glow, si, st):
     for b in range(low.shape[0]):
         assert sorted(idx[b].tolist()) == glow[f"s{si}_sel_{st}"][b].tolist()
         assert idx[b].tolist() == glow[f"s{si}_order_{st}"][b].tolist()
+
+
+# ---- cv2.GaussianBlur (datasets/base_dataset.py:192-208): closes "parity unpinned" the moment a cv2-written fixture exists ------
+def _cv2_blur_fixture(golden_dir):
+    p = os.path.join(golden_dir, "aug_blur_cv2.npz")
+    if not os.path.exists(p):
+        pytest.skip("no cv2-written fixture (tools/gen_golden_blur_cv2.py needs a box with opencv; this image has none): the blur's "
+                    "parity with the real library stays unpinned")
+    return np.load(p)
+
+
+def test_blur_oracle_equals_cv2_fixture(golden_dir):
+    """oracle/augment.py:gaussian_blur (OpenCV's 8-bit fixed-point path restated) against cv2.GaussianBlur's own outputs: every
+    pixel of every (ksize, sigma) case.  Skips only while the fixture file does not exist; a mismatch is a failure."""
+    import sys
+    g = _cv2_blur_fixture(golden_dir)
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "tools"))
+    from gen_golden_blur_cv2 import image
+    from oracle import augment as aug
+    for ks, sg, seed, ref in zip(g["ksize"], g["sigma"], g["seed"], g["blurred"]):
+        got = aug.gaussian_blur(image(int(seed)), int(ks), float(sg))
+        assert np.array_equal(got, ref), (int(ks), float(sg), str(g["cv2_version"]), int(np.abs(got.astype(int) - ref).max()))

@@ -4,6 +4,7 @@ one box (box-to-box variance is +-0.1 ms, more than most single optimisations).
   python tools/ab_step.py pp_debug_set_dw_variant 0 1
   python tools/ab_step.py pp_debug_set_conv_variant 0 64"""
 import os, sys, time, warnings
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 from argparse import Namespace
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -3,6 +3,7 @@
 HBM rate against the algorithmic bytes (fwd: read x, write y = 2S - the second read of x is an L2/MALL hit when it fits;
 bwd: read x, dy, write dx = 3S).  `python tools/bn_bench.py [bytes_per_block ...]` sweeps the large-map grid knob."""
 import os
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import sys
 
 import torch

@@ -3,6 +3,7 @@
 situation of the train step's backward (profiles/r02_train_ablation.txt).  Prints the BatchNorm launch's duration (HIP events on its
 stream) for several grid targets, and the weight gradient's own duration with / without the BatchNorm next to it."""
 import os
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import sys
 
 import torch

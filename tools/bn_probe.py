@@ -3,6 +3,7 @@
 entry -> statistics pass -> block reduction -> publish -> strip combine (waits for the slowest sibling) -> rows written,
 for the large and the small maps of the DeepLab step, with the launch as the event pair sees it next to them."""
 import os
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import sys
 
 import torch

@@ -2,6 +2,7 @@
 """A/B of the LDS-DMA 128x128 convolution kernel (pp_debug_set_conv_variant: bits 8 / 18 = 128x128 / 64x64 variant off, bit 15 = 128x128 backward-data too) against the register-staged one:
 outputs must be bit-identical (same tiles, same MFMA order); prints per-shape timings."""
 import os, sys
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pixelpick_amd import _lib, engine as E

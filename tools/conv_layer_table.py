@@ -3,6 +3,7 @@
 config: shape, call count, and µs / TFLOP/s of forward, backward-data and backward-weight, each timed alone
 through the C ABI.  Tells which layer shapes the implicit-GEMM kernels serve badly."""
 import os, sys, warnings, collections
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 from argparse import Namespace
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

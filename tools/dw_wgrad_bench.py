@@ -3,6 +3,7 @@
 (partial kernel + combine, 20 back-to-back calls) per geometry word of pp_debug_set_dw_variant, next to the bytes a call has
 to read (x + dy once) at 5 TB/s.   python tools/dw_wgrad_bench.py [word ...]"""
 import os
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import sys
 
 import torch

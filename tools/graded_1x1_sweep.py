@@ -2,6 +2,7 @@
 """The graded pointwise shapes (bench.py roofline_mfma_1x1) under the library's planning knobs: which existing kernel / tile is fastest
 for each, against the vendor sgemm.  GPU box:  python tools/graded_1x1_sweep.py"""
 import os, sys
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pixelpick_amd import _lib

@@ -5,6 +5,7 @@
 """
 import sys
 import os
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 
 import torch
 

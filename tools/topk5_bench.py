@@ -2,6 +2,7 @@
 """Op-level timing of the reference's default top-5 % mode (args.py:25: k = 5 % of the pixels) on BASELINE configs[1]:
 pp_acq_score_topk at B=256 x 256x512x19, entropy, k = 6553.  Run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import os, sys
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pixelpick_amd import acquisition as acq, _lib

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Quick timing of the DeepLabv3+-MNv2 (NET=FPN: FPNSeg-ResNet50) train step (FlatTrainer) at the BASELINE config: B=4, 256x512, C=19."""
 import contextlib, os, sys, time, json, warnings
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 from argparse import Namespace
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -2,6 +2,7 @@
 """Kernel-level timing of conv_x3_kernel variants (pp_debug_set_x3 modes) on the SegmentHead shapes: rocprofv3 gives the per-kernel
 durations; this script runs forward, backward-data and the weight gradient of the two layers N times per mode."""
 import os, sys
+os.environ.setdefault("PIXELPICK_KNOBS_BUILD", "1")      # the pp_debug_* planner switches live in the test build only
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pixelpick_amd import _lib, engine as E
