@@ -616,6 +616,21 @@ def main():
                                    "allreduce_alone_GBps_per_rank": round(tr.n * 4 / (ar_ms * 1e-3) / 1e9, 1),
                                    "overlapped": bool(__import__("pixelpick_amd.trainer", fromlist=["x"]).OVERLAP_ALLREDUCE)}
 
+        # the depthwise layers of MobileNetV2 against the HBM roofline (north_star: "bandwidth-bound and justified against the HBM roofline";
+        # SURVEY 8(d)): every depthwise call of the RECORDED step re-issued on its own with the step's arguments (pixelpick_amd/profiling.py;
+        # the per-layer table with cold timings and copy yardsticks is tools/dw_bench.py -> profiles/r06_dw_layers.txt)
+        if world == 1 and a.network == "deeplab" and not a.no_other_configs:
+            from pixelpick_amd import profiling
+            was_replay = tr._plan is not None
+            if not was_replay:
+                tr.enable_replay(*synth_train_batch(TB, C, H, W, a.n_labelled, dev, 1), warmup=1)
+            rows_dw = profiling.depthwise_table(tr._plan, iters=10, with_cold=False, yardsticks=False)
+            if not was_replay:
+                tr.disable_replay()
+            line["roofline_hbm_depthwise"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "what": "mobilenet_v2.py:38,52 - the 17 depthwise 3x3 layers of one train step (B = %d, %dx%d), each launch timed alone with the "
+                                                      "step's own arguments, warm; bytes = every tensor once" % (TB, H, W),
+                                              **profiling.depthwise_summary(rows_dw)}
         # dominant train kernel vs the fp32 MFMA roofline: SegmentHead conv 3x3 304->256 on [TB,64,128] (decoders.py:107)
         Hq, Wq = H // 4, W // 4
         xa = torch.randn((TB, Hq, Wq, 304), device=dev)

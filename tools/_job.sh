@@ -1,12 +1,7 @@
-# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
+# scratch job for `gpurun -- 'bash tools/_job.sh'`
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/job; mkdir -p $O
-timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+O=gpurun_out/r6a; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu -x > $O/tall.txt 2>&1; tail -3 $O/tall.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
-cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-cp $(find $O/prof_head -name "*kernel_stats.csv" | head -1) $O/bench_headline_kernel_stats.csv
+timeout 600 python tools/dw_bench.py > $O/dw_layers.txt 2> $O/dw_layers.err; tail -3 $O/dw_layers.txt; tail -3 $O/dw_layers.err
+timeout 900 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo; tail -3 $O/bench.err
