@@ -216,7 +216,9 @@ int pp_conv2d_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C
  * a caller may split a tensor ONCE with pp_x3_split and pass the planes to every *_pre call that reads it (NULL = split
  * inside, as the plain entry points do; planes are ignored by calls that do not run a bf16x3 kernel).
  * pp_conv2d_x3_planes_bytes(which, ...): 0 if the call (which = 0 forward, 1 backward-data, 2 weight gradient) would not use
- * planes, else the size of its activation planes (forward / weight gradient: of x; backward-data: of dy). */
+ * planes, else the size of its activation planes (forward / weight gradient: of x; backward-data: of dy).
+ * which = 3 / 4: the forward / backward-data call reads WEIGHT planes (pp_x3_split_weights, that direction's
+ * layout) when it gets them through *_pre2 - asked by callers that keep the weight planes of a step - else 0. */
 /* Backward-data of up to four convolutions that read ONE input, as one launch (+ its split-K reduce): the ASPP branches of
  * /root/reference/networks/aspp.py:49-57,64-67 - x1..x4 = aspp1..4(x): a 1x1 and three dilated 3x3 convolutions, stride 1, "same"
  * padding d*(k-1)/2 - whose input gradient torch forms as four conv-backward results added up.  dy [B,H,W,>= nb*Cout] holds branch b's

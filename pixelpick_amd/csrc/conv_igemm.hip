@@ -23,10 +23,10 @@
 
 #include "pp_common.h"
 #include "bn_xchg.h"
+#include "conv_types.h"
 
 namespace pp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static int g_conv_xcd_remap = 1;
 static int g_conv_novec = 0;
@@ -34,77 +34,11 @@ static int g_conv_lds_pad = 0;     // extra dynamic LDS bytes for the 128x128 ke
 static int g_conv_variant = 0;   // large-tile kernel: 0 = 128x128 tiles (default), 2 = 128x64 tiles (A/B)
 
 typedef float f32x16s __attribute__((ext_vector_type(16)));      // sixteen consecutive floats at a wave-uniform, 64-byte aligned address: one s_load_dwordx16
-constexpr int kThreads = 256;
 constexpr int BK = 16;
-constexpr int kMaxTaps = 49;
-
-struct ConvTaps {
-    int n;                  // number of live taps
-    int dh[kMaxTaps];       // input row offset of tap (already includes -pad / flip); int: wave-uniform s_load
-    int dw[kMaxTaps];
-    int widx[kMaxTaps];     // index of the tap in the weight tensor (kh*KW + kw)
-};
-
-// Training BatchNorm finished in the convolution's own epilogue (conv_epilogue_bn): the blocks of a column strip exchange their
-// column sums exactly as the blocks of the single-launch BatchNorm kernel do (bn_xchg.h), then every block normalises the tile it
-// still holds in registers.  part == NULL: off.
-struct BnTrain {
-    const float* gamma; const float* beta; float eps, momentum;
-    float* running_mean; float* running_var; float* mean; float* invstd;
-    const float* res; int64_t ldr; int act;
-    float* y; int64_t ldy;              // the normalised (+ residual, activation) output; ConvParams::y receives the raw convolution
-    xword* part; int* sync; int R;      // exchange area [strips][R][64] words, launch epoch, M tiles of the grid
-    // backward form (a backward-data convolution that also runs the BatchNorm backward of the layer in FRONT of it, conv_epilogue_bn_bwd):
-    // bx = the BatchNorm's input, mean / invstd are inputs, y receives the gradient of that input, dgamma / dbeta the parameter gradients
-    const float* bx; int64_t ldbx; float* dgamma; float* dbeta;
-    // backward form, a BatchNorm output with MORE consumers / a residual input: gin = the gradient the output already holds from the
-    // consumers whose backward ran earlier (added to the tile before anything else, the `accumulate` of a plain backward-data), dres =
-    // where the gradient of the BatchNorm's residual input goes (the masked gradient itself).  NULL: none.
-    const float* gin; int64_t ldgin; float* dres; int64_t lddr;
-};
-
 // dword-aligned wide loads (global loads need dword alignment only): the packed three-channel image of the stem
 struct __attribute__((packed, aligned(4))) StemF4 { float x, y, z, w; };
 struct __attribute__((packed, aligned(4))) StemF3 { float x, y, z; };
 struct __attribute__((packed, aligned(4))) StemF2 { float x, y; };
-
-struct ConvParams {
-    const uint16_t* a_pre;   // bf16x3 planes of the A operand the CALLER already holds (pp_x3_split), or NULL: split here
-    const uint16_t* b_pre;   // bf16x3 planes of the WEIGHTS the caller already holds (pp_x3_split_weights, the layout of this direction), or NULL
-    const float* x;   // A-side activations (X for fwd/wgrad, dY for bwd-data)
-    const float* w;   // HWIO weights
-    const float* bias;
-    float* y;         // output (Y, dX)
-    int64_t ldx, ldy;
-    int B, H, W;      // A-side spatial size
-    int Ho, Wo;       // output spatial size (rows of the GEMM)
-    int Ck;           // reduction channels (Cin for fwd, Cout for bwd-data)
-    int Cn;           // output channels  (Cout for fwd, Cin for bwd-data)
-    int Cin, Cout;    // weight tensor dims (for addressing)
-    int stride;
-    int64_t M;        // B*Ho*Wo
-    int bwd_stride;   // backward-data of a strided conv: source row = (row + dh) / bwd_stride when divisible (else 1)
-    int n_tiles;      // tiles along the output-channel axis (grid.x is 1-D: m_tiles * n_tiles blocks)
-    int xcd_remap;
-    int splits;       // split-K: grid.y slices of the (tap, channel-chunk) loop; > 1 -> partial sums go to `part`
-    int ks_per_split;
-    float* part;      // [splits][M][Cn] partial outputs (no bias)
-    Epilogue epi;     // inference only: folded BatchNorm + residual + activation (all NULL / 0 in training)
-    int accumulate;   // y += result (backward-data into a gradient that already holds the residual branch's part)
-    int tap_inner;    // K loop order (A/B knob)
-    const float* in_scale;   // forward of a 1x1 / pad-0 convolution BEHIND a training BatchNorm whose apply pass was skipped: the A
-    const float* in_shift;   // operand is act(fma(x, in_scale[c], in_shift[c])) (bn_apply_kernel's arithmetic), applied where the
-    int in_act;              // operand is read.  NULL: x as it is.  (conv_igemm_kernel VEC path, conv1x1_ksplit_dma_kernel)
-    // several convolutions' backward-data as ONE implicit GEMM (pp_conv2d_bwd_data_multi: the ASPP branches, aspp.py:49-57, all read
-    // one input): tap t of the merged reduction reads the A operand tap_coff[t] channels into its row and its weights tap_woff[t]
-    // elements behind `w` (conv_igemm_dma_kernel only; 0: the tap table's own addressing)
-    int multi;
-    int tap_coff[32], tap_woff[32];
-    BnTrain bn;
-    float* stats;     // training forward in front of a BatchNorm: per-wave column sums / sums of squares of the stored outputs,
-                      // [rows_partial][2][Cn], rows_partial = m0 / (TM*32) + wm (see conv_epilogue); NULL: none
-    ConvTaps taps;
-};
 
 // ---- LDS tiles ---------------------------------------------------------------------------------------
 // "MK" form: tile[rows][BK + 4]   (K contiguous, 80-B row pitch: conflict-free ds_read_b128)
@@ -158,61 +92,6 @@ __device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][tm][j], b[q][tn][j], acc[tm][tn], 0, 0, 0);
-}
-
-// ---- epilogue shared by the register-staged and the LDS-DMA kernels --------------------------------------
-template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn)
-{
-    const int tid = threadIdx.x;
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wn * TN + tn) * 32 + l31;
-        if (n >= p.Cn) continue;
-        const bool final_pass = p.splits <= 1;
-        const float bv = (p.bias && final_pass) ? p.bias[n] : 0.0f;
-        const bool affine = final_pass && p.epi.gamma != nullptr;
-        float sc = 1.0f, sf = 0.0f;
-        if (affine) {
-            const float is = 1.0f / sqrtf(p.epi.var[n] + p.epi.eps);
-            sc = p.epi.gamma[n] * is;
-            sf = p.epi.beta[n] - p.epi.mean[n] * sc;
-        }
-        const float* res = final_pass ? p.epi.res : nullptr;
-        const int act = final_pass ? p.epi.act : 0;
-        float* out = p.splits > 1 ? p.part + (int64_t)blockIdx.y * p.M * p.Cn : p.y;
-        const int64_t ldo = p.splits > 1 ? (int64_t)p.Cn : p.ldy;
-        float s1 = 0.0f, s2 = 0.0f;           // column sum / sum of squares of what this lane stores (BatchNorm statistics)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m < p.M) {
-                    float o = acc[tm][tn][r] + bv;
-                    if (affine) o = fmaf(o, sc, sf);
-                    if (res) o += res[m * p.epi.ldr + n];
-                    if (final_pass && p.accumulate) o += out[m * ldo + n];
-                    o = epi_act(o, act);
-                    out[m * ldo + n] = o;
-                    s1 += o;
-                    s2 = fmaf(o, o, s2);
-                }
-            }
-        }
-        if (p.stats && final_pass) {
-            // lanes l and l+32 hold the same column (rows 4*hh apart): one fixed-order add, then one store per column
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (hh == 0) {
-                const int64_t pr = m0 / (TM * 32) + wm;
-                p.stats[(pr * 2 + 0) * p.Cn + n] = s1;
-                p.stats[(pr * 2 + 1) * p.Cn + n] = s2;
-            }
-        }
-    }
 }
 
 // ---- epilogue that also finishes a training BatchNorm (+ residual, activation) --------------------------------------------------
@@ -2791,19 +2670,6 @@ __global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* part,
 //   tile 128 x BN (BN = 128 | 64), 4 waves (2 x 2), K step = 16 bf16 per plane (32-byte rows), three stages of
 //   3 x (128 + BN) x 32 B; a wave DMAs 32 A rows and 32 B rows of each plane per step (1-KiB pieces, lane -> (row, 16-byte half),
 //   half swizzled by bit 3 of the row so that the fragment reads are conflict-free); fragments are ds_read_b128.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
-struct X3Operands {
-    const uint16_t* a;        // A planes [3][Kp/16][rows_a + 1][16] (row rows_a = zeros)
-    const uint16_t* b;        // B planes [3][Kp/16][ntaps * n_rows + 1][16] (last row = zeros); row = tap_w * n_rows + n
-    int64_t a_plane, b_plane; // elements per plane
-    int Kp;                   // reduction channels per tap, padded to a multiple of 16 (pads are zeros in both operands)
-    int n_rows;               // B rows per tap (= output channels of this GEMM)
-    uint32_t a_zero, b_zero;  // byte offset of the zero row inside a plane (chunk 0)
-    uint32_t a_chunk, b_chunk;   // bytes per 16-channel chunk: (rows + 1) * 32
-    int col_base;             // first output column of this launch (ragged widths run as a 128-wide launch + a 64-wide one)
-};
-
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
 {
     uint32_t u = __float_as_uint(f);
@@ -3554,10 +3420,17 @@ static int64_t conv_stats_rows(const ConvPlan& pl, int64_t M, int Cn)
 // bf16x3 path (conv_x3_kernel): which problems take it, and what the caller's workspace must hold for it
 static int g_conv_x3 = 1;
 static int g_x3_var = 0;      // pp_debug_set_x3_variant: experiment forms of conv_x3_kernel<256,128> (see the kernel)
-struct X3Plan { bool ok; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes; };
+// ok: some bf16x3 kernel serves the problem.  classic: conv_x3_kernel on pre-split A planes (the caller's, or split here by x3_split_kernel) -
+// the round-3 rule.  f32: conv_x3f_kernel (conv_x3f.hip) may serve it - the A operand is read as fp32 and split inside the kernel, so
+// the layer pays no split launch and needs no A planes; taken whenever the caller holds no A planes, and it opens the path to the
+// mid-size layers the split launches priced out (ResNet50 Bottleneck 1x1 / 3x3 at 8192 rows, resnet_models.py:58-94).
+struct X3Plan { bool ok, classic, f32; int Kp; int64_t rows_a, a_plane, b_rows, b_plane; size_t bytes, b_off; };
 static int g_conv_x3_mid = 1;
 static double g_x3_mid_flop = 16e9, g_x3w_flop = 8e9;     // least work of a mid-size layer / a weight gradient (pp_debug_set_x3 bits 9-11 / 14-16)
 static int g_x3_mid_tiles = 256;                          // least 128 x 128 tiles of a mid-size layer (bits 12-13)
+static int g_x3f = 0;                                     // in-kernel A split (conv_x3f.hip; test build only, pp_debug_set_x3f bit 0 switches it ON: measured slower)
+static double g_x3f_flop = 1e9;                           // least work of a layer that takes it without being a classic one
+static int g_x3f_tiles = 128, g_x3f_k = 256;              // least 128-row tiles (128 or 64 wide) / least reduction length
 static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int n_rows, int ntaps_w, int ntaps_live, bool vec)
 {
     X3Plan x{};
@@ -3567,25 +3440,37 @@ static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int
     const int64_t t128 = cdiv(M, 128) * cdiv(n_rows, 128);
     // (measured, FPN-ResNet50: with half a wave of blocks / below 16 GFLOP the operand splits and the idle CUs cost more than the
     // matrix rate gains - 256 -> 256 3x3 at 8192 rows 94 -> 150 us, 2048 -> 256 87 -> 155 us; 512 -> 512 3x3 345 -> 279 us)
-    const bool mid = g_conv_x3_mid && pl.cfg == 2 && t128 >= g_x3_mid_tiles && 2.0 * (double)M * n_rows * ntaps_live * Ck >= g_x3_mid_flop;
-    if (!g_conv_x3 || !(pl.cfg == 1 || mid) || pl.splits > 1 || !vec || ntaps_live > 32 || (int64_t)ntaps_live * Ck < 512) return x;
+    const double flop = 2.0 * (double)M * n_rows * ntaps_live * Ck;
+    const bool mid = g_conv_x3_mid && pl.cfg == 2 && t128 >= g_x3_mid_tiles && flop >= g_x3_mid_flop;
+    if (!g_conv_x3 || !vec || ntaps_live > 32) return x;
+    x.classic = (pl.cfg == 1 || mid) && pl.splits <= 1 && (int64_t)ntaps_live * Ck >= 512;
+    // in-kernel split: every classic layer (it replaces the split launch when the caller brings no planes), and whatever fills half the
+    // chip with 128-row tiles of either width and has a reduction long enough to amortise the tile's prologue
+    const int64_t t64 = n_rows % 64 == 0 ? cdiv(M, 128) * (n_rows / 64) : 0;
+    x.f32 = g_x3f && n_rows >= 64 && (x.classic || (flop >= g_x3f_flop && (int64_t)ntaps_live * Ck >= g_x3f_k &&
+                                                    std::max(t128, t64) >= g_x3f_tiles && (pl.cfg == 1 || pl.cfg == 2 || pl.cfg == 3 || pl.cfg == 4)));
+    if (!x.classic && !x.f32) return x;
     x.Kp = (int)cdiv(Ck, 16) * 16;
     x.rows_a = rows_a;
     x.a_plane = (rows_a + 1) * x.Kp;
     x.b_rows = (int64_t)ntaps_w * n_rows;
     x.b_plane = (x.b_rows + 1) * x.Kp;
-    if (x.a_plane * 2 >= (1ll << 32) - 4096 || x.b_plane * 2 >= (1ll << 32) - 4096) return x;
-    x.bytes = align_up((size_t)3 * x.a_plane * 2, 256) + align_up((size_t)3 * x.b_plane * 2, 256);
+    if (x.b_plane * 2 >= (1ll << 32) - 4096) { x.classic = x.f32 = false; return x; }
+    if (x.a_plane * 2 >= (1ll << 32) - 4096) x.classic = false;
+    if (!x.classic && !x.f32) return x;
+    x.b_off = x.classic ? align_up((size_t)3 * x.a_plane * 2, 256) : 0;      // (layers only the in-kernel split serves keep no room for A planes)
+    x.bytes = x.b_off + align_up((size_t)3 * x.b_plane * 2, 256);
     x.ok = true;
     return x;
 }
 
 template <bool BWD>
-static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, int kh_kw, void* workspace, hipStream_t st)
+static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, int kh_kw, void* workspace, hipStream_t st, bool f32path)
 {
+    // f32path: conv_x3f_kernel reads the fp32 A operand itself - no x3_split_kernel launch, no A planes
     const uint16_t* ap = p.a_pre ? p.a_pre : reinterpret_cast<uint16_t*>(workspace);
-    uint16_t* bp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)3 * x.a_plane * 2, 256));
-    if (!p.a_pre) {
+    uint16_t* bp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + x.b_off);
+    if (!p.a_pre && !f32path) {
         const int64_t ta = (x.rows_a + 1) * (x.Kp / 8);          // (chunk, row, half) items
         hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ta, 256), 4096)), dim3(256), 0, st, p.x, p.ldx, x.rows_a, p.Ck,
                            reinterpret_cast<uint16_t*>(workspace), x.Kp, x.a_plane);
@@ -3610,8 +3495,11 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
     // one with 64-wide tiles - 384 blocks of 256 x 128 on 256 CUs were two rounds for 1.19x the work (349 us; bit 2: that form)
     const int full128 = p.Cn / 128, rem = p.Cn - full128 * 128;
     const bool two = rem > 0 && rem <= 64 && full128 > 0 && !(g_conv_x3 & 4);
-    const bool n128_only = !two && (rem == 0 || rem > 64 || (g_conv_x3 & 4));
+    bool n128_only = !two && (rem == 0 || rem > 64 || (g_conv_x3 & 4));
     const int64_t mt256 = cdiv(p.M, 256);
+    // a narrow layer of the in-kernel-split path (1024 -> 256 at 8192 rows: 128 tiles of 128 x 128) takes 64-wide tiles when that is what
+    // gives every CU a block
+    if (f32path && n128_only && rem == 0 && cdiv(p.M, 128) * full128 < 200 && cdiv(p.M, 128) * full128 * 2 >= 128) n128_only = false;
     auto go = [&](bool n128, int ntile, int col_base) {
         // (the 64-wide remainder launch of a ragged width decides for itself: 128 blocks of 256 x 64 leave half of the CUs idle for
         // as long as a full tile column takes - 96 us for 16 % of the layer; 256 blocks of 128 x 64 do it in one short round)
@@ -3620,6 +3508,12 @@ static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, in
         o.col_base = col_base;
         p.n_tiles = ntile;
         const dim3 grid((unsigned)(mtiles * ntile));
+#ifdef PP_DEBUG_KNOBS
+        if (f32path) {
+            (void)launch_conv_x3f(p, o, m256, n128, grid.x, st);
+            return;
+        }
+#endif
         if (m256) {
             if (n128) {
                 switch (g_x3_var) {
@@ -3807,9 +3701,16 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     if (kh_kw > 0 && !p.in_scale && p.bwd_stride <= 1) {
         // large-tile layers: six bf16 MFMAs per product instead of the fp32 MFMA (operands split once into the workspace)
         const X3Plan x = x3_plan(pl, p.M, (int64_t)p.B * p.H * p.W, p.Ck, p.Cn, kh_kw, p.taps.n, vec);
-        if (x.ok && workspace && ws_bytes >= x.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
-            (reinterpret_cast<uintptr_t>(p.b_pre) & 255) == 0)
-            return launch_conv_x3<BWD>(p, pl, x, kh_kw, workspace, st);
+        // the caller's A planes -> conv_x3_kernel; no planes -> the in-kernel split where it applies, else (classic layers) split here
+#ifdef PP_DEBUG_KNOBS
+        const bool f32path = x.f32 && !p.a_pre && conv_x3f_supported(p);
+#else
+        const bool f32path = false;
+#endif
+        const bool ws_ok = (workspace && ws_bytes >= x.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) ||
+                           (f32path && p.b_pre != nullptr);          // (both operands provided for: nothing is written to the workspace)
+        if (x.ok && (f32path || x.classic) && ws_ok && (reinterpret_cast<uintptr_t>(p.b_pre) & 255) == 0)
+            return launch_conv_x3<BWD>(p, pl, x, kh_kw, workspace, st, f32path);
     }
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
@@ -4180,6 +4081,18 @@ int pp_yardstick_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t 
     return check_launch("mfma_stream_kernel");
 }
 
+#ifdef PP_DEBUG_KNOBS
+void pp_debug_set_x3f(int v)
+{
+    g_x3f = (v & 1) ? 1 : 0;
+    static const double gf[8] = {1e9, 0.5e9, 2e9, 4e9, 8e9, 0.25e9, 0.0, 1e9};
+    g_x3f_flop = gf[(v >> 1) & 7];
+    static const int tl[4] = {128, 64, 192, 256};
+    g_x3f_tiles = tl[(v >> 4) & 3];
+    static const int kk[4] = {256, 128, 512, 16};
+    g_x3f_k = kk[(v >> 6) & 3];
+}
+#endif
 #ifdef PP_DEBUG_KNOBS
 void pp_debug_set_x3_variant(int v) { g_x3_var = (v >= 0 && v <= 11) ? v : 0; }
 #endif
@@ -5039,8 +4952,10 @@ int pp_conv2d_bwd_weight_pre(const float* x, int64_t ldx, int B, int H, int W, i
                                   x_planes, dy_planes);
 }
 
-// 0: the call would not run a bf16x3 kernel (planes would be ignored); else the bytes of the A-operand planes it reads
-// (which: 0 forward -> planes of x, 1 backward-data -> planes of dy, 2 weight gradient -> planes of x AND of dy are used)
+// 0: the call would not run a bf16x3 kernel on such planes (they would be ignored); else the bytes of the planes it reads
+// (which: 0 forward -> A planes of x, 1 backward-data -> A planes of dy, 2 weight gradient -> planes of x AND of dy are used;
+//  3 / 4: forward / backward-data -> the WEIGHT planes in that direction's layout - also asked for by the layers that split their
+//  activations inside the kernel (conv_x3f.hip) and therefore want no A planes: 0 / 1 answer 0 for those)
 size_t pp_conv2d_x3_planes_bytes(int which, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
@@ -5048,20 +4963,24 @@ size_t pp_conv2d_x3_planes_bytes(int which, int B, int H, int W, int Cin, int Co
     if (Ho < 1 || Wo < 1) return 0;
     const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
     ConvTaps t;
-    if (which == 0) {
+    if (which == 0 || which == 3) {
         build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);
         const int64_t M = (int64_t)B * Ho * Wo;
         if (ksplit_shape_ok(M, Cout, Cin, t.n, stride)) return 0;
         const ConvPlan pl = plan_conv(M, Cout, Cin, t.n, vec);
-        return x3_plan(pl, M, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec).ok ? pp_x3_planes_bytes((int64_t)B * H * W, Cin) : 0;
+        const X3Plan xf = x3_plan(pl, M, (int64_t)B * H * W, Cin, Cout, kh * kw, t.n, vec);
+        if (which == 3) return xf.ok ? pp_x3_weight_planes_bytes(kh * kw, Cin, Cout, 1) : 0;
+        return xf.classic ? pp_x3_planes_bytes((int64_t)B * H * W, Cin) : 0;
     }
-    if (which == 1) {
+    if (which == 1 || which == 4) {
         if (stride != 1) return 0;
         build_taps(t, kh, kw, 1, pad, dil, Ho, Wo, H, W, true, stride);
         const int64_t M = (int64_t)B * H * W;
         if (ksplit_shape_ok(M, Cin, Cout, t.n, stride)) return 0;
         const ConvPlan pl = plan_conv(M, Cin, Cout, t.n, vec);
-        return x3_plan(pl, M, (int64_t)B * Ho * Wo, Cout, Cin, kh * kw, t.n, vec).ok ? pp_x3_planes_bytes((int64_t)B * Ho * Wo, Cout) : 0;
+        const X3Plan xb = x3_plan(pl, M, (int64_t)B * Ho * Wo, Cout, Cin, kh * kw, t.n, vec);
+        if (which == 4) return xb.ok ? pp_x3_weight_planes_bytes(kh * kw, Cin, Cout, 0) : 0;
+        return xb.classic ? pp_x3_planes_bytes((int64_t)B * Ho * Wo, Cout) : 0;
     }
     if (which == 2) {
         build_taps(t, kh, kw, stride, pad, dil, H, W, Ho, Wo, false);

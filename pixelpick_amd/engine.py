@@ -921,11 +921,13 @@ def conv2d(tape: Tape, x: Var, w: torch.Tensor, bias: Optional[torch.Tensor], st
     if (tape.enabled and w.requires_grad and _x3_planes(0, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
             and _x3_planes(2, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
         xp = _x3_split(x.t, ldx, B * H * W, Cin)          # read by this forward and, in backward(), by the weight gradient
-    if xp is not None:
+    # weight planes of the step (split at begin_step on the second queue) for every layer a bf16x3 kernel serves - with the caller's
+    # activation planes (xp) or, without them, through the in-kernel split (csrc/conv_x3f.hip: no x3_split launch at all)
+    if xp is not None or (tape.enabled and w.requires_grad and _x3_planes(3, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
         wp = _weight_planes(w, 1)
         _register_weight_planes(w, 1)
         rc = _lib.lib().pp_conv2d_fwd_pre2(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, xp.data_ptr(), wp, _stream())
+                                           kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, xp.data_ptr() if xp is not None else None, wp, _stream())
     else:
         rc = _lib.lib().pp_conv2d_fwd(x.t.data_ptr(), ldx, B, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                       kh, kw, stride, pad, dil, y.data_ptr(), ldy, Cout, ws, wsn, _stream())
@@ -1052,12 +1054,13 @@ def _conv2d_bwd(tape: Tape, dy: torch.Tensor, x: Var, w, bias, stride, pad, dil,
                 return
             dx = acc_into if acc_into is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
             ws, wsn = _conv_ws(True, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)
-            if dyp is not None:
+            if dyp is not None or (stride == 1 and w.requires_grad and _x3_planes(4, B, H, W, Cin, Cout, kh, kw, stride, pad, dil)):
                 wp = _weight_planes(w, 0) if stride == 1 else None
                 if stride == 1:
                     _register_weight_planes(w, 0)
                 rc = L.pp_conv2d_bwd_data_pre2(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
-                                               dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, dyp.data_ptr(), wp, _stream())
+                                               dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn,
+                                               dyp.data_ptr() if dyp is not None else None, wp, _stream())
             else:
                 rc = L.pp_conv2d_bwd_data(dy.data_ptr(), lddy, B, Ho, Wo, Cout, w.data_ptr(), kh, kw, stride, pad, dil,
                                           dx.data_ptr(), Cin, H, W, Cin, 1 if acc_into is not None else 0, ws, wsn, _stream())
