@@ -42,6 +42,7 @@ void pp_debug_conv_plan(int64_t M, int Cn, int Ck, int ntaps, int* out4);   /* t
 void pp_debug_set_conv_rows(int bits);      /* whole-row VALU kernels of the narrow pointwise layers: bit 0 off, bit 1 forward rows kernel only from 65536 rows (A/B) */
 void pp_debug_set_conv_bn_fuse(int bits);   /* fused conv + BatchNorm launches offered: bit 0 tiled fwd, 1 split-K fwd, 2 bwd 64x64, 3 bwd split-K / 128x32 (default 15; A/B) */
 void pp_debug_set_x3_variant(int v);   /* experiment forms of conv_x3_kernel<256,128> (ring depth, priority, DMA placement, timing ablations); 0 = product */
+void pp_debug_set_gemm_pw(int v);   /* pointwise GEMM kernel (gemm_pw.hip): low 4 bits 0 off, 1 rule (default), 2..7 force tile form 0..5; bits 4..: least rows (default 4096) */
 void pp_debug_set_x3f(int v);   /* in-kernel activation split (conv_x3f.hip, an experiment that lives in the test build only - measured slower): bit 0 ON; bits 1-3 least GFLOP of a non-classic layer {1, 0.5, 2, 4, 8, 0.25, 0}; bits 4-5 least tiles {128, 64, 192, 256}; bits 6-7 least K {256, 128, 512, 16} (A/B) */
 void pp_debug_set_x3(int on);   /* large-tile conv layers: 1 = bf16x3-split MFMA kernel (default), 0 = fp32 MFMA kernels (A/B, parity) */
 void pp_debug_set_conv_variant(int v);

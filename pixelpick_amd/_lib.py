@@ -173,6 +173,7 @@ KNOB_SIGNATURES = {
     "pp_debug_set_conv_bn_fuse": (None, [_int]),
     "pp_debug_set_x3": (None, [_int]),
     "pp_debug_set_x3f": (None, [_int]),
+    "pp_debug_set_gemm_pw": (None, [_int]),
     "pp_debug_set_x3_variant": (None, [_int]),
     "pp_debug_occupy_cus": (_int, [_int, _p, _u64, _p, _p]),
 }

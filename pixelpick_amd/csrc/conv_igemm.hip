@@ -3464,6 +3464,31 @@ static X3Plan x3_plan(const ConvPlan& pl, int64_t M, int64_t rows_a, int Ck, int
     return x;
 }
 
+// ---- pointwise layers on the plain GEMM kernel (gemm_pw.hip) ----------------------------------------------------------------------
+// Which tile form serves an M x N x K pointwise problem, or -1: the one with the least work on the busiest CU (tiles are handed out
+// round-robin and a CU shares its matrix pipes among its resident blocks, so a launch lasts ceil(tiles / CUs) tiles), each tile
+// priced at its MFMA time over the form's measured efficiency plus a fixed prologue / epilogue (profiles/r06_gemm_pw.txt).
+static int g_gemm_pw = 1;                 // 0 off, 1 rule, 2.. force form (v - 2) (pp_debug_set_gemm_pw)
+static int64_t g_gemm_pw_rows_min = 4096; // fewer rows: the in-block split-K kernel / the 64x64 tiles fill the chip better
+static int device_cus();
+static int gemm_pw_choose(int64_t M, int N, int K)
+{
+    if (!g_gemm_pw || M < g_gemm_pw_rows_min || K < 64 || N < 64) return -1;      // (narrower layers have their own whole-row kernels)
+    if (g_gemm_pw >= 2) return g_gemm_pw - 2;
+    static const double eff[6] = {0.88, 0.86, 0.85, 0.80, 0.78, 0.70}, fixed_us[6] = {10.0, 10.5, 6.0, 4.5, 4.5, 2.5};
+    const int cus = device_cus();
+    int best = -1;
+    double best_t = 1e30;
+    for (int f = 0; f < 6; ++f) {
+        const int bm = gemm_pw_tile_rows(f), bn = gemm_pw_tile_cols(f);
+        const int64_t tiles = cdiv(M, bm) * cdiv(N, bn);
+        const double tile_us = 2.0 * bm * bn * (double)K / (4 * 64 * 2.4e3) / eff[f] + fixed_us[f];      // 4 SIMDs x 64 flop / cycle at 2.4 GHz; fill + store per tile
+        const double t = (double)cdiv(tiles, cus) * tile_us;
+        if (t < best_t) { best_t = t; best = f; }
+    }
+    return best;
+}
+
 template <bool BWD>
 static int launch_conv_x3(ConvParams& p, const ConvPlan& pl, const X3Plan& x, int kh_kw, void* workspace, hipStream_t st, bool f32path)
 {
@@ -3714,6 +3739,20 @@ static int launch_conv(const ConvParams& p_in, void* workspace, size_t ws_bytes,
     }
     if (pl.splits > 1 && (!workspace || ws_bytes < (size_t)pl.splits * p.M * p.Cn * 4)) {
         pl.splits = 1;                   // no (or too small a) workspace: single pass
+    }
+    {
+        // pointwise layers with enough rows: the plain GEMM kernel (one large tile per CU, gemm_pw.hip).  Forward: B = W [Cin][Cout] as it
+        // lies; backward-data: dX = dY x W^T, the same weight read as the TRANSPOSED operand (b[n = Cin][k = Cout])
+        const bool pw = p.taps.n == 1 && p.taps.dh[0] == 0 && p.taps.dw[0] == 0 && p.stride == 1 && vec && !p.stats && !p.in_scale && !p.epi.gamma &&
+                        !p.epi.res && p.epi.act == 0 && !p.bn.part && p.bwd_stride <= 1 && !p.multi;
+        if (pw) {
+            // (backward-data: the transposed-operand form stores column by column; it pays where the reduction is long - measured per shape,
+            // profiles/r06_gemm_pw.txt - and loses to the implicit-GEMM kernel on wide, shallow problems)
+            const bool bt_ok = !BWD || g_gemm_pw >= 2 || (p.Ck >= 512 && 2 * p.Ck >= p.Cn) || p.Cn <= 128;
+            const int form = bt_ok ? gemm_pw_choose(p.M, p.Cn, p.Ck) : -1;
+            if (form >= 0 && gemm_pw_supported(p.x, p.ldx, p.w, p.Cout, p.y, p.ldy, p.M, p.Cn, p.Ck))
+                return launch_gemm_pw(p.x, p.ldx, p.w, p.Cout, p.bias, p.y, p.ldy, p.M, p.Cn, p.Ck, p.accumulate, form, g_conv_xcd_remap, st, BWD ? 1 : 0);
+        }
     }
     // few-row, deep-K pointwise layers: in-block split-K over wave-private LDS-DMA rings (conv1x1_ksplit_dma_kernel)
     const bool use_ksplit = ksplit_shape_ok(p.M, p.Cn, p.Ck, p.taps.n, p.stride) && vec && !p.stats && p.bwd_stride <= 1 && p.Cout % 4 == 0 &&
@@ -4081,6 +4120,13 @@ int pp_yardstick_mfma_stream(int data_kind, int iters, float* sink, pp_stream_t 
     return check_launch("mfma_stream_kernel");
 }
 
+#ifdef PP_DEBUG_KNOBS
+void pp_debug_set_gemm_pw(int v)
+{
+    g_gemm_pw = (v & 15) <= 7 ? (v & 15) : 1;                 // 0 off, 1 rule, 2..7 force tile form 0..5
+    g_gemm_pw_rows_min = (v >> 4) > 0 ? (v >> 4) : 4096;      // bits 4..: least rows
+}
+#endif
 #ifdef PP_DEBUG_KNOBS
 void pp_debug_set_x3f(int v)
 {

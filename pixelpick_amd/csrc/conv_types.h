@@ -147,4 +147,11 @@ struct X3Operands {
 int launch_conv_x3f(const ConvParams& p, const X3Operands& o, bool m256, bool n128, unsigned blocks, hipStream_t st);
 int conv_x3f_supported(const ConvParams& p);
 
+// gemm_pw.hip: pointwise convolutions as a plain row-major GEMM (tile forms 0..5, see the file)
+int launch_gemm_pw(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, int64_t M, int N, int K,
+                   int accumulate, int form, int xcd_remap, hipStream_t st, int b_transposed = 0);
+int gemm_pw_supported(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc, int64_t M, int N, int K);
+int gemm_pw_tile_rows(int form);
+int gemm_pw_tile_cols(int form);
+
 }  // namespace pp

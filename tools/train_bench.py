@@ -17,6 +17,9 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = get_model(args).cuda().train()
+    if os.environ.get("GEMMPW"):                      # pp_debug_set_gemm_pw word (0: the pointwise GEMM kernel off)
+        from pixelpick_amd import _lib
+        _lib.lib().pp_debug_set_gemm_pw(int(os.environ["GEMMPW"], 0))
     if os.environ.get("X3F"):                         # pp_debug_set_x3f word (A/B of the in-kernel activation split, csrc/conv_x3f.hip)
         from pixelpick_amd import _lib
         _lib.lib().pp_debug_set_x3f(int(os.environ["X3F"], 0))
