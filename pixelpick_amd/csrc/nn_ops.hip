@@ -941,19 +941,26 @@ __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t 
         int q, ow, oh, b;
         decode_bhwq(e, cq, Wo, Ho, q, ow, oh, b);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // all nine loads are UNCONDITIONAL (from a clamped pixel, zeroed afterwards where the tap falls outside): behind a branch per
+        // tap the loads of a row waited for the row before - three dependent round trips per output (profiles/r06_dw_layers.txt)
+        float4 v[9];
 #pragma unroll
         for (int th = 0; th < 3; ++th) {
             const int ih = oh * stride - pad + th * dil;
-            if ((unsigned)ih >= (unsigned)H) continue;
+            const bool rok = (unsigned)ih < (unsigned)H;
 #pragma unroll
             for (int tw = 0; tw < 3; ++tw) {
                 const int iw = ow * stride - pad + tw * dil;
-                if ((unsigned)iw >= (unsigned)W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + ih) * W + iw) * ldx + q * 4);
-                const float4 ww = *reinterpret_cast<const float4*>(w + (th * 3 + tw) * C + q * 4);
-                acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
-                acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+                const bool ok = rok && (unsigned)iw < (unsigned)W;
+                const float4 t = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + (ok ? ih : 0)) * W + (ok ? iw : 0)) * ldx + q * 4);
+                v[th * 3 + tw] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + t * C + q * 4);
+            acc.x = fmaf(v[t].x, ww.x, acc.x); acc.y = fmaf(v[t].y, ww.y, acc.y);
+            acc.z = fmaf(v[t].z, ww.z, acc.z); acc.w = fmaf(v[t].w, ww.w, acc.w);
         }
         const int64_t row = ((int64_t)b * Ho + oh) * Wo + ow;
         if (epi.gamma) {       // inference: folded eval-mode BatchNorm (same arithmetic as bn_eval_affine + bn_apply)
@@ -979,11 +986,14 @@ __global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* x, int64_t 
 // 72).  FLIP == false: forward (taps read x at (oh - pad + th, ow - pad + tw)); FLIP == true: backward-data of the
 // same layer (dx(ih,iw) = sum dy(ih + pad - th, iw + pad - tw) w[th][tw], i.e. the forward with the weights
 // mirrored and padding 2 - pad).
-template <bool FLIP>
+template <bool FLIP, int DIL = 1>
 __global__ __launch_bounds__(kT) void dwconv_s1_x4_kernel(const float* x, int64_t ldx, int B, int H, int W, int cq,
                                                          const float* w, int pad, float* y, int64_t ldy, int Ho, int Wo,
                                                          Epilogue epi)
 {
+    // DIL = 2: the dilated last block of the backbone (features.17, mobilenet_v2.py:99-106): a 3 x 8 window for four outputs, same tap
+    // order and fma chain as the generic kernel it replaces there (bit-identical)
+    constexpr int NW = 4 + 2 * DIL;
     const int C = cq * 4;
     const int wq = (Wo + 3) / 4;
     const int64_t total = (int64_t)B * Ho * wq * cq;
@@ -996,12 +1006,12 @@ __global__ __launch_bounds__(kT) void dwconv_s1_x4_kernel(const float* x, int64_
         for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int th = 0; th < 3; ++th) {
-            const int ih = oh - pad + th;
+            const int ih = oh - pad + th * DIL;
             if ((unsigned)ih >= (unsigned)H) continue;
             const float* row = x + ((int64_t)b * H + ih) * W * ldx + q * 4;
-            float4 v[6];
+            float4 v[NW];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < NW; ++j) {
                 const int iw = ow0 - pad + j;
                 v[j] = (unsigned)iw < (unsigned)W ? *reinterpret_cast<const float4*>(row + (int64_t)iw * ldx)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1012,8 +1022,8 @@ __global__ __launch_bounds__(kT) void dwconv_s1_x4_kernel(const float* x, int64_
                 const float4 ww = *reinterpret_cast<const float4*>(w + wi * C + q * 4);
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    acc[o].x = fmaf(v[o + tw].x, ww.x, acc[o].x); acc[o].y = fmaf(v[o + tw].y, ww.y, acc[o].y);
-                    acc[o].z = fmaf(v[o + tw].z, ww.z, acc[o].z); acc[o].w = fmaf(v[o + tw].w, ww.w, acc[o].w);
+                    acc[o].x = fmaf(v[o + tw * DIL].x, ww.x, acc[o].x); acc[o].y = fmaf(v[o + tw * DIL].y, ww.y, acc[o].y);
+                    acc[o].z = fmaf(v[o + tw * DIL].z, ww.z, acc[o].z); acc[o].w = fmaf(v[o + tw * DIL].w, ww.w, acc[o].w);
                 }
             }
         }
@@ -1179,23 +1189,27 @@ __global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* dy, in
         int q, iw, ih, b;
         decode_bhwq(e, cq, W, H, q, iw, ih, b);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // nine UNCONDITIONAL loads (clamped pixel, zeroed where the tap is dead) instead of a branch in front of each
+        float4 g[9];
 #pragma unroll
         for (int th = 0; th < 3; ++th) {
             const int nh = ih + pad - th * dil;
-            if (nh < 0 || nh % stride != 0) continue;
             const int oh = nh / stride;
-            if (oh >= Ho) continue;
+            const bool rok = nh >= 0 && oh * stride == nh && oh < Ho;
 #pragma unroll
             for (int tw = 0; tw < 3; ++tw) {
                 const int nw = iw + pad - tw * dil;
-                if (nw < 0 || nw % stride != 0) continue;
                 const int ow = nw / stride;
-                if (ow >= Wo) continue;
-                const float4 g = *reinterpret_cast<const float4*>(dy + (((int64_t)b * Ho + oh) * Wo + ow) * lddy + q * 4);
-                const float4 ww = *reinterpret_cast<const float4*>(w + (th * 3 + tw) * C + q * 4);
-                acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
-                acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+                const bool ok = rok && nw >= 0 && ow * stride == nw && ow < Wo;
+                const float4 t = *reinterpret_cast<const float4*>(dy + (((int64_t)b * Ho + (ok ? oh : 0)) * Wo + (ok ? ow : 0)) * lddy + q * 4);
+                g[th * 3 + tw] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + t * C + q * 4);
+            acc.x = fmaf(g[t].x, ww.x, acc.x); acc.y = fmaf(g[t].y, ww.y, acc.y);
+            acc.z = fmaf(g[t].z, ww.z, acc.z); acc.w = fmaf(g[t].w, ww.w, acc.w);
         }
         *reinterpret_cast<float4*>(dx + (((int64_t)b * H + ih) * W + iw) * lddx + q * 4) = acc;
     }
@@ -2632,6 +2646,11 @@ static int dwconv_fwd_impl(const float* x, int64_t ldx, int B, int H, int W, int
                            as_stream(stream), x, ldx, B, H, W, C / 4, w, pad, y, ldy, Ho, Wo, epi);
         return check_launch("dwconv_s1_x4_kernel");
     }
+    if (stride == 1 && dil == 2 && g_dw_x4) {
+        hipLaunchKernelGGL((dwconv_s1_x4_kernel<false, 2>), dim3(grid_for((int64_t)B * Ho * ((Wo + 3) / 4) * (C / 4))), dim3(kT), 0,
+                           as_stream(stream), x, ldx, B, H, W, C / 4, w, pad, y, ldy, Ho, Wo, epi);
+        return check_launch("dwconv_s1_x4_kernel<2>");
+    }
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(kT), 0, as_stream(stream), x,
                        ldx, B, H, W, C / 4, w, stride, pad, dil, y, ldy, Ho, Wo, epi);
     return check_launch("dwconv_fwd_kernel");
@@ -2665,6 +2684,11 @@ int pp_dwconv3x3_bwd_data(const float* dy, int64_t lddy, int B, int H, int W, in
         hipLaunchKernelGGL((dwconv_s1_x4_kernel<true>), dim3(grid_for((int64_t)B * H * ((W + 3) / 4) * (C / 4))), dim3(kT), 0,
                            as_stream(stream), dy, lddy, B, Ho, Wo, C / 4, w, 2 - pad, dx, lddx, H, W, Epilogue{});
         return check_launch("dwconv_s1_x4_kernel");
+    }
+    if (stride == 1 && dil == 2 && g_dw_x4) {          // the forward with mirrored weights and padding 2 * dil - pad
+        hipLaunchKernelGGL((dwconv_s1_x4_kernel<true, 2>), dim3(grid_for((int64_t)B * H * ((W + 3) / 4) * (C / 4))), dim3(kT), 0,
+                           as_stream(stream), dy, lddy, B, Ho, Wo, C / 4, w, 4 - pad, dx, lddx, H, W, Epilogue{});
+        return check_launch("dwconv_s1_x4_kernel<2>");
     }
     if (stride == 2 && dil == 1 && pad >= 0 && pad <= 2 && g_dw_s2) {
         const int64_t items = (int64_t)B * ((H + pad + 1) / 2 + 1) * ((W + pad + 1) / 2 + 1) * (C / 4);

@@ -621,7 +621,8 @@ def test_conv2d_channel_slices():
 
 
 DW_CASES = [(2, 18, 34, 32, 1, 0, 1), (2, 19, 35, 96, 2, 0, 1), (2, 20, 36, 960, 1, 0, 2), (1, 13, 9, 144, 2, 0, 1),
-            (2, 16, 16, 24, 1, 1, 1), (1, 7, 11, 16, 1, 1, 1), (2, 9, 6, 8, 1, 0, 1), (1, 5, 5, 4, 1, 2, 1), (3, 6, 13, 192, 1, 1, 1)]
+            (2, 16, 16, 24, 1, 1, 1), (1, 7, 11, 16, 1, 1, 1), (2, 9, 6, 8, 1, 0, 1), (1, 5, 5, 4, 1, 2, 1), (3, 6, 13, 192, 1, 1, 1),
+            (2, 12, 14, 32, 1, 2, 2), (1, 9, 7, 8, 1, 1, 2), (1, 5, 6, 4, 1, 3, 2)]      # (dilation 2 with padding: the four-outputs-per-thread form)
 
 
 @pytest.mark.parametrize("case", DW_CASES, ids=[str(c) for c in DW_CASES])

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6k; mkdir -p $O
-for i in 1 2 3; do for w in 1 0; do echo "== deeplab GEMMPW=$w" >> $O/train_ab.txt; NET=deeplab GEMMPW=$w STEPS=30 timeout 600 python tools/train_bench.py >> $O/train_ab.txt 2>&1; done; done; grep -E "==|img" $O/train_ab.txt | tail -20
-python bench.py --mode train --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['train']['host_enqueue_ms_per_step'])"
+O=gpurun_out/r6m; mkdir -p $O
+timeout 1500 python -m pytest tests/test_nn_ops_gpu.py tests/test_blocks_gpu.py tests/test_networks_gpu.py -q -x 2>&1 | tail -4
+timeout 600 python tools/dw_bench.py > $O/dw_layers.txt 2> $O/dw.err; grep -E "x960  1 0 2|130x258|128x256" $O/dw_layers.txt | cut -c1-140
+for i in 1 2 3; do NET=deeplab STEPS=30 timeout 600 python tools/train_bench.py 2>&1 | tail -1; done
