@@ -1537,7 +1537,8 @@ __global__ __launch_bounds__(kBlock) void softmax_sum_kernel(const float* logits
     if (uc_out) uc_out[pix] = accumulate ? fmaf(scale, uc, uc_out[pix]) : scale * uc;
 }
 
-static int next_pow2(int64_t v) { int p = 1; while (p < v) p <<= 1; return p; }
+// (k <= N < 2^31 is checked by every caller: for k above 2^30 the doubling used to overflow and never end - found by tests/test_abi_asan.py)
+static int next_pow2(int64_t v) { int64_t p = 1; while (p < v && p < (1ll << 30)) p <<= 1; return (int)p; }
 
 struct Plan {
     bool nhwc = false;    // dense channels-last input: LDS-transposed path
@@ -1994,7 +1995,7 @@ void pp_debug_set_acq_tuning(int occ, int ppt)
 
 size_t pp_topk_workspace_bytes(int64_t B, int64_t N, int64_t k)
 {
-    if (B < 1 || N < 1 || k < 1) return 0;
+    if (B < 1 || N < 1 || k < 1 || N > 0x7FFFFFFFll || k > N || B > 0x7FFFFFFFll) return 0;
     if (k <= kSmallKMax) {
         Plan pl = make_plan(B, N, false);
         return merge_ws_bytes(B, (int64_t)pl.waves_per_image * k, k);
@@ -2005,7 +2006,7 @@ size_t pp_topk_workspace_bytes(int64_t B, int64_t N, int64_t k)
 size_t pp_acq_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_t k)
 {
     (void)C;
-    if (B < 1 || H < 1 || W < 1 || k < 1) return 0;
+    if (B < 1 || H < 1 || W < 1 || k < 1 || H > 0x7FFFFFFFll || W > 0x7FFFFFFFll || H * W > 0x7FFFFFFFll || k > H * W || B > 0x7FFFFFFFll) return 0;
     const int64_t N = H * W;
     if (k <= kSmallKMax) {
         // sized for the 4-pixel tile (most waves), an upper bound for every plan
@@ -2103,7 +2104,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
 size_t pp_acq_lowres_workspace_bytes(int64_t B, int64_t C, int64_t Hc, int64_t Wc, int64_t k)
 {
     (void)C;
-    if (B < 1 || Hc < 1 || Wc < 1 || k < 1) return 0;
+    if (B < 1 || Hc < 1 || Wc < 1 || k < 1 || Hc > 0x7FFFFFFFll || Wc > 0x7FFFFFFFll || Hc * Wc > 0x7FFFFFFFll || k > Hc * Wc || B > 0x7FFFFFFFll) return 0;
     if (k <= kSmallKMax) {   // sized for the 4-row tile (most waves)
         const int64_t waves = cdiv(Wc, kWave) * cdiv(Hc, (kBlock / kWave) * 4) * (kBlock / kWave);
         return merge_ws_bytes(B, waves * k, k);

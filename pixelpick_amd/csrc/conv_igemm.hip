@@ -4051,13 +4051,20 @@ static int launch_wgrad_narrow(WgradParams p, int kh, int kw, float* dw, float* 
     return 0;
 }
 
+// sizes whose 32-bit output-size arithmetic (in + 2 pad - dil (k - 1) - 1) cannot overflow (found by tests/test_abi_asan.py: a hostile
+// kernel size wrapped kh * kw below the tap table's bound and build_taps wrote past it)
+static inline bool conv_geom_sane(int H, int W, int stride, int pad, int dil)
+{
+    return H <= (1 << 24) && W <= (1 << 24) && stride <= (1 << 16) && pad >= 0 && pad <= (1 << 20) && dil <= (1 << 16);
+}
+
 static int conv_common_check(const void* a, const void* b, const void* c, int B, int H, int W, int Cin, int Cout,
                              int kh, int kw, int stride, int pad, int dil)
 {
     if (!a || !b || !c) return fail(PP_ERR_BAD_ARG, "conv: null pointer");
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(PP_ERR_BAD_ARG, "conv: bad shape");
-    if (kh < 1 || kw < 1 || kh * kw > kMaxTaps) return fail(PP_ERR_UNSUPPORTED, "conv: kernel %dx%d unsupported", kh, kw);
-    if (stride < 1 || dil < 1 || pad < 0) return fail(PP_ERR_BAD_ARG, "conv: bad stride/dilation/padding");
+    if (kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps) return fail(PP_ERR_UNSUPPORTED, "conv: kernel %dx%d unsupported", kh, kw);
+    if (stride < 1 || dil < 1 || pad < 0 || !conv_geom_sane(H, W, stride, pad, dil)) return fail(PP_ERR_BAD_ARG, "conv: bad stride/dilation/padding");
     return PP_OK;
 }
 
@@ -4207,7 +4214,7 @@ void pp_debug_set_conv_variant(int v)
 
 size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
-    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride < 1 || dil < 1) return 0;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     if (Ho < 1 || Wo < 1) return 0;
     ConvTaps t;
@@ -4223,7 +4230,7 @@ size_t pp_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int
 
 int64_t pp_conv2d_fwd_stats_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
-    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride < 1 || dil < 1) return 0;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     if (Ho < 1 || Wo < 1) return 0;
     ConvTaps t;
@@ -4317,7 +4324,7 @@ static size_t bwd_phases_workspace(int B, int H, int W, int Cin, int Cout, int k
 
 size_t pp_conv2d_bwd_data_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
-    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride < 1 || dil < 1) return 0;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     if (Ho < 1 || Wo < 1) return 0;
     ConvTaps t;
@@ -4464,7 +4471,7 @@ int pp_conv2d_fwd_pre2(const float* x, int64_t ldx, int B, int H, int W, int Cin
 static bool conv_bn_shape(ConvParams& p, ConvPlan& pl, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil,
                           int64_t ldx, int* R_out = nullptr)
 {
-    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return false;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride < 1 || dil < 1) return false;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     if (Ho < 1 || Wo < 1) return false;
     p = ConvParams{};
@@ -4723,7 +4730,7 @@ int pp_x3_split(const float* x, int64_t ldx, int64_t rows, int C, void* planes, 
 static bool conv_bn_bwd_shape(ConvParams& p, ConvPlan& pl, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil,
                               int64_t lddy, int* R_out)
 {
-    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride != 1 || dil < 1) return false;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride != 1 || dil < 1) return false;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     if (Ho < 1 || Wo < 1) return false;
     p = ConvParams{};
@@ -4812,6 +4819,8 @@ static X3WPlan x3w_plan(int B, int H, int W, int Cin, int Cout, int64_t M, int n
 size_t pp_conv2d_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                             int dil)
 {
+    // (found by the AddressSanitizer driver, tests/test_abi_asan.py: a zero stride divided by zero here - every other query checks first)
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride < 1 || dil < 1 || pad < 0) return 0;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     const int64_t M = (int64_t)B * Ho * Wo;
     // splits chosen in pp_conv2d_bwd_weight never exceed 64
@@ -5004,7 +5013,7 @@ int pp_conv2d_bwd_weight_pre(const float* x, int64_t ldx, int B, int H, int W, i
 //  activations inside the kernel (conv_x3f.hip) and therefore want no A planes: 0 / 1 answer 0 for those)
 size_t pp_conv2d_x3_planes_bytes(int which, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil)
 {
-    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh * kw > kMaxTaps || stride < 1 || dil < 1) return 0;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1 || kh > kMaxTaps || kw > kMaxTaps || kh * kw > kMaxTaps || !conv_geom_sane(H, W, stride, pad, dil) || stride < 1 || dil < 1) return 0;
     const int Ho = out_size(H, kh, stride, pad, dil), Wo = out_size(W, kw, stride, pad, dil);
     if (Ho < 1 || Wo < 1) return 0;
     const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
