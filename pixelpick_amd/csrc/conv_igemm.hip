@@ -19,6 +19,7 @@
 // registers (next K-step's global loads are in flight while the current one is multiplied).  A fragment
 // reads are ds_read_b128 using a permuted K order (lane-half h consumes k = 8q+4h+j), B fragment reads
 // are conflict-free ds_read_b32.
+#include <atomic>
 #include <type_traits>
 
 #include "pp_common.h"
@@ -1770,8 +1771,81 @@ struct WgradParams {
     int pointwise;      // 1x1, stride 1, pad 0: input pixel == output pixel, no index decode
     int xcd_remap;
     float* bias_part;   // optional [splits][Cout]: column sums of dy (the bias gradient), taken by the blocks of tile column 0
+    // split-K reduction folded into this launch (wgrad_fold_tail): arrival counters of the launch's tiles (zero before and after), the
+    // final gradient and the slice count; counters == NULL: the partial sums are all this launch leaves (a reduce launch follows)
+    int* counters; float* dw; int splits;
     ConvTaps taps;
 };
+
+// Arrival counters of the weight-gradient launches that reduce their own split-K slices: a block adds one to its tile's counter when its
+// partial tile is out; the block that finds splits - 1 there is the last of the tile, re-arms the counter and sums the tile's slices in
+// SLICE ORDER (the order wgrad_reduce4_kernel used: bit-identical, whichever block arrives last).  The words are zero at module load and
+// zero again after every launch; launches take disjoint ranges of the ring in turn (host: wgrad_counters_take), so launches that overlap on
+// two queues never share a word.
+constexpr int kWgradCounters = 1 << 16;
+__device__ int g_wgrad_counters[kWgradCounters];
+
+// A partial sum of a launch that reduces its own slices leaves the block as an agent-scope (sc1, write-through) store and is read back by
+// the tile's last block with agent-scope loads: the slices cross XCDs, whose L2s are not coherent for ordinary accesses, and the
+// alternative - ordinary stores + a release fence per block - is a buffer_wbl2 of the whole L2 per block (measured: the DeepLab step 5.26
+// -> 6.90 ms, FPNSeg 19.4 -> 26.3 ms).  With every data access agent-scope, s_waitcnt vmcnt(0) in front of the arrival is the release.
+__device__ __forceinline__ void wgrad_put(const WgradParams& p, float* dst, float v)
+{
+#ifdef PP_DEBUG_KNOBS
+    if (p.counters) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+#endif
+    *dst = v;
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void wgrad_fold_tail(const WgradParams& p, int ti, int ctile, int ctiles, int ntile, int c0, int n0)
+{
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my partial tile has been written through before my arrival is counted
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* ctr = p.counters + ((int64_t)ti * ctiles + ctile) * gridDim.y + ntile;
+        const int seen = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = seen == p.splits - 1;
+        if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int64_t cn = (int64_t)p.Cin * p.Cout, stride = (int64_t)p.taps.n * cn;
+    const float* src0 = p.part + (int64_t)ti * cn;
+    float* dst0 = p.dw + (int64_t)p.taps.widx[ti] * cn;
+    constexpr int NQ = BN / 4;
+    auto ld4 = [](const float* q) -> float4 {                // four agent-scope loads (past this XCD's L2)
+        float4 v;
+        v.x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    for (int e = threadIdx.x; e < BM * NQ; e += kThreads) {
+        const int r = e / NQ, q = e - r * NQ;
+        const int c = c0 + r, n = n0 + q * 4;
+        if (c >= p.Cin || n >= p.Cout) continue;
+        const float* src = src0 + (int64_t)c * p.Cout + n;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 4 <= p.splits; k += 4) {                  // four slices in flight, added in slice order
+            const float4 a = ld4(src + (int64_t)k * stride), b = ld4(src + (int64_t)(k + 1) * stride);
+            const float4 cc = ld4(src + (int64_t)(k + 2) * stride), d = ld4(src + (int64_t)(k + 3) * stride);
+            sacc.x += a.x; sacc.y += a.y; sacc.z += a.z; sacc.w += a.w;
+            sacc.x += b.x; sacc.y += b.y; sacc.z += b.z; sacc.w += b.w;
+            sacc.x += cc.x; sacc.y += cc.y; sacc.z += cc.z; sacc.w += cc.w;
+            sacc.x += d.x; sacc.y += d.y; sacc.z += d.z; sacc.w += d.w;
+        }
+        for (; k < p.splits; ++k) {
+            const float4 a = ld4(src + (int64_t)k * stride);
+            sacc.x += a.x; sacc.y += a.y; sacc.z += a.z; sacc.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dst0 + (int64_t)c * p.Cout + n) = sacc;
+    }
+}
 
 template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
@@ -1993,9 +2067,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = c0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (c < p.Cin) out[(int64_t)c * p.Cout + n] = acc[tm][tn][r];
+                if (c < p.Cin) wgrad_put(p, out + (int64_t)c * p.Cout + n, acc[tm][tn][r]);
             }
     }
+#ifdef PP_DEBUG_KNOBS
+    if (p.counters) wgrad_fold_tail<BM, BN>(p, ti, (int)(bx % (unsigned)ctiles), ctiles, (int)by, c0, n0);
+#endif
 }
 
 // (b, oh, ow) of an output pixel, advanced without divisions
@@ -2250,9 +2327,12 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128 ? 3 : 4)) void conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = c0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (c < p.Cin) out[(int64_t)c * p.Cout + nn] = acc[tm][tn][r];
+                if (c < p.Cin) wgrad_put(p, out + (int64_t)c * p.Cout + nn, acc[tm][tn][r]);
             }
     }
+#ifdef PP_DEBUG_KNOBS
+    if (p.counters) wgrad_fold_tail<BM, BN>(p, ti, (int)(bx % (unsigned)ctiles), ctiles, (int)by, c0, n0);
+#endif
 }
 
 // dW[widx[ti]][c][n] = sum_split part[split][ti][c][n]  (fixed order: deterministic); dead taps stay 0.
@@ -3265,25 +3345,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(WgradParams 
         }
         if (k < n) kstep(std::false_type{}, live_tag, k, k % NSTAGE, F0, F1);
     };
-    if (__builtin_amdgcn_readfirstlane(c0 + wm * (TM * 32) < p.Cin ? 1 : 0)) run(std::true_type{});
-    else {
-        run(std::false_type{});
-        return;                                              // nothing of this wave's rows exists
-    }
+    const bool wave_live = __builtin_amdgcn_readfirstlane(c0 + wm * (TM * 32) < p.Cin ? 1 : 0) != 0;
+    if (wave_live) run(std::true_type{});
+    else run(std::false_type{});                             // nothing of this wave's rows exists: it only feeds the ring
 
     float* out = p.part + ((int64_t)split * p.taps.n + ti) * p.Cin * p.Cout;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int nn = n0 + (wn * TN + tn) * 32 + l31;
-        if (nn >= p.Cout) continue;
+        if (nn >= p.Cout || !wave_live) continue;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = c0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (c < p.Cin) out[(int64_t)c * p.Cout + nn] = acc[tm][tn][r];
+                if (c < p.Cin) wgrad_put(p, out + (int64_t)c * p.Cout + nn, acc[tm][tn][r]);
             }
     }
+#ifdef PP_DEBUG_KNOBS
+    if (p.counters) wgrad_fold_tail<BM, 128>(p, ti, (int)(bx % (unsigned)ctiles), ctiles, (int)by, c0, n0);
+#endif
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
@@ -3914,6 +3995,26 @@ static const int g_wgrad_lds_pad_default = 0;
 static int g_wgrad_lds_pad = 0;     // unused dynamic LDS per weight-gradient block: caps the blocks per CU (see pp_debug_set_wgrad_target)
 static int g_wgrad_target = 1024;   // blocks aimed at by the split-M choice of the MFMA weight-gradient kernels
 static int g_wgrad_balance = 1;     // pp_debug_set_wgrad_target bit 24: CU-balanced split choice of the MFMA-bound layers off (A/B)
+static int g_wgrad_fold = 0;        // split-K reduction inside the weight-gradient launch: an experiment of the TEST BUILD (pp_debug_set_wgrad_target bit 25
+                                    // switches it ON) - bit-identical, measured 20-50 % SLOWER per step (profiles/r06_wgrad_fold.txt)
+// a range of `n` arrival counters no launch in flight shares: the ring is handed out in turn (64 K words; a launch takes at most 16 K)
+static int* wgrad_counters_take(int n)
+{
+    static std::atomic<uint32_t> next{0};
+    static int* base = nullptr;
+    if (!base) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_wgrad_counters)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        base = reinterpret_cast<int*>(q);
+    }
+    uint32_t at;
+    for (;;) {
+        uint32_t cur = next.load(std::memory_order_relaxed);
+        at = (cur + (uint32_t)n > (uint32_t)kWgradCounters) ? 0u : cur;
+        if (next.compare_exchange_weak(cur, at + (uint32_t)n, std::memory_order_relaxed)) break;
+    }
+    return base + at;
+}
 
 static int device_cus()
 {
@@ -4170,6 +4271,7 @@ void pp_debug_set_wgrad_target(int v)
     g_wgrad_target = (v & 0xFFFF) > 0 ? (v & 0xFFFF) : 1024;
     g_wgrad_lds_pad = v > 0 ? ((v >> 16) & 0xFF) * 1024 : g_wgrad_lds_pad_default;   // bits 16-23: KiB of LDS padding (A/B)
     g_wgrad_balance = (v > 0 && ((v >> 24) & 1)) ? 0 : 1;                             // bit 24: CU-balanced split choice off
+    g_wgrad_fold = (v > 0 && ((v >> 25) & 1)) ? 1 : 0;                                // bit 25: split-K reduction folded into the launch (experiment)
 }
 #endif
 /* v = big_tile_min | wgrad_rows_min << 12 (0 fields: defaults 384 / 128) */
@@ -4907,6 +5009,15 @@ static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
         if (hipMemsetAsync(dw, 0, (size_t)kh * kw * Cin * Cout * 4, st) != hipSuccess)
             return fail(PP_ERR_LAUNCH, "conv bwd_weight: memset failed");
     dim3 grid((unsigned)(cdiv(Cin, bm) * p.taps.n), (unsigned)cdiv(Cout, bn), (unsigned)splits);
+    // the split-K reduction inside the launch: the last block of a tile to arrive sums the tile's slices in slice order (bit-identical
+    // to the reduce launch it replaces: wgrad_reduce4_kernel, 38 launches of a DeepLab step).  Not with a fused bias gradient (its
+    // partials have their own final launch) and not when the caller defers the reduce into a batch
+    p.counters = nullptr; p.dw = dw; p.splits = (int)splits;
+    if (g_wgrad_fold && splits > 1 && !fuse_bias && !job && (int64_t)Cin * Cout % 4 == 0 && Cout % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
+        const int64_t tiles_ctr = (int64_t)grid.x * grid.y;
+        if (tiles_ctr <= kWgradCounters / 4) p.counters = wgrad_counters_take((int)tiles_ctr);
+    }
     // LDS-DMA kernels: vector operands, no fused bias gradient, 32-bit safe row pitch; bits of g_wgrad_dma: 1 = 128-wide tiles, 2 = 64x64
     const bool dma = vec && p.bias_part == nullptr && (int64_t)p.M * std::max(ldx, lddy) < (1ll << 40);
     {
@@ -4956,6 +5067,10 @@ static int conv2d_bwd_weight_impl(const float* x, int64_t ldx, int B, int H, int
 reduce_partials:
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
     const int64_t cn = (int64_t)Cin * Cout;
+    if (p.counters) {                         // the launch reduced its own slices (wgrad_fold_tail)
+        if (job) job->kind = 0;
+        goto bias_part;
+    }
     if (cn % 4 == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 &&
         reduce_deferrable(job, p.taps, cn, splits, dbias)) {
         fill_reduce_job(job, 1, p.part, dw, cn, splits, p.taps);
