@@ -64,6 +64,14 @@ struct AcqParams {
     float qscale = 0.0f;
     int xcd_per = 0;     // > 0: XCD-contiguous block order (acq_kernel only): hardware block b works on logical block
     int nb = 0;          //      (b % 8) * xcd_per + b / 8 of nb, so that the blocks one XCD holds walk ONE contiguous eighth of the launch
+    // EMIT kernels (large-k selection without the score map): every wave appends the (key, index) words of its pixels at or beyond the image's
+    // sampled threshold key to its OWN fixed segment of the image's list and stores how many it wrote - no atomics, no block-level exchange
+    const uint32_t* tkey = nullptr;   // [B] threshold order key (acq_sample_thr_kernel)
+    uint64_t* elist = nullptr;        // [B][eimg]; wave (blk, w) owns entries [(blk * 4 + w) * PPT * 64, +PPT * 64)
+    uint32_t* ecnt = nullptr;         // [B][nseg]
+    int64_t eimg = 0;
+    int nseg = 0;
+    int sample_locs = 0, sample_gpl = 0;   // acq_sample_thr_kernel: locations per image, 4-pixel groups per location
 };
 
 // ---- per-pixel score ----------------------------------------------------------------------------
@@ -321,11 +329,12 @@ __device__ __forceinline__ uint32_t qbin(float s, bool lg, float scale)
 // HIST (map-writing launches of the large-k selection, VEC == 4): the block also counts its scores into the image's kQBins-bin histogram
 // (LDS bins in the survivor lists' storage - no candidates are extracted in that mode - then one global atomic per non-empty bin): what
 // select_qhist_kernel did in a second pass over the map.
-template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1, bool HIST = false, bool NT = true>
+template <int CMAX, bool EXACT, int VEC, int G, int MATH, int OCC = 3, int STRAT = -1, bool HIST = false, bool NT = true, bool EMIT = false>
 __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
 {
     constexpr int PPT = VEC * G;
     static_assert(!HIST || VEC == 4, "histogram epilogue: the flat float4 form");
+    static_assert(!EMIT || (VEC == 4 && !HIST), "candidate emission: the flat float4 form");
     __shared__ uint64_t s_surv[kBlock / kWave][kSurvCap];
     static_assert(sizeof(uint64_t) * (kBlock / kWave) * kSurvCap >= sizeof(uint32_t) * kQBins, "the bins live in the survivor lists");
     uint32_t* lh = reinterpret_cast<uint32_t*>(&s_surv[0][0]);
@@ -410,6 +419,25 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (EMIT) {
+        // keys at or beyond the image's threshold key form an upper set of the (key, index) order: if the image's lists hold >= k words
+        // the k picks are among them (topk_lsel_kernel checks that).  Ballot order inside the segment; the select ranks exactly.
+        const uint32_t tk = p.tkey[img];
+        const int wave = tid >> 6, lane = tid & (kWave - 1);
+        const int seg = blk * (kBlock / kWave) + wave;
+        uint64_t* dst = p.elist + (int64_t)img * p.eimg + (int64_t)seg * (PPT * kWave);
+        const uint64_t below = (1ull << lane) - 1ull;
+        uint32_t n = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const bool sv = kh[j] >= tk;                 // (pixels past the end of the image carry key 0, tk >= 1)
+            const uint64_t bal = __ballot(sv);
+            if (sv) dst[n + (uint32_t)__popcll(bal & below)] = ((uint64_t)kh[j] << 32) | kl[j];
+            n += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) p.ecnt[(int64_t)img * p.nseg + seg] = n;
+        return;
+    }
     if constexpr (HIST) {
         __syncthreads();
         uint32_t* Hg = p.qhist + (int64_t)img * kQBins;
@@ -1489,6 +1517,231 @@ __global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* s
     }
 }
 
+// ---- large-k WITHOUT the score map: sampled threshold -> candidate emission in the scorer -> list select ---------------------------------
+// The map-writing scorer pays 16 % for a 5 % larger stream (mixed read / write traffic).  Instead: (1) acq_sample_thr_kernel scores a sample of
+// the image - sample_locs jittered locations of 4 * sample_gpl consecutive pixels (spatially correlated maps give about one independent draw
+// per location) - and takes the edge of the quantised bin at which the sample's count from the top reaches mult * k / N of the sample as the
+// image's threshold key (a conservative guess: about mult * k pixels pass); (2) the scorer (acq_kernel<..., EMIT>) writes only the pixels at or
+// beyond that key, as (key, index) words into per-wave segments (~1 B / pixel instead of 4); (3) topk_lsel_kernel histograms the image's lists
+// into kLBins bins spanning only [threshold, end of the score range] (the lists hold nothing else: bins ~30x finer than topk_qsel_kernel's for
+// the same LDS), finds the bin of the k-th element, drops that bin and the ones above into LDS and ranks every candidate inside its bin.  The
+// RESULT never depends on the sample: an image whose lists hold fewer than k words (the sample misled), or whose candidates do not fit (ties),
+// is put on the flagged list and redone exactly (acq_flagged_map_kernel: its score map -> topk_large_kernel).
+constexpr int kSampleThreads = 512;
+constexpr int kLBins = 4096;
+constexpr int kFlagSlots = 2;                           // images the fallback scorer works on at a time (it loops over the flagged list)
+
+template <int CMAX>
+__global__ __launch_bounds__(kSampleThreads) void acq_sample_thr_kernel(AcqParams p, float qscale, uint32_t want, uint32_t* tkey_out)
+{
+    __shared__ uint32_t lh[kQBins];
+    __shared__ uint32_t wsum[kSampleThreads / kWave];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    const float* base = p.logits + (int64_t)img * p.sB;
+    const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+    for (int i = tid; i < kQBins; i += kSampleThreads) lh[i] = 0u;
+    __syncthreads();
+    const int gpl = p.sample_gpl, groups = p.sample_locs * gpl;
+    const int64_t stride = p.N / p.sample_locs;                    // >= 4 * gpl pixels (host)
+    const uint32_t slots = (uint32_t)(stride / (4 * gpl));
+#pragma unroll 1
+    for (int g = tid; g < groups; g += kSampleThreads) {
+        const uint32_t loc = (uint32_t)(g / gpl);
+        const uint32_t h = (loc * 2654435761u + (uint32_t)img * 40503u + 0x9E3779B9u) >> 7;
+        const int64_t pix0 = ((int64_t)loc * stride + (int64_t)(h % slots) * (4 * gpl) + (g - (int)loc * gpl) * 4) & ~3ll;
+        float x[4][CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * p.sC + pix0);
+            x[0][c] = v.x; x[1][c] = v.y; x[2][c] = v.z; x[3][c] = v.w;
+        }
+        const uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float sc = pixel_score_fast<CMAX, true>(x[v], p.C, p.strategy);
+            if ((ex >> (8 * v)) & 0xFFu) sc = fill;
+            atomicAdd(&lh[qbin(sc, largest, qscale)], 1u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    // thread t owns OWN bins from the top: kQBins - 1 - OWN t - u; inclusive scan over the threads
+    constexpr int OWN = kQBins / kSampleThreads;
+    uint32_t own[OWN], tot = 0;
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) { own[u] = lh[kQBins - 1 - (OWN * tid + u)]; tot += own[u]; }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t cum = incl - tot;
+    for (int w = 0; w < wave; ++w) cum += wsum[w];
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) {
+        const uint32_t before = cum;
+        cum += own[u];
+        if (before < want && want <= cum) {
+            const int qb = kQBins - 1 - (OWN * tid + u);                // qbin value: every score with qbin >= qb should pass
+            const int qi = largest ? qb : kQBins - 1 - qb;             // linear bin of the score
+            const float edge = largest ? (float)qi / qscale : (float)(qi + 1) / qscale;      // the bin's far edge
+            uint32_t tk = order_key(edge, largest);
+            if (qb == 0 || tk < 1u) tk = 1u;                            // the last bin: everything passes
+            tkey_out[img] = tk;
+        }
+    }
+}
+
+// bins of the list select: linear in the distance from the image's threshold towards the selected end of the score range
+__device__ __forceinline__ uint32_t lbin(uint32_t key, bool lg, float tv, float lscale)
+{
+    const float s = key_to_float(key, lg);
+    if (s != s) return lg ? (uint32_t)(kLBins - 1) : 0u;
+    const float t = (lg ? s - tv : tv - s) * lscale;
+    return (uint32_t)(t >= (float)(kLBins - 1) ? kLBins - 1 : (t > 0.0f ? (int)t : 0));
+}
+
+// One 1024-thread block per image; cnt / list: the scorer's per-wave segments (nseg segments of segsz entries).  range: the scorers' value
+// range (ln C or 1).  Flagged images are appended to flag_ids (nflag zeroed by the host).
+__global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(const uint64_t* list, const uint32_t* cnt, const uint32_t* tkey, int64_t eimg,
+                                                                 int nseg, int segsz, int k, int largest, float range, int32_t* out_idx,
+                                                                 float* out_val, int* overflow, int* nflag, int* flag_ids)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);                                   // kQCap candidates, grouped by bin
+    uint32_t* start = reinterpret_cast<uint32_t*>(smem + (size_t)kQCap * 8);             // [kLBins] first slot of a bin's segment
+    uint32_t* hist = start + kLBins;                                                     // [kLBins] bin counts, then the drop cursors
+    uint32_t* misc = hist + kLBins;                                                      // 32 words
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool lg = largest != 0;
+    const uint64_t* L = list + (int64_t)blockIdx.x * eimg;
+    const uint32_t* C = cnt + (int64_t)blockIdx.x * nseg;
+    const uint32_t tk = tkey[blockIdx.x];
+    float tv = key_to_float(tk, lg);
+    if (tk == 1u) tv = lg ? 0.0f : range;                              // "everything passes"
+    if (tv != tv) tv = lg ? range : 0.0f;
+    if (lg && tv < 0.0f) tv = 0.0f;
+    const float span = lg ? range - tv : tv;
+    const float lscale = (float)kLBins / (span > 1e-12f ? span : 1e-12f);
+    constexpr int OWN = kLBins / kLargeThreads;
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) hist[tid + u * kLargeThreads] = 0u;
+    if (tid < 4) misc[tid] = 0u;
+    __syncthreads();
+    // every wave walks four segments at a time (a segment usually holds fewer than 64 words: one load per segment in flight)
+    auto sweep = [&](auto&& fn) {
+        for (int s0 = wave * 4; s0 < nseg; s0 += (kLargeThreads / 64) * 4) {
+            uint32_t c[4];
+            uint64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = s0 + u < nseg ? C[s0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (uint32_t)lane < c[u] ? L[(int64_t)(s0 + u) * segsz + lane] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((uint32_t)lane < c[u]) fn(v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                for (uint32_t e = (uint32_t)lane + 64u; e < c[u]; e += 64u) fn(L[(int64_t)(s0 + u) * segsz + e]);
+        }
+    };
+    sweep([&](uint64_t w) { atomicAdd(&hist[lbin((uint32_t)(w >> 32), lg, tv, lscale)], 1u); });
+    __syncthreads();
+    {
+        // thread t owns bins kLBins - 1 - OWN t - u (from the top)
+        uint32_t own[OWN], tot = 0;
+#pragma unroll
+        for (int u = 0; u < OWN; ++u) { own[u] = hist[kLBins - 1 - (OWN * tid + u)]; tot += own[u]; }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) misc[8 + wave] = incl;
+        __syncthreads();
+        uint32_t cum = incl - tot;
+        for (int w = 0; w < wave; ++w) cum += misc[8 + w];
+#pragma unroll
+        for (int u = 0; u < OWN; ++u) {
+            const int bin = kLBins - 1 - (OWN * tid + u);
+            const uint32_t excl = cum;
+            cum += own[u];
+            start[bin] = excl;
+            hist[bin] = 0u;                                                    // from here on: the bin's drop cursor
+            if (excl < (uint32_t)k && (uint32_t)k <= cum) { misc[0] = (uint32_t)bin; misc[1] = cum; misc[3] = 1u; }
+            if (excl < (uint32_t)k && own[u] > (uint32_t)kQMaxPop) misc[2] = 1;   // an over-full bin among those that hold candidates
+        }
+        __syncthreads();
+    }
+    const uint32_t tb = misc[0], count = misc[1];
+    // fewer than k words in the lists (misc[3] unset: the sampled threshold was too high), or no room: the exact fallback
+    if (!misc[3] || count > (uint32_t)kQCap || misc[2]) {
+        if (tid == 0) {
+            overflow[blockIdx.x] = 1;
+            flag_ids[atomicAdd(nflag, 1)] = (int)blockIdx.x;
+        }
+        return;
+    }
+    if (tid == 0) overflow[blockIdx.x] = 0;
+    sweep([&](uint64_t w) {
+        const uint32_t q = lbin((uint32_t)(w >> 32), lg, tv, lscale);
+        if (q >= tb) buf[start[q] + atomicAdd(&hist[q], 1u)] = w;
+    });
+    __syncthreads();
+    for (uint32_t p = (uint32_t)tid; p < count; p += kLargeThreads) {
+        const uint64_t me = buf[p];
+        const uint32_t q = lbin((uint32_t)(me >> 32), lg, tv, lscale);
+        const uint32_t a = start[q], b = a + hist[q];
+        uint32_t rank = a;
+        for (uint32_t t = a; t < b; ++t) rank += buf[t] > me ? 1u : 0u;
+        if (rank < (uint32_t)k) {
+            out_idx[(int64_t)blockIdx.x * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)me);
+            if (out_val) out_val[(int64_t)blockIdx.x * k + rank] = key_to_float((uint32_t)(me >> 32), lg);
+        }
+    }
+}
+constexpr int kLSelLds = kQCap * 8 + 2 * kLBins * 4 + 128;
+
+// Score maps of the flagged images only (the default scorer's arithmetic, 4 pixels per thread): kFlagSlots x blocks-per-image blocks; when
+// nothing is flagged - the usual case - every block reads one word and leaves.
+template <int CMAX>
+__global__ __launch_bounds__(kBlock) void acq_flagged_map_kernel(AcqParams p, const int* nflag, const int* flag_ids, int bpf)
+{
+    const int n = *nflag;
+    const int slot0 = blockIdx.x / bpf, blk = blockIdx.x - slot0 * bpf;
+    const bool largest = p.strategy != PP_ACQ_MARGIN;
+    const float fill = largest ? 0.0f : 1.0f;
+    for (int slot = slot0; slot < n; slot += kFlagSlots) {
+        const int img = flag_ids[slot];
+        const float* base = p.logits + (int64_t)img * p.sB;
+        const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+        float* omap = p.out_map + (int64_t)img * p.N;
+        const int64_t pix0 = ((int64_t)blk * kBlock + threadIdx.x) * 4;
+        if (pix0 >= p.N) continue;
+        float x[4][CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * p.sC + pix0);
+            x[0][c] = v.x; x[1][c] = v.y; x[2][c] = v.z; x[3][c] = v.w;
+        }
+        const uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
+        float s4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            s4[v] = pixel_score_fast<CMAX, true>(x[v], p.C, p.strategy);
+            if ((ex >> (8 * v)) & 0xFFu) s4[v] = fill;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        *reinterpret_cast<float4*>(omap + pix0) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 // Sum over T forward passes of softmax(logits[t]) per pixel and of the strategy's score of each pass (the MC-dropout
 // branch, query.py:181-187: `uc_map += uc_map_; prob += prob_`), scaled: p_c = exp(x_c - m) / S and the score formulas in
@@ -1749,6 +2002,20 @@ static int launch_acq(const AcqParams& p, const Plan& pl, int64_t B, hipStream_t
                     q.xcd_per = (int)cdiv(q.nb, 8);
                     grid = dim3((unsigned)(q.xcd_per * 8));
                 }
+                if (q.elist) {       // large-k selection without the map: candidates beyond the sampled threshold key
+#define PP_ACQ_EMIT(G, S) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, G, 0, 3, S, false, true, true>), grid, block, 0, st, q)
+                    if (g == 2) {
+                        if (q.strategy == PP_ACQ_ENTROPY) PP_ACQ_EMIT(2, PP_ACQ_ENTROPY);
+                        else if (q.strategy == PP_ACQ_LEAST_CONFIDENCE) PP_ACQ_EMIT(2, PP_ACQ_LEAST_CONFIDENCE);
+                        else PP_ACQ_EMIT(2, PP_ACQ_MARGIN);
+                    } else {
+                        if (q.strategy == PP_ACQ_ENTROPY) PP_ACQ_EMIT(1, PP_ACQ_ENTROPY);
+                        else if (q.strategy == PP_ACQ_LEAST_CONFIDENCE) PP_ACQ_EMIT(1, PP_ACQ_LEAST_CONFIDENCE);
+                        else PP_ACQ_EMIT(1, PP_ACQ_MARGIN);
+                    }
+#undef PP_ACQ_EMIT
+                    return check_launch("acq_kernel<emit>");
+                }
                 if (q.qhist) {       // large-k selection: map + the image's score histogram in one pass (run_large skips its histogram pass)
                     constexpr int O = CMAX == 21 ? kAcqOcc21 : (CMAX == 11 ? kAcqOcc11 : 3);
                     if (g == 2) hipLaunchKernelGGL((acq_kernel<CMAX, EXACT, 4, 2, 0, O, -1, true>), grid, block, 0, st, q);
@@ -1817,6 +2084,94 @@ static bool acq_hist_fusable(const AcqParams& p, const Plan& pl)
 {
     return g_hist_fuse && pl.vec4 && !p.from_prob && !exact_formula() && !g_tune_occ && !stream_classes(p.C) && p.out_map && !p.cand &&
            (p.C == 11 || p.C == 19 || p.C == 21);
+}
+
+// ---- the list select (sampled threshold + candidate emission) ---------------------------------------------------------------------
+static int g_emit = 1;             // pp_debug_set_reduce_mode bit 11: off (A/B: the map-writing scorer + topk_qsel_kernel)
+static int g_emit_mult16 = 40;     // sampled threshold aims at mult16 / 16 x k pixels passing (pp_debug_set_reduce_mode bits 12-17; 0 = default)
+static int g_sample_locs = 128;    // pp_debug_set_reduce_mode bits 18-19: 128 / 64 / 256 / 512 locations per image
+static int g_sample_gpl = 4;       // bits 20-21: 4 / 2 / 1 / 8 four-pixel groups per location
+static bool emit_size_ok(int64_t N, int64_t k) { return N >= 16384 && k * 8 <= N; }
+static size_t emit_list_entries(int64_t N) { return align_up((size_t)N, 2048); }
+// first region of the large-k workspace: the score map, or the per-wave candidate segments (the fallback's map of the flagged images
+// is written over them after the list select has consumed them)
+static size_t map_region_bytes(int64_t B, int64_t N, int64_t k)
+{
+    return emit_size_ok(N, k) ? align_up((size_t)B * emit_list_entries(N) * 8, 256) : align_up((size_t)B * N * 4, 256);
+}
+static size_t emit_extra_bytes(int64_t B, int64_t N, int64_t k)
+{
+    if (!emit_size_ok(N, k)) return 0;
+    // threshold keys + the flagged count, flagged list, per-wave counts
+    return align_up((size_t)(B + 1) * 4, 256) + align_up((size_t)B * 4, 256) + align_up((size_t)B * (emit_list_entries(N) / 256) * 4, 256);
+}
+static bool acq_emit_ok(const AcqParams& p, const Plan& pl, int64_t B, int64_t k, float qs, bool caller_map)
+{
+    return g_emit && !caller_map && emit_size_ok(p.N, k) && large_q_ok(B, k, qs) && pl.vec4 && !p.from_prob && !exact_formula() &&
+           !g_tune_occ && !stream_classes(p.C) && (p.C == 11 || p.C == 19 || p.C == 21);
+}
+
+static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st);
+
+// p: the map-writing launch's parameters (out_map = the first workspace region); tail: what follows the large-k scratch in the workspace
+static int run_emit_select(AcqParams p, const Plan& pl, int64_t B, int64_t k, int largest, float qs, void* region0, void* gbuf, void* tail,
+                           int32_t* out_idx, float* out_val, hipStream_t st)
+{
+    uint32_t* tkey = reinterpret_cast<uint32_t*>(tail);
+    int* nflag = reinterpret_cast<int*>(tkey + B);
+    int* flag_ids = reinterpret_cast<int*>(reinterpret_cast<char*>(tail) + align_up((size_t)(B + 1) * 4, 256));
+    uint32_t* ecnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(flag_ids) + align_up((size_t)B * 4, 256));
+    uint32_t* hist = large_hist(gbuf, B, k);
+    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + align_up((size_t)B * kQBins * 4, 256));
+    const int P = next_pow2(k);
+    const bool in_lds = P <= kLargeLdsMaxP;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_lsel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLSelLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_large_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
+        attr_set = true;
+    }
+    const int segsz = pl.ppt * kWave;
+    AcqParams q = p;
+    q.out_map = nullptr;
+    q.tkey = tkey;
+    q.elist = reinterpret_cast<uint64_t*>(region0);
+    q.ecnt = ecnt;
+    q.eimg = (int64_t)emit_list_entries(p.N);
+    q.nseg = pl.blocks_per_image * (kBlock / kWave);
+    q.sample_locs = g_sample_locs;
+    q.sample_gpl = g_sample_gpl;
+    while ((int64_t)q.sample_locs * q.sample_gpl * 4 * 4 > p.N && q.sample_locs > 16) q.sample_locs >>= 1;      // (16384 pixels and up: >= 4 slots per location)
+    const int64_t sample_n = (int64_t)q.sample_locs * q.sample_gpl * 4;
+    int64_t want = (sample_n * g_emit_mult16 * k + 16 * p.N - 1) / (16 * p.N);
+    if (want < 1) want = 1;
+    if (want > sample_n) want = sample_n;
+    const int bpf = (int)cdiv(p.N, (int64_t)kBlock * 4);
+    const dim3 sgrid((unsigned)B), sblock(kSampleThreads), fgrid((unsigned)(kFlagSlots * bpf)), fblock(kBlock);
+    if (hipMemsetAsync(nflag, 0, 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+#define PP_BY_C(KERNEL, GRID, BLOCK, ...)                                                                    \
+    switch (p.C) {                                                                                           \
+        case 11: hipLaunchKernelGGL((KERNEL<11>), GRID, BLOCK, 0, st, __VA_ARGS__); break;                   \
+        case 19: hipLaunchKernelGGL((KERNEL<19>), GRID, BLOCK, 0, st, __VA_ARGS__); break;                   \
+        default: hipLaunchKernelGGL((KERNEL<21>), GRID, BLOCK, 0, st, __VA_ARGS__); break;                   \
+    }
+    PP_BY_C(acq_sample_thr_kernel, sgrid, sblock, q, qs, (uint32_t)want, tkey);
+    if (int rc = check_launch("acq_sample_thr_kernel")) return rc;
+    if (int rc = dispatch_acq(q, pl, B, st)) return rc;
+    hipLaunchKernelGGL(topk_lsel_kernel, dim3((unsigned)B), dim3(kLargeThreads), kLSelLds, st, (const uint64_t*)q.elist, (const uint32_t*)ecnt,
+                       (const uint32_t*)tkey, q.eimg, q.nseg, segsz, (int)k, largest, (float)kQBins / qs, out_idx, out_val, flags, nflag,
+                       flag_ids);
+    if (int rc = check_launch("topk_lsel_kernel")) return rc;
+    // flagged images (sample misled, ties at the threshold, constant maps): their score maps, then the exact one-block radix select;
+    // both launches return at once when there are none
+    PP_BY_C(acq_flagged_map_kernel, fgrid, fblock, p, (const int*)nflag, (const int*)flag_ids, bpf);
+#undef PP_BY_C
+    if (int rc = check_launch("acq_flagged_map_kernel")) return rc;
+    const size_t lds = (256 + 64) * 4 + (in_lds ? (size_t)P * 8 : 0);
+    hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, (const float*)p.out_map, p.N, (int)k, largest,
+                       in_lds ? (uint64_t*)nullptr : reinterpret_cast<uint64_t*>(gbuf), P, out_idx, out_val, (const int*)flags);
+    return check_launch("topk_large_kernel");
 }
 
 static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
@@ -1972,6 +2327,10 @@ void pp_debug_set_reduce_mode(int mode)
     g_large_multiblock = (mode & 256) ? 0 : 1;      // bit 8: large-k selection through the one-block-per-image radix select (A/B)
     g_large_q = (mode & 512) ? 0 : 1;               // bit 9: no quantised-histogram select where the score range is known (A/B)
     g_hist_fuse = (mode & 1024) ? 0 : 1;            // bit 10: the score histogram in its own pass over the map (select_qhist_kernel), not in the scorer launch
+    g_emit = (mode & 2048) ? 0 : 1;                 // bit 11: no sampled-threshold candidate emission (the map-writing scorer + topk_qsel_kernel)
+    g_emit_mult16 = ((mode >> 12) & 63) ? ((mode >> 12) & 63) : 40;    // bits 12-17: the sample aims at this / 16 x k passing pixels
+    { static const int locs[4] = {128, 64, 256, 512}, gpl[4] = {4, 2, 1, 8};
+      g_sample_locs = locs[(mode >> 18) & 3]; g_sample_gpl = gpl[(mode >> 20) & 3]; }      // bits 18-21: the sample's shape
     mode &= 255;
     g_reduce_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
@@ -2013,8 +2372,8 @@ size_t pp_acq_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_
         Plan pl = make_plan(B, N, true, true);
         return merge_ws_bytes(B, (int64_t)pl.waves_per_image * k, k);
     }
-    // score map (used when the caller passes no out_map) + large-k scratch
-    return align_up((size_t)B * N * 4, 256) + pp_topk_workspace_bytes(B, N, k);
+    // score map (used when the caller passes no out_map) or candidate segments + large-k scratch + the list select's threshold keys / counts
+    return map_region_bytes(B, N, k) + pp_topk_workspace_bytes(B, N, k) + emit_extra_bytes(B, N, k);
 }
 
 int pp_acq_score_map(const float* logits, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sB, int64_t sC,
@@ -2086,11 +2445,14 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
     }
     // large k: materialise the score map once, then radix-select + sort per image
     float* map = out_map ? out_map : reinterpret_cast<float*>(workspace);
-    uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * N * 4, 256));
+    uint64_t* gbuf = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + map_region_bytes(B, N, k));
     Plan pl = make_plan(B, N, is_flat_vec4(logits, exclude, map, H, W, sB, sC, sH, sW), exact_formula() != 0 || stream_classes(C));
     AcqParams p{logits, exclude, map, nullptr, sB, sC, sH, sW, (int)C, (int)W, N, pl.blocks_per_image, 0, strategy,
                 g_reduce_mode, 0};
     const float qs = score_qscale(strategy, C);
+    if (acq_emit_ok(p, pl, B, k, qs, out_map != nullptr))
+        return run_emit_select(p, pl, B, k, largest, qs, workspace, gbuf, reinterpret_cast<char*>(gbuf) + pp_topk_workspace_bytes(B, N, k),
+                               out_idx, out_val, st);
     const bool fuse_hist = large_q_ok(B, k, qs) && acq_hist_fusable(p, pl);
     if (fuse_hist) {
         p.qhist = large_hist(gbuf, B, k);

@@ -418,6 +418,55 @@ def test_quantised_select_equals_the_radix_select(st):
             assert got[0][b].cpu().numpy().tolist() == e_idx.tolist(), (name, st, b)
 
 
+@pytest.mark.parametrize("st", STRATS)
+def test_list_select_equals_the_map_select(st):
+    """Large k without a caller's map (query.py:36 top_n_percent as QuerySelector calls it): a sampled threshold key per image, the
+    scorer writes only the (key, index) words beyond it, topk_lsel_kernel selects from the lists; whatever the sample says, the picks
+    and values must be those of the map-writing scorer + topk_qsel_kernel (pp_debug_set_reduce_mode bit 11) - with exclusions, ties
+    and constant maps (flagged -> the exact fallback), NaN scores, ragged sizes, both pixel tiles, the XCD block order, and with the
+    sample's aim forced far too high (every image falls back) and far too low (a fifth of the pixels pass)."""
+    L = _lib.lib()
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    C = 19
+    cases = []
+    logits = torch.randn((8, C, 256, 512), device=DEV, generator=gen) * 3
+    excl = torch.rand((8, 256, 512), device=DEV, generator=gen) < 0.05
+    cases.append(("random-8px-tile", logits, excl, 6553))
+    cases.append(("random-4px-tile", logits[:3], excl[:3], 6553))
+    cases.append(("no-exclusion", logits[:2], None, 4000))
+    cases.append(("ragged", logits[:2, :, :100, :172].contiguous(), excl[:2, :100, :172].contiguous(), 860))
+    tied = torch.round(torch.randn((2, C, 128, 256), device=DEV, generator=gen))
+    cases.append(("ties", tied, None, 1638))
+    const = torch.zeros((2, C, 128, 256), device=DEV)
+    const[1] = logits[0, :, :128, :256]
+    ex2 = torch.zeros((2, 128, 256), dtype=torch.bool, device=DEV)
+    ex2[1, :100] = True
+    cases.append(("constant+mostly-excluded", const, ex2, 1638))
+    smooth = torch.nn.functional.interpolate(torch.randn((2, C, 16, 32), device=DEV, generator=gen) * 4, size=(256, 512), mode="bilinear")
+    cases.append(("smooth", smooth.contiguous(), None, 6553))                                 # spatially correlated scores: the sample's locations are not independent
+    if st == "entropy":
+        nanl = logits[:2, :, :128, :128].clone()
+        nanl[0, 0, 3, 5:40] = 200.0
+        cases.append(("nan", nanl.contiguous(), None, 819))
+    for Cx in (11, 21):
+        lx = torch.randn((2, Cx, 128, 160), device=DEV, generator=gen) * 3
+        cases.append((f"random-C{Cx}", lx, torch.rand((2, 128, 160), device=DEV, generator=gen) < 0.05, 1024))
+    cases.append(("xcd-order", torch.randn((1, C, 1024, 1024), device=DEV, generator=gen) * 3, None, 5000))
+    for name, lg, ex, k in cases:
+        try:
+            L.pp_debug_set_reduce_mode(2048)
+            ref = acq.score_topk(lg, ex, st, k)
+            outs = []
+            for mode in (0, 1 << 12, 63 << 12, 1 << 18, (2 << 18) | (2 << 20)):    # default; aim of k / 16 and of 3.9 k passing pixels; 64 x 16- and 256 x 4-pixel samples
+                L.pp_debug_set_reduce_mode(mode)
+                outs.append(acq.score_topk(lg, ex, st, k))
+        finally:
+            L.pp_debug_set_reduce_mode(0)
+        for got in outs:
+            assert torch.equal(ref[0], got[0]), (name, st, k)
+            assert torch.equal(torch.nan_to_num(ref[1], nan=-7.0), torch.nan_to_num(got[1], nan=-7.0)), (name, st, k)
+
+
 @pytest.mark.parametrize("C", [11, 19, 21])
 def test_block_order_and_tile_variants_are_bit_identical(C):
     """The XCD-contiguous block order (default for class planes >= 4 MB, forced here on small ragged ones), 4 / 8 pixels per
