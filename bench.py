@@ -876,10 +876,11 @@ def main():
                                         if yard else None)}
 
         if ka > 48:
-            # large k: the scorer must also WRITE the [B, N] score map the selection passes read back (4 B/pixel); `frac` above counts the
-            # logits only, so that it stays comparable with the k = 20 lines
-            roof["algorithmic_bytes_incl_map_write"] = alg_bytes + 4 * B * Ha * Wa
-            roof["frac_incl_map_write"] = round((alg_bytes + 4 * B * Ha * Wa) / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # large k (round 6): no score map any more - the scorer writes only the (key, index) words of the pixels beyond a sampled
+            # threshold key (~1 B / pixel, not counted as algorithmic), the list select picks from them; the op-level fraction is the
+            # figure that includes the sample launch and the select
+            roof["selection"] = "sampled threshold -> candidate emission in the scorer -> list select (exact fallback for flagged images)"
+            roof["op_frac"] = round(alg_bytes / (el / steps) / 1e9 / HBM_PEAK_GBS, 4)
         # the same selection straight from the classifier output at 1/4 resolution (what DeepLab's
         # head writes before deeplab.py:55-56), interpolated on the fly - the production path of QuerySelector for DeepLab
         if headline and layout == "nchw" and Ha % 4 == 0 and Wa % 4 == 0:

@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6e7; mkdir -p $O
+O=gpurun_out/r6e11; mkdir -p $O
+timeout 600 python -m pytest tests/test_acq_gpu.py -x -q > $O/tacq.txt 2>&1; tail -3 $O/tacq.txt
+for m in 2048 0 $((32<<12)); do echo "RMODE=$m"; RMODE=$m timeout 120 python tools/topk5_bench.py 2>&1 | tail -2 | head -1; done | tee $O/topk5.txt
 cp tools/probe/libpp_timing.so pixelpick_amd/libpixelpick_hip_knobs.so
 cat > /tmp/t.py <<'P'
 import os, sys
@@ -16,9 +18,8 @@ idx = torch.empty((B, k), dtype=torch.int32, device="cuda"); val = torch.empty((
 ws = torch.empty(int(L.pp_acq_workspace_bytes(B, C, H, W, k)), dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 L.pp_debug_set_reduce_mode(int(os.environ.get("RMODE", "0")))
-for i in range(3):
-    print("---- launch", i, flush=True)
+for i in range(4):
     _lib.check(L.pp_acq_score_topk(x.data_ptr(), B, C, H, W, *x.stride(), None, 0, k, idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "op")
     torch.cuda.synchronize()
 P
-RMODE=0 timeout 120 python /tmp/t.py > $O/timing_fused.txt 2>&1; tail -28 $O/timing_fused.txt
+RMODE=0 timeout 120 python /tmp/t.py > $O/timing_lsel.txt 2>&1; tail -6 $O/timing_lsel.txt
