@@ -63,7 +63,9 @@ const char* pp_last_error(void);
  *   out_idx  i32 [B,k] flat index h*W+w, value-sorted; ties -> lower index first; NaN scores
  *            (0*log 0, query.py:230) sort first for largest, last for smallest.
  *   out_val  f32 [B,k] or NULL — the scores of out_idx.
- *   out_map  f32 [B,H,W] or NULL — the score map after exclusion (what query.py calls uc_map).
+ *   out_map  f32 [B,H,W] or NULL — the score map after exclusion (what query.py calls uc_map).  With k > 48 and no out_map the
+ *   map is never formed (flat fp32 class planes, C = 11 / 19 / 21, k <= H*W / 8, H*W >= 16384): a sampled per-image threshold, the
+ *   scorer writes only the candidates beyond it, a list select picks from them; images the sample misleads are redone exactly.
  *   k larger than the number of un-excluded pixels is NOT an error (as in the reference, excluded
  *   pixels are then returned, lowest index first).
  *   (SURVEY.md 8(b)'s sketch carries a `sorted` flag after k.  It is deliberately absent: the reference's torch.topk runs with its

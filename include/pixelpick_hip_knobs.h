@@ -11,6 +11,9 @@
  *              ds_bpermute (__shfl) reductions, 2 = plain k-round extraction loop (no prefilter).
  *              bit 8: large-k selection through the one-block radix select, bit 9: no quantised-histogram select,
  *              bit 10: the score histogram of the large-k selection in its own pass over the map instead of inside the scorer launch (A/B).
+ *              bit 11: large k without a caller's map through the map-writing scorer + map select instead of the sampled threshold +
+ *              candidate emission + list select (A/B); bits 12-17: the sample's aim in sixteenths of k (0 = 40: 2.5 k pixels pass);
+ *              bits 18-19: 128 / 64 / 256 / 512 sample locations per image; bits 20-21: 16 / 8 / 4 / 32 pixels per location.
  * exact formula: 0 = default scorer (entropy = log S + sum e_c (m - x_c) / S, v_exp_f32 exponentials;
  *              identical NaN behaviour), 1 = the reference's operation order p_c = exp(x_c - m) / S,
  *              sum(-p_c log p_c) with libm-accurate exp/log (query.py:190,230). */
