@@ -1380,13 +1380,57 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_sel_kernel(const flo
 constexpr int kQSub = 8;             // sub-histograms per block (lane & 7)
 constexpr int kQCap = 8192;          // candidates per image held in LDS (64 KiB of (key, index) words)
 
+// Generic maps (pp_topk_select: the random strategy's maps, MC-dropout means - no score range known): one pass takes every image's finite
+// minimum and maximum as order keys (mm[2 b] = largest key seen, mm[2 b + 1] = largest complemented key, both zeroed by the host), and the
+// quantised select bins (s - lo) * kQBins / (hi - lo) per image.  Infinities fall into the end bins, NaN where order_key puts it; an image
+// with a single value fills one bin and goes to the exact fallback like any heavily tied map.
+__device__ __forceinline__ void image_range(const uint32_t* mm, int b, float& lo, float& scale)
+{
+    const uint32_t kmax = mm[2 * b], kmin = ~mm[2 * b + 1];
+    const float hi = key_to_float(kmax, true);
+    lo = key_to_float(kmin, true);
+    if (kmax == 0u || !(hi > lo)) { lo = 0.0f; scale = 1.0f; return; }          // no finite value, or a single one
+    scale = (float)kQBins / (hi - lo);
+    if (!(scale < 3.0e38f)) scale = 3.0e38f;
+}
+
+__global__ __launch_bounds__(kBlock) void select_minmax_kernel(const float* scores, int64_t N, uint32_t* mm)
+{
+    __shared__ uint32_t smax[kBlock / kWave], smin[kBlock / kWave];
+    const int b = blockIdx.y;
+    const float* s = scores + (int64_t)b * N;
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+    uint32_t kx = 0u, kn = 0u;                                  // largest key, largest complemented key (0 = nothing seen)
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kBlock) {
+        const float v = s[i];
+        if (fabsf(v) <= 3.4028234e38f) {                        // finite (NaN compares false)
+            const uint32_t key = order_key(v, true);
+            kx = key > kx ? key : kx;
+            kn = ~key > kn ? ~key : kn;
+        }
+    }
+    kx = wave_umax(kx, 0);
+    kn = wave_umax(kn, 0);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) { smax[wave] = kx; smin[wave] = kn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; ++w) { kx = smax[w] > kx ? smax[w] : kx; kn = smin[w] > kn ? smin[w] : kn; }
+        if (kx) atomicMax(&mm[2 * b], kx);
+        if (kn) atomicMax(&mm[2 * b + 1], kn);
+    }
+}
+
 // hist: [B][kQBins], zeroed by the host
-__global__ __launch_bounds__(kBlock) void select_qhist_kernel(const float* scores, int64_t N, int largest, float scale, uint32_t* hist)
+__global__ __launch_bounds__(kBlock) void select_qhist_kernel(const float* scores, int64_t N, int largest, float scale, uint32_t* hist, const uint32_t* mm = nullptr)
 {
     __shared__ uint32_t lh[kQSub][kQBins];
     const int b = blockIdx.y;
     const float* s = scores + (int64_t)b * N;
     const bool lg = largest != 0;
+    float lo = 0.0f;
+    if (mm) image_range(mm, b, lo, scale);                     // generic maps: the image's own finite value range (select_minmax_kernel)
     for (int i = threadIdx.x; i < kQSub * kQBins; i += kBlock) (&lh[0][0])[i] = 0u;
     __syncthreads();
     const int sub = threadIdx.x & (kQSub - 1);
@@ -1398,8 +1442,8 @@ __global__ __launch_bounds__(kBlock) void select_qhist_kernel(const float* score
         const int64_t n4 = (i1 - i0) >> 2;                      // (a ragged end of the last block goes through the scalar loop below)
         int64_t j = threadIdx.x;
         auto add4 = [&](const float4& q) {
-            atomicAdd(&lh[sub][qbin(q.x, lg, scale)], 1u); atomicAdd(&lh[sub][qbin(q.y, lg, scale)], 1u);
-            atomicAdd(&lh[sub][qbin(q.z, lg, scale)], 1u); atomicAdd(&lh[sub][qbin(q.w, lg, scale)], 1u);
+            atomicAdd(&lh[sub][qbin(q.x - lo, lg, scale)], 1u); atomicAdd(&lh[sub][qbin(q.y - lo, lg, scale)], 1u);
+            atomicAdd(&lh[sub][qbin(q.z - lo, lg, scale)], 1u); atomicAdd(&lh[sub][qbin(q.w - lo, lg, scale)], 1u);
         };
         for (; j + 3 * kBlock < n4; j += 4 * kBlock) {          // four 16-byte loads in flight per thread
             const float4 q0 = s4[j], q1 = s4[j + kBlock], q2 = s4[j + 2 * kBlock], q3 = s4[j + 3 * kBlock];
@@ -1410,12 +1454,12 @@ __global__ __launch_bounds__(kBlock) void select_qhist_kernel(const float* score
     }
     for (; i + 3 * kBlock < i1; i += 4 * kBlock) {            // four loads in flight per thread
         const float v0 = s[i], v1 = s[i + kBlock], v2 = s[i + 2 * kBlock], v3 = s[i + 3 * kBlock];
-        atomicAdd(&lh[sub][qbin(v0, lg, scale)], 1u);
-        atomicAdd(&lh[sub][qbin(v1, lg, scale)], 1u);
-        atomicAdd(&lh[sub][qbin(v2, lg, scale)], 1u);
-        atomicAdd(&lh[sub][qbin(v3, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v0 - lo, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v1 - lo, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v2 - lo, lg, scale)], 1u);
+        atomicAdd(&lh[sub][qbin(v3 - lo, lg, scale)], 1u);
     }
-    for (; i < i1; i += kBlock) atomicAdd(&lh[sub][qbin(s[i], lg, scale)], 1u);
+    for (; i < i1; i += kBlock) atomicAdd(&lh[sub][qbin(s[i] - lo, lg, scale)], 1u);
     __syncthreads();
     uint32_t* H = hist + (int64_t)b * kQBins;
     for (int d = threadIdx.x; d < kQBins; d += kBlock) {
@@ -1435,7 +1479,8 @@ constexpr int kQMaxPop = 1024;
 constexpr int kQSelLds = kQCap * 8 + 2 * kQBins * 4 + 128;       // a bin holding more candidates than this (ties, constant regions) sends the image to the fallback
 
 __global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* scores, int64_t N, int k, int largest, float scale,
-                                                                 const uint32_t* hist, int32_t* out_idx, float* out_val, int* overflow)
+                                                                 const uint32_t* hist, int32_t* out_idx, float* out_val, int* overflow,
+                                                                 const uint32_t* mm = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);                                   // kQCap candidates, grouped by bin
@@ -1445,6 +1490,8 @@ __global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* s
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* s = scores + (int64_t)blockIdx.x * N;
     const bool lg = largest != 0;
+    float lo = 0.0f;
+    if (mm) image_range(mm, (int)blockIdx.x, lo, scale);
     // thread t owns bin kQBins - 1 - t; an inclusive scan over the threads counts the elements at or above each bin
     {
         const int bin = kQBins - 1 - tid;
@@ -1475,7 +1522,7 @@ __global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* s
     }
     if (tid == 0) overflow[blockIdx.x] = 0;
     auto drop = [&](float v, int64_t i) {
-        const uint32_t q = qbin(v, lg, scale);
+        const uint32_t q = qbin(v - lo, lg, scale);
         if (q >= tb) {
             const uint32_t pos = start[q] + atomicAdd(&cursor[q], 1u);
             buf[pos] = ((uint64_t)order_key(v, lg) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
@@ -1506,7 +1553,7 @@ __global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* s
     // rank inside the bin's segment; neighbouring slots share a segment, so most of a wave's reads are broadcasts
     for (uint32_t p = (uint32_t)tid; p < count; p += kLargeThreads) {
         const uint64_t me = buf[p];
-        const uint32_t q = qbin(key_to_float((uint32_t)(me >> 32), lg), lg, scale);
+        const uint32_t q = qbin(key_to_float((uint32_t)(me >> 32), lg) - lo, lg, scale);
         const uint32_t a = start[q], b = a + cursor[q];
         uint32_t rank = a;
         for (uint32_t t = a; t < b; ++t) rank += buf[t] > me ? 1u : 0u;
@@ -1868,13 +1915,15 @@ static int run_merge(uint64_t* cand, int64_t n_cand, uint64_t* other, int64_t B,
 
 static int g_large_multiblock = 1;     // 0: the one-block-per-image radix select (pp_debug_set_reduce_mode bit 8), for A/B
 static int g_large_q = 1;              // 0: no quantised-histogram select (pp_debug_set_reduce_mode bit 9), for A/B
+static int g_generic_q = 1;            // 0: generic maps through the radix select (pp_debug_set_reduce_mode bit 22), for A/B
 
 static size_t large_ws_bytes(int64_t B, int64_t k)
 {
     const int P = next_pow2(k);
     const size_t g = P <= kLargeLdsMaxP ? 256 : align_up((size_t)B * P * 8, 256);
     // histograms: four 256-bin radix passes, or the 1024 linear bins of the quantised select (the same bytes) + its overflow flags
-    return g + align_up((size_t)B * kSelPasses * kSelBins * 4, 256) + align_up((size_t)B * 4, 256);
+    // + the per-image value range of the generic quantised select
+    return g + align_up((size_t)B * kSelPasses * kSelBins * 4, 256) + align_up((size_t)B * 4, 256) + align_up((size_t)B * 8, 256);
 }
 
 // The scorers' value range as bins per unit score (0: unknown - the generic radix select)
@@ -1914,21 +1963,36 @@ static int run_large(const float* map, int64_t B, int64_t N, int64_t k, int larg
                             hipFuncAttributeMaxDynamicSharedMemorySize, kQSelLds);
         attr_set = true;
     }
-    // known score range and room for the threshold bin's population beside the k picks: the quantised select
-    if (large_q_ok(B, k, qscale)) {
+    // room for the threshold bin's population beside the k picks: the quantised select - over the scorers' known range, or (generic maps,
+    // qscale == 0) over every image's own finite range, taken in one more pass: three passes over the map instead of the radix select's five
+    const bool generic_q = qscale <= 0.0f && g_generic_q && large_q_ok(B, k, 1.0f);
+    if (large_q_ok(B, k, qscale) || generic_q) {
         static_assert(kQBins * 4 == kSelPasses * kSelBins * 4, "the two histogram layouts share their workspace slot");
         int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + align_up((size_t)B * kQBins * 4, 256));
+        uint32_t* mm = nullptr;
+        if (generic_q) {
+            mm = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(flags) + align_up((size_t)B * 4, 256));
+            if (hipMemsetAsync(mm, 0, (size_t)B * 8, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
+            int64_t bpi = cdiv(2048, B);
+            const int64_t by_size = cdiv(N, 4096);
+            if (bpi > by_size) bpi = by_size;
+            if (bpi < 1) bpi = 1;
+            hipLaunchKernelGGL(select_minmax_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, mm);
+            if (int rc = check_launch("select_minmax_kernel")) return rc;
+            qscale = 1.0f;
+        }
         if (!hist_done) {
             if (hipMemsetAsync(hist, 0, (size_t)B * kQBins * 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
             int64_t bpi = cdiv(2048, B);
             const int64_t by_size = cdiv(N, 4096);
             if (bpi > by_size) bpi = by_size;
             if (bpi < 1) bpi = 1;
-            hipLaunchKernelGGL(select_qhist_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, largest, qscale, hist);
+            hipLaunchKernelGGL(select_qhist_kernel, dim3((unsigned)bpi, (unsigned)B), dim3(kBlock), 0, st, map, N, largest, qscale, hist,
+                               (const uint32_t*)mm);
             if (int rc = check_launch("select_qhist_kernel")) return rc;
         }
         hipLaunchKernelGGL(topk_qsel_kernel, dim3((unsigned)B), dim3(kLargeThreads), kQSelLds, st, map, N, (int)k, largest, qscale,
-                           hist, out_idx, out_val, flags);
+                           hist, out_idx, out_val, flags, (const uint32_t*)mm);
         if (int rc = check_launch("topk_qsel_kernel")) return rc;
         // images whose candidates did not fit (ties at the threshold, constant maps): the exact one-block radix select; the others return at once
         hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, map, N, (int)k, largest,
@@ -2327,6 +2391,7 @@ void pp_debug_set_reduce_mode(int mode)
     g_large_multiblock = (mode & 256) ? 0 : 1;      // bit 8: large-k selection through the one-block-per-image radix select (A/B)
     g_large_q = (mode & 512) ? 0 : 1;               // bit 9: no quantised-histogram select where the score range is known (A/B)
     g_hist_fuse = (mode & 1024) ? 0 : 1;            // bit 10: the score histogram in its own pass over the map (select_qhist_kernel), not in the scorer launch
+    g_generic_q = (mode & (1 << 22)) ? 0 : 1;       // bit 22: maps without a known range (pp_topk_select) through the four-pass radix select
     g_emit = (mode & 2048) ? 0 : 1;                 // bit 11: no sampled-threshold candidate emission (the map-writing scorer + topk_qsel_kernel)
     g_emit_mult16 = ((mode >> 12) & 63) ? ((mode >> 12) & 63) : 40;    // bits 12-17: the sample aims at this / 16 x k passing pixels
     { static const int locs[4] = {128, 64, 256, 512}, gpl[4] = {4, 2, 1, 8};

@@ -142,6 +142,40 @@ def test_large_k_select_with_ties_at_the_threshold(B, N, k, levels, largest):
     assert torch.equal(idx, idx2) and torch.equal(val.view(torch.int32), val2.view(torch.int32))
 
 
+@pytest.mark.parametrize("largest", [True, False])
+def test_generic_select_over_the_images_own_range_equals_the_radix_select(largest):
+    """pp_topk_select on maps whose value range nobody states (the random strategy's torch.rand maps, query.py:216-221; MC-dropout mean
+    scores, query.py:181-187): one min / max pass, then the quantised histogram select over every image's own finite range - three
+    passes over the map instead of the radix select's five.  Same picks and values as the radix select (pp_debug_set_reduce_mode bit 22)
+    and as the oracle's stable sort: negative and huge ranges, infinities, NaN, a constant image, a two-valued image, a range of a few ulps."""
+    from pixelpick_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(5)
+    N, k = 131072, 6553
+    s = np.empty((8, N), dtype=np.float32)
+    s[0] = rng.rand(N)                                     # the random strategy
+    s[1] = rng.randn(N) * 1e6 - 3e6                        # large negative range
+    s[2] = rng.randn(N) * 1e-30                            # tiny magnitudes
+    s[3] = rng.rand(N); s[3, ::1000] = np.inf; s[3, 5::1000] = -np.inf; s[3, 7::5000] = np.nan
+    s[4] = 0.25                                            # constant -> one bin -> exact fallback
+    s[5] = (rng.rand(N) < 0.5).astype(np.float32)          # two values
+    s[6] = np.float32(1.0) + rng.randint(0, 4, N).astype(np.float32) * np.float32(2.0 ** -23)      # four neighbouring floats
+    s[7] = np.log(19.0) * rng.beta(0.5, 3.0, N)            # an entropy-like map
+    t = torch.from_numpy(s).to(DEV)
+    for kk in (k, 100, 7000):
+        try:
+            L.pp_debug_set_reduce_mode(1 << 22)
+            ref = acq.topk_select(t, kk, largest)
+        finally:
+            L.pp_debug_set_reduce_mode(0)
+        got = acq.topk_select(t, kk, largest)
+        assert torch.equal(ref[0], got[0]), kk
+        assert torch.equal(torch.nan_to_num(ref[1], nan=-7.0), torch.nan_to_num(got[1], nan=-7.0)), kk
+    for b in range(8):
+        e_idx, _ = orc.topk(s[b], k, largest)
+        assert acq.topk_select(t[b:b + 1], k, largest)[0][0].cpu().numpy().tolist() == e_idx.tolist(), b
+
+
 @pytest.mark.parametrize("st", STRATS)
 def test_select_modes_golden(golden_dir, st):
     m = np.load(os.path.join(golden_dir, "acq_select_modes.npz"))
