@@ -71,6 +71,7 @@ struct AcqParams {
     uint32_t* ecnt = nullptr;         // [B][nseg]
     int64_t eimg = 0;
     int nseg = 0;
+    int segst = 0;                    // entries from one segment to the next: PPT * 64 + kSegPad (not a multiple of 4 KB: see emit_list_entries)
     int sample_locs = 0, sample_gpl = 0;   // acq_sample_thr_kernel: locations per image, 4-pixel groups per location
 };
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(kBlock, OCC) void acq_kernel(AcqParams p)
         const uint32_t tk = p.tkey[img];
         const int wave = tid >> 6, lane = tid & (kWave - 1);
         const int seg = blk * (kBlock / kWave) + wave;
-        uint64_t* dst = p.elist + (int64_t)img * p.eimg + (int64_t)seg * (PPT * kWave);
+        uint64_t* dst = p.elist + (int64_t)img * p.eimg + (int64_t)seg * p.segst;
         const uint64_t below = (1ull << lane) - 1ull;
         uint32_t n = 0;
 #pragma unroll
@@ -2156,7 +2157,11 @@ static int g_emit_mult16 = 40;     // sampled threshold aims at mult16 / 16 x k 
 static int g_sample_locs = 128;    // pp_debug_set_reduce_mode bits 18-19: 128 / 64 / 256 / 512 locations per image
 static int g_sample_gpl = 4;       // bits 20-21: 4 / 2 / 1 / 8 four-pixel groups per location
 static bool emit_size_ok(int64_t N, int64_t k) { return N >= 16384 && k * 8 <= N; }
-static size_t emit_list_entries(int64_t N) { return align_up((size_t)N, 2048); }
+// Entries per image: a wave's segment holds PPT * 64 words and is followed by kSegPad unused ones, so that the segments do not all start
+// on a 4 KB boundary.  (The scorer launch costs 0.365 ms without the list stores and 0.38-0.42 with them - the spread is between boxes /
+// hours, not between layouts: the pad, whole-wave stores from an LDS staging list and non-temporal stores all measured the same.)
+constexpr int kSegPad = 32;
+static size_t emit_list_entries(int64_t N) { return align_up((size_t)N, 2048) / 256 * (256 + kSegPad); }
 // first region of the large-k workspace: the score map, or the per-wave candidate segments (the fallback's map of the flagged images
 // is written over them after the list select has consumed them)
 static size_t map_region_bytes(int64_t B, int64_t N, int64_t k)
@@ -2167,7 +2172,7 @@ static size_t emit_extra_bytes(int64_t B, int64_t N, int64_t k)
 {
     if (!emit_size_ok(N, k)) return 0;
     // threshold keys + the flagged count, flagged list, per-wave counts
-    return align_up((size_t)(B + 1) * 4, 256) + align_up((size_t)B * 4, 256) + align_up((size_t)B * (emit_list_entries(N) / 256) * 4, 256);
+    return align_up((size_t)(B + 1) * 4, 256) + align_up((size_t)B * 4, 256) + align_up((size_t)B * (align_up((size_t)N, 2048) / 256) * 4, 256);
 }
 static bool acq_emit_ok(const AcqParams& p, const Plan& pl, int64_t B, int64_t k, float qs, bool caller_map)
 {
@@ -2196,7 +2201,7 @@ static int run_emit_select(AcqParams p, const Plan& pl, int64_t B, int64_t k, in
                             hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
         attr_set = true;
     }
-    const int segsz = pl.ppt * kWave;
+    const int segsz = pl.ppt * kWave + kSegPad;
     AcqParams q = p;
     q.out_map = nullptr;
     q.tkey = tkey;
@@ -2204,6 +2209,7 @@ static int run_emit_select(AcqParams p, const Plan& pl, int64_t B, int64_t k, in
     q.ecnt = ecnt;
     q.eimg = (int64_t)emit_list_entries(p.N);
     q.nseg = pl.blocks_per_image * (kBlock / kWave);
+    q.segst = segsz;
     q.sample_locs = g_sample_locs;
     q.sample_gpl = g_sample_gpl;
     while ((int64_t)q.sample_locs * q.sample_gpl * 4 * 4 > p.N && q.sample_locs > 16) q.sample_locs >>= 1;      // (16384 pixels and up: >= 4 slots per location)

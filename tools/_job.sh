@@ -1,26 +1,10 @@
-# scratch job for `gpurun -- 'bash tools/_job.sh'`: generic quantised select - tests + timing against the radix select
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6g1; mkdir -p $O
-timeout 600 python -m pytest tests/test_acq_gpu.py -x -q > $O/tacq.txt 2>&1; tail -3 $O/tacq.txt
-cat > /tmp/t.py <<'P'
-import os, sys
-os.environ["PIXELPICK_KNOBS_BUILD"] = "1"
-import torch
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-from pixelpick_amd import _lib, acquisition as acq
-L = _lib.lib()
-torch.manual_seed(0)
-for B, N, k in ((256, 131072, 6553), (32, 131072, 6553), (1, 131072, 6553)):
-    m = torch.rand(B, N, device="cuda")
-    for mode, name in ((1 << 22, "radix select (4 histogram passes + sort)"), (0, "min/max + quantised select")):
-        L.pp_debug_set_reduce_mode(mode)
-        for _ in range(3): acq.topk_select(m, k, False)
-        ts = []
-        for _ in range(20):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); acq.topk_select(m, k, False); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-        ts.sort()
-        print(f"B={B} N={N} k={k}: {name}: {ts[len(ts)//2]*1e3:.1f} us (median of 20, incl. the output allocation)")
-    L.pp_debug_set_reduce_mode(0)
-P
-timeout 120 python /tmp/t.py 2>&1 | tee $O/generic_select.txt
+O=gpurun_out/r6e18; mkdir -p $O
+timeout 300 python -m pytest tests/test_acq_gpu.py -x -q -k "list_select" 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+for m in 0 $((32<<12)); do
+RMODE=$m timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof$m -o t -- python $GRAFT_REPO_ROOT/tools/topk5_bench.py > $GRAFT_REPO_ROOT/$O/out$m.txt 2>&1
+cp $(find $GRAFT_REPO_ROOT/$O/prof$m -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/ks_$m.csv; rm -rf $GRAFT_REPO_ROOT/$O/prof$m
+echo "RMODE=$m"; grep "^k=" $GRAFT_REPO_ROOT/$O/out$m.txt; grep "pp::" $GRAFT_REPO_ROOT/$O/ks_$m.csv | head -3 | cut -c1-60,100-260 
+done
+cd $GRAFT_REPO_ROOT; RMODE=2048 timeout 120 python tools/topk5_bench.py 2>&1 | tail -2 | head -1

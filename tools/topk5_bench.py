@@ -15,8 +15,9 @@ idx = torch.empty((B, k), dtype=torch.int32, device="cuda"); val = torch.empty((
 ws = torch.empty(int(L.pp_acq_workspace_bytes(B, C, H, W, k)), dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 L.pp_debug_set_acq_tuning(int(os.environ.get("TUNE", "0")), 0); L.pp_debug_set_reduce_mode(int(os.environ.get("RMODE", "0")))
+excl = (torch.rand(B, H, W, device="cuda") < 0.05).to(torch.uint8) if os.environ.get("MASK") else None     # MASK=1: bench.py's 5 % exclusion mask
 def op():
-    _lib.check(L.pp_acq_score_topk(x.data_ptr(), B, C, H, W, *x.stride(), None, 0, k, idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "op")
+    _lib.check(L.pp_acq_score_topk(x.data_ptr(), B, C, H, W, *x.stride(), excl.data_ptr() if excl is not None else None, 0, k, idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "op")
 for _ in range(5): op()
 ts = []
 for _ in range(30):
@@ -28,7 +29,7 @@ gb = B * H * W * (C * 4 + 1) / 1e9
 print(f"k={k}: op {t * 1e3:.1f} us (median of 30; min {ts[0] * 1e3:.1f}) = {gb / (t * 1e-3):.1f} GB/s = {gb / (t * 1e-3) / 8000:.3f} of 8 TB/s; with the map write counted {(gb + B * H * W * 4 / 1e9) / (t * 1e-3) / 8000:.3f}")
 # picks = the k best of the device's own map
 L.pp_debug_set_acq_tuning(0, 0); L.pp_debug_set_reduce_mode(0)
-i2, v2, m = acq.score_topk(x[:2], None, "entropy", k, return_map=True)
+i2, v2, m = acq.score_topk(x[:2], excl[:2].bool() if excl is not None else None, "entropy", k, return_map=True)
 ref = torch.sort(m[0].reshape(-1), descending=True, stable=True)
 assert torch.equal(ref.indices[:k].to(torch.int32), i2[0]), "picks differ from a stable sort of the map"
 print("picks == stable descending sort of the map")
