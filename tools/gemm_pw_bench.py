@@ -16,7 +16,12 @@ SHAPES = [("R50 256->1024 @8192", 8192, 256, 1024), ("R50 1024->256 @8192", 8192
           ("R50 512->256 @8192", 8192, 512, 256), ("R50 1024->512 @8192", 8192, 1024, 512), ("R50 512->2048 @8192", 8192, 512, 2048),
           ("R50 1024->2048 @8192", 8192, 1024, 2048), ("R50 256->128 @8192", 8192, 256, 128), ("R50 512->128 @8192", 8192, 512, 128),
           ("R50 128->512 @8192", 8192, 128, 512), ("ASPP-R50 2048->256 @8192", 8192, 2048, 256), ("FPN 2048->256 @8192", 8192, 2048, 256),
-          ("FPN 256->256 @32768", 32768, 256, 256), ("x16 256->1024 @131072", 131072, 256, 1024)]
+          ("FPN 256->256 @32768", 32768, 256, 256), ("x16 256->1024 @131072", 131072, 256, 1024),
+          # the 1/16-resolution layers of the MobileNetV2 model (2048 rows at B = 4: below the planner's row limit - forced forms show why)
+          ("MNv2 960->320 @2048", 2048, 960, 320), ("ASPP fuse 1280->256 @2048", 2048, 1280, 256), ("MNv2 160->960 @2448", 2448, 160, 960),
+          ("MNv2 960->160 @2048", 2048, 960, 160), ("ASPP 320->256 @2048", 2048, 320, 256)]
+if os.environ.get("ONLY"):
+    SHAPES = [s_ for s_ in SHAPES if os.environ["ONLY"] in s_[0]]
 FORMS = ["128x256", "256x128", "128x128", "64x128", "128x64", "64x64"]
 
 
