@@ -3556,12 +3556,11 @@ static int gemm_pw_choose(int64_t M, int N, int K)
 {
     if (!g_gemm_pw || K < 64 || N < 64) return -1;      // (narrower layers have their own whole-row kernels)
     if (g_gemm_pw >= 2) return M >= g_gemm_pw_rows_min ? g_gemm_pw - 2 : -1;
-    if (M < g_gemm_pw_rows_min) {
-        // Below the row limit the in-block split-K kernel wins (ASPP fuse 1280 -> 256 @2048 rows: 22.9 against 32.6 us) - except where
-        // the output is wider than its 256-column tiles cover in one round: MobileNetV2's 960 -> 320 projection (mobilenet_v2.py:56,
-        // 2048 rows at B = 4) runs 160 tiles of 64 x 64 in 26.4 us against 30.3 (vendor sgemm 24.2; profiles/r06_gemm_pw.txt)
-        return (g_gemm_pw_rows_min == 4096 && M >= 2048 && N > 256 && N <= 384 && K >= 512) ? 5 : -1;
-    }
+    // Below the row limit the in-block split-K kernel stays (ASPP fuse 1280 -> 256 @2048 rows: 22.9 against 32.6 us for the best tile form
+    // here).  The one exception measured - MobileNetV2's 960 -> 320 projection, 26.4 us on 64 x 64 tiles against 30.3 (vendor 24.2) - is NOT
+    // taken: that layer's input-affine form (BatchNorm applied where the operand is read) runs on the split-K kernel, and the two must add
+    // in the same order (tests/test_bn_on_load_gpu.py: bit-equal to the plain convolution of the materialised input).
+    if (M < g_gemm_pw_rows_min) return -1;
     static const double eff[6] = {0.88, 0.86, 0.85, 0.80, 0.78, 0.70}, fixed_us[6] = {10.0, 10.5, 6.0, 4.5, 4.5, 2.5};
     const int cus = device_cus();
     int best = -1;

@@ -82,28 +82,6 @@ def test_channel_slices_and_the_planner_rule():
     assert torch.equal(y2w, yw)
 
 
-def test_the_rule_takes_the_wide_projection_below_the_row_limit():
-    """mobilenet_v2.py:56, features.17: 960 -> 320 at 16 x 32 (2048 rows at B = 4) - below the planner's row limit, but wider than the
-    in-block split-K kernel's 256-column tiles: the rule sends it to the 64 x 64 form (same bits as the forced form), its neighbours at the
-    same resolution (1280 -> 256, 960 -> 160) stay on the split-K kernel (same bits as with the GEMM kernel off)."""
-    L = _lib.lib()
-    gen = torch.Generator(device=DEV).manual_seed(3)
-    for Cin, Cout, taken in ((960, 320, True), (1280, 256, False), (960, 160, False)):
-        B, H, W = 4, 16, 32
-        x = torch.randn(B, H, W, Cin, device=DEV, generator=gen)
-        w = torch.randn(1, 1, Cin, Cout, device=DEV, generator=gen) / np.sqrt(Cin)
-        ys = []
-        for mode in (1, 7 | (1 << 4), 0):          # rule; 64 x 64 form forced from one row on; GEMM kernel off
-            L.pp_debug_set_gemm_pw(mode)
-            y = torch.empty(B, H, W, Cout, device=DEV)
-            _conv1x1(x, w, y, B, H, W, Cin, Cout, Cin, Cout)
-            ys.append(y)
-        L.pp_debug_set_gemm_pw(1)
-        assert torch.equal(ys[0], ys[1 if taken else 2]), (Cin, Cout)
-        ref = (x.double().reshape(-1, Cin) @ w.double().reshape(Cin, Cout)).reshape(B, H, W, Cout)
-        assert ((ys[0].double() - ref).norm() / ref.norm()).item() <= 3e-7
-
-
 @pytest.mark.parametrize("K", [64, 68, 96, 100, 128, 132, 160, 224])
 def test_reduction_tails(K):
     """2 .. 7 K steps of 32 with and without a ragged last step: prologue with fewer steps than the ring holds, steady loop of 0 .. 4 steps, tail."""
