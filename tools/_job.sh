@@ -1,6 +1,6 @@
 # scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6fin3; mkdir -p $O
+O=gpurun_out/r6fin4; mkdir -p $O
 timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python tools/measure_acq_traffic.py > $O/traffic.log 2>&1; tail -2 $O/traffic.log | cut -c1-200; cp profiles/acq_traffic.json $O/acq_traffic.json
