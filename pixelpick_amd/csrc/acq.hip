@@ -1031,18 +1031,12 @@ __global__ __launch_bounds__(kBlock) void cand_merge_kernel(const uint64_t* in, 
 
 // ---- large-k: radix select + bitonic sort, one 1024-thread block per image ------------------------------
 // query.py:36 top_n_percent mode: k = int(h*w*0.05) (6553 at 256x512) value-sorted indices.
-__global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* scores, int64_t N, int k, int largest,
-                                                                  uint64_t* gbuf, int P, int32_t* out_idx,
-                                                                  float* out_val, const int* only_if = nullptr)
+// s: the image's scores; hist: 256 words, misc: 64 words of LDS; buf: P 64-bit words (LDS or global); oi / ov: the image's output rows.
+// All kLargeThreads threads of the block.
+__device__ __forceinline__ void topk_large_body(const float* s, int64_t N, int k, bool lg, uint32_t* hist, uint32_t* misc, uint64_t* buf,
+                                                int P, int32_t* oi, float* ov)
 {
-    if (only_if && !only_if[blockIdx.x]) return;      // fallback launch of the quantised select: flagged images only
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);            // 256
-    uint32_t* misc = hist + 256;                                   // 64
-    uint64_t* buf = gbuf ? gbuf + (int64_t)blockIdx.x * P : reinterpret_cast<uint64_t*>(smem + (256 + 64) * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* s = scores + (int64_t)blockIdx.x * N;
-    const bool lg = largest != 0;
 
     // 1. radix select: T = k-th largest key, need_eq = how many keys == T to take (lowest index first)
     uint32_t prefix = 0, mask = 0, remaining = (uint32_t)k;
@@ -1117,9 +1111,22 @@ __global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* 
     }
     for (int j = tid; j < k; j += kLargeThreads) {
         const uint64_t v = buf[j];
-        out_idx[(int64_t)blockIdx.x * k + j] = (int32_t)(0xFFFFFFFFu - (uint32_t)v);
-        if (out_val) out_val[(int64_t)blockIdx.x * k + j] = key_to_float((uint32_t)(v >> 32), lg);
+        oi[j] = (int32_t)(0xFFFFFFFFu - (uint32_t)v);
+        if (ov) ov[j] = key_to_float((uint32_t)(v >> 32), lg);
     }
+}
+
+__global__ __launch_bounds__(kLargeThreads) void topk_large_kernel(const float* scores, int64_t N, int k, int largest,
+                                                                  uint64_t* gbuf, int P, int32_t* out_idx,
+                                                                  float* out_val, const int* only_if = nullptr)
+{
+    if (only_if && !only_if[blockIdx.x]) return;      // fallback launch of the quantised select: flagged images only
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);            // 256
+    uint32_t* misc = hist + 256;                                   // 64
+    uint64_t* buf = gbuf ? gbuf + (int64_t)blockIdx.x * P : reinterpret_cast<uint64_t*>(smem + (256 + 64) * 4);
+    topk_large_body(scores + (int64_t)blockIdx.x * N, N, k, largest != 0, hist, misc, buf, P, out_idx + (int64_t)blockIdx.x * k,
+                    out_val ? out_val + (int64_t)blockIdx.x * k : nullptr);
 }
 
 
@@ -1574,10 +1581,9 @@ __global__ __launch_bounds__(kLargeThreads) void topk_qsel_kernel(const float* s
 // into kLBins bins spanning only [threshold, end of the score range] (the lists hold nothing else: bins ~30x finer than topk_qsel_kernel's for
 // the same LDS), finds the bin of the k-th element, drops that bin and the ones above into LDS and ranks every candidate inside its bin.  The
 // RESULT never depends on the sample: an image whose lists hold fewer than k words (the sample misled), or whose candidates do not fit (ties),
-// is put on the flagged list and redone exactly (acq_flagged_map_kernel: its score map -> topk_large_kernel).
+// is redone exactly by its own block (score map + one-block radix select, see topk_lsel_kernel).
 constexpr int kSampleThreads = 512;
 constexpr int kLBins = 4096;
-constexpr int kFlagSlots = 2;                           // images the fallback scorer works on at a time (it loops over the flagged list)
 
 template <int CMAX>
 __global__ __launch_bounds__(kSampleThreads) void acq_sample_thr_kernel(AcqParams p, float qscale, uint32_t want, uint32_t* tkey_out)
@@ -1654,11 +1660,15 @@ __device__ __forceinline__ uint32_t lbin(uint32_t key, bool lg, float tv, float 
     return (uint32_t)(t >= (float)(kLBins - 1) ? kLBins - 1 : (t > 0.0f ? (int)t : 0));
 }
 
-// One 1024-thread block per image; cnt / list: the scorer's per-wave segments (nseg segments of segsz entries).  range: the scorers' value
-// range (ln C or 1).  Flagged images are appended to flag_ids (nflag zeroed by the host).
-__global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(const uint64_t* list, const uint32_t* cnt, const uint32_t* tkey, int64_t eimg,
-                                                                 int nseg, int segsz, int k, int largest, float range, int32_t* out_idx,
-                                                                 float* out_val, int* overflow, int* nflag, int* flag_ids)
+// One 1024-thread block per image; cnt / list: the scorer's per-wave segments (nseg segments, segsz entries apart).  range: the scorers'
+// value range (ln C or 1).  An image whose lists do not do (fewer than k words: the sample misled; candidates that do not fit: ties) is
+// redone exactly by its own block, right here: the score map of the image - the default scorer's arithmetic, written over the image's own,
+// by then consumed, list segments - and the one-block radix select on it.  Slow (one block scores 10 MB of logits) and rare; nothing is
+// launched for it, so the usual case pays nothing (two idle launches - a map kernel over a flagged list and topk_large_kernel - cost 9 us).
+template <int CMAX>
+__global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(AcqParams p, const uint64_t* list, const uint32_t* cnt, const uint32_t* tkey,
+                                                                 int64_t eimg, int nseg, int segsz, int k, int largest, float range,
+                                                                 int32_t* out_idx, float* out_val)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);                                   // kQCap candidates, grouped by bin
@@ -1729,14 +1739,28 @@ __global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(const uint64_t
     }
     const uint32_t tb = misc[0], count = misc[1];
     // fewer than k words in the lists (misc[3] unset: the sampled threshold was too high), or no room: the exact fallback
-    if (!misc[3] || count > (uint32_t)kQCap || misc[2]) {
-        if (tid == 0) {
-            overflow[blockIdx.x] = 1;
-            flag_ids[atomicAdd(nflag, 1)] = (int)blockIdx.x;
+    if (!misc[3] || count > (uint32_t)kQCap || misc[2]) {              // block-uniform
+        const int img = blockIdx.x;
+        const float fill = lg ? 0.0f : 1.0f;
+        const float* base = p.logits + (int64_t)img * p.sB;
+        const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
+        float* fmap = reinterpret_cast<float*>(const_cast<uint64_t*>(L));          // N floats <= eimg words
+        for (int64_t pix = tid; pix < p.N; pix += kLargeThreads) {                  // (flat planes: sW == 1, sH == W)
+            float x[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) x[c] = base[(int64_t)c * p.sC + pix];
+            float sc = pixel_score_fast<CMAX, true>(x, p.C, p.strategy);
+            if (excl && excl[pix]) sc = fill;
+            fmap[pix] = sc;
         }
+        __syncthreads();
+        uint32_t* rh = reinterpret_cast<uint32_t*>(smem);                           // 256 + 64 words, then P 64-bit words (P <= 8192: k <= 7281)
+        int P = 1;
+        while (P < k) P <<= 1;
+        topk_large_body(fmap, p.N, k, lg, rh, rh + 256, reinterpret_cast<uint64_t*>(smem + (256 + 64) * 4), P, out_idx + (int64_t)img * k,
+                        out_val ? out_val + (int64_t)img * k : nullptr);
         return;
     }
-    if (tid == 0) overflow[blockIdx.x] = 0;
     sweep([&](uint64_t w) {
         const uint32_t q = lbin((uint32_t)(w >> 32), lg, tv, lscale);
         if (q >= tb) buf[start[q] + atomicAdd(&hist[q], 1u)] = w;
@@ -1755,40 +1779,6 @@ __global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(const uint64_t
     }
 }
 constexpr int kLSelLds = kQCap * 8 + 2 * kLBins * 4 + 128;
-
-// Score maps of the flagged images only (the default scorer's arithmetic, 4 pixels per thread): kFlagSlots x blocks-per-image blocks; when
-// nothing is flagged - the usual case - every block reads one word and leaves.
-template <int CMAX>
-__global__ __launch_bounds__(kBlock) void acq_flagged_map_kernel(AcqParams p, const int* nflag, const int* flag_ids, int bpf)
-{
-    const int n = *nflag;
-    const int slot0 = blockIdx.x / bpf, blk = blockIdx.x - slot0 * bpf;
-    const bool largest = p.strategy != PP_ACQ_MARGIN;
-    const float fill = largest ? 0.0f : 1.0f;
-    for (int slot = slot0; slot < n; slot += kFlagSlots) {
-        const int img = flag_ids[slot];
-        const float* base = p.logits + (int64_t)img * p.sB;
-        const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
-        float* omap = p.out_map + (int64_t)img * p.N;
-        const int64_t pix0 = ((int64_t)blk * kBlock + threadIdx.x) * 4;
-        if (pix0 >= p.N) continue;
-        float x[4][CMAX];
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * p.sC + pix0);
-            x[0][c] = v.x; x[1][c] = v.y; x[2][c] = v.z; x[3][c] = v.w;
-        }
-        const uint32_t ex = excl ? *reinterpret_cast<const uint32_t*>(excl + pix0) : 0u;
-        float s4[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            s4[v] = pixel_score_fast<CMAX, true>(x[v], p.C, p.strategy);
-            if ((ex >> (8 * v)) & 0xFFu) s4[v] = fill;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        *reinterpret_cast<float4*>(omap + pix0) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-    }
-}
 
 // ---- host side ---------------------------------------------------------------------------------------
 // Sum over T forward passes of softmax(logits[t]) per pixel and of the strategy's score of each pass (the MC-dropout
@@ -2162,8 +2152,8 @@ static bool emit_size_ok(int64_t N, int64_t k) { return N >= 16384 && k * 8 <= N
 // hours, not between layouts: the pad, whole-wave stores from an LDS staging list and non-temporal stores all measured the same.)
 constexpr int kSegPad = 32;
 static size_t emit_list_entries(int64_t N) { return align_up((size_t)N, 2048) / 256 * (256 + kSegPad); }
-// first region of the large-k workspace: the score map, or the per-wave candidate segments (the fallback's map of the flagged images
-// is written over them after the list select has consumed them)
+// first region of the large-k workspace: the score map, or the per-wave candidate segments (the exact fallback writes an image's score
+// map over that image's own segments once its block has consumed them)
 static size_t map_region_bytes(int64_t B, int64_t N, int64_t k)
 {
     return emit_size_ok(N, k) ? align_up((size_t)B * emit_list_entries(N) * 8, 256) : align_up((size_t)B * N * 4, 256);
@@ -2171,8 +2161,8 @@ static size_t map_region_bytes(int64_t B, int64_t N, int64_t k)
 static size_t emit_extra_bytes(int64_t B, int64_t N, int64_t k)
 {
     if (!emit_size_ok(N, k)) return 0;
-    // threshold keys + the flagged count, flagged list, per-wave counts
-    return align_up((size_t)(B + 1) * 4, 256) + align_up((size_t)B * 4, 256) + align_up((size_t)B * (align_up((size_t)N, 2048) / 256) * 4, 256);
+    // threshold keys, per-wave counts
+    return align_up((size_t)B * 4, 256) + align_up((size_t)B * (align_up((size_t)N, 2048) / 256) * 4, 256);
 }
 static bool acq_emit_ok(const AcqParams& p, const Plan& pl, int64_t B, int64_t k, float qs, bool caller_map)
 {
@@ -2182,23 +2172,17 @@ static bool acq_emit_ok(const AcqParams& p, const Plan& pl, int64_t B, int64_t k
 
 static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st);
 
-// p: the map-writing launch's parameters (out_map = the first workspace region); tail: what follows the large-k scratch in the workspace
-static int run_emit_select(AcqParams p, const Plan& pl, int64_t B, int64_t k, int largest, float qs, void* region0, void* gbuf, void* tail,
+// p: the map-writing launch's parameters; region0: the first workspace region (candidate segments); tail: what follows the large-k scratch
+static int run_emit_select(AcqParams p, const Plan& pl, int64_t B, int64_t k, int largest, float qs, void* region0, void* tail,
                            int32_t* out_idx, float* out_val, hipStream_t st)
 {
     uint32_t* tkey = reinterpret_cast<uint32_t*>(tail);
-    int* nflag = reinterpret_cast<int*>(tkey + B);
-    int* flag_ids = reinterpret_cast<int*>(reinterpret_cast<char*>(tail) + align_up((size_t)(B + 1) * 4, 256));
-    uint32_t* ecnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(flag_ids) + align_up((size_t)B * 4, 256));
-    uint32_t* hist = large_hist(gbuf, B, k);
-    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + align_up((size_t)B * kQBins * 4, 256));
-    const int P = next_pow2(k);
-    const bool in_lds = P <= kLargeLdsMaxP;
+    uint32_t* ecnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tail) + align_up((size_t)B * 4, 256));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_lsel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLSelLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_large_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 64) * 4 + kLargeLdsMaxP * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_lsel_kernel<11>), hipFuncAttributeMaxDynamicSharedMemorySize, kLSelLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_lsel_kernel<19>), hipFuncAttributeMaxDynamicSharedMemorySize, kLSelLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_lsel_kernel<21>), hipFuncAttributeMaxDynamicSharedMemorySize, kLSelLds);
         attr_set = true;
     }
     const int segsz = pl.ppt * kWave + kSegPad;
@@ -2217,31 +2201,21 @@ static int run_emit_select(AcqParams p, const Plan& pl, int64_t B, int64_t k, in
     int64_t want = (sample_n * g_emit_mult16 * k + 16 * p.N - 1) / (16 * p.N);
     if (want < 1) want = 1;
     if (want > sample_n) want = sample_n;
-    const int bpf = (int)cdiv(p.N, (int64_t)kBlock * 4);
-    const dim3 sgrid((unsigned)B), sblock(kSampleThreads), fgrid((unsigned)(kFlagSlots * bpf)), fblock(kBlock);
-    if (hipMemsetAsync(nflag, 0, 4, st) != hipSuccess) return fail(PP_ERR_LAUNCH, "topk: memset failed");
-#define PP_BY_C(KERNEL, GRID, BLOCK, ...)                                                                    \
-    switch (p.C) {                                                                                           \
-        case 11: hipLaunchKernelGGL((KERNEL<11>), GRID, BLOCK, 0, st, __VA_ARGS__); break;                   \
-        case 19: hipLaunchKernelGGL((KERNEL<19>), GRID, BLOCK, 0, st, __VA_ARGS__); break;                   \
-        default: hipLaunchKernelGGL((KERNEL<21>), GRID, BLOCK, 0, st, __VA_ARGS__); break;                   \
+    const dim3 sgrid((unsigned)B), sblock(kSampleThreads), lblock(kLargeThreads);
+    const float range = (float)kQBins / qs;
+#define PP_BY_C(KERNEL, GRID, BLOCK, LDS, ...)                                                                 \
+    switch (p.C) {                                                                                             \
+        case 11: hipLaunchKernelGGL((KERNEL<11>), GRID, BLOCK, LDS, st, __VA_ARGS__); break;                   \
+        case 19: hipLaunchKernelGGL((KERNEL<19>), GRID, BLOCK, LDS, st, __VA_ARGS__); break;                   \
+        default: hipLaunchKernelGGL((KERNEL<21>), GRID, BLOCK, LDS, st, __VA_ARGS__); break;                   \
     }
-    PP_BY_C(acq_sample_thr_kernel, sgrid, sblock, q, qs, (uint32_t)want, tkey);
+    PP_BY_C(acq_sample_thr_kernel, sgrid, sblock, 0, q, qs, (uint32_t)want, tkey);
     if (int rc = check_launch("acq_sample_thr_kernel")) return rc;
     if (int rc = dispatch_acq(q, pl, B, st)) return rc;
-    hipLaunchKernelGGL(topk_lsel_kernel, dim3((unsigned)B), dim3(kLargeThreads), kLSelLds, st, (const uint64_t*)q.elist, (const uint32_t*)ecnt,
-                       (const uint32_t*)tkey, q.eimg, q.nseg, segsz, (int)k, largest, (float)kQBins / qs, out_idx, out_val, flags, nflag,
-                       flag_ids);
-    if (int rc = check_launch("topk_lsel_kernel")) return rc;
-    // flagged images (sample misled, ties at the threshold, constant maps): their score maps, then the exact one-block radix select;
-    // both launches return at once when there are none
-    PP_BY_C(acq_flagged_map_kernel, fgrid, fblock, p, (const int*)nflag, (const int*)flag_ids, bpf);
+    PP_BY_C(topk_lsel_kernel, sgrid, lblock, kLSelLds, q, (const uint64_t*)q.elist, (const uint32_t*)ecnt, (const uint32_t*)tkey, q.eimg, q.nseg,
+            segsz, (int)k, largest, range, out_idx, out_val);
 #undef PP_BY_C
-    if (int rc = check_launch("acq_flagged_map_kernel")) return rc;
-    const size_t lds = (256 + 64) * 4 + (in_lds ? (size_t)P * 8 : 0);
-    hipLaunchKernelGGL(topk_large_kernel, dim3((unsigned)B), dim3(kLargeThreads), lds, st, (const float*)p.out_map, p.N, (int)k, largest,
-                       in_lds ? (uint64_t*)nullptr : reinterpret_cast<uint64_t*>(gbuf), P, out_idx, out_val, (const int*)flags);
-    return check_launch("topk_large_kernel");
+    return check_launch("topk_lsel_kernel");
 }
 
 static int dispatch_acq(const AcqParams& p, Plan pl, int64_t B, hipStream_t st)
@@ -2522,7 +2496,7 @@ int pp_acq_score_topk(const float* logits, int64_t B, int64_t C, int64_t H, int6
                 g_reduce_mode, 0};
     const float qs = score_qscale(strategy, C);
     if (acq_emit_ok(p, pl, B, k, qs, out_map != nullptr))
-        return run_emit_select(p, pl, B, k, largest, qs, workspace, gbuf, reinterpret_cast<char*>(gbuf) + pp_topk_workspace_bytes(B, N, k),
+        return run_emit_select(p, pl, B, k, largest, qs, workspace, reinterpret_cast<char*>(gbuf) + pp_topk_workspace_bytes(B, N, k),
                                out_idx, out_val, st);
     const bool fuse_hist = large_q_ok(B, k, qs) && acq_hist_fusable(p, pl);
     if (fuse_hist) {
