@@ -1,9 +1,16 @@
+# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6e19; mkdir -p $O
-timeout 600 python -m pytest tests/test_acq_gpu.py -x -q > $O/tacq.txt 2>&1; tail -3 $O/tacq.txt
-for m in 2048 0; do echo "RMODE=$m"; RMODE=$m timeout 120 python tools/topk5_bench.py 2>&1 | tail -2 | head -1; done | tee $O/topk5.txt
-echo "every image falls back (aim k/16):"; RMODE=$((1<<12)) timeout 120 python tools/topk5_bench.py 2>&1 | tail -2 | head -1
+O=gpurun_out/r6fin5; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python tools/measure_acq_traffic.py > $O/traffic.log 2>&1; tail -2 $O/traffic.log | cut -c1-200; cp profiles/acq_traffic.json $O/acq_traffic.json
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
 cd /tmp && export TMPDIR=/tmp
-RMODE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o t -- python $GRAFT_REPO_ROOT/tools/topk5_bench.py > /dev/null 2>&1
-cp $(find $GRAFT_REPO_ROOT/$O/prof -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/ks.csv; rm -rf $GRAFT_REPO_ROOT/$O/prof
-grep "pp::" $GRAFT_REPO_ROOT/$O/ks.csv | head -5 | cut -c1-60,100-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_step -o s -- python $GRAFT_REPO_ROOT/tools/train_bench.py > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+cp $(find $O/prof_head -name "*kernel_stats.csv" | head -1) $O/bench_headline_kernel_stats.csv
+python tools/timeline.py $(find $O/prof_step -name "*kernel_trace.csv" | head -1) --list > $O/train_step_timeline.txt 2>&1; head -4 $O/train_step_timeline.txt
+rm -rf $O/prof_bench $O/prof_head $O/prof_step
