@@ -84,6 +84,26 @@ def test_abi_argument_validation_without_gpu():
     assert L.pp_topk_select(None, 1, 10, 3, 1, None, None, None, 0, None) == -1
 
 
+def test_acquisition_workspace_sizes_cover_every_large_k_path():
+    """pp_acq_workspace_bytes is the one place a caller learns how much scratch the large-k selection needs (host arithmetic only).  It must
+    hold a score map (4 B / pixel) in every case - the map path, and the exact fallback of the list select, write one - and where the list
+    select is offered (k <= N / 8, N >= 16384) the per-wave candidate segments (8 B per pixel + the pad) plus the per-image keys and per-wave
+    counts; it grows with B and is 0 for arguments no launch would accept (instead of wrapping around)."""
+    L = _lib.lib()
+    for B, H, W, k in ((256, 256, 512, 6553), (8, 1024, 1024, 5000), (3, 128, 160, 1024), (2, 64, 96, 307), (1, 100, 172, 860)):
+        N = H * W
+        ws = L.pp_acq_workspace_bytes(B, 19, H, W, k)
+        topk = L.pp_topk_workspace_bytes(B, N, k)
+        assert ws >= B * N * 4 + topk
+        if k * 8 <= N and N >= 16384:
+            segs = -(-N // 2048) * 8                    # 256-pixel segments
+            assert ws >= B * segs * (256 + 32) * 8 + topk + B * 4 + B * segs * 4
+        assert L.pp_acq_workspace_bytes(2 * B, 19, H, W, k) > ws
+    assert L.pp_acq_workspace_bytes(1, 19, 1 << 16, 1 << 16, 100) == 0          # H * W beyond int32
+    assert L.pp_acq_workspace_bytes(1, 19, 64, 64, 64 * 64 + 1) == 0             # k > H * W
+    assert L.pp_topk_workspace_bytes(4, 131072, 1 << 31) == 0
+
+
 def test_launch_plan_executor_knows_every_enqueuing_entry_point():
     """csrc/plan.hip holds one typed thunk per entry point that enqueues work; its arity comes from the function's own prototype
     and must agree with the ctypes table.  The plan API itself (create / add / host break / replay of an empty stretch) needs no GPU."""
