@@ -853,7 +853,8 @@ class ConvBwdGroup:
         ptrs = [w.data_ptr() for w, _, _ in specs]
         if max(ptrs) - min(ptrs) + max(w.numel() for w, _, _ in specs) * 4 >= (1 << 33) - (1 << 26):
             return 0
-        return int(_lib.lib().pp_conv2d_bwd_data_multi_workspace_bytes(B, H, W, Cin, Cout, len(specs), *flat))
+        # (memoised per shape, dropped when a planner knob changes: an eager step asks on every forward)
+        return _wsbytes("pp_conv2d_bwd_data_multi_workspace_bytes", B, H, W, Cin, Cout, len(specs), *flat)
 
     def arrive(self, tape: "Tape", i: int, dy: torch.Tensor):
         if self.arrived[i]:
@@ -1671,6 +1672,7 @@ def _register_weight_planes(w: torch.Tensor, transpose: int):
     ent = _X3_WPL.get(id(w))
     if ent is None or ent["w"]() is not w:
         ent = _X3_WPL[id(w)] = {"w": weakref.ref(w), "planes": {}, "epoch": -1}      # (weak: a new model per active-learning stage, model.py:250)
+    ent["used"] = _STEP_EPOCH[0]
     if transpose not in ent["planes"]:
         kh, kw, Cin, Cout = w.shape
         nb = int(_lib.lib().pp_x3_weight_planes_bytes(kh * kw, Cin, Cout, transpose))
@@ -1685,6 +1687,11 @@ def _prefetch_weight_planes():
         w = ent["w"]()
         if w is None or not w.is_cuda:
             del _X3_WPL[key]
+            continue
+        # only the weights the PREVIOUS step used (begin_step and end_step each advance the epoch): the registry is process-wide, and
+        # another trainer's model, or a weight a stand-alone conv2d call registered once, would otherwise be re-split - two launches and
+        # a plane buffer each - at every step of this one.  An idle weight's planes simply go stale; its next step splits inline once.
+        if ent.get("used", -10) < _STEP_EPOCH[0] - 3:
             continue
         by_dev.setdefault(w.device, []).append((ent, w))
     for dev, ents in by_dev.items():
@@ -1709,6 +1716,8 @@ def _prefetch_weight_planes():
 def _weight_planes(w: torch.Tensor, transpose: int):
     """Device pointer of this step's pre-split planes of w in the given layout (the main stream has waited for them), or None."""
     ent = _X3_WPL.get(id(w))
+    if ent is not None and ent["w"]() is w:
+        ent["used"] = _STEP_EPOCH[0]
     if ent is None or ent["w"]() is not w or ent["epoch"] != _STEP_EPOCH[0] or transpose not in ent["planes"]:
         return None
     rec = _X3_WPL_EVENT.get((w.device.type, w.device.index))

@@ -196,3 +196,40 @@ def test_engine_keeps_weight_planes_for_layers_that_split_in_the_kernel():
     dx_plain = _bwd(dy, w.detach(), H, W, 1, 0, 1)
     for y, dx in outs:
         assert torch.equal(y, y_plain) and torch.equal(dx, dx_plain)
+
+
+def test_idle_weights_are_not_split_again_by_other_steps():
+    """engine._X3_WPL is process-wide: begin_step() re-splits only the weights the previous step used.  A layer that ran in two steps
+    and then sits idle (another trainer's model, a stand-alone conv2d call) keeps stale planes - its entry's epoch stops advancing -
+    while a layer that keeps running is split at every begin_step(); when the idle layer runs again it splits inline (same bits) and is
+    back in the prefetch from the step after."""
+    L = _lib.lib()
+    L.pp_debug_set_x3f(X3F_ON)
+    B, H, W, Cin, Cout = 4, 32, 64, 1024, 256
+    xa, wa = _data(B, H, W, Cin, Cout, 1, 5)
+    xb, wb = _data(B, H, W, Cin, Cout, 1, 6)
+    wa.requires_grad_(True)
+    wb.requires_grad_(True)
+    bias = torch.zeros(Cout, device=DEV)
+
+    def step(pairs):
+        E.begin_step()
+        tape = E.Tape()
+        ys = [E.conv2d(tape, E.Var(x), w, bias, 1, 0, 1).t.clone() for x, w in pairs]
+        torch.cuda.synchronize()
+        E.end_step()
+        return ys
+
+    for _ in range(2):
+        step([(xa, wa), (xb, wb)])
+    ea, eb = E._X3_WPL[id(wa)], E._X3_WPL[id(wb)]
+    assert ea["epoch"] == eb["epoch"] == E._STEP_EPOCH[0] - 1            # both split at the last begin_step()
+    for _ in range(3):
+        ya = step([(xa, wa)])[0]
+    assert ea["epoch"] == E._STEP_EPOCH[0] - 1                            # the running layer: split at every begin_step()
+    assert eb["epoch"] < E._STEP_EPOCH[0] - 4                             # the idle one: left alone
+    ya2, yb = step([(xa, wa), (xb, wb)])                                   # idle layer runs again: inline split, same bits
+    assert torch.equal(ya, ya2) and torch.equal(yb, _fwd(xb, wb.detach(), 1, 0, 1))
+    step([(xa, wa), (xb, wb)])
+    assert eb["epoch"] == E._STEP_EPOCH[0] - 1                            # and is prefetched again
+
