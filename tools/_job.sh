@@ -1,21 +1,16 @@
+# scratch job for `gpurun -- 'bash tools/_job.sh'`: the round-end checks (GPU suite, smoke, bench line + rocprofv3 stats of the same command)
 cd $GRAFT_REPO_ROOT
-cp tools/probe/libpp_timing.so pixelpick_amd/libpixelpick_hip_knobs.so
-cat > /tmp/t.py <<'P'
-import os, sys
-os.environ["PIXELPICK_KNOBS_BUILD"] = "1"
-import torch
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-from pixelpick_amd import _lib
-B, C, H, W = 256, 19, 256, 512
-k = H * W * 5 // 100
-torch.manual_seed(0)
-x = torch.randn(B, C, H, W, device="cuda") * 3
-L = _lib.lib()
-idx = torch.empty((B, k), dtype=torch.int32, device="cuda"); val = torch.empty((B, k), device="cuda")
-ws = torch.empty(int(L.pp_acq_workspace_bytes(B, C, H, W, k)), dtype=torch.uint8, device="cuda")
-st = torch.cuda.current_stream().cuda_stream
-for i in range(4):
-    _lib.check(L.pp_acq_score_topk(x.data_ptr(), B, C, H, W, *x.stride(), None, 0, k, idx.data_ptr(), val.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "op")
-    torch.cuda.synchronize()
-P
-timeout 120 python /tmp/t.py 2>&1 | tail -4
+O=gpurun_out/rfin; mkdir -p $O
+timeout 2700 python -m pytest tests/ -q -m gpu > $O/tall.txt 2>&1; tail -2 $O/tall.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python tools/measure_acq_traffic.py > $O/traffic.log 2>&1; tail -2 $O/traffic.log | cut -c1-200; cp profiles/acq_traffic.json $O/acq_traffic.json
+python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 300 $O/bench_line.json; echo
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -o b -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_step -o s -- python $GRAFT_REPO_ROOT/tools/train_bench.py > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+cp $(find $O/prof_head -name "*kernel_stats.csv" | head -1) $O/bench_headline_kernel_stats.csv
+python tools/timeline.py $(find $O/prof_step -name "*kernel_trace.csv" | head -1) --list > $O/train_step_timeline.txt 2>&1; head -4 $O/train_step_timeline.txt
+rm -rf $O/prof_bench $O/prof_head $O/prof_step
