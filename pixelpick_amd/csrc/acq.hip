@@ -1691,24 +1691,38 @@ __global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(AcqParams p, c
     for (int u = 0; u < OWN; ++u) hist[tid + u * kLargeThreads] = 0u;
     if (tid < 4) misc[tid] = 0u;
     __syncthreads();
-    // every wave walks four segments at a time (a segment usually holds fewer than 64 words: one load per segment in flight)
-    auto sweep = [&](auto&& fn) {
-        for (int s0 = wave * 4; s0 < nseg; s0 += (kLargeThreads / 64) * 4) {
-            uint32_t c[4];
-            uint64_t v[4];
+    // A wave takes kSegW consecutive segments of every 16 * kSegW: their counts in one load, then one load per segment in flight (a segment
+    // usually holds fewer than 64 words; the rest of a fuller one is walked afterwards).  With <= 16 * kSegW segments per image (256 x 512 at
+    // 8 pixels per thread: exactly) the words stay in registers between the histogram pass and the drop pass: the lists are read once
+    // (PMC: 61.9 -> ~35 MB fetched per launch).
+    constexpr int kSegW = 16;
+    const bool one_chunk = nseg <= (kLargeThreads / 64) * kSegW;
+    uint32_t c[kSegW];
+    uint64_t v[kSegW];
+    auto load_chunk = [&](int c0) {
+        const int s0 = c0 + wave * kSegW;
+        const uint32_t mine = (lane < kSegW && s0 + lane < nseg) ? C[s0 + lane] : 0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = s0 + u < nseg ? C[s0 + u] : 0u;
+        for (int u = 0; u < kSegW; ++u) c[u] = (uint32_t)__shfl((int)mine, u, 64);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (uint32_t)lane < c[u] ? L[(int64_t)(s0 + u) * segsz + lane] : 0ull;
+        for (int u = 0; u < kSegW; ++u) v[u] = (uint32_t)lane < c[u] ? L[(int64_t)(s0 + u) * segsz + lane] : 0ull;
+    };
+    auto walk_chunk = [&](int c0, auto&& fn) {
+        const int s0 = c0 + wave * kSegW;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if ((uint32_t)lane < c[u]) fn(v[u]);
+        for (int u = 0; u < kSegW; ++u)
+            if ((uint32_t)lane < c[u]) fn(v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                for (uint32_t e = (uint32_t)lane + 64u; e < c[u]; e += 64u) fn(L[(int64_t)(s0 + u) * segsz + e]);
+        for (int u = 0; u < kSegW; ++u)
+            for (uint32_t e = (uint32_t)lane + 64u; e < c[u]; e += 64u) fn(L[(int64_t)(s0 + u) * segsz + e]);
+    };
+    auto sweep = [&](bool reload, auto&& fn) {
+        for (int c0 = 0; c0 < nseg; c0 += (kLargeThreads / 64) * kSegW) {
+            if (reload) load_chunk(c0);
+            walk_chunk(c0, fn);
         }
     };
-    sweep([&](uint64_t w) { atomicAdd(&hist[lbin((uint32_t)(w >> 32), lg, tv, lscale)], 1u); });
+    sweep(true, [&](uint64_t w) { atomicAdd(&hist[lbin((uint32_t)(w >> 32), lg, tv, lscale)], 1u); });
     __syncthreads();
     {
         // thread t owns bins kLBins - 1 - OWN t - u (from the top)
@@ -1761,7 +1775,7 @@ __global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(AcqParams p, c
                         out_val ? out_val + (int64_t)img * k : nullptr);
         return;
     }
-    sweep([&](uint64_t w) {
+    sweep(!one_chunk, [&](uint64_t w) {
         const uint32_t q = lbin((uint32_t)(w >> 32), lg, tv, lscale);
         if (q >= tb) buf[start[q] + atomicAdd(&hist[q], 1u)] = w;
     });
