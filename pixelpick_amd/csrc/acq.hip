@@ -38,7 +38,8 @@ static int g_acq_strat_spec = 1;   // strategy-specialised scorers of the three 
 static int g_nt_off = 0;          // A/B: ordinary instead of non-temporal logit loads in the strategy-specialised scorers (pp_debug_set_acq_tuning bit 11 of `occ`)
 static int g_tune_xcd = 0;        // 0: by plane size, 1: never, 2: always (pp_debug_set_acq_tuning bits 8-9 of `occ`)
 
-typedef float f32x4_nt __attribute__((ext_vector_type(4)));      // (native vector type: __builtin_nontemporal_load does not take HIP's float4 struct)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef float f32x2_nt __attribute__((ext_vector_type(2)));      // (native vector type: __builtin_nontemporal_load does not take HIP's float4 struct)
 
 constexpr int kBlock = 256;
 constexpr int kSmallKMax = 48;        // fused per-wave extraction up to this k (measured: 0.74/0.70/0.62 of HBM at k=20/32/48, 0.37 at 64); beyond: map + radix select
@@ -1759,13 +1760,83 @@ __global__ __launch_bounds__(kLargeThreads) void topk_lsel_kernel(AcqParams p, c
         const float* base = p.logits + (int64_t)img * p.sB;
         const uint8_t* excl = p.exclude ? p.exclude + (int64_t)img * p.N : nullptr;
         float* fmap = reinterpret_cast<float*>(const_cast<uint64_t*>(L));          // N floats <= eimg words
-        for (int64_t pix = tid; pix < p.N; pix += kLargeThreads) {                  // (flat planes: sW == 1, sH == W)
-            float x[CMAX];
+        const float qscale = (float)kQBins / range;
+        __syncthreads();                                                             // (the list passes' bins are read no more)
+        hist[tid] = 0u;                                                              // kQBins == kLargeThreads words
+        __syncthreads();
+        auto score1 = [&](const float (&xx)[CMAX]) -> float {       // (the strategy-specialised scorers: the same bits as the generic one, fewer registers)
+            if (p.strategy == PP_ACQ_ENTROPY) return pixel_score_fast<CMAX, true, PP_ACQ_ENTROPY>(xx, p.C, p.strategy);
+            if (p.strategy == PP_ACQ_LEAST_CONFIDENCE) return pixel_score_fast<CMAX, true, PP_ACQ_LEAST_CONFIDENCE>(xx, p.C, p.strategy);
+            return pixel_score_fast<CMAX, true, PP_ACQ_MARGIN>(xx, p.C, p.strategy);
+        };
+        constexpr int PXF = CMAX > 19 ? 1 : 2;                       // pixels per thread and pass: PXF x CMAX registers under the 1024-thread budget
+        for (int64_t pix = (int64_t)tid * PXF; pix < p.N; pix += kLargeThreads * PXF) {  // (flat planes, N % 4 == 0: the emitting scorer's layout)
+            float x[PXF][CMAX], sc[PXF];
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) x[c] = base[(int64_t)c * p.sC + pix];
-            float sc = pixel_score_fast<CMAX, true>(x, p.C, p.strategy);
-            if (excl && excl[pix]) sc = fill;
-            fmap[pix] = sc;
+            for (int c = 0; c < CMAX; ++c) {
+                if constexpr (PXF == 2) {
+                    const f32x2_nt v = *reinterpret_cast<const f32x2_nt*>(base + (int64_t)c * p.sC + pix);
+                    x[0][c] = v.x; x[1][c] = v.y;
+                } else {
+                    x[0][c] = base[(int64_t)c * p.sC + pix];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PXF; ++u) {
+                sc[u] = score1(x[u]);
+                if (excl && excl[pix + u]) sc[u] = fill;
+                fmap[pix + u] = sc[u];
+                atomicAdd(&hist[qbin(sc[u], lg, qscale)], 1u);
+                __builtin_amdgcn_sched_barrier(0);                  // one pixel's temporaries at a time
+            }
+        }
+        __syncthreads();
+        // First the quantised select over the whole score range on the map just written (what topk_qsel_kernel does: kQBins bins were
+        // counted while scoring): an image that is here because the sample misled - not because of ties - is done in two more passes
+        // over its 0.5 MB map; only ties / constant regions go on to the radix select (one bad sample would otherwise cost 1.4 ms).
+        {
+            const int bin = kQBins - 1 - tid;                       // kLargeThreads == kQBins
+            const uint32_t own = hist[bin];
+            uint32_t incl = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x2 = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += x2;
+            }
+            if (lane == 63) misc[8 + wave] = incl;
+            if (tid == 0) { misc[2] = 0u; misc[3] = 0u; }
+            __syncthreads();
+            uint32_t pre = 0;
+            for (int w = 0; w < wave; ++w) pre += misc[8 + w];
+            incl += pre;
+            const uint32_t excl2 = incl - own;
+            __syncthreads();                                        // (every thread has read its bin: the words become the drop cursors)
+            start[bin] = excl2;
+            hist[bin] = 0u;
+            if (excl2 < (uint32_t)k && (uint32_t)k <= incl) { misc[0] = (uint32_t)bin; misc[1] = incl; misc[3] = 1u; }
+            if (excl2 < (uint32_t)k && own > (uint32_t)kQMaxPop) misc[2] = 1u;
+            __syncthreads();
+        }
+        if (misc[3] && misc[1] <= (uint32_t)kQCap && !misc[2]) {     // block-uniform
+            const uint32_t tb2 = misc[0], cnt2 = misc[1];
+            for (int64_t pix = tid; pix < p.N; pix += kLargeThreads) {
+                const float sc = fmap[pix];
+                const uint32_t q = qbin(sc, lg, qscale);
+                if (q >= tb2) buf[start[q] + atomicAdd(&hist[q], 1u)] = ((uint64_t)order_key(sc, lg) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)pix);
+            }
+            __syncthreads();
+            for (uint32_t e = (uint32_t)tid; e < cnt2; e += kLargeThreads) {
+                const uint64_t me = buf[e];
+                const uint32_t q = qbin(key_to_float((uint32_t)(me >> 32), lg), lg, qscale);
+                const uint32_t a = start[q], b = a + hist[q];
+                uint32_t rank = a;
+                for (uint32_t t = a; t < b; ++t) rank += buf[t] > me ? 1u : 0u;
+                if (rank < (uint32_t)k) {
+                    out_idx[(int64_t)img * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)me);
+                    if (out_val) out_val[(int64_t)img * k + rank] = key_to_float((uint32_t)(me >> 32), lg);
+                }
+            }
+            return;
         }
         __syncthreads();
         uint32_t* rh = reinterpret_cast<uint32_t*>(smem);                           // 256 + 64 words, then P 64-bit words (P <= 8192: k <= 7281)
